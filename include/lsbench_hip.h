@@ -1,0 +1,275 @@
+/*
+ * C-ABI of the MI355X (gfx950) sparse-solve backend for lsbench.
+ *
+ * Everything here is `extern "C"`, plain pointers and sizes.  The library that
+ * exports it is liblsbench_hip.so (built by lsbench_amd/csrc/Makefile).  Three
+ * layers, outermost first:
+ *
+ *   1. the backend trio  hip_cdna4_{init,finalize,bench}  -- the drop-in
+ *      boundary: the same three-function contract every reference backend
+ *      implements (reference: src/lsbench-impl.h:42-68; template
+ *      src/cusparse.c:137-213);
+ *   2. the solver-handle API  lsb_hip_solver_*  -- what hip_cdna4_bench is made
+ *      of, exposed so a caller can keep the operator resident in HBM and solve
+ *      repeatedly (bench.py, tests);
+ *   3. kernel-level entry points  lsb_hip_<op>_f64  -- one per hand-written HIP
+ *      kernel, raw device pointers + a hipStream_t passed as void*.
+ *
+ * Return convention (reference: src/cusparse.c:139-140,154-155,166-167):
+ * 0 = ok, 1 = backend not initialised / already initialised / no device,
+ * 2 = bad argument.  A failing HIP or RCCL call is fatal: errx(EXIT_FAILURE,
+ * "file:line ...") exactly like the reference's chk_rt macro
+ * (src/cusparse.c:24-31).  Nothing in this library falls back to a CPU path.
+ */
+#ifndef LSBENCH_HIP_H
+#define LSBENCH_HIP_H
+
+#include "lsbench.h"
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------ */
+/* Data layouts handed across the boundary                                   */
+/* ------------------------------------------------------------------------ */
+
+/* Run configuration.  Layout = reference src/lsbench-impl.h:14-20. */
+struct lsbench {
+  char *matrix;
+  lsbench_solver_t solver;
+  lsbench_ordering_t ordering;
+  lsbench_precision_t precision;
+  unsigned verbose, trials;
+};
+
+/* CSR container.  Layout = reference src/lsbench-impl.h:22-26.
+ * offs[nrows+1] is always 0-based; cols[] keep the file's base (0 or 1); rows
+ * are sorted by column with duplicates summed (src/lsbench-csr.c:54-63). */
+struct csr {
+  unsigned nrows, base;
+  unsigned *offs, *cols;
+  double *vals;
+};
+
+/* ------------------------------------------------------------------------ */
+/* 1. Backend trio (drop-in boundary)                                        */
+/* ------------------------------------------------------------------------ */
+
+/* Replaces nothing, adds the 7th backend next to cusparse_init
+ * (src/lsbench-impl.h:42).  Creates the HIP stream; returns 1 quietly when no
+ * device is present, because lsbench_init initialises every backend whatever
+ * --solver says (src/lsbench.c:143-147). */
+int hip_cdna4_init(void);
+
+/* Counterpart of cusparse_finalize (src/lsbench-impl.h:43). */
+int hip_cdna4_finalize(void);
+
+/* Counterpart of cusparse_bench / cholmod_bench (src/lsbench-impl.h:44-45,
+ * 57-58).  x: caller-owned, length nrows, zero on entry (initial guess),
+ * receives the solution in original row order (src/cusparse.c:203-204).
+ * r: right-hand side, length nrows.  Protocol (src/cholmod-impl.h:34-71):
+ * untimed setup, cb->trials warm-up solves, cb->trials timed solves, one CSV
+ * record on stdout.  The operator solved is the one CHOLMOD is given:
+ * S = triu(A) + triu(A,1)^T (src/cholmod-impl.h:5-16). */
+int hip_cdna4_bench(double *x, struct csr *A, const double *r,
+                    const struct lsbench *cb);
+
+/* ------------------------------------------------------------------------ */
+/* Options / results (additive; the reference has no such knobs)             */
+/* ------------------------------------------------------------------------ */
+
+enum { LSB_OP_CHOLMOD_UPPER = 0, /* S = triu(A)+triu(A,1)^T (default)      */
+       LSB_OP_RAW = 1 };         /* the CSR exactly as handed in            */
+enum { LSB_PRECOND_JACOBI = 0, LSB_PRECOND_NONE = 1 };
+enum { LSB_SPMV_AUTO = 0,     /* pick by mean row length                    */
+       LSB_SPMV_ADAPTIVE = 1, /* row-blocked: LDS-streamed short rows +
+                                 wavefront-per-row long rows                */
+       LSB_SPMV_SUBWAVE = 2,  /* 2..64 lanes per row, shuffle reduction     */
+       LSB_SPMV_SCALAR = 3 }; /* one lane per row (test/debug baseline)     */
+enum { LSB_STATUS_RUNNING = 0, LSB_STATUS_CONVERGED = 1,
+       LSB_STATUS_BREAKDOWN = 2, LSB_STATUS_MAXIT = 3 };
+
+struct lsb_hip_opts {
+  double tol;        /* stop when ||r||_2 <= tol*||b||_2            [1e-12] */
+  unsigned maxit;    /* iteration cap                               [20000] */
+  int op_mode;       /* LSB_OP_*                          [CHOLMOD_UPPER]   */
+  int precond;       /* LSB_PRECOND_*                             [JACOBI]  */
+  int spmv_variant;  /* LSB_SPMV_*                                  [AUTO]  */
+  int check_every;   /* iterations enqueued per host poll             [0=auto] */
+  int use_graph;     /* replay iterations from a hipGraph (1 rank)     [1]  */
+  int sample_spmv;   /* HIP-event-time every Nth SpMV launch (0=off)   [0]  */
+  int nvirt;         /* >1: split into that many row-range shards on ONE
+                        device, exchanging by device copies (test mode) [1] */
+  int overlap;       /* overlap halo exchange with interior rows        [1] */
+  int verbose;
+};
+
+struct lsb_hip_result {
+  unsigned iters;        /* PCG iterations performed                        */
+  int status;            /* LSB_STATUS_*                                    */
+  double relres;         /* sqrt(r.r / b.b) of the recurrence residual      */
+  double seconds;        /* wall-clock of this solve (host, after sync)     */
+  double spmv_ms;        /* mean duration of the sampled SpMV launches      */
+  unsigned spmv_samples; /* how many launches were sampled                  */
+};
+
+void lsb_hip_opts_default(struct lsb_hip_opts *o);
+/* Options used by hip_cdna4_bench (which has no room for them in its
+ * signature).  Also read from the environment at hip_cdna4_init:
+ * LSBENCH_HIP_TOL, LSBENCH_HIP_MAXIT, LSBENCH_HIP_OPERATOR=raw|upper,
+ * LSBENCH_HIP_NVIRT, LSBENCH_HIP_GRAPH, LSBENCH_HIP_SPMV. */
+void lsb_hip_set_opts(const struct lsb_hip_opts *o);
+void lsb_hip_get_opts(struct lsb_hip_opts *o);
+/* Result of the last timed trial of the last hip_cdna4_bench call. */
+void lsb_hip_last_result(struct lsb_hip_result *res);
+int lsb_hip_device_count(void);
+
+/* ------------------------------------------------------------------------ */
+/* Host-side matrix helpers (no GPU needed)                                  */
+/* ------------------------------------------------------------------------ */
+
+/* The operator CHOLMOD factorises, as a full 0-based CSR (both triangles):
+ * restates the triplet construction of src/cholmod-impl.h:5-21.  Caller frees
+ * with lsbench_matrix_free. */
+struct csr *lsb_csr_symmetrize_upper(const struct csr *A);
+/* Deep copy with cols rebased to 0. */
+struct csr *lsb_csr_copy_base0(const struct csr *A);
+/* Rows [r0, r1) as a new CSR that keeps GLOBAL column ids (base 0 in, base 0
+ * out): the shard one rank owns under 1-D row-range partitioning. */
+struct csr *lsb_csr_row_slice(const struct csr *A, unsigned r0, unsigned r1);
+/* Row-range partition balanced by non-zeros: bounds[0..nparts], with
+ * bounds[0]=0, bounds[nparts]=nrows (prefix-sum split of offs). */
+int lsb_csr_partition_rows(const struct csr *A, unsigned nparts,
+                           unsigned *bounds);
+/* Row blocks for the adaptive SpMV: consecutive rows are packed greedily into
+ * blocks of at most `cap` non-zeros; a row longer than `cap` gets a block of
+ * its own.  Returns the number of blocks and a malloc'd array of nblk+1 row
+ * ids in *rowblk (caller frees with free()). */
+unsigned lsb_csr_row_blocks(const struct csr *A, unsigned cap,
+                            unsigned **rowblk);
+/* Synthetic operators (BASELINE.json configs 3-5), rows [r0,r1) only, global
+ * 0-based column ids, generated on the host.  spec:
+ *   "lap2d:nx=3162,ny=3162"          5-point Laplacian, diag 4, off -1
+ *   "lap3d:nx=400,ny=400,nz=400"     7-point Laplacian, diag 6, off -1
+ *   "powerlaw:n=8000000,avg=32,max=4096,seed=20240607[,spd=1]"
+ * r1 = 0 means "to the last row".  *n_global receives the full row count. */
+struct csr *lsbench_matrix_synth(const char *spec, unsigned r0, unsigned r1,
+                                 unsigned *n_global);
+
+/* ------------------------------------------------------------------------ */
+/* 2. Solver handle: operator resident in HBM, repeated solves               */
+/* ------------------------------------------------------------------------ */
+
+typedef struct lsb_hip_solver lsb_hip_solver;
+
+/* Whole matrix on this process' device (or on o->nvirt virtual shards of it).
+ * Applies o->op_mode.  Untimed setup: counterpart of csr_init
+ * (src/cusparse.c:47-125, src/cholmod-impl.h:1-32). */
+lsb_hip_solver *lsb_hip_solver_create(const struct csr *A,
+                                      const struct lsb_hip_opts *o);
+/* One rank's shard of a row-partitioned operator: rows
+ * [row_begin, row_begin + A_rows->nrows) with GLOBAL 0-based column ids, used
+ * as-is (LSB_OP_RAW).  Collective over the communicator set up by
+ * lsb_hip_comm_init_rank; every rank must call it. */
+lsb_hip_solver *lsb_hip_solver_create_dist(const struct csr *A_rows,
+                                           unsigned row_begin,
+                                           unsigned n_global,
+                                           const struct lsb_hip_opts *o);
+void lsb_hip_solver_destroy(lsb_hip_solver *s);
+
+/* Jacobi-PCG from x0 = 0.  Host buffers, local rows only (length n_local);
+ * H2D of b and D2H of x are outside res->seconds. */
+int lsb_hip_solver_solve(lsb_hip_solver *s, const double *b, double *x,
+                         struct lsb_hip_result *res);
+/* Same with device-resident b and x (length n_local each). */
+int lsb_hip_solver_solve_dev(lsb_hip_solver *s, const double *d_b, double *d_x,
+                             struct lsb_hip_result *res);
+/* y_local = Op * x: d_x holds this rank's rows (length n_local); remote
+ * entries are exchanged first when the solver is distributed. */
+int lsb_hip_solver_spmv_dev(lsb_hip_solver *s, const double *d_x, double *d_y);
+/* Time `reps` back-to-back launches of the solver's SpMV kernel with HIP
+ * events on the solver's stream (after `warm` untimed ones); *ms_avg = mean
+ * milliseconds per launch.  No exchange, local shard 0. */
+int lsb_hip_solver_time_spmv(lsb_hip_solver *s, int warm, int reps,
+                             double *ms_avg);
+/* One weighted-Jacobi sweep x <- x + w D^-1 (b - Op x), device buffers. */
+int lsb_hip_solver_jacobi_sweep_dev(lsb_hip_solver *s, double w,
+                                    const double *d_b, double *d_x);
+
+unsigned lsb_hip_solver_nrows_local(const lsb_hip_solver *s);
+unsigned lsb_hip_solver_nrows_global(const lsb_hip_solver *s);
+unsigned long long lsb_hip_solver_nnz_local(const lsb_hip_solver *s);
+unsigned lsb_hip_solver_nblocks(const lsb_hip_solver *s);
+int lsb_hip_solver_spmv_variant(const lsb_hip_solver *s);
+/* hipStream_t of the backend (as void*), for callers that time with events. */
+void *lsb_hip_stream(void);
+
+/* ------------------------------------------------------------------------ */
+/* Multi-GPU: one process per GPU, RCCL over xGMI                            */
+/* ------------------------------------------------------------------------ */
+
+#define LSB_HIP_UNIQUE_ID_BYTES 128
+/* Rank 0 calls get_unique_id and ships the 128 bytes to the other ranks by
+ * whatever side channel the launcher offers (bench.py: torch.distributed
+ * broadcast); then every rank calls init_rank. */
+int lsb_hip_comm_get_unique_id(void *id128);
+int lsb_hip_comm_init_rank(const void *id128, int nranks, int rank);
+int lsb_hip_comm_destroy(void);
+int lsb_hip_comm_rank(void);
+int lsb_hip_comm_size(void);
+/* In-place sum of `count` doubles over all ranks, device buffer, on the
+ * backend stream; and a barrier built from it. */
+int lsb_hip_comm_allreduce_sum_dev(double *d_buf, int count);
+int lsb_hip_comm_barrier(void);
+
+/* ------------------------------------------------------------------------ */
+/* 3. Kernel-level entry points (device pointers; stream = hipStream_t)      */
+/* ------------------------------------------------------------------------ */
+
+/* y = A x for a 0-based int32 CSR.  variant = LSB_SPMV_*; d_rowblk/nblk from
+ * lsb_csr_row_blocks (needed by ADAPTIVE, ignored otherwise).  If d_dot != NULL
+ * the kernel also leaves sum_i xdot[i]*y[i] in d_dot[0] (two-stage, fixed
+ * order; d_work must then hold lsb_hip_partials_capacity() doubles). */
+int lsb_hip_spmv_csr_f64(int variant, unsigned n, const int *d_offs,
+                         const int *d_cols, const double *d_vals,
+                         const int *d_rowblk, unsigned nblk,
+                         unsigned mean_row_len, const double *d_x, double *d_y,
+                         const double *d_xdot, double *d_dot, double *d_work,
+                         void *stream);
+unsigned lsb_hip_partials_capacity(void);
+/* d_out[0] = sum a_i b_i (deterministic two-stage reduction). */
+int lsb_hip_dot_f64(unsigned n, const double *d_a, const double *d_b,
+                    double *d_out, double *d_work, void *stream);
+/* d_out[0] = sqrt(sum a_i^2). */
+int lsb_hip_nrm2_f64(unsigned n, const double *d_a, double *d_out,
+                     double *d_work, void *stream);
+/* y += alpha x, alpha read from device memory (no host sync). */
+int lsb_hip_axpy_f64(unsigned n, const double *d_alpha, const double *d_x,
+                     double *d_y, void *stream);
+/* y = x + beta y, beta read from device memory. */
+int lsb_hip_xpay_f64(unsigned n, const double *d_beta, const double *d_x,
+                     double *d_y, void *stream);
+/* dinv[i] = 1 / A(i, i + row_begin); *d_nzero counts rows without a usable
+ * diagonal (their dinv is set to 0). */
+int lsb_hip_jacobi_setup_f64(unsigned n, unsigned row_begin, const int *d_offs,
+                             const int *d_cols, const double *d_vals,
+                             double *d_dinv, int *d_nzero, void *stream);
+/* z = dinv .* r */
+int lsb_hip_jacobi_apply_f64(unsigned n, const double *d_dinv,
+                             const double *d_r, double *d_z, void *stream);
+
+/* Device memory helpers so that a C caller without HIP headers can drive the
+ * kernel-level API (tests use torch tensors instead). */
+void *lsb_hip_malloc(size_t bytes);
+void lsb_hip_free(void *d_ptr);
+int lsb_hip_memcpy_h2d(void *d_dst, const void *src, size_t bytes);
+int lsb_hip_memcpy_d2h(void *dst, const void *d_src, size_t bytes);
+int lsb_hip_sync(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* LSBENCH_HIP_H */

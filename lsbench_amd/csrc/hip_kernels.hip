@@ -1,0 +1,725 @@
+// gfx950 (MI355X, CDNA4) kernels of the lsbench HIP backend + their C-ABI
+// launchers ("the shim").  Host code (hip_cdna4.c, plain C) never sees a
+// kernel symbol, only the extern "C" lsb_k_* functions at the bottom.
+//
+// None of this arithmetic exists in the reference's source: every reference
+// backend hands its CSR to a third-party library; the
+// nearest call site is the Krylov+Jacobi apply of src/ginkgo.cpp:55-69,91-99.
+// Kernel inventory = SURVEY.md section 8 (a2):
+//   a2-1  spmv (adaptive row-blocked / sub-wavefront / scalar), fused p.q
+//   a2-2  dot, nrm2           two-stage, fixed-order => run-to-run identical
+//   a2-3  axpy, xpay          scalars read from HBM, no host sync
+//   a2-4  jacobi setup/apply/sweep
+//   a2-5  fused PCG sweeps    (x,r update + r.z + r.r) and (p update)
+//
+// Everything here is HBM-bandwidth bound (0.125 flop/B for a 5-point row):
+// 64-wide wavefronts, coalesced 8-16 B/lane streams, LDS staging of the
+// per-non-zero products, XCD-contiguous work assignment so that the x-vector
+// window a row block gathers from is re-used out of one XCD's L2.  No MFMA.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lsb_impl.h"
+
+#define WG 256      // threads per workgroup = 4 wavefronts of 64
+#define NXCD 8      // XCDs per MI355X; blocks are dealt round-robin over them
+
+// --------------------------------------------------------------------------
+// Reductions: wavefront butterfly -> LDS across the 4 waves, fixed order.
+// Every thread of the workgroup returns with the same bits.
+// --------------------------------------------------------------------------
+template <int W>
+__device__ __forceinline__ void wg_sum(double (&v)[W], double *sred /*4*W*/) {
+#pragma unroll
+  for (int k = 0; k < W; k++) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+      v[k] += __shfl_xor(v[k], off, 64);
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads(); // sred may still be read from a previous call
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < W; k++)
+      sred[wave * W + k] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < W; k++)
+    v[k] = (sred[0 * W + k] + sred[1 * W + k]) + (sred[2 * W + k] + sred[3 * W + k]);
+}
+
+// Sum `nparts` partial records of width W (written by an earlier launch, one
+// record per workgroup) in an order that depends only on nparts.
+template <int W>
+__device__ __forceinline__ void wg_sum_partials(const double *__restrict__ parts,
+                                                unsigned nparts, double (&v)[W],
+                                                double *sred) {
+#pragma unroll
+  for (int k = 0; k < W; k++)
+    v[k] = 0.0;
+  for (unsigned i = threadIdx.x; i < nparts; i += WG) {
+#pragma unroll
+    for (int k = 0; k < W; k++)
+      v[k] += parts[(size_t)i * W + k];
+  }
+  wg_sum<W>(v, sred);
+}
+
+// Logical workgroup id such that each XCD owns a contiguous range of logical
+// ids (gridDim.x is a multiple of NXCD).  Placement is a speed matter only.
+__device__ __forceinline__ unsigned xcd_contiguous_wg() {
+  const unsigned b = blockIdx.x, per = gridDim.x / NXCD;
+  return (b % NXCD) * per + b / NXCD;
+}
+
+// --------------------------------------------------------------------------
+// a2-1  SpMV, adaptive row blocks.
+// rowblk[k]..rowblk[k+1] is a run of consecutive rows holding <= CAP
+// non-zeros, or a single row longer than CAP (lsb_csr_row_blocks).  A
+// workgroup walks a contiguous range of row blocks.  Short-row blocks: the
+// non-zeros are streamed (fully coalesced vals/cols, gather of x), the
+// products parked in LDS, then L = 1..64 lanes per row add them up.  A long
+// row is swept by the whole workgroup.
+// --------------------------------------------------------------------------
+template <int CAP>
+__global__ __launch_bounds__(WG) void k_spmv_adaptive(
+    const int *__restrict__ rowblk, unsigned nblk, unsigned blk_per_wg,
+    const int *__restrict__ offs, const int *__restrict__ cols,
+    const double *__restrict__ vals, const double *__restrict__ x,
+    double *__restrict__ y, const double *__restrict__ xdot,
+    double *__restrict__ partials, const lsb_pcg_state *__restrict__ st) {
+  if (st && st->status)
+    return;
+  __shared__ double sprod[CAP];
+  __shared__ double sred[4];
+  const unsigned tid = threadIdx.x;
+  const unsigned w = xcd_contiguous_wg();
+  const unsigned k0 = w * blk_per_wg;
+  const unsigned k1 = min(k0 + blk_per_wg, nblk);
+  constexpr int U = CAP / WG;
+  double dot = 0.0;
+
+  for (unsigned k = k0; k < k1; k++) {
+    const int r0 = rowblk[k], r1 = rowblk[k + 1];
+    const int j0 = offs[r0], j1 = offs[r1];
+    const int cnt = j1 - j0, nr = r1 - r0;
+    if (cnt <= CAP) {
+      // ---- stream the block's non-zeros ------------------------------
+      int c[U];
+      double v[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int t = tid + u * WG;
+        if (t < cnt) {
+          c[u] = cols[j0 + t];
+          v[u] = vals[j0 + t];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int t = tid + u * WG;
+        if (t < cnt)
+          sprod[t] = v[u] * x[c[u]];
+      }
+      __syncthreads();
+      // ---- L lanes per row add the products up -----------------------
+      unsigned L = 1;
+      while (L < 64 && (unsigned)nr * (L * 2) <= WG)
+        L <<= 1;
+      const unsigned slot = tid / L, l = tid % L, slots = WG / L;
+      for (unsigned rb = 0; rb < (unsigned)nr; rb += slots) {
+        const unsigned r = rb + slot;
+        double s = 0.0;
+        if (r < (unsigned)nr) {
+          const int a = offs[r0 + r] - j0, b = offs[r0 + r + 1] - j0;
+          for (int j = a + (int)l; j < b; j += (int)L)
+            s += sprod[j];
+        }
+        for (unsigned off = L >> 1; off > 0; off >>= 1)
+          s += __shfl_xor(s, off, 64);
+        if (r < (unsigned)nr && l == 0) {
+          y[r0 + r] = s;
+          if (xdot)
+            dot += s * xdot[r0 + r];
+        }
+      }
+      __syncthreads(); // sprod is overwritten by the next block
+    } else {
+      // ---- one long row: the whole workgroup strides over it ----------
+      double s[1] = {0.0};
+      for (int j = j0 + (int)tid; j < j1; j += WG)
+        s[0] += vals[j] * x[cols[j]];
+      wg_sum<1>(s, sred);
+      if (tid == 0) {
+        y[r0] = s[0];
+        if (xdot)
+          dot += s[0] * xdot[r0];
+      }
+      // rows after a long row in the same block cannot happen (nr == 1)
+    }
+  }
+  if (partials) {
+    double d[1] = {dot};
+    wg_sum<1>(d, sred);
+    if (tid == 0)
+      partials[w] = d[0];
+  }
+}
+
+// --------------------------------------------------------------------------
+// a2-1  SpMV, L lanes per row (L = 2..64; L = 64 is the classic
+// one-wavefront-per-row kernel), rows dealt to workgroups in contiguous,
+// XCD-contiguous chunks; shuffle (DPP) reduction of the L partial sums.
+// --------------------------------------------------------------------------
+template <int L>
+__global__ __launch_bounds__(WG) void k_spmv_subwave(
+    unsigned n, unsigned rows_per_wg, const int *__restrict__ offs,
+    const int *__restrict__ cols, const double *__restrict__ vals,
+    const double *__restrict__ x, double *__restrict__ y,
+    const double *__restrict__ xdot, double *__restrict__ partials,
+    const lsb_pcg_state *__restrict__ st) {
+  if (st && st->status)
+    return;
+  __shared__ double sred[4];
+  const unsigned tid = threadIdx.x, slot = tid / L, l = tid % L;
+  constexpr unsigned SLOTS = WG / L;
+  const unsigned w = xcd_contiguous_wg();
+  const unsigned ra = min(w * rows_per_wg, n), rb = min(ra + rows_per_wg, n);
+  double dot = 0.0;
+  for (unsigned base = ra; base < rb; base += SLOTS) {
+    const unsigned r = base + slot;
+    double s = 0.0;
+    if (r < rb) {
+      const int j0 = offs[r], j1 = offs[r + 1];
+      for (int j = j0 + (int)l; j < j1; j += L)
+        s += vals[j] * x[cols[j]];
+    }
+#pragma unroll
+    for (int off = L >> 1; off > 0; off >>= 1)
+      s += __shfl_xor(s, off, 64);
+    if (r < rb && l == 0) {
+      y[r] = s;
+      if (xdot)
+        dot += s * xdot[r];
+    }
+  }
+  if (partials) {
+    double d[1] = {dot};
+    wg_sum<1>(d, sred);
+    if (tid == 0)
+      partials[w] = d[0];
+  }
+}
+
+// one lane per row: debug / test baseline only
+__global__ __launch_bounds__(WG) void k_spmv_scalar(
+    unsigned n, unsigned rows_per_wg, const int *__restrict__ offs,
+    const int *__restrict__ cols, const double *__restrict__ vals,
+    const double *__restrict__ x, double *__restrict__ y,
+    const double *__restrict__ xdot, double *__restrict__ partials,
+    const lsb_pcg_state *__restrict__ st) {
+  if (st && st->status)
+    return;
+  __shared__ double sred[4];
+  const unsigned w = xcd_contiguous_wg();
+  const unsigned ra = min(w * rows_per_wg, n), rb = min(ra + rows_per_wg, n);
+  double dot = 0.0;
+  for (unsigned r = ra + threadIdx.x; r < rb; r += WG) {
+    double s = 0.0;
+    for (int j = offs[r]; j < offs[r + 1]; j++)
+      s += vals[j] * x[cols[j]];
+    y[r] = s;
+    if (xdot)
+      dot += s * xdot[r];
+  }
+  if (partials) {
+    double d[1] = {dot};
+    wg_sum<1>(d, sred);
+    if (threadIdx.x == 0)
+      partials[w] = d[0];
+  }
+}
+
+// --------------------------------------------------------------------------
+// a2-2  second stage of every reduction: one workgroup, fixed order.
+// out[k] = sum over records of parts[i*width+k]   (sqrt'ed for nrm2)
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_reduce_final(
+    const double *__restrict__ parts, unsigned nparts, unsigned width,
+    double *__restrict__ out, int take_sqrt,
+    const lsb_pcg_state *__restrict__ st) {
+  if (st && st->status)
+    return;
+  __shared__ double sred[4];
+  for (unsigned k = 0; k < width; k++) {
+    double v[1] = {0.0};
+    for (unsigned i = threadIdx.x; i < nparts; i += WG)
+      v[0] += parts[(size_t)i * width + k];
+    wg_sum<1>(v, sred);
+    if (threadIdx.x == 0)
+      out[k] = take_sqrt ? sqrt(v[0]) : v[0];
+  }
+}
+
+// first stage of dot / nrm2 (b == a gives sum a_i^2)
+__global__ __launch_bounds__(WG) void k_dot(unsigned n,
+                                            const double *__restrict__ a,
+                                            const double *__restrict__ b,
+                                            double *__restrict__ partials) {
+  __shared__ double sred[4];
+  double v[1] = {0.0};
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * WG)
+    v[0] += a[i] * b[i];
+  wg_sum<1>(v, sred);
+  if (threadIdx.x == 0)
+    partials[blockIdx.x] = v[0];
+}
+
+// --------------------------------------------------------------------------
+// a2-3  axpy / xpay with the scalar in HBM
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_axpy(unsigned n,
+                                             const double *__restrict__ alpha,
+                                             const double *__restrict__ x,
+                                             double *__restrict__ y) {
+  const double a = alpha[0];
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * WG)
+    y[i] += a * x[i];
+}
+
+__global__ __launch_bounds__(WG) void k_xpay(unsigned n,
+                                             const double *__restrict__ beta,
+                                             const double *__restrict__ x,
+                                             double *__restrict__ y) {
+  const double b = beta[0];
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * WG)
+    y[i] = x[i] + b * y[i];
+}
+
+// --------------------------------------------------------------------------
+// a2-4  Jacobi
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void k_jacobi_setup(
+    unsigned n, unsigned row_begin, const int *__restrict__ offs,
+    const int *__restrict__ cols, const double *__restrict__ vals,
+    double *__restrict__ dinv, int *__restrict__ nzero) {
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * WG) {
+    const int want = (int)(i + row_begin);
+    double d = 0.0;
+    for (int j = offs[i]; j < offs[i + 1]; j++)
+      if (cols[j] == want)
+        d = vals[j];
+    if (d != 0.0) {
+      dinv[i] = 1.0 / d;
+    } else {
+      dinv[i] = 0.0;
+      atomicAdd(nzero, 1);
+    }
+  }
+}
+
+__global__ __launch_bounds__(WG) void k_jacobi_apply(
+    unsigned n, const double *__restrict__ dinv, const double *__restrict__ r,
+    double *__restrict__ z) {
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * WG)
+    z[i] = dinv[i] * r[i];
+}
+
+// x <- x + w * dinv .* (b - ax)      (ax = Op x from a preceding SpMV)
+__global__ __launch_bounds__(WG) void k_jacobi_sweep(
+    unsigned n, double w, const double *__restrict__ dinv,
+    const double *__restrict__ b, const double *__restrict__ ax,
+    double *__restrict__ x) {
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * WG)
+    x[i] += w * dinv[i] * (b[i] - ax[i]);
+}
+
+__global__ __launch_bounds__(WG) void k_fill_index(unsigned n, unsigned first,
+                                                   double *__restrict__ v) {
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * WG)
+    v[i] = (double)(i + first);
+}
+
+// --------------------------------------------------------------------------
+// a2-5  fused PCG sweeps.  Vector loads are 16 B/lane (double2) when every
+// operand is 16-B aligned, 8 B/lane otherwise (a shard that starts on an odd
+// row); the tail element, if any, is handled by the last thread.
+// --------------------------------------------------------------------------
+
+// x = 0, r = b, p = dinv.*b ; partials (r.z, b.b)
+template <bool V2>
+__global__ __launch_bounds__(WG) void k_pcg_init(
+    unsigned n, const double *__restrict__ b, const double *__restrict__ dinv,
+    double *__restrict__ x, double *__restrict__ r, double *__restrict__ p,
+    double *__restrict__ partials2) {
+  __shared__ double sred[8];
+  double acc[2] = {0.0, 0.0};
+  const size_t gtid = (size_t)blockIdx.x * WG + threadIdx.x;
+  const size_t gsz = (size_t)gridDim.x * WG;
+  if (V2) {
+    const size_t n2 = n / 2;
+    const double2 *b2 = (const double2 *)b, *d2 = (const double2 *)dinv;
+    double2 *x2 = (double2 *)x, *r2 = (double2 *)r, *p2 = (double2 *)p;
+    for (size_t i = gtid; i < n2; i += gsz) {
+      const double2 bv = b2[i], dv = d2[i];
+      double2 pv;
+      pv.x = dv.x * bv.x, pv.y = dv.y * bv.y;
+      x2[i] = make_double2(0.0, 0.0);
+      r2[i] = bv;
+      p2[i] = pv;
+      acc[0] += bv.x * pv.x;
+      acc[0] += bv.y * pv.y;
+      acc[1] += bv.x * bv.x;
+      acc[1] += bv.y * bv.y;
+    }
+    if ((n & 1) && gtid == gsz - 1) {
+      const size_t i = n - 1;
+      const double bv = b[i], pv = dinv[i] * bv;
+      x[i] = 0.0, r[i] = bv, p[i] = pv;
+      acc[0] += bv * pv, acc[1] += bv * bv;
+    }
+  } else {
+    for (size_t i = gtid; i < n; i += gsz) {
+      const double bv = b[i], pv = dinv[i] * bv;
+      x[i] = 0.0, r[i] = bv, p[i] = pv;
+      acc[0] += bv * pv, acc[1] += bv * bv;
+    }
+  }
+  wg_sum<2>(acc, sred);
+  if (threadIdx.x == 0) {
+    partials2[2 * blockIdx.x + 0] = acc[0];
+    partials2[2 * blockIdx.x + 1] = acc[1];
+  }
+}
+
+__global__ __launch_bounds__(WG) void k_pcg_init_state(
+    lsb_pcg_state *__restrict__ st, const double *__restrict__ partials2,
+    unsigned nparts, double tol, int maxit) {
+  __shared__ double sred[8];
+  double v[2];
+  wg_sum_partials<2>(partials2, nparts, v, sred);
+  if (threadIdx.x == 0) {
+    st->rz[0] = v[0];
+    st->rz[1] = 0.0;
+    st->bb = v[1];
+    st->thresh2 = tol * tol * v[1];
+    st->rr = v[1];
+    st->pq = 0.0;
+    st->iters = 0;
+    st->maxit = maxit;
+    // b == 0 => x = 0 is the solution; maxit == 0 => nothing to do
+    st->status = (v[1] == 0.0) ? LSB_STATUS_CONVERGED
+                               : (maxit <= 0 ? LSB_STATUS_MAXIT : LSB_STATUS_RUNNING);
+  }
+}
+
+// alpha = rz/pq ; x += alpha p ; r -= alpha q ; partials (r.dinv.r, r.r)
+template <bool V2>
+__global__ __launch_bounds__(WG) void k_pcg_update_xr(
+    unsigned n, const double *__restrict__ p, const double *__restrict__ q,
+    const double *__restrict__ dinv, double *__restrict__ x,
+    double *__restrict__ r, lsb_pcg_state *__restrict__ st, int parity,
+    const double *__restrict__ pq_parts, unsigned npq,
+    double *__restrict__ partials2) {
+  if (st->status)
+    return;
+  __shared__ double sred[8];
+  double pqv[1];
+  wg_sum_partials<1>(pq_parts, npq, pqv, sred);
+  const double pq = pqv[0];
+  if (!(pq != 0.0) || !isfinite(pq)) { // same decision in every workgroup
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+      st->status = LSB_STATUS_BREAKDOWN;
+    return;
+  }
+  const double alpha = st->rz[parity] / pq;
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    st->pq = pq;
+  double acc[2] = {0.0, 0.0};
+  const size_t gtid = (size_t)blockIdx.x * WG + threadIdx.x;
+  const size_t gsz = (size_t)gridDim.x * WG;
+  if (V2) {
+    const size_t n2 = n / 2;
+    const double2 *p2 = (const double2 *)p, *q2 = (const double2 *)q,
+                  *d2 = (const double2 *)dinv;
+    double2 *x2 = (double2 *)x, *r2 = (double2 *)r;
+    for (size_t i = gtid; i < n2; i += gsz) {
+      const double2 pv = p2[i], qv = q2[i], dv = d2[i];
+      double2 xv = x2[i], rv = r2[i];
+      xv.x += alpha * pv.x, xv.y += alpha * pv.y;
+      rv.x -= alpha * qv.x, rv.y -= alpha * qv.y;
+      x2[i] = xv, r2[i] = rv;
+      acc[0] += rv.x * (dv.x * rv.x);
+      acc[0] += rv.y * (dv.y * rv.y);
+      acc[1] += rv.x * rv.x;
+      acc[1] += rv.y * rv.y;
+    }
+    if ((n & 1) && gtid == gsz - 1) {
+      const size_t i = n - 1;
+      x[i] += alpha * p[i];
+      const double rv = r[i] - alpha * q[i];
+      r[i] = rv;
+      acc[0] += rv * (dinv[i] * rv), acc[1] += rv * rv;
+    }
+  } else {
+    for (size_t i = gtid; i < n; i += gsz) {
+      x[i] += alpha * p[i];
+      const double rv = r[i] - alpha * q[i];
+      r[i] = rv;
+      acc[0] += rv * (dinv[i] * rv), acc[1] += rv * rv;
+    }
+  }
+  wg_sum<2>(acc, sred);
+  if (threadIdx.x == 0) {
+    partials2[2 * blockIdx.x + 0] = acc[0];
+    partials2[2 * blockIdx.x + 1] = acc[1];
+  }
+}
+
+// (rz', rr) = sum partials ; stop test ; beta = rz'/rz ; p = dinv.*r + beta p
+template <bool V2>
+__global__ __launch_bounds__(WG) void k_pcg_update_p(
+    unsigned n, const double *__restrict__ r, const double *__restrict__ dinv,
+    double *__restrict__ p, lsb_pcg_state *__restrict__ st, int parity,
+    const double *__restrict__ parts2, unsigned nparts2) {
+  if (st->status)
+    return;
+  __shared__ double sred[8];
+  double v[2];
+  wg_sum_partials<2>(parts2, nparts2, v, sred);
+  const double rz_new = v[0], rr = v[1];
+  const double rz_old = st->rz[parity];
+  const bool conv = rr <= st->thresh2;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // only this thread touches iters/rr/rz[parity^1]/status in this launch
+    const int it = st->iters + 1;
+    st->iters = it;
+    st->rr = rr;
+    st->rz[parity ^ 1] = rz_new;
+    if (conv)
+      st->status = LSB_STATUS_CONVERGED;
+    else if (it >= st->maxit)
+      st->status = LSB_STATUS_MAXIT;
+  }
+  if (conv)
+    return;
+  const double beta = rz_new / rz_old;
+  const size_t gtid = (size_t)blockIdx.x * WG + threadIdx.x;
+  const size_t gsz = (size_t)gridDim.x * WG;
+  if (V2) {
+    const size_t n2 = n / 2;
+    const double2 *r2 = (const double2 *)r, *d2 = (const double2 *)dinv;
+    double2 *p2 = (double2 *)p;
+    for (size_t i = gtid; i < n2; i += gsz) {
+      const double2 rv = r2[i], dv = d2[i];
+      double2 pv = p2[i];
+      pv.x = dv.x * rv.x + beta * pv.x;
+      pv.y = dv.y * rv.y + beta * pv.y;
+      p2[i] = pv;
+    }
+    if ((n & 1) && gtid == gsz - 1)
+      p[n - 1] = dinv[n - 1] * r[n - 1] + beta * p[n - 1];
+  } else {
+    for (size_t i = gtid; i < n; i += gsz)
+      p[i] = dinv[i] * r[i] + beta * p[i];
+  }
+}
+
+// Virtual-rank stand-in for the all-reduce: `nshard` shards on ONE device keep
+// their scalars at base[q*stride + off .. +cnt); sum over q in rank order and
+// hand every shard the same bits.
+__global__ void k_vreduce(double *__restrict__ base, unsigned stride,
+                          unsigned nshard, unsigned off, unsigned cnt) {
+  const unsigned t = threadIdx.x;
+  if (t < cnt) {
+    double s = 0.0;
+    for (unsigned q = 0; q < nshard; q++)
+      s += base[(size_t)q * stride + off + t];
+    for (unsigned q = 0; q < nshard; q++)
+      base[(size_t)q * stride + off + t] = s;
+  }
+}
+
+// --------------------------------------------------------------------------
+// Launchers (C ABI)
+// --------------------------------------------------------------------------
+static inline unsigned div_up(unsigned a, unsigned b) { return (a + b - 1) / b; }
+static inline unsigned round_up(unsigned a, unsigned b) { return div_up(a, b) * b; }
+static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+
+extern "C" {
+
+unsigned lsb_k_blas1_grid(unsigned n) {
+  // 16 B/lane => WG*2 elements per workgroup per trip; cap at MAX_PARTIALS
+  unsigned g = div_up(n, WG * 2);
+  if (g > LSB_MAX_PARTIALS)
+    g = LSB_MAX_PARTIALS;
+  return g ? g : 1;
+}
+
+// number of workgroups (== number of dot partials) a given SpMV launch uses
+unsigned lsb_k_spmv_grid(int variant, unsigned n, unsigned nblk,
+                         unsigned lanes_per_row) {
+  unsigned items;
+  if (variant == LSB_SPMV_ADAPTIVE)
+    items = nblk;
+  else if (variant == LSB_SPMV_SUBWAVE)
+    items = div_up(n, WG / (lanes_per_row ? lanes_per_row : 1));
+  else
+    items = div_up(n, WG);
+  unsigned g = round_up(items ? items : 1, NXCD);
+  if (g > LSB_MAX_PARTIALS)
+    g = LSB_MAX_PARTIALS; // multiple of NXCD
+  return g;
+}
+
+void lsb_k_spmv(int variant, unsigned n, const int *offs, const int *cols,
+                const double *vals, const int *rowblk, unsigned nblk,
+                unsigned lanes_per_row, const double *x, double *y,
+                const double *xdot, double *partials, unsigned *npartials,
+                const struct lsb_pcg_state *st, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned g = lsb_k_spmv_grid(variant, n, nblk, lanes_per_row);
+  if (npartials)
+    *npartials = g;
+  if (variant == LSB_SPMV_ADAPTIVE) {
+    const unsigned per = div_up(nblk ? nblk : 1, g);
+    k_spmv_adaptive<LSB_BLOCK_NNZ><<<g, WG, 0, s>>>(rowblk, nblk, per, offs, cols, vals,
+                                                   x, y, xdot, partials, st);
+  } else if (variant == LSB_SPMV_SUBWAVE) {
+    const unsigned L = lanes_per_row;
+    const unsigned slots = WG / L;
+    const unsigned rpw = round_up(div_up(n, g), slots);
+#define LSB_SUBWAVE(LL)                                                        \
+  case LL:                                                                     \
+    k_spmv_subwave<LL><<<g, WG, 0, s>>>(n, rpw, offs, cols, vals, x, y, xdot,  \
+                                        partials, st);                         \
+    break;
+    switch (L) {
+      LSB_SUBWAVE(2)
+      LSB_SUBWAVE(4)
+      LSB_SUBWAVE(8)
+      LSB_SUBWAVE(16)
+      LSB_SUBWAVE(32)
+    default:
+      k_spmv_subwave<64><<<g, WG, 0, s>>>(n, round_up(div_up(n, g), 4), offs, cols, vals,
+                                          x, y, xdot, partials, st);
+    }
+#undef LSB_SUBWAVE
+  } else {
+    const unsigned rpw = div_up(n, g);
+    k_spmv_scalar<<<g, WG, 0, s>>>(n, rpw, offs, cols, vals, x, y, xdot, partials, st);
+  }
+}
+
+void lsb_k_reduce_final(const double *partials, unsigned nparts, unsigned width,
+                        double *out, int take_sqrt,
+                        const struct lsb_pcg_state *st, void *stream) {
+  k_reduce_final<<<1, WG, 0, (hipStream_t)stream>>>(partials, nparts, width, out,
+                                                    take_sqrt, st);
+}
+
+void lsb_k_dot(unsigned n, const double *a, const double *b, double *partials,
+               unsigned *npartials, void *stream) {
+  unsigned g = div_up(n ? n : 1, WG * 4);
+  if (g > LSB_MAX_PARTIALS)
+    g = LSB_MAX_PARTIALS;
+  *npartials = g;
+  k_dot<<<g, WG, 0, (hipStream_t)stream>>>(n, a, b, partials);
+}
+
+static unsigned ew_grid(unsigned n) {
+  unsigned g = div_up(n ? n : 1, WG * 4);
+  return g > 2048 ? 2048 : g;
+}
+
+void lsb_k_axpy(unsigned n, const double *alpha, const double *x, double *y,
+                void *stream) {
+  k_axpy<<<ew_grid(n), WG, 0, (hipStream_t)stream>>>(n, alpha, x, y);
+}
+
+void lsb_k_xpay(unsigned n, const double *beta, const double *x, double *y,
+                void *stream) {
+  k_xpay<<<ew_grid(n), WG, 0, (hipStream_t)stream>>>(n, beta, x, y);
+}
+
+void lsb_k_jacobi_setup(unsigned n, unsigned row_begin, const int *offs,
+                        const int *cols, const double *vals, double *dinv,
+                        int *nzero, void *stream) {
+  k_jacobi_setup<<<ew_grid(n), WG, 0, (hipStream_t)stream>>>(n, row_begin, offs, cols,
+                                                             vals, dinv, nzero);
+}
+
+void lsb_k_jacobi_apply(unsigned n, const double *dinv, const double *r,
+                        double *z, void *stream) {
+  k_jacobi_apply<<<ew_grid(n), WG, 0, (hipStream_t)stream>>>(n, dinv, r, z);
+}
+
+void lsb_k_jacobi_sweep(unsigned n, double w, const double *dinv,
+                        const double *b, const double *ax, double *x,
+                        void *stream) {
+  k_jacobi_sweep<<<ew_grid(n), WG, 0, (hipStream_t)stream>>>(n, w, dinv, b, ax, x);
+}
+
+void lsb_k_vreduce(double *base, unsigned stride, unsigned nshard, unsigned off,
+                   unsigned cnt, void *stream) {
+  k_vreduce<<<1, 64, 0, (hipStream_t)stream>>>(base, stride, nshard, off, cnt);
+}
+
+void lsb_k_fill_index(unsigned n, unsigned first, double *v, void *stream) {
+  k_fill_index<<<ew_grid(n), WG, 0, (hipStream_t)stream>>>(n, first, v);
+}
+
+void lsb_k_pcg_init(unsigned n, const double *b, const double *dinv, double *x,
+                    double *r, double *p, double *partials2,
+                    unsigned *npartials, void *stream) {
+  const unsigned g = lsb_k_blas1_grid(n);
+  *npartials = g;
+  if (aligned16(b) && aligned16(dinv) && aligned16(x) && aligned16(r) && aligned16(p))
+    k_pcg_init<true><<<g, WG, 0, (hipStream_t)stream>>>(n, b, dinv, x, r, p, partials2);
+  else
+    k_pcg_init<false><<<g, WG, 0, (hipStream_t)stream>>>(n, b, dinv, x, r, p, partials2);
+}
+
+void lsb_k_pcg_init_state(struct lsb_pcg_state *st, const double *partials2,
+                          unsigned nparts, double tol, int maxit,
+                          void *stream) {
+  k_pcg_init_state<<<1, WG, 0, (hipStream_t)stream>>>(st, partials2, nparts, tol, maxit);
+}
+
+void lsb_k_pcg_update_xr(unsigned n, const double *p, const double *q,
+                         const double *dinv, double *x, double *r,
+                         struct lsb_pcg_state *st, int parity,
+                         const double *pq_parts, unsigned npq,
+                         double *partials2, unsigned *npartials, void *stream) {
+  const unsigned g = lsb_k_blas1_grid(n);
+  *npartials = g;
+  if (aligned16(p) && aligned16(q) && aligned16(dinv) && aligned16(x) && aligned16(r))
+    k_pcg_update_xr<true><<<g, WG, 0, (hipStream_t)stream>>>(n, p, q, dinv, x, r, st, parity,
+                                                             pq_parts, npq, partials2);
+  else
+    k_pcg_update_xr<false><<<g, WG, 0, (hipStream_t)stream>>>(n, p, q, dinv, x, r, st, parity,
+                                                              pq_parts, npq, partials2);
+}
+
+void lsb_k_pcg_update_p(unsigned n, const double *r, const double *dinv,
+                        double *p, struct lsb_pcg_state *st, int parity,
+                        const double *parts2, unsigned nparts2, void *stream) {
+  const unsigned g = lsb_k_blas1_grid(n);
+  if (aligned16(r) && aligned16(dinv) && aligned16(p))
+    k_pcg_update_p<true><<<g, WG, 0, (hipStream_t)stream>>>(n, r, dinv, p, st, parity, parts2,
+                                                            nparts2);
+  else
+    k_pcg_update_p<false><<<g, WG, 0, (hipStream_t)stream>>>(n, r, dinv, p, st, parity, parts2,
+                                                             nparts2);
+}
+
+} // extern "C"

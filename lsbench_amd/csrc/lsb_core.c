@@ -1,0 +1,196 @@
+/*
+ * The caller side of the hot path: run configuration, right-hand side and
+ * dispatch -- this library's counterpart of the reference's src/lsbench.c,
+ * reduced to what the hip backend needs and wired exactly where SURVEY.md
+ * section 8(b) lists the seven hand-wiring points:
+ *   (1) enum value ............. include/lsbench.h  (LSBENCH_SOLVER_HIP = 6)
+ *   (2) prototypes ............. include/lsbench_hip.h
+ *   (3) solver name "hip" ...... solver_from_name() below   (src/lsbench.c:15-35)
+ *   (4) help text .............. usage()                    (src/lsbench.c:69-80)
+ *   (5) init call .............. lsbench_init()             (src/lsbench.c:143-147)
+ *   (6) dispatch case .......... lsbench_bench()            (src/lsbench.c:162-184)
+ *   (7) finalize call .......... lsbench_finalize()         (src/lsbench.c:189-194)
+ * The other six solvers are not built into this library; selecting one is the
+ * reference's "disabled backend" no-op (stubs returning 1, src/cholmod.c:74-81)
+ * plus a warning.
+ *
+ * Flag behaviour follows src/lsbench.c:82-150 (names, defaults, fall-backs);
+ * deliberate differences: --ordering/--precision/--verbose/--trials accept
+ * "--flag value" as well as "--flag=value" (the reference segfaults on the
+ * first form), --help prints the program name, and
+ * --tol/--maxit/--operator/--nvirt are new.
+ */
+#define _GNU_SOURCE
+#include "lsb_impl.h"
+#include <ctype.h>
+#include <getopt.h>
+#include <string.h>
+#include <strings.h>
+
+static lsbench_solver_t solver_from_name(const char *s) {
+  static const struct {
+    const char *name;
+    lsbench_solver_t id;
+  } tab[] = {{"CUSOLVER", LSBENCH_SOLVER_CUSOLVER}, {"HYPRE", LSBENCH_SOLVER_HYPRE},
+             {"AMGX", LSBENCH_SOLVER_AMGX},         {"CHOLMOD", LSBENCH_SOLVER_CHOLMOD},
+             {"PARALMOND", LSBENCH_SOLVER_PARALMOND}, {"GINKGO", LSBENCH_SOLVER_GINKGO},
+             {"HIP", LSBENCH_SOLVER_HIP}};
+  for (size_t i = 0; i < sizeof tab / sizeof tab[0]; i++)
+    if (strcasecmp(s, tab[i].name) == 0) /* reference upper-cases, :8-13 */
+      return tab[i].id;
+  warnx("Invalid solver: \"%s\". Defaulting to CHOLMOD.", s); /* :32-33 */
+  return LSBENCH_SOLVER_CHOLMOD;
+}
+
+static lsbench_ordering_t ordering_from_name(const char *s) {
+  if (strcasecmp(s, "RCM") == 0)
+    return LSBENCH_ORDERING_RCM;
+  if (strcasecmp(s, "AMD") == 0)
+    return LSBENCH_ORDERING_AMD;
+  if (strcasecmp(s, "METIS") == 0)
+    return LSBENCH_ORDERING_METIS;
+  warnx("Invalid ordering: \"%s\". Defaulting to AMD.", s); /* :48-49 */
+  return LSBENCH_ORDERING_AMD;
+}
+
+static lsbench_precision_t precision_from_name(const char *s) {
+  if (strcasecmp(s, "FP64") == 0)
+    return LSBENCH_PRECISION_FP64;
+  if (strcasecmp(s, "FP32") == 0)
+    return LSBENCH_PRECISION_FP32;
+  if (strcasecmp(s, "FP16") == 0)
+    return LSBENCH_PRECISION_FP16;
+  warnx("Invalid precision: \"%s\". Defaulting to FP64.", s); /* :64-65 */
+  return LSBENCH_PRECISION_FP64;
+}
+
+static void usage(const char *prog) {
+  printf("Usage: %s [OPTIONS]\n", prog);
+  printf("Options:\n");
+  printf("  --matrix <FILE | synth:SPEC>\n");
+  printf("  --solver <SOLVER>, Values: cusolver, hypre, amgx, cholmod, ginkgo, hip\n");
+  printf("  --ordering <ORDERING>, Values: RCM, AMD, METIS\n");
+  printf("  --precision <PRECISION>, Values: FP64, FP32, FP16\n");
+  printf("  --verbose <VERBOSITY>, Values: 0, 1, 2, ...\n");
+  printf("  --trials <TRIALS>, Values: 1, 2, ...\n");
+  printf("  --tol <TOL>          (hip) stop at ||r|| <= TOL*||b||, default 1e-12\n");
+  printf("  --maxit <N>          (hip) iteration cap, default 20000\n");
+  printf("  --operator <upper|raw> (hip) upper = CHOLMOD's triu-mirrored matrix\n");
+  printf("  --nvirt <P>          (hip) P row-range shards on one device (test)\n");
+  printf("  --help\n");
+}
+
+struct lsbench *lsbench_init(int argc, char *argv[]) {
+  static struct option longopts[] = {
+      {"matrix", required_argument, 0, 10},   {"solver", required_argument, 0, 20},
+      {"ordering", required_argument, 0, 30}, {"precision", required_argument, 0, 40},
+      {"verbose", required_argument, 0, 50},  {"trials", required_argument, 0, 60},
+      {"help", no_argument, 0, 70},           {"tol", required_argument, 0, 80},
+      {"maxit", required_argument, 0, 81},    {"operator", required_argument, 0, 82},
+      {"nvirt", required_argument, 0, 83},    {0, 0, 0, 0}};
+
+  /* zero-filled => solver 0 (CUSOLVER), ordering 0 (RCM), FP64: the
+   * reference's de-facto defaults (src/lsbench.c:95-96) */
+  struct lsbench *cb = lsb_calloc(struct lsbench, 1);
+  cb->trials = 100;
+  struct lsb_hip_opts o;
+  lsb_hip_get_opts(&o);
+
+  optind = 1;
+  for (;;) {
+    int c = getopt_long(argc, argv, "", longopts, NULL);
+    if (c == -1)
+      break;
+    switch (c) {
+    case 10:
+      free(cb->matrix);
+      cb->matrix = strndup(optarg, BUFSIZ);
+      break;
+    case 20:
+      cb->solver = solver_from_name(optarg);
+      break;
+    case 30:
+      cb->ordering = ordering_from_name(optarg);
+      break;
+    case 40:
+      cb->precision = precision_from_name(optarg);
+      break;
+    case 50:
+      cb->verbose = (unsigned)atoi(optarg);
+      break;
+    case 60:
+      cb->trials = (unsigned)atoi(optarg);
+      break;
+    case 70:
+      usage(argv[0]);
+      exit(EXIT_SUCCESS);
+    case 80:
+      o.tol = atof(optarg);
+      break;
+    case 81:
+      o.maxit = (unsigned)strtoul(optarg, NULL, 10);
+      break;
+    case 82:
+      o.op_mode = strcasecmp(optarg, "raw") == 0 ? LSB_OP_RAW : LSB_OP_CHOLMOD_UPPER;
+      break;
+    case 83:
+      o.nvirt = atoi(optarg);
+      break;
+    default:
+      usage(argv[0]);
+      exit(EXIT_FAILURE);
+    }
+  }
+  if (cb->matrix == NULL) /* src/lsbench.c:138-139 */
+    errx(EXIT_FAILURE, "Input matrix file not provided. Try `--help`.");
+  if (cb->precision != LSBENCH_PRECISION_FP64) /* :140-141 */
+    errx(EXIT_FAILURE, "Precisions other than FP64 are not implemented yet.");
+  o.verbose = (int)cb->verbose;
+  lsb_hip_set_opts(&o);
+
+  /* every built backend is initialised whatever --solver says (:143-147);
+   * here that is the hip backend alone.  Return value ignored like there. */
+  hip_cdna4_init();
+  return cb;
+}
+
+const char *lsbench_get_matrix_name(struct lsbench *cb) { return cb->matrix; }
+
+void lsbench_bench(struct csr *A, const struct lsbench *cb) {
+  /* x = 0 (initial guess), r_i = i: src/lsbench.c:157-160, one allocation */
+  const unsigned m = A->nrows;
+  double *x = lsb_calloc(double, 2 * (size_t)m), *r = x + m;
+  for (unsigned i = 0; i < m; i++)
+    r[i] = (double)i;
+
+  switch (cb->solver) {
+  case LSBENCH_SOLVER_HIP:
+    if (hip_cdna4_bench(x, A, r, cb) == 1)
+      warnx("solver hip: no usable GPU (backend not initialised); nothing run.");
+    else if (cb->verbose > 1)
+      for (unsigned i = 0; i < m; i++)
+        printf("x[%u] = %.17g\n", i, x[i]);
+    break;
+  case LSBENCH_SOLVER_CUSOLVER:
+  case LSBENCH_SOLVER_HYPRE:
+  case LSBENCH_SOLVER_AMGX:
+  case LSBENCH_SOLVER_CHOLMOD:
+  case LSBENCH_SOLVER_PARALMOND:
+  case LSBENCH_SOLVER_GINKGO:
+    /* reference behaviour for a backend compiled out: stub returns 1, the
+     * return value is dropped, exit code 0 */
+    warnx("solver %d is not built into this library (only `hip` is); nothing run.",
+          (int)cb->solver);
+    break;
+  default:
+    errx(EXIT_FAILURE, "Unknown solver: %d.", cb->solver); /* :181-182 */
+  }
+  free(x);
+}
+
+void lsbench_finalize(struct lsbench *cb) {
+  hip_cdna4_finalize();
+  if (cb)
+    free(cb->matrix);
+  free(cb);
+}

@@ -1,0 +1,114 @@
+/*
+ * Internal header of liblsbench_hip.so: the role src/lsbench-impl.h plays in
+ * the reference (struct layouts + backend prototypes), plus the launcher
+ * prototypes of the HIP shim (hip_kernels.hip) that hip_cdna4.c calls.
+ */
+#ifndef LSB_IMPL_H
+#define LSB_IMPL_H
+
+#include "lsbench_hip.h"
+#include <err.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define lsb_calloc(T, n) ((T *)calloc((size_t)(n) > 0 ? (size_t)(n) : 1, sizeof(T)))
+
+/* ---- device-side PCG scalars (one per shard, lives in HBM) -------------- */
+struct lsb_pcg_state {
+  double rz[2];    /* r.z, double-buffered by iteration parity              */
+  double bb;       /* b.b                                                    */
+  double thresh2;  /* tol^2 * b.b                                            */
+  double rr;       /* r.r after the last completed iteration                 */
+  double pq;       /* p.q of the last completed iteration (diagnostic)       */
+  int iters;       /* completed iterations                                   */
+  int status;      /* LSB_STATUS_*; != 0 makes every later kernel a no-op    */
+  int maxit;
+  int pad;
+};
+
+/* Upper bound on per-launch partial sums any reduction kernel writes; the
+ * consumer kernels re-reduce them in fixed order (deterministic). */
+#define LSB_MAX_PARTIALS 2048
+/* Non-zeros staged in LDS per row block of the adaptive SpMV (16 KiB). */
+#define LSB_BLOCK_NNZ 2048
+
+/* ---- HIP shim: kernel launchers (hip_kernels.hip) ------------------------
+ * All take raw device pointers and a hipStream_t as void*.  `st` may be NULL
+ * for the stand-alone (non-PCG) use of a kernel; when given, a non-zero
+ * st->status turns the launch into a no-op on the device. */
+void lsb_k_spmv(int variant, unsigned n, const int *offs, const int *cols,
+                const double *vals, const int *rowblk, unsigned nblk,
+                unsigned lanes_per_row, const double *x, double *y,
+                const double *xdot, double *partials, unsigned *npartials,
+                const struct lsb_pcg_state *st, void *stream);
+unsigned lsb_k_spmv_grid(int variant, unsigned n, unsigned nblk,
+                         unsigned lanes_per_row);
+void lsb_k_reduce_final(const double *partials, unsigned nparts, unsigned width,
+                        double *out, int take_sqrt,
+                        const struct lsb_pcg_state *st, void *stream);
+void lsb_k_dot(unsigned n, const double *a, const double *b, double *partials,
+               unsigned *npartials, void *stream);
+void lsb_k_axpy(unsigned n, const double *alpha, const double *x, double *y,
+                void *stream);
+void lsb_k_xpay(unsigned n, const double *beta, const double *x, double *y,
+                void *stream);
+void lsb_k_jacobi_setup(unsigned n, unsigned row_begin, const int *offs,
+                        const int *cols, const double *vals, double *dinv,
+                        int *nzero, void *stream);
+void lsb_k_jacobi_apply(unsigned n, const double *dinv, const double *r,
+                        double *z, void *stream);
+void lsb_k_jacobi_sweep(unsigned n, double w, const double *dinv,
+                        const double *b, const double *ax, double *x,
+                        void *stream);
+/* PCG fused sweeps */
+void lsb_k_pcg_init(unsigned n, const double *b, const double *dinv, double *x,
+                    double *r, double *p, double *partials2,
+                    unsigned *npartials, void *stream);
+void lsb_k_pcg_init_state(struct lsb_pcg_state *st, const double *partials2,
+                          unsigned nparts, double tol, int maxit,
+                          void *stream);
+void lsb_k_pcg_update_xr(unsigned n, const double *p, const double *q,
+                         const double *dinv, double *x, double *r,
+                         struct lsb_pcg_state *st, int parity,
+                         const double *pq_parts, unsigned npq,
+                         double *partials2, unsigned *npartials, void *stream);
+void lsb_k_pcg_update_p(unsigned n, const double *r, const double *dinv,
+                        double *p, struct lsb_pcg_state *st, int parity,
+                        const double *parts2, unsigned nparts2, void *stream);
+unsigned lsb_k_blas1_grid(unsigned n);
+void lsb_k_fill_index(unsigned n, unsigned first, double *v, void *stream);
+void lsb_k_vreduce(double *base, unsigned stride, unsigned nshard, unsigned off,
+                   unsigned cnt, void *stream);
+
+/* ---- backend internals shared between hip_cdna4.c and hip_comm.c -------- */
+void *lsb_hip_stream(void);
+int lsb_hip_is_initialized(void);
+/* grouped point-to-point exchange of contiguous ranges of a device vector */
+struct lsb_xfer {
+  int peer;
+  size_t offset, count; /* in doubles, into the full-length vector */
+};
+int lsb_hip_comm_exchange(double *d_full, const struct lsb_xfer *sends,
+                          int nsend, const struct lsb_xfer *recvs, int nrecv,
+                          void *stream);
+int lsb_hip_comm_allgather_u32(const unsigned *mine, unsigned count,
+                               unsigned *all);
+int lsb_hip_comm_allreduce_stream(double *d_buf, int count, void *stream);
+
+#define LSB_CHK_HIP(call)                                                      \
+  do {                                                                         \
+    hipError_t e_ = (call);                                                    \
+    if (e_ != hipSuccess)                                                      \
+      errx(EXIT_FAILURE, "%s:%d hip error: %s", __FILE__, __LINE__,            \
+           hipGetErrorString(e_));                                             \
+  } while (0)
+
+#ifdef __cplusplus
+}
+#endif
+#endif

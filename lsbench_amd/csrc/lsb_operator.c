@@ -1,0 +1,184 @@
+/*
+ * Host-side preparation of the operator the HIP backend solves with
+ * (SURVEY.md section 8 a2-8): everything between the `struct csr` the caller
+ * hands over and the int32 CSR shards that are uploaded to HBM.  Pure C, no
+ * GPU needed -- unit-tested on the CPU.
+ */
+#include "lsb_impl.h"
+#include <string.h>
+
+static struct csr *csr_alloc(unsigned nrows, unsigned long long nnz) {
+  if (nnz > 0xFFFFFFFFull)
+    errx(EXIT_FAILURE, "CSR with %llu non-zeros does not fit 32-bit offsets "
+                       "(reference layout, src/lsbench-impl.h:22-26)", nnz);
+  struct csr *S = lsb_calloc(struct csr, 1);
+  S->nrows = nrows, S->base = 0;
+  S->offs = lsb_calloc(unsigned, (size_t)nrows + 1);
+  S->cols = lsb_calloc(unsigned, (size_t)nnz);
+  S->vals = lsb_calloc(double, (size_t)nnz);
+  if (!S->offs || !S->cols || !S->vals)
+    errx(EXIT_FAILURE, "out of host memory for a %u-row / %llu-nnz CSR", nrows, nnz);
+  return S;
+}
+
+/*
+ * The matrix CHOLMOD is given by the reference (src/cholmod-impl.h:5-21): of
+ * each row i only the entries with column >= i are kept, as triplets of a
+ * symmetric matrix with stype = -1, which CHOLMOD completes by transposition.
+ * So S(i,j) = S(j,i) = A(i,j) for j >= i: S = triu(A) + triu(A,1)^T.
+ *
+ * Built without sorting: row r of S is [ A(i,r) for i < r, i ascending ] ++
+ * [ A(r,j) for j >= r ], and scanning the rows of A in ascending order appends
+ * the mirrored entries of every row in ascending column order.
+ */
+struct csr *lsb_csr_symmetrize_upper(const struct csr *A) {
+  const unsigned n = A->nrows, base = A->base;
+  unsigned *first_upper = lsb_calloc(unsigned, (size_t)n + 1);
+  unsigned long long *cnt = lsb_calloc(unsigned long long, (size_t)n + 1);
+  for (unsigned i = 0; i < n; i++) {
+    unsigned j = A->offs[i];
+    const unsigned je = A->offs[i + 1];
+    while (j < je && A->cols[j] - base < i) /* strictly lower part: dropped */
+      j++;
+    first_upper[i] = j;
+    for (; j < je; j++) {
+      const unsigned c = A->cols[j] - base;
+      if (c >= n)
+        errx(EXIT_FAILURE, "column %u of row %u is outside the %u x %u matrix",
+             c + base, i + base, n, n);
+      cnt[i]++;
+      if (c != i)
+        cnt[c]++;
+    }
+  }
+  unsigned long long nnz = 0;
+  for (unsigned i = 0; i < n; i++)
+    nnz += cnt[i];
+  struct csr *S = csr_alloc(n, nnz);
+  /* fill[r] = next free slot of row r; mirrored (lower) entries first */
+  unsigned *fill = lsb_calloc(unsigned, (size_t)n + 1);
+  unsigned long long acc = 0;
+  for (unsigned i = 0; i < n; i++) {
+    S->offs[i] = (unsigned)acc, fill[i] = (unsigned)acc;
+    acc += cnt[i];
+  }
+  S->offs[n] = (unsigned)acc;
+  for (unsigned i = 0; i < n; i++) {
+    for (unsigned j = first_upper[i]; j < A->offs[i + 1]; j++) {
+      const unsigned c = A->cols[j] - base;
+      if (c != i) {
+        S->cols[fill[c]] = i, S->vals[fill[c]] = A->vals[j];
+        fill[c]++;
+      }
+    }
+  }
+  for (unsigned i = 0; i < n; i++) {
+    for (unsigned j = first_upper[i]; j < A->offs[i + 1]; j++) {
+      S->cols[fill[i]] = A->cols[j] - base, S->vals[fill[i]] = A->vals[j];
+      fill[i]++;
+    }
+  }
+  free(first_upper), free(cnt), free(fill);
+  return S;
+}
+
+struct csr *lsb_csr_copy_base0(const struct csr *A) {
+  const unsigned n = A->nrows, nnz = A->offs[n];
+  struct csr *S = csr_alloc(n, nnz);
+  memcpy(S->offs, A->offs, ((size_t)n + 1) * sizeof(unsigned));
+  memcpy(S->vals, A->vals, (size_t)nnz * sizeof(double));
+  for (unsigned j = 0; j < nnz; j++)
+    S->cols[j] = A->cols[j] - A->base;
+  return S;
+}
+
+struct csr *lsb_csr_row_slice(const struct csr *A, unsigned r0, unsigned r1) {
+  if (r1 > A->nrows || r0 > r1)
+    return NULL;
+  const unsigned j0 = A->offs[r0], j1 = A->offs[r1];
+  struct csr *S = csr_alloc(r1 - r0, j1 - j0);
+  for (unsigned i = r0; i <= r1; i++)
+    S->offs[i - r0] = A->offs[i] - j0;
+  memcpy(S->vals, A->vals + j0, (size_t)(j1 - j0) * sizeof(double));
+  for (unsigned j = j0; j < j1; j++)
+    S->cols[j - j0] = A->cols[j] - A->base;
+  return S;
+}
+
+/* first row whose offset is >= target (offs is non-decreasing) */
+static unsigned lower_bound_offs(const unsigned *offs, unsigned n,
+                                 unsigned long long target) {
+  unsigned lo = 0, hi = n;
+  while (lo < hi) {
+    unsigned mid = lo + (hi - lo) / 2;
+    if (offs[mid] < target)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+/*
+ * 1-D row-range partition balanced by non-zeros:
+ * bounds[p] = first row whose offset reaches p/nparts of nnz, rounded to an
+ * even row so that every shard's vectors stay 16-byte aligned inside the
+ * full-length vector (keeps the BLAS-1 kernels on their 16 B/lane path).
+ */
+int lsb_csr_partition_rows(const struct csr *A, unsigned nparts,
+                           unsigned *bounds) {
+  if (nparts == 0)
+    return 2;
+  const unsigned n = A->nrows;
+  const unsigned long long nnz = A->offs[n];
+  bounds[0] = 0;
+  for (unsigned p = 1; p < nparts; p++) {
+    unsigned r = lower_bound_offs(A->offs, n, nnz * p / nparts);
+    r &= ~1u;
+    if (r < bounds[p - 1])
+      r = bounds[p - 1];
+    bounds[p] = r;
+  }
+  bounds[nparts] = n;
+  return 0;
+}
+
+/*
+ * Row blocks of the adaptive SpMV (hip_kernels.hip k_spmv_adaptive): greedy
+ * packing of consecutive rows into blocks of <= cap non-zeros; a row longer
+ * than cap is a block by itself.  Each step is one binary search on offs.
+ */
+unsigned lsb_csr_row_blocks(const struct csr *A, unsigned cap,
+                            unsigned **rowblk_out) {
+  const unsigned n = A->nrows;
+  size_t capb = (size_t)(A->offs[n] / (cap ? cap : 1)) * 2 + 16, nb = 0;
+  unsigned *rb = (unsigned *)malloc(capb * sizeof(unsigned));
+  unsigned r = 0;
+  rb[nb++] = 0;
+  while (r < n) {
+    /* last row index e (exclusive) with offs[e] - offs[r] <= cap */
+    const unsigned long long lim = (unsigned long long)A->offs[r] + cap;
+    unsigned lo = r + 1, hi = n; /* invariant: offs[lo] may exceed; find max e */
+    unsigned e = r + 1;          /* at least one row per block */
+    if (A->offs[e] <= lim) {
+      /* largest e in [r+1, n] with offs[e] <= lim */
+      lo = r + 1, hi = n;
+      while (lo < hi) {
+        unsigned mid = lo + (hi - lo + 1) / 2;
+        if (A->offs[mid] <= lim)
+          lo = mid;
+        else
+          hi = mid - 1;
+      }
+      e = lo;
+    }
+    if (nb + 1 >= capb) {
+      capb *= 2;
+      rb = (unsigned *)realloc(rb, capb * sizeof(unsigned));
+    }
+    rb[nb++] = e;
+    r = e;
+  }
+  *rowblk_out = rb;
+  return (unsigned)(nb - 1);
+}
