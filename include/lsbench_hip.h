@@ -149,6 +149,20 @@ int lsb_csr_partition_rows(const struct csr *A, unsigned nparts,
  * ids in *rowblk (caller frees with free()). */
 unsigned lsb_csr_row_blocks(const struct csr *A, unsigned cap,
                             unsigned **rowblk);
+/* [lo,hi) column range referenced by A (0-based). */
+void lsb_csr_col_hull(const struct csr *A, unsigned *lo, unsigned *hi);
+/* One contiguous range [offset, offset+count) (in doubles) of the exchanged
+ * vector, to or from shard/rank `peer`. */
+struct lsb_xfer {
+  int peer;
+  size_t offset, count;
+};
+/* Exchange plan of shard `me` out of `nall`, from the table
+ * hull[4q..4q+3] = {row_begin, nrows, col_lo, col_hi}; recv/send hold nall
+ * entries.  Pure host logic (tested on the CPU with gloo ranks). */
+void lsb_plan_exchange(int me, int nall, const unsigned *hull,
+                       struct lsb_xfer *recv, int *nrecv,
+                       struct lsb_xfer *send, int *nsend);
 /* Synthetic operators (BASELINE.json configs 3-5), rows [r0,r1) only, global
  * 0-based column ids, generated on the host.  spec:
  *   "lap2d:nx=3162,ny=3162"          5-point Laplacian, diag 4, off -1

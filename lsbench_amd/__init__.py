@@ -1,0 +1,19 @@
+"""lsbench_amd -- MI355X-native sparse-solve backend for lsbench.
+
+The product is the C/HIP library under lsbench_amd/csrc (C-ABI in include/);
+this package is the ctypes binding the tests and bench.py drive it through.
+"""
+from . import _lib
+from ._lib import (LsbenchHipError, OP_CHOLMOD_UPPER, OP_RAW, PRECOND_JACOBI,
+                   PRECOND_NONE, SPMV_ADAPTIVE, SPMV_AUTO, SPMV_SCALAR,
+                   SPMV_SUBWAVE, STATUS_BREAKDOWN, STATUS_CONVERGED,
+                   STATUS_MAXIT, STATUS_RUNNING)
+from .api import (Matrix, Solver, default_opts, hip_cdna4_bench,
+                  hip_cdna4_finalize, hip_cdna4_init, last_result,
+                  lsb_csr_col_hull, lsb_csr_copy_base0, lsb_csr_partition_rows,
+                  lsb_plan_exchange,
+                  lsb_csr_row_blocks, lsb_csr_row_slice,
+                  lsb_csr_symmetrize_upper, lsbench_matrix_read,
+                  lsbench_matrix_synth)
+
+__all__ = [n for n in dir() if not n.startswith("_")]

@@ -1,0 +1,175 @@
+"""ctypes binding of liblsbench_hip.so -- the C-ABI declared in include/*.h.
+
+This is plumbing: every function below is one C symbol with its C signature.
+There is no Python implementation of anything and no CPU fallback; when the
+library is missing the import fails, and when there is no GPU the backend's
+own return code 1 ("not initialised") surfaces as LsbenchHipError.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(_CSRC, "liblsbench_hip.so")
+
+UNIQUE_ID_BYTES = 128
+
+# enums of include/lsbench.h / include/lsbench_hip.h
+SOLVER_HIP = 6
+OP_CHOLMOD_UPPER, OP_RAW = 0, 1
+PRECOND_JACOBI, PRECOND_NONE = 0, 1
+SPMV_AUTO, SPMV_ADAPTIVE, SPMV_SUBWAVE, SPMV_SCALAR = 0, 1, 2, 3
+STATUS_RUNNING, STATUS_CONVERGED, STATUS_BREAKDOWN, STATUS_MAXIT = 0, 1, 2, 3
+
+
+class LsbenchHipError(RuntimeError):
+    pass
+
+
+class CsrStruct(C.Structure):
+    """struct csr (reference layout, src/lsbench-impl.h:22-26)."""
+    _fields_ = [("nrows", C.c_uint), ("base", C.c_uint),
+                ("offs", C.POINTER(C.c_uint)), ("cols", C.POINTER(C.c_uint)),
+                ("vals", C.POINTER(C.c_double))]
+
+
+class LsbenchStruct(C.Structure):
+    """struct lsbench (reference layout, src/lsbench-impl.h:14-20)."""
+    _fields_ = [("matrix", C.c_char_p), ("solver", C.c_int), ("ordering", C.c_int),
+                ("precision", C.c_int), ("verbose", C.c_uint), ("trials", C.c_uint)]
+
+
+class Opts(C.Structure):
+    """struct lsb_hip_opts."""
+    _fields_ = [("tol", C.c_double), ("maxit", C.c_uint), ("op_mode", C.c_int),
+                ("precond", C.c_int), ("spmv_variant", C.c_int),
+                ("check_every", C.c_int), ("use_graph", C.c_int),
+                ("sample_spmv", C.c_int), ("nvirt", C.c_int), ("overlap", C.c_int),
+                ("verbose", C.c_int)]
+
+
+class Result(C.Structure):
+    """struct lsb_hip_result."""
+    _fields_ = [("iters", C.c_uint), ("status", C.c_int), ("relres", C.c_double),
+                ("seconds", C.c_double), ("spmv_ms", C.c_double),
+                ("spmv_samples", C.c_uint)]
+
+
+class Xfer(C.Structure):
+    """struct lsb_xfer."""
+    _fields_ = [("peer", C.c_int), ("offset", C.c_size_t), ("count", C.c_size_t)]
+
+
+_vp, _u, _i, _d = C.c_void_p, C.c_uint, C.c_int, C.c_double
+_csrp = C.POINTER(CsrStruct)
+
+# name -> (restype, argtypes): every symbol include/*.h declares
+SIGNATURES = {
+    # include/lsbench.h
+    "lsbench_matrix_read": (_csrp, [C.c_char_p]),
+    "lsbench_matrix_print": (None, [_csrp]),
+    "lsbench_matrix_free": (None, [_csrp]),
+    "lsbench_init": (C.POINTER(LsbenchStruct), [_i, C.POINTER(C.c_char_p)]),
+    "lsbench_get_matrix_name": (C.c_char_p, [C.POINTER(LsbenchStruct)]),
+    "lsbench_bench": (None, [_csrp, C.POINTER(LsbenchStruct)]),
+    "lsbench_finalize": (None, [C.POINTER(LsbenchStruct)]),
+    # include/lsbench_hip.h -- backend trio
+    "hip_cdna4_init": (_i, []),
+    "hip_cdna4_finalize": (_i, []),
+    "hip_cdna4_bench": (_i, [C.POINTER(C.c_double), _csrp, C.POINTER(C.c_double),
+                             C.POINTER(LsbenchStruct)]),
+    # options / results
+    "lsb_hip_opts_default": (None, [C.POINTER(Opts)]),
+    "lsb_hip_set_opts": (None, [C.POINTER(Opts)]),
+    "lsb_hip_get_opts": (None, [C.POINTER(Opts)]),
+    "lsb_hip_last_result": (None, [C.POINTER(Result)]),
+    "lsb_hip_device_count": (_i, []),
+    # host helpers
+    "lsb_csr_symmetrize_upper": (_csrp, [_csrp]),
+    "lsb_csr_copy_base0": (_csrp, [_csrp]),
+    "lsb_csr_row_slice": (_csrp, [_csrp, _u, _u]),
+    "lsb_csr_partition_rows": (_i, [_csrp, _u, C.POINTER(_u)]),
+    "lsb_csr_row_blocks": (_u, [_csrp, _u, C.POINTER(C.POINTER(_u))]),
+    "lsb_csr_col_hull": (None, [_csrp, C.POINTER(_u), C.POINTER(_u)]),
+    "lsb_plan_exchange": (None, [_i, _i, C.POINTER(_u), C.POINTER(Xfer), C.POINTER(_i),
+                                 C.POINTER(Xfer), C.POINTER(_i)]),
+    "lsbench_matrix_synth": (_csrp, [C.c_char_p, _u, _u, C.POINTER(_u)]),
+    # solver handle
+    "lsb_hip_solver_create": (_vp, [_csrp, C.POINTER(Opts)]),
+    "lsb_hip_solver_create_dist": (_vp, [_csrp, _u, _u, C.POINTER(Opts)]),
+    "lsb_hip_solver_destroy": (None, [_vp]),
+    "lsb_hip_solver_solve": (_i, [_vp, _vp, _vp, C.POINTER(Result)]),
+    "lsb_hip_solver_solve_dev": (_i, [_vp, _vp, _vp, C.POINTER(Result)]),
+    "lsb_hip_solver_spmv_dev": (_i, [_vp, _vp, _vp]),
+    "lsb_hip_solver_time_spmv": (_i, [_vp, _i, _i, C.POINTER(_d)]),
+    "lsb_hip_solver_jacobi_sweep_dev": (_i, [_vp, _d, _vp, _vp]),
+    "lsb_hip_solver_nrows_local": (_u, [_vp]),
+    "lsb_hip_solver_nrows_global": (_u, [_vp]),
+    "lsb_hip_solver_nnz_local": (C.c_ulonglong, [_vp]),
+    "lsb_hip_solver_nblocks": (_u, [_vp]),
+    "lsb_hip_solver_spmv_variant": (_i, [_vp]),
+    "lsb_hip_stream": (_vp, []),
+    # communicator
+    "lsb_hip_comm_get_unique_id": (_i, [_vp]),
+    "lsb_hip_comm_init_rank": (_i, [_vp, _i, _i]),
+    "lsb_hip_comm_destroy": (_i, []),
+    "lsb_hip_comm_rank": (_i, []),
+    "lsb_hip_comm_size": (_i, []),
+    "lsb_hip_comm_allreduce_sum_dev": (_i, [_vp, _i]),
+    "lsb_hip_comm_barrier": (_i, []),
+    # kernel-level entry points
+    "lsb_hip_spmv_csr_f64": (_i, [_i, _u, _vp, _vp, _vp, _vp, _u, _u, _vp, _vp, _vp,
+                                  _vp, _vp, _vp]),
+    "lsb_hip_partials_capacity": (_u, []),
+    "lsb_hip_dot_f64": (_i, [_u, _vp, _vp, _vp, _vp, _vp]),
+    "lsb_hip_nrm2_f64": (_i, [_u, _vp, _vp, _vp, _vp]),
+    "lsb_hip_axpy_f64": (_i, [_u, _vp, _vp, _vp, _vp]),
+    "lsb_hip_xpay_f64": (_i, [_u, _vp, _vp, _vp, _vp]),
+    "lsb_hip_jacobi_setup_f64": (_i, [_u, _u, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "lsb_hip_jacobi_apply_f64": (_i, [_u, _vp, _vp, _vp, _vp]),
+    "lsb_hip_malloc": (_vp, [C.c_size_t]),
+    "lsb_hip_free": (None, [_vp]),
+    "lsb_hip_memcpy_h2d": (_i, [_vp, _vp, C.c_size_t]),
+    "lsb_hip_memcpy_d2h": (_i, [_vp, _vp, C.c_size_t]),
+    "lsb_hip_sync": (_i, []),
+}
+
+_LIB = None
+
+
+def build(force=False):
+    """make -C lsbench_amd/csrc (hipcc --offload-arch=gfx950 + gcc)."""
+    if force:
+        subprocess.run(["make", "-s", "-C", _CSRC, "clean"], check=True)
+    subprocess.run(["make", "-s", "-C", _CSRC, "all"], check=True)
+
+
+def load():
+    """dlopen the library and attach the C signatures.  torch (when present) is
+    imported first so that its bundled libamdhip64/librccl are the ones this
+    library binds to -- two HIP runtimes in one process do not mix."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is plumbing, not a dependency
+        pass
+    if not os.path.exists(LIB_PATH):
+        raise LsbenchHipError(
+            "%s not built: run `make -C lsbench_amd/csrc` or __graft_entry__.build(); "
+            "there is no fallback path" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError = header/library mismatch
+        fn.restype, fn.argtypes = res, args
+    _LIB = lib
+    return lib
+
+
+def check(rc, what):
+    if rc == 1:
+        raise LsbenchHipError("%s: hip_cdna4 backend not initialised (no GPU, or "
+                              "hip_cdna4_init not called) -- there is no CPU path" % what)
+    if rc != 0:
+        raise LsbenchHipError("%s: bad argument (rc=%d)" % (what, rc))

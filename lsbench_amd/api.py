@@ -1,0 +1,250 @@
+"""Thin Python handles over the C-ABI (include/lsbench.h, include/lsbench_hip.h).
+
+Names follow the reference's C API (lsbench_matrix_read, lsbench_bench, ...;
+reference: src/lsbench.h:32-40) so that tests read like a driver program.
+Nothing is computed here: every method is one call into liblsbench_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _ptr(a):
+    """Device or host address of a torch tensor / numpy array / int."""
+    if a is None:
+        return None
+    if hasattr(a, "data_ptr"):
+        return a.data_ptr()
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    return int(a)
+
+
+class Matrix:
+    """Owner of a `struct csr *` allocated by the library."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise L.LsbenchHipError("NULL struct csr")
+        self._h = handle
+
+    @classmethod
+    def from_arrays(cls, offs, cols, vals, base=0):
+        """Wrap numpy arrays as a struct csr (arrays are kept alive by self)."""
+        self = cls.__new__(cls)
+        self._offs = np.ascontiguousarray(offs, dtype=np.uint32)
+        self._cols = np.ascontiguousarray(cols, dtype=np.uint32)
+        self._vals = np.ascontiguousarray(vals, dtype=np.float64)
+        s = L.CsrStruct(len(self._offs) - 1, base,
+                        self._offs.ctypes.data_as(C.POINTER(C.c_uint)),
+                        self._cols.ctypes.data_as(C.POINTER(C.c_uint)),
+                        self._vals.ctypes.data_as(C.POINTER(C.c_double)))
+        self._own = s
+        self._h = C.pointer(s)
+        return self
+
+    @property
+    def ptr(self):
+        return self._h
+
+    @property
+    def nrows(self):
+        return int(self._h.contents.nrows)
+
+    @property
+    def base(self):
+        return int(self._h.contents.base)
+
+    @property
+    def nnz(self):
+        return int(self._h.contents.offs[self.nrows])
+
+    @property
+    def offs(self):
+        return np.ctypeslib.as_array(self._h.contents.offs, shape=(self.nrows + 1,))
+
+    @property
+    def cols(self):
+        return np.ctypeslib.as_array(self._h.contents.cols, shape=(max(self.nnz, 1),))[:self.nnz]
+
+    @property
+    def vals(self):
+        return np.ctypeslib.as_array(self._h.contents.vals, shape=(max(self.nnz, 1),))[:self.nnz]
+
+    def free(self):
+        if getattr(self, "_own", None) is None and self._h:
+            L.load().lsbench_matrix_free(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def lsbench_matrix_read(path):
+    return Matrix(L.load().lsbench_matrix_read(str(path).encode()))
+
+
+def lsbench_matrix_synth(spec, r0=0, r1=0):
+    n = C.c_uint()
+    h = L.load().lsbench_matrix_synth(spec.encode(), r0, r1, C.byref(n))
+    if not h:
+        raise L.LsbenchHipError("bad synthetic spec %r" % spec)
+    m = Matrix(h)
+    m.n_global = n.value
+    return m
+
+
+def lsb_csr_symmetrize_upper(A):
+    return Matrix(L.load().lsb_csr_symmetrize_upper(A.ptr))
+
+
+def lsb_csr_copy_base0(A):
+    return Matrix(L.load().lsb_csr_copy_base0(A.ptr))
+
+
+def lsb_csr_row_slice(A, r0, r1):
+    return Matrix(L.load().lsb_csr_row_slice(A.ptr, r0, r1))
+
+
+def lsb_csr_partition_rows(A, nparts):
+    b = (C.c_uint * (nparts + 1))()
+    L.check(L.load().lsb_csr_partition_rows(A.ptr, nparts, b), "partition_rows")
+    return np.array(b[:], dtype=np.int64)
+
+
+def lsb_csr_row_blocks(A, cap):
+    p = C.POINTER(C.c_uint)()
+    nb = L.load().lsb_csr_row_blocks(A.ptr, cap, C.byref(p))
+    out = np.ctypeslib.as_array(p, shape=(nb + 1,)).copy()
+    C.CDLL(None).free(p)
+    return out
+
+
+def lsb_csr_col_hull(A):
+    lo, hi = C.c_uint(), C.c_uint()
+    L.load().lsb_csr_col_hull(A.ptr, C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
+
+
+def lsb_plan_exchange(me, hull):
+    """hull: (nall, 4) array of {row_begin, nrows, col_lo, col_hi}.
+    Returns (recvs, sends) as lists of (peer, offset, count)."""
+    hull = np.ascontiguousarray(hull, dtype=np.uint32)
+    nall = hull.shape[0]
+    recv, send = (L.Xfer * nall)(), (L.Xfer * nall)()
+    nr, ns = C.c_int(), C.c_int()
+    L.load().lsb_plan_exchange(me, nall, hull.ctypes.data_as(C.POINTER(C.c_uint)),
+                               recv, C.byref(nr), send, C.byref(ns))
+    f = lambda a, n: [(a[i].peer, a[i].offset, a[i].count) for i in range(n)]
+    return f(recv, nr.value), f(send, ns.value)
+
+
+def default_opts(**kw):
+    o = L.Opts()
+    L.load().lsb_hip_opts_default(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+def hip_cdna4_init():
+    return L.load().hip_cdna4_init()
+
+
+def hip_cdna4_finalize():
+    return L.load().hip_cdna4_finalize()
+
+
+def hip_cdna4_bench(A, r=None, trials=1, matrix_name="(memory)", opts=None):
+    """The drop-in entry point, called the way lsbench_bench calls a backend
+    (reference: src/lsbench.c:156-187): x = zeros, r_i = i unless given.
+    Returns x (numpy)."""
+    lib = L.load()
+    m = A.nrows
+    x = np.zeros(m, np.float64)
+    r = np.arange(m, dtype=np.float64) if r is None else np.ascontiguousarray(r, np.float64)
+    if opts is not None:
+        lib.lsb_hip_set_opts(C.byref(opts))
+    cb = L.LsbenchStruct(matrix_name.encode(), L.SOLVER_HIP, 0, 0, 0, trials)
+    rc = lib.hip_cdna4_bench(x.ctypes.data_as(C.POINTER(C.c_double)), A.ptr,
+                             r.ctypes.data_as(C.POINTER(C.c_double)), C.byref(cb))
+    L.check(rc, "hip_cdna4_bench")
+    return x
+
+
+def last_result():
+    r = L.Result()
+    L.load().lsb_hip_last_result(C.byref(r))
+    return r
+
+
+class Solver:
+    """lsb_hip_solver handle: operator resident in HBM."""
+
+    def __init__(self, A, opts=None, row_begin=None, n_global=None):
+        lib = L.load()
+        self.opts = opts if opts is not None else default_opts()
+        if row_begin is None:
+            h = lib.lsb_hip_solver_create(A.ptr, C.byref(self.opts))
+        else:
+            h = lib.lsb_hip_solver_create_dist(A.ptr, row_begin, n_global, C.byref(self.opts))
+        if not h:
+            raise L.LsbenchHipError("lsb_hip_solver_create failed: backend not "
+                                    "initialised (no GPU?) -- there is no CPU path")
+        self._h = h
+        self.n_local = lib.lsb_hip_solver_nrows_local(h)
+        self.n_global = lib.lsb_hip_solver_nrows_global(h)
+        self.nnz_local = lib.lsb_hip_solver_nnz_local(h)
+
+    def solve(self, b):
+        x = np.empty(self.n_local, np.float64)
+        b = np.ascontiguousarray(b, np.float64)
+        res = L.Result()
+        L.check(L.load().lsb_hip_solver_solve(self._h, b.ctypes.data, x.ctypes.data,
+                                              C.byref(res)), "solve")
+        return x, res
+
+    def solve_dev(self, d_b, d_x):
+        res = L.Result()
+        L.check(L.load().lsb_hip_solver_solve_dev(self._h, _ptr(d_b), _ptr(d_x),
+                                                  C.byref(res)), "solve_dev")
+        return res
+
+    def spmv_dev(self, d_x, d_y):
+        L.check(L.load().lsb_hip_solver_spmv_dev(self._h, _ptr(d_x), _ptr(d_y)), "spmv_dev")
+
+    def time_spmv(self, warm=5, reps=50):
+        ms = C.c_double()
+        L.check(L.load().lsb_hip_solver_time_spmv(self._h, warm, reps, C.byref(ms)),
+                "time_spmv")
+        return ms.value
+
+    def jacobi_sweep_dev(self, w, d_b, d_x):
+        L.check(L.load().lsb_hip_solver_jacobi_sweep_dev(self._h, w, _ptr(d_b), _ptr(d_x)),
+                "jacobi_sweep_dev")
+
+    @property
+    def nblocks(self):
+        return L.load().lsb_hip_solver_nblocks(self._h)
+
+    @property
+    def spmv_variant(self):
+        return L.load().lsb_hip_solver_spmv_variant(self._h)
+
+    def destroy(self):
+        if self._h:
+            L.load().lsb_hip_solver_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass

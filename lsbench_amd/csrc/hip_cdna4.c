@@ -322,36 +322,10 @@ static void shard_free(struct shard *s) {
   free(s->recv), free(s->send);
 }
 
-/*
- * Exchange plan.  hull[q] = {row_begin, n, col_lo, col_hi} of every shard
- * (virtual or remote), indexed by shard/rank id; `me` is this shard's id.  A
- * shard receives, from every other shard q, the part of q's rows that falls
- * inside its own column hull, and sends the mirror image.
- */
 static void plan_exchange(struct shard *s, int me, int nall, const unsigned *hull) {
   s->recv = lsb_calloc(struct lsb_xfer, nall);
   s->send = lsb_calloc(struct lsb_xfer, nall);
-  s->nrecv = s->nsend = 0;
-  const unsigned my_b = hull[4 * me], my_e = my_b + hull[4 * me + 1];
-  for (int q = 0; q < nall; q++) {
-    if (q == me)
-      continue;
-    const unsigned qb = hull[4 * q], qe = qb + hull[4 * q + 1];
-    /* what I need of q's rows */
-    unsigned lo = s->col_lo > qb ? s->col_lo : qb;
-    unsigned hi = s->col_hi < qe ? s->col_hi : qe;
-    if (lo < hi) {
-      s->recv[s->nrecv].peer = q, s->recv[s->nrecv].offset = lo;
-      s->recv[s->nrecv].count = hi - lo, s->nrecv++;
-    }
-    /* what q needs of my rows */
-    lo = hull[4 * q + 2] > my_b ? hull[4 * q + 2] : my_b;
-    hi = hull[4 * q + 3] < my_e ? hull[4 * q + 3] : my_e;
-    if (lo < hi) {
-      s->send[s->nsend].peer = q, s->send[s->nsend].offset = lo;
-      s->send[s->nsend].count = hi - lo, s->nsend++;
-    }
-  }
+  lsb_plan_exchange(me, nall, hull, s->recv, &s->nrecv, s->send, &s->nsend);
 }
 
 static lsb_hip_solver *solver_alloc(int nshard, const struct lsb_hip_opts *o) {

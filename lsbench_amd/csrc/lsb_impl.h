@@ -89,10 +89,6 @@ void lsb_k_vreduce(double *base, unsigned stride, unsigned nshard, unsigned off,
 void *lsb_hip_stream(void);
 int lsb_hip_is_initialized(void);
 /* grouped point-to-point exchange of contiguous ranges of a device vector */
-struct lsb_xfer {
-  int peer;
-  size_t offset, count; /* in doubles, into the full-length vector */
-};
 int lsb_hip_comm_exchange(double *d_full, const struct lsb_xfer *sends,
                           int nsend, const struct lsb_xfer *recvs, int nrecv,
                           void *stream);

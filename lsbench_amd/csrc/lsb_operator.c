@@ -182,3 +182,51 @@ unsigned lsb_csr_row_blocks(const struct csr *A, unsigned cap,
   *rowblk_out = rb;
   return (unsigned)(nb - 1);
 }
+
+/* [lo, hi) = smallest column range covering every entry of A (0-based ids). */
+void lsb_csr_col_hull(const struct csr *A, unsigned *lo_out, unsigned *hi_out) {
+  unsigned lo = 0xFFFFFFFFu, hi = 0;
+  const unsigned nnz = A->offs[A->nrows];
+  for (unsigned j = 0; j < nnz; j++) {
+    const unsigned c = A->cols[j] - A->base;
+    if (c < lo)
+      lo = c;
+    if (c + 1 > hi)
+      hi = c + 1;
+  }
+  if (nnz == 0)
+    lo = hi = 0;
+  *lo_out = lo, *hi_out = hi;
+}
+
+/*
+ * Exchange plan of one shard under 1-D row-range partitioning (SURVEY.md
+ * section 8(e)).  hull[4q..4q+3] = {row_begin, nrows, col_lo, col_hi} of shard
+ * q (a rank, or a virtual shard), `me` is this shard's id.  Every shard keeps
+ * the exchanged vector in GLOBAL index space, so a transfer is just a range
+ * [offset, offset+count) of it: shard `me` receives from q the part of q's
+ * rows inside its own column hull, and sends the mirror image.  Both sides
+ * derive the same ranges from the same table, so sends and receives pair up.
+ * recv/send must hold nall entries each.
+ */
+void lsb_plan_exchange(int me, int nall, const unsigned *hull,
+                       struct lsb_xfer *recv, int *nrecv, struct lsb_xfer *send,
+                       int *nsend) {
+  const unsigned my_b = hull[4 * me], my_e = my_b + hull[4 * me + 1];
+  const unsigned my_lo = hull[4 * me + 2], my_hi = hull[4 * me + 3];
+  int nr = 0, ns = 0;
+  for (int q = 0; q < nall; q++) {
+    if (q == me)
+      continue;
+    const unsigned qb = hull[4 * q], qe = qb + hull[4 * q + 1];
+    unsigned lo = my_lo > qb ? my_lo : qb;
+    unsigned hi = my_hi < qe ? my_hi : qe;
+    if (lo < hi)
+      recv[nr].peer = q, recv[nr].offset = lo, recv[nr].count = hi - lo, nr++;
+    lo = hull[4 * q + 2] > my_b ? hull[4 * q + 2] : my_b;
+    hi = hull[4 * q + 3] < my_e ? hull[4 * q + 3] : my_e;
+    if (lo < hi)
+      send[ns].peer = q, send[ns].offset = lo, send[ns].count = hi - lo, ns++;
+  }
+  *nrecv = nr, *nsend = ns;
+}
