@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the hip_cdna4 backend (BASELINE.json metric:
+"fp64 CSR SpMV GB/s (% HBM roofline) + CG solves/sec at 1/2/4/8 MI355X").
+
+One "step" = one Jacobi-PCG solve of the workload to the stated tolerance from
+x0 = 0 with b_i = i (reference RHS, src/lsbench.c:157-160), operator and b
+already resident in HBM.  value = solves / second, whole job.  For N > 1 the
+same operator is row-range partitioned over the ranks (strong scaling): one
+process per GPU, halo exchange + dot-product all-reduces over RCCL inside the
+C library, launched as
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Default workload = BASELINE.json configs[2], the roofline run: 5-point 2-D
+Laplacian, 3162^2 = 9,998,244 rows, 49,978,572 nnz.  Others:
+    --workload lap3d     configs[3]: 7-point 400^3, 64 M rows (the 8-GPU config)
+    --workload powerlaw  configs[4]: SpMV-only (unsymmetric), reports GB/s
+    --workload file:tests/golden/matrices/xn3b_A_18.txt.gz   configs[1]
+
+The JSON line also carries
+  roofline      dominant kernel (SpMV): algorithmic bytes 12*nnz + 20*n + 4 per
+                launch / mean launch time, HIP events on the library's stream,
+                sampled INSIDE the timed solves; peak 8000 GB/s
+  cpu_baseline  the oracle's OpenMP Jacobi-PCG (a CPU port of the same
+                algorithm, oracle/lsb_oracle.c) on this host's cores, timed on
+                a bounded number of iterations of the SAME operator and scaled
+                to whole solves; rank 0, N = 1 only.  CHOLMOD, the reference's
+                own CPU solver, is not installable here.
+"""
+import argparse
+import ctypes
+import gzip
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402  (first: the library binds to torch's HIP/RCCL)
+import torch.distributed as dist  # noqa: E402
+
+import lsbench_amd as la  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md, chip-level parameters
+WORKLOADS = {
+    "lap2d": "lap2d:nx=3162,ny=3162",
+    "lap3d": "lap3d:nx=400,ny=400,nz=400",
+    "powerlaw": "powerlaw:n=8000000,gamma=1.585350372615855,max=4096,seed=20240607",
+}
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=3)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--workload", default="lap2d")
+    p.add_argument("--tol", type=float, default=1e-8)
+    p.add_argument("--maxit", type=int, default=100000)
+    p.add_argument("--spmv", type=int, default=0, help="LSB_SPMV_* variant (0 = auto)")
+    p.add_argument("--cpu-seconds", type=float, default=12.0,
+                   help="budget of the CPU baseline leg (0 = skip)")
+    return p.parse_args()
+
+
+def read_file_matrix(path):
+    if path.endswith(".gz"):
+        tmp = os.path.join(tempfile.gettempdir(), os.path.basename(path)[:-3])
+        with gzip.open(path, "rb") as fi, open(tmp, "wb") as fo:
+            fo.write(fi.read())
+        path = tmp
+    return la.lsbench_matrix_read(path)
+
+
+def cpu_baseline(A, gpu_iters, budget_s, is_spd):
+    """Oracle PCG (OpenMP, all cores) on a bounded number of iterations."""
+    from oracle import oracle as O  # the checker, used here only as the CPU baseline
+    import numpy as np
+    cores = O.max_threads()
+    b = O.rhs(A.nrows)
+    t = time.perf_counter()
+    O.pcg_jacobi(A.offs, A.cols, A.vals, b, 0.0, 5, jacobi=is_spd, threads=cores)
+    t5 = (time.perf_counter() - t)
+    its = int(max(10, min(2000, budget_s / max(t5 / 5, 1e-6))))
+    its = min(its, max(gpu_iters, 10))
+    t = time.perf_counter()
+    _, done, _, _ = O.pcg_jacobi(A.offs, A.cols, A.vals, b, 0.0, its, jacobi=is_spd, threads=cores)
+    dt = time.perf_counter() - t
+    per_iter = dt / max(done, 1)
+    return {"value": 1.0 / (per_iter * max(gpu_iters, 1)), "unit": "solves/s", "cores": cores,
+            "kind": "port",
+            "sample": "%d OpenMP Jacobi-PCG iterations of the same operator in %.2f s "
+                      "(%.3f ms/iteration), scaled to the %d iterations one GPU solve took"
+                      % (done, dt, per_iter * 1e3, gpu_iters)}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
+                     "--nproc-per-node %d" % (a.gpus, a.gpus))
+        a.gpus = world
+    torch.cuda.set_device(local)
+    lib = la._lib.load()
+    if la.hip_cdna4_init() != 0:
+        sys.exit("hip_cdna4_init failed: no MI355X visible (there is no CPU path)")
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local))
+        idb = ctypes.create_string_buffer(la._lib.UNIQUE_ID_BYTES)
+        if rank == 0:
+            lib.lsb_hip_comm_get_unique_id(idb)
+        t = torch.frombuffer(bytearray(idb.raw), dtype=torch.uint8).cuda()
+        dist.broadcast(t, 0)
+        idb = ctypes.create_string_buffer(bytes(t.cpu().tolist()), la._lib.UNIQUE_ID_BYTES)
+        la._lib.check(lib.lsb_hip_comm_init_rank(idb, world, rank), "comm_init_rank")
+
+    # ---- operator: this rank's rows only --------------------------------
+    t_setup = time.perf_counter()
+    spmv_only = False
+    if a.workload.startswith("file:"):
+        Afile = read_file_matrix(a.workload[5:])
+        A = la.lsb_csr_symmetrize_upper(Afile)  # the operator CHOLMOD factorises
+        n = A.nrows
+        name = os.path.basename(a.workload[5:])
+        if world > 1:
+            b = la.lsb_csr_partition_rows(A, world)
+            r0, r1 = int(b[rank]), int(b[rank + 1])
+            Aloc = la.lsb_csr_row_slice(A, r0, r1)
+        else:
+            r0, r1, Aloc = 0, n, A
+    else:
+        spec = WORKLOADS.get(a.workload, a.workload)
+        spmv_only = spec.startswith("powerlaw")
+        probe = la.lsbench_matrix_synth(spec, 0, 1)
+        n = probe.n_global
+        r0, r1 = (n * rank // world) & ~1, ((n * (rank + 1) // world) & ~1 if rank + 1 < world else n)
+        Aloc = la.lsbench_matrix_synth(spec, r0, r1)
+        name = spec
+    small = Aloc.nnz < 2000000
+    opts = la.default_opts(op_mode=la.OP_RAW, tol=a.tol, maxit=a.maxit, spmv_variant=a.spmv,
+                           use_graph=1 if small else 0, sample_spmv=0 if small else 16,
+                           precond=la.PRECOND_NONE if spmv_only else la.PRECOND_JACOBI)
+    if world > 1:
+        solver = la.Solver(Aloc, opts, row_begin=r0, n_global=n)
+    else:
+        solver = la.Solver(Aloc, opts)
+    nl = r1 - r0
+    d_b = torch.arange(r0, r1, dtype=torch.float64, device="cuda")  # b_i = i
+    d_x = torch.zeros(nl, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t_setup
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    nnz_loc = Aloc.nnz
+    bytes_spmv = 12 * nnz_loc + 20 * nl + 4
+
+    if spmv_only:
+        # config 5: SpMV throughput only (the operator is unsymmetric)
+        ms = solver.time_spmv(a.warmup * 10, a.steps * 20)
+        barrier()
+        gbps = bytes_spmv / ms / 1e6
+        line = {"metric": "fp64_csr_spmv_GBps", "value": gbps * world, "unit": "GB/s",
+                "n_gpus": world, "steps": a.steps * 20, "warmup": a.warmup * 10,
+                "ms_per_step": ms, "higher_is_better": True, "scaling": "strong",
+                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": name, "rows": n, "nnz_per_gpu": nnz_loc},
+                "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS,
+                             "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS, "traffic": None,
+                             "kernel": "k_spmv_adaptive", "algorithmic_bytes": bytes_spmv}}
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        return
+
+    # ---- warm-up, then EXACTLY --steps timed solves ------------------------
+    for _ in range(a.warmup):
+        res = solver.solve_dev(d_b, d_x)
+    barrier()
+    t0 = time.perf_counter()
+    iters, spmv_ms, spmv_n = 0, 0.0, 0
+    for _ in range(a.steps):
+        res = solver.solve_dev(d_b, d_x)
+        iters += res.iters
+        spmv_ms += res.spmv_ms * res.spmv_samples
+        spmv_n += res.spmv_samples
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    if res.status != la.STATUS_CONVERGED:
+        sys.exit("solve did not converge (status %d after %d iterations): no valid number"
+                 % (res.status, res.iters))
+    its = iters // max(a.steps, 1)
+
+    # ---- dominant kernel: SpMV, HIP events on the library's stream ---------
+    if spmv_n:
+        spmv_avg_ms = spmv_ms / spmv_n  # sampled inside the timed solves
+        how = "hipEvent pairs around %d SpMV launches inside the timed solves" % spmv_n
+    else:
+        spmv_avg_ms = solver.time_spmv(20, 200)  # graph replay: events do not fit inside
+        how = "hipEvents around 200 back-to-back launches after the timed solves"
+    gbps = bytes_spmv / spmv_avg_ms / 1e6
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            traffic = json.load(f).get(a.workload if world == 1 else None)
+    except OSError:
+        pass
+    n_tot_nnz = nnz_loc
+    if world > 1:
+        tt = torch.tensor([float(nnz_loc)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt)
+        n_tot_nnz = int(tt.item())
+    bytes_iter = 12 * n_tot_nnz + 20 * n + 136 * n  # unfused-PCG accounting, SURVEY 8(d)
+    line = {
+        "metric": "cg_solves_per_sec", "value": a.steps / dt, "unit": "solves/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not a.workload.startswith("file:") else "reference tests/ matrix",
+        "config": {"workload": name, "rows": n, "nnz": n_tot_nnz, "solver": "PCG+Jacobi",
+                   "tol": a.tol, "rhs": "b_i=i", "partition": "row-range x%d" % world,
+                   "iterations_per_solve": its, "relres": res.relres},
+        "iterations_per_sec": iters / dt,
+        "pcg_iteration_GBps": bytes_iter * iters / dt / 1e9,
+        "setup_seconds": t_setup,
+        "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": gbps / HBM_PEAK_GBPS, "traffic": traffic,
+                     "kernel": "k_spmv_adaptive (fused p.q)", "launch_ms": spmv_avg_ms,
+                     "algorithmic_bytes": bytes_spmv, "measured": how},
+    }
+    if rank == 0 and world == 1 and a.cpu_seconds > 0:
+        line["cpu_baseline"] = cpu_baseline(Aloc, its, a.cpu_seconds, True)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    solver.destroy()
+    if world > 1:
+        lib.lsb_hip_comm_destroy()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

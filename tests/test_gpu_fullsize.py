@@ -1,0 +1,106 @@
+"""BASELINE.json configs 3-5 at FULL size on the MI355X: the oracle's CPU SpMV
+is fast enough to check every element, and size-independent properties cover
+the solves (true residual with an independent SpMV, A*1 = boundary indicator,
+linearity, identical early iterates)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+EPS = np.finfo(np.float64).eps
+GAMMA = 1.585350372615855
+
+
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+
+
+def _spmv_check(hip, A, s, x, threads):
+    import torch
+    d_y = torch.full((A.nrows,), float("nan"), dtype=torch.float64, device="cuda:0")
+    s.spmv_dev(_dev(x), d_y)
+    y = d_y.cpu().numpy()
+    yo = O.spmv(A.offs, A.cols, A.vals, x, threads=threads)
+    bound = 4 * EPS * np.maximum(np.diff(A.offs.astype(np.int64)), 1) * \
+        O.spmv(A.offs, A.cols, np.abs(A.vals), np.abs(x), threads=threads)
+    assert np.all(np.abs(y - yo) <= bound)
+    return y
+
+
+def test_lap2d_10m_rows(hip):
+    """config 3: 3162 x 3162 5-point Laplacian, n = 9,998,244, nnz = 49,978,572."""
+    import torch
+    thr = min(O.max_threads(), 16)
+    A = hip.lsbench_matrix_synth("lap2d:nx=3162,ny=3162")
+    n = A.nrows
+    assert (n, A.nnz) == (9998244, 49978572)
+    s = hip.Solver(A, hip.default_opts(op_mode=hip.OP_RAW, tol=1e-8, use_graph=0))
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal(n)
+    y = _spmv_check(hip, A, s, x, thr)
+    # A*1: 4 - (number of neighbours) exactly
+    d_y = torch.empty(n, dtype=torch.float64, device="cuda:0")
+    s.spmv_dev(torch.ones(n, dtype=torch.float64, device="cuda:0"), d_y)
+    y1 = d_y.cpu().numpy().reshape(3162, 3162)
+    assert y1[1:-1, 1:-1].max() == 0 and y1[0, 0] == 2 and y1[0, 5] == 1 and y1[-1, -1] == 2
+    # linearity: A(2x - 3z) = 2Ax - 3Az to round-off
+    z = rng.standard_normal(n)
+    s.spmv_dev(_dev(z), d_y)
+    yz = d_y.cpu().numpy()
+    s.spmv_dev(_dev(2 * x - 3 * z), d_y)
+    assert np.allclose(d_y.cpu().numpy(), 2 * y - 3 * yz, rtol=0, atol=1e-12 * 50)
+    # early iterates equal the oracle's (same recurrences, different summation order)
+    b = O.rhs(n)
+    s60 = hip.Solver(A, hip.default_opts(op_mode=hip.OP_RAW, tol=0.0, maxit=60, use_graph=0))
+    x60, r60 = s60.solve(b)
+    s60.destroy()
+    xo, ito, relo, sto = O.pcg_jacobi(A.offs, A.cols, A.vals, b, 0.0, 60, threads=thr)
+    assert r60.iters == 60 and r60.status == hip.STATUS_MAXIT and ito == 60
+    assert np.linalg.norm(x60 - xo) / np.linalg.norm(xo) <= 1e-10
+    assert abs(r60.relres - relo) <= 1e-9 * relo
+    # the bench's solve: tol 1e-8, true residual from the oracle's SpMV
+    d_b, d_x = _dev(b), torch.empty(n, dtype=torch.float64, device="cuda:0")
+    res = s.solve_dev(d_b, d_x)
+    xs = d_x.cpu().numpy()
+    assert res.status == hip.STATUS_CONVERGED and res.relres <= 1e-8
+    true = np.linalg.norm(b - O.spmv(A.offs, A.cols, A.vals, xs, threads=thr)) / np.linalg.norm(b)
+    assert true <= 2e-8
+    res2 = s.solve_dev(d_b, d_x)
+    assert res2.iters == res.iters and np.array_equal(d_x.cpu().numpy(), xs)  # deterministic
+    s.destroy()
+
+
+def test_powerlaw_8m_rows_spmv(hip):
+    """config 5: 8M rows, mean 32 / max 4096 nnz per row (load-balance stress)."""
+    thr = min(O.max_threads(), 16)
+    A = hip.lsbench_matrix_synth("powerlaw:n=8000000,gamma=%r,max=4096,seed=20240607" % GAMMA)
+    d = np.diff(A.offs.astype(np.int64))
+    assert d.max() <= 4096 and d.min() >= 1 and 31 < d.mean() < 33
+    x = np.random.default_rng(1).standard_normal(A.nrows)
+    for variant in (hip.SPMV_ADAPTIVE, hip.SPMV_SUBWAVE):
+        s = hip.Solver(A, hip.default_opts(op_mode=hip.OP_RAW, precond=hip.PRECOND_NONE,
+                                           spmv_variant=variant))
+        _spmv_check(hip, A, s, x, thr)
+        s.destroy()
+
+
+def test_lap3d_64m_rows(hip):
+    """config 4 on ONE device: 400^3 7-point Laplacian, n = 64e6, nnz = 447,040,000."""
+    import torch
+    thr = min(O.max_threads(), 16)
+    A = hip.lsbench_matrix_synth("lap3d:nx=400,ny=400,nz=400")
+    n = A.nrows
+    assert (n, A.nnz) == (64000000, 447040000)
+    s = hip.Solver(A, hip.default_opts(op_mode=hip.OP_RAW, tol=1e-6, use_graph=0))
+    x = np.random.default_rng(2).standard_normal(n)
+    _spmv_check(hip, A, s, x, thr)
+    b = O.rhs(n)
+    d_b, d_x = _dev(b), torch.empty(n, dtype=torch.float64, device="cuda:0")
+    res = s.solve_dev(d_b, d_x)
+    assert res.status == hip.STATUS_CONVERGED
+    xs = d_x.cpu().numpy()
+    true = np.linalg.norm(b - O.spmv(A.offs, A.cols, A.vals, xs, threads=thr)) / np.linalg.norm(b)
+    assert true <= 2e-6
+    s.destroy()

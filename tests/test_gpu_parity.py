@@ -1,0 +1,327 @@
+"""Parity of the HIP path against the oracle and the golden vectors, all through
+the C-ABI of liblsbench_hip.so.  Needs an MI355X (`pytest -m gpu`).
+
+Tolerances (fp64; the summation order on the GPU differs from the oracle's):
+  SpMV        |y - y_oracle|_i <= 4 eps * nnz_i * sum_j |a_ij x_j|
+  dot / nrm2  relative 1e-13 (n <= 1e7 terms, pairwise-ish tree)
+  axpy/xpay/Jacobi: exact (one rounding per element, same expression)
+  solve       ||x - x_golden|| / ||x_golden|| <= 1e-10 at PCG tol 1e-12
+              (measured ~5e-14)
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, ROOT, SPD, TOY
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+EPS = np.finfo(np.float64).eps
+GAMMA = 1.585350372615855  # power law with mean 32 on [1,4096]
+
+
+def _dev(a, dtype=None):
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(a if dtype is None else a.astype(dtype)))
+    return t.to("cuda:0")
+
+
+def _spmv_kernel(hip, A, x, variant, mean=0, with_dot=True):
+    import torch
+    lib = hip._lib.load()
+    rb = hip.lsb_csr_row_blocks(A, 2048)
+    d = dict(offs=_dev(A.offs, np.int32), cols=_dev(A.cols, np.int32), vals=_dev(A.vals),
+             rb=_dev(rb, np.int32), x=_dev(x))
+    y = torch.full((A.nrows,), float("nan"), dtype=torch.float64, device="cuda:0")
+    w = torch.zeros(lib.lsb_hip_partials_capacity(), dtype=torch.float64, device="cuda:0")
+    dot = torch.zeros(1, dtype=torch.float64, device="cuda:0")
+    xd = d["x"][:A.nrows]
+    rc = lib.lsb_hip_spmv_csr_f64(variant, A.nrows, d["offs"].data_ptr(), d["cols"].data_ptr(),
+                                  d["vals"].data_ptr(), d["rb"].data_ptr(), len(rb) - 1, mean,
+                                  d["x"].data_ptr(), y.data_ptr(),
+                                  xd.data_ptr() if with_dot else None,
+                                  dot.data_ptr() if with_dot else None, w.data_ptr(),
+                                  lib.lsb_hip_stream())
+    assert rc == 0
+    lib.lsb_hip_sync()
+    return y.cpu().numpy(), dot.item()
+
+
+def _check_spmv(A, x, y):
+    yo = O.spmv(A.offs, A.cols, A.vals, x)
+    bound = 4 * EPS * np.maximum(np.diff(A.offs.astype(np.int64)), 1) * \
+        O.spmv(A.offs, A.cols, np.abs(A.vals), np.abs(x))
+    assert not np.isnan(y).any()
+    assert np.all(np.abs(y - yo) <= bound), float((np.abs(y - yo) - bound).max())
+    return yo
+
+
+VARIANTS = [(1, 0), (2, 2), (2, 4), (2, 8), (2, 16), (2, 32), (2, 64), (3, 0)]
+
+
+def _edge_matrix(hip):
+    """empty rows (leading, in runs, trailing), a 1-entry row, a 5000-entry row
+    (> the 2048-nnz LDS block => workgroup-per-row path), rectangular gather."""
+    rng = np.random.default_rng(5)
+    lens = [0, 0, 1, 3, 0, 0, 0, 5000, 2, 2048, 2049, 64, 0, 7, 0, 0]
+    ncol = 6000
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    cols = np.concatenate([np.sort(rng.choice(ncol, k, replace=False)) for k in lens if k] or [[]])
+    vals = rng.standard_normal(len(cols))
+    return hip.Matrix.from_arrays(offs, cols, vals), ncol
+
+
+@pytest.mark.parametrize("variant,mean", VARIANTS)
+def test_spmv_kernels_vs_oracle(hip, variant, mean, matrix_path):
+    rng = np.random.default_rng(variant * 100 + mean)
+    mats = [hip.lsb_csr_symmetrize_upper(hip.lsbench_matrix_read(matrix_path("xn3b_A_18"))),
+            hip.lsbench_matrix_synth("lap2d:nx=301,ny=97"),
+            hip.lsbench_matrix_synth("lap3d:nx=31,ny=17,nz=23"),
+            hip.lsbench_matrix_synth("powerlaw:n=40000,gamma=%r,max=4096,seed=3" % GAMMA),
+            hip.lsbench_matrix_synth("lap2d:nx=1,ny=1")]
+    for A in mats:
+        x = rng.standard_normal(A.nrows)
+        y, dot = _spmv_kernel(hip, A, x, variant, mean)
+        yo = _check_spmv(A, x, y)
+        ref = float(x @ yo)
+        assert abs(dot - ref) <= 1e-12 * max(np.abs(x * yo).sum(), 1e-300)
+    E, ncol = _edge_matrix(hip)
+    x = rng.standard_normal(ncol)
+    y, _ = _spmv_kernel(hip, E, x, variant, mean, with_dot=False)
+    _check_spmv(E, x, y)
+    assert y[0] == 0 and y[1] == 0 and y[-1] == 0  # empty rows are written, as zeros
+
+
+def test_spmv_is_deterministic(hip):
+    A = hip.lsbench_matrix_synth("powerlaw:n=60000,gamma=%r,max=4096,seed=8" % GAMMA)
+    x = np.random.default_rng(0).standard_normal(A.nrows)
+    y1, d1 = _spmv_kernel(hip, A, x, 1)
+    y2, d2 = _spmv_kernel(hip, A, x, 1)
+    assert np.array_equal(y1, y2) and d1 == d2
+
+
+def test_blas1_and_jacobi_kernels(hip):
+    import torch
+    lib = hip._lib.load()
+    st = lib.lsb_hip_stream()
+    rng = np.random.default_rng(11)
+    for n in (1, 2, 63, 64, 65, 1000, 262144 + 7, 3000001):
+        a, b = rng.standard_normal(n), rng.standard_normal(n)
+        da, db = _dev(a), _dev(b)
+        w = torch.zeros(lib.lsb_hip_partials_capacity(), dtype=torch.float64, device="cuda:0")
+        out = torch.zeros(1, dtype=torch.float64, device="cuda:0")
+        assert lib.lsb_hip_dot_f64(n, da.data_ptr(), db.data_ptr(), out.data_ptr(), w.data_ptr(), st) == 0
+        lib.lsb_hip_sync()
+        assert abs(out.item() - float(a @ b)) <= 1e-13 * float(np.abs(a * b).sum())
+        first = out.item()
+        assert lib.lsb_hip_dot_f64(n, da.data_ptr(), db.data_ptr(), out.data_ptr(), w.data_ptr(), st) == 0
+        lib.lsb_hip_sync()
+        assert out.item() == first  # fixed-order reduction: bitwise repeatable
+        assert lib.lsb_hip_nrm2_f64(n, da.data_ptr(), out.data_ptr(), w.data_ptr(), st) == 0
+        lib.lsb_hip_sync()
+        assert abs(out.item() - np.linalg.norm(a)) <= 1e-13 * np.linalg.norm(a)
+        # axpy / xpay with the scalar in device memory
+        alpha = _dev(np.array([0.37]))
+        dy = _dev(b)
+        assert lib.lsb_hip_axpy_f64(n, alpha.data_ptr(), da.data_ptr(), dy.data_ptr(), st) == 0
+        lib.lsb_hip_sync()
+        got = dy.cpu().numpy()
+        assert np.allclose(got, b + 0.37 * a, rtol=2 * EPS, atol=0)
+        dy = _dev(b)
+        assert lib.lsb_hip_xpay_f64(n, alpha.data_ptr(), da.data_ptr(), dy.data_ptr(), st) == 0
+        lib.lsb_hip_sync()
+        assert np.allclose(dy.cpu().numpy(), a + 0.37 * b, rtol=2 * EPS, atol=0)
+        # jacobi apply
+        dz = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+        assert lib.lsb_hip_jacobi_apply_f64(n, da.data_ptr(), db.data_ptr(), dz.data_ptr(), st) == 0
+        lib.lsb_hip_sync()
+        assert np.array_equal(dz.cpu().numpy(), a * b)
+    # jacobi setup: dinv = 1/diag, counts rows without a diagonal; shard offset
+    A = hip.lsbench_matrix_synth("lap3d:nx=12,ny=9,nz=7", 100, 500)
+    dinv = torch.zeros(A.nrows, dtype=torch.float64, device="cuda:0")
+    nz = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+    assert lib.lsb_hip_jacobi_setup_f64(A.nrows, 100, _dev(A.offs, np.int32).data_ptr(),
+                                        _dev(A.cols, np.int32).data_ptr(), _dev(A.vals).data_ptr(),
+                                        dinv.data_ptr(), nz.data_ptr(), st) == 0
+    lib.lsb_hip_sync()
+    assert nz.item() == 0 and np.array_equal(dinv.cpu().numpy(), np.full(A.nrows, 1 / 6))
+    nz.zero_()
+    assert lib.lsb_hip_jacobi_setup_f64(A.nrows, 0, _dev(A.offs, np.int32).data_ptr(),
+                                        _dev(A.cols, np.int32).data_ptr(), _dev(A.vals).data_ptr(),
+                                        dinv.data_ptr(), nz.data_ptr(), st) == 0
+    lib.lsb_hip_sync()
+    assert nz.item() > 0  # wrong row offset => diagonals not found => reported
+
+
+@pytest.mark.parametrize("name", TOY + SPD)
+def test_backend_trio_reaches_golden(hip, name, matrix_path, golden_x, golden_meta, capfd):
+    """hip_cdna4_bench, called like lsbench_bench calls a backend
+    (src/lsbench.c:156-187), on the reference's own matrices."""
+    A = hip.lsbench_matrix_read(matrix_path(name))
+    x = hip.hip_cdna4_bench(A, trials=2, matrix_name=name + ".txt", opts=hip.default_opts())
+    res = hip.last_result()
+    xg = golden_x(name)
+    want_it = golden_meta["matrices"][name]["pcg_tol1e-12"]["iters"]
+    assert res.status == hip.STATUS_CONVERGED
+    assert abs(int(res.iters) - want_it) <= 2
+    if name in TOY:
+        assert np.allclose(x, xg, rtol=1e-15, atol=1e-16)
+    else:
+        assert np.linalg.norm(x - xg) / np.linalg.norm(xg) <= 1e-10
+    # the reference's CSV record (src/cholmod-impl.h:68-70): header + one row
+    out = capfd.readouterr().out.splitlines()
+    i = out.index("===matrix,n,nnz,trials,solver,ordering,elapsed===")
+    f = out[i + 1].split(",")
+    assert f[0] == name + ".txt" and int(f[1]) == A.nrows and int(f[2]) == A.nnz
+    assert int(f[3]) == 2 and int(f[4]) == 6 and int(f[5]) == 0 and float(f[6]) > 0
+
+
+def test_solver_handle_matches_oracle_iterates(hip, matrix_path):
+    """Same operator, same stop rule => same iteration count (+-1) and the same
+    x as the oracle's PCG to round-off; graph replay == plain launches bitwise;
+    run-to-run bitwise."""
+    import torch
+    A = hip.lsbench_matrix_read(matrix_path("xn3b_A_15"))
+    So = O.operator_upper(O.matrix_read(matrix_path("xn3b_A_15")))
+    b = O.rhs(A.nrows)
+    xs = {}
+    for tol in (1e-6, 1e-12):
+        xo, ito, relo, sto = O.pcg_jacobi(So.offs, So.cols, So.vals, b, tol)
+        for graph in (0, 1):
+            s = hip.Solver(A, hip.default_opts(tol=tol, use_graph=graph))
+            d_b, d_x = _dev(b), torch.empty(A.nrows, dtype=torch.float64, device="cuda:0")
+            res = s.solve_dev(d_b, d_x)
+            x = d_x.cpu().numpy()
+            res2 = s.solve_dev(d_b, d_x)  # x is reset inside: not a 0-iteration solve
+            assert res2.iters == res.iters and np.array_equal(d_x.cpu().numpy(), x)
+            assert res.status == 1 and abs(int(res.iters) - ito) <= 1
+            assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 50 * tol
+            xs[(tol, graph)] = x
+            xh, resh = s.solve(b)  # host-buffer flavour
+            assert np.array_equal(xh, x) and resh.iters == res.iters
+            s.destroy()
+        assert np.array_equal(xs[(tol, 0)], xs[(tol, 1)])
+
+
+def test_stop_rules(hip, matrix_path):
+    A = hip.lsbench_matrix_read(matrix_path("tj7a_A_18"))
+    n = A.nrows
+    s = hip.Solver(A, hip.default_opts(maxit=17, tol=1e-12))
+    x, res = s.solve(O.rhs(n))
+    assert res.status == hip.STATUS_MAXIT and res.iters == 17
+    x, res = s.solve(np.zeros(n))                      # b = 0 -> x = 0, no iterations
+    assert res.status == hip.STATUS_CONVERGED and res.iters == 0 and not x.any()
+    s.destroy()
+    s = hip.Solver(A, hip.default_opts(maxit=17, tol=1e-12, check_every=4))
+    x2, res2 = s.solve(O.rhs(n))                       # poll interval does not change the result
+    assert res2.iters == 17
+    s.destroy()
+    # unpreconditioned CG through the same kernels
+    So = O.operator_upper(O.matrix_read(matrix_path("tj7a_A_18")))
+    xo, ito, _, _ = O.pcg_jacobi(So.offs, So.cols, So.vals, O.rhs(n), 1e-8, jacobi=False)
+    s = hip.Solver(A, hip.default_opts(tol=1e-8, precond=hip.PRECOND_NONE))
+    x, res = s.solve(O.rhs(n))
+    assert abs(int(res.iters) - ito) <= 2 and np.linalg.norm(x - xo) / np.linalg.norm(xo) < 1e-6
+    s.destroy()
+
+
+def test_raw_operator_differs_from_cholmod_operator(hip, matrix_path, golden_x):
+    """The parity trap of SURVEY.md section 0.4: solving the file matrix as-is
+    misses CHOLMOD's answer by ~6e-7; the default (upper) mode does not."""
+    A = hip.lsbench_matrix_read(matrix_path("xn3b_A_18"))
+    xg = golden_x("xn3b_A_18")
+    s = hip.Solver(A, hip.default_opts(op_mode=hip.OP_RAW))
+    x, res = s.solve(O.rhs(A.nrows))
+    s.destroy()
+    err = np.linalg.norm(x - xg) / np.linalg.norm(xg)
+    assert 1e-8 < err < 1e-5
+
+
+@pytest.mark.parametrize("nvirt", [2, 3, 8])
+def test_virtual_shards_reproduce_single_shard(hip, nvirt, matrix_path, golden_x):
+    """Row-range partition + exchange + all-reduce on ONE device (shards
+    exchange by device copies): iterates must match the 1-shard run."""
+    for name, op in [("xn3b_A_12", hip.OP_CHOLMOD_UPPER)]:
+        A = hip.lsbench_matrix_read(matrix_path(name))
+        b = O.rhs(A.nrows)
+        s1 = hip.Solver(A, hip.default_opts(op_mode=op))
+        x1, r1 = s1.solve(b)
+        s1.destroy()
+        sp = hip.Solver(A, hip.default_opts(op_mode=op, nvirt=nvirt))
+        xp, rp = sp.solve(b)
+        sp.destroy()
+        assert abs(int(rp.iters) - int(r1.iters)) <= 1 and rp.status == 1
+        assert np.linalg.norm(xp - x1) / np.linalg.norm(x1) <= 1e-11
+        xg = golden_x(name)
+        assert np.linalg.norm(xp - xg) / np.linalg.norm(xg) <= 1e-10
+    # banded synthetic operator, SpMV through the sharded path
+    import torch
+    L = hip.lsbench_matrix_synth("lap3d:nx=40,ny=30,nz=20")
+    x = np.random.default_rng(2).standard_normal(L.nrows)
+    sp = hip.Solver(L, hip.default_opts(op_mode=hip.OP_RAW, nvirt=nvirt))
+    d_y = torch.empty(L.nrows, dtype=torch.float64, device="cuda:0")
+    sp.spmv_dev(_dev(x), d_y)
+    _check_spmv(L, x, d_y.cpu().numpy())
+    sp.destroy()
+
+
+def test_single_rank_communicator_and_dist_create(hip, matrix_path):
+    """RCCL with one rank: unique id, init, all-reduce, barrier, and the
+    distributed constructor on the full row range == the plain constructor."""
+    import torch
+    lib = hip._lib.load()
+    import ctypes
+    idb = ctypes.create_string_buffer(hip._lib.UNIQUE_ID_BYTES)
+    assert lib.lsb_hip_comm_get_unique_id(idb) == 0
+    assert lib.lsb_hip_comm_init_rank(idb, 1, 0) == 0
+    assert (lib.lsb_hip_comm_size(), lib.lsb_hip_comm_rank()) == (1, 0)
+    t = _dev(np.array([1.5, 2.5]))
+    assert lib.lsb_hip_comm_allreduce_sum_dev(t.data_ptr(), 2) == 0
+    assert lib.lsb_hip_comm_barrier() == 0
+    assert t.cpu().tolist() == [1.5, 2.5]
+    L = hip.lsbench_matrix_synth("lap2d:nx=120,ny=90")
+    b = O.rhs(L.nrows)
+    o = hip.default_opts(op_mode=hip.OP_RAW, tol=1e-10)
+    s0 = hip.Solver(L, o)
+    x0, r0 = s0.solve(b)
+    s0.destroy()
+    sd = hip.Solver(L, o, row_begin=0, n_global=L.nrows)
+    xd, rd = sd.solve(b)
+    sd.destroy()
+    assert rd.iters == r0.iters and np.array_equal(xd, x0)
+    assert lib.lsb_hip_comm_destroy() == 0
+
+
+def test_jacobi_sweep(hip):
+    import torch
+    L = hip.lsbench_matrix_synth("lap2d:nx=64,ny=48")
+    n = L.nrows
+    rng = np.random.default_rng(4)
+    b, x = rng.standard_normal(n), rng.standard_normal(n)
+    s = hip.Solver(L, hip.default_opts(op_mode=hip.OP_RAW))
+    d_x = _dev(x)
+    s.jacobi_sweep_dev(0.8, _dev(b), d_x)
+    want = x + 0.8 * (b - O.spmv(L.offs, L.cols, L.vals, x)) / 4.0
+    assert np.allclose(d_x.cpu().numpy(), want, rtol=1e-14, atol=1e-14)
+    s.destroy()
+
+
+def test_driver_binary_end_to_end(hip, matrix_path):
+    """`driver --solver hip --matrix F` (bin/driver.c:5-15 equivalent)."""
+    drv = os.path.join(ROOT, "lsbench_amd", "csrc", "driver")
+    r = subprocess.run([drv, "--solver", "hip", "--matrix", matrix_path("xn3b_A_18"),
+                        "--trials=3", "--verbose", "2"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.splitlines()
+    i = lines.index("===matrix,n,nnz,trials,solver,ordering,elapsed===")
+    f = lines[i + 1].split(",")
+    assert (int(f[1]), int(f[2]), int(f[3]), int(f[4])) == (3461, 76591, 3, 6)
+    x = np.array([float(l.split("=")[1]) for l in lines if l.startswith("x[")])
+    xg = np.fromfile(os.path.join(GOLD, "x", "xn3b_A_18.x.f64"), "<f8")
+    assert np.linalg.norm(x - xg) / np.linalg.norm(xg) <= 1e-10
+    r = subprocess.run([drv, "--solver", "hip", "--matrix", "synth:lap2d:nx=200,ny=100",
+                        "--operator", "raw", "--tol", "1e-8", "--trials=2"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and "===hip_cdna4:" in r.stdout
