@@ -103,6 +103,10 @@ struct lsb_hip_opts {
   int nvirt;         /* >1: split into that many row-range shards on ONE
                         device, exchanging by device copies (test mode) [1] */
   int overlap;       /* overlap halo exchange with interior rows        [1] */
+  int spmv_tune;     /* -1: time the SpMV flavours at creation and keep the
+                        fastest; >= 0: force flags (bit 0 prefetch, bit 1
+                        nontemporal)                                   [-1] */
+  int spmv_grid;     /* workgroup cap of the SpMV launch, 0 = tuned     [0] */
   int verbose;
 };
 
@@ -149,6 +153,10 @@ int lsb_csr_partition_rows(const struct csr *A, unsigned nparts,
  * ids in *rowblk (caller frees with free()). */
 unsigned lsb_csr_row_blocks(const struct csr *A, unsigned cap,
                             unsigned **rowblk);
+/* Lanes per row (1..64, a power of two) the adaptive SpMV uses to add up the
+ * rows of each block; lanes[] holds nblk entries. */
+void lsb_csr_block_lanes(const struct csr *A, const unsigned *rowblk,
+                         unsigned nblk, unsigned char *lanes);
 /* [lo,hi) column range referenced by A (0-based). */
 void lsb_csr_col_hull(const struct csr *A, unsigned *lo, unsigned *hi);
 /* One contiguous range [offset, offset+count) (in doubles) of the exchanged
@@ -217,6 +225,10 @@ unsigned lsb_hip_solver_nrows_global(const lsb_hip_solver *s);
 unsigned long long lsb_hip_solver_nnz_local(const lsb_hip_solver *s);
 unsigned lsb_hip_solver_nblocks(const lsb_hip_solver *s);
 int lsb_hip_solver_spmv_variant(const lsb_hip_solver *s);
+/* What the timing pass at creation picked for shard 0: flags (bit 0 prefetch,
+ * bit 1 nontemporal) and the workgroup cap of the SpMV launch. */
+unsigned lsb_hip_solver_spmv_flags(const lsb_hip_solver *s);
+unsigned lsb_hip_solver_spmv_grid(const lsb_hip_solver *s);
 /* hipStream_t of the backend (as void*), for callers that time with events. */
 void *lsb_hip_stream(void);
 
@@ -243,13 +255,17 @@ int lsb_hip_comm_barrier(void);
 /* ------------------------------------------------------------------------ */
 
 /* y = A x for a 0-based int32 CSR.  variant = LSB_SPMV_*; d_rowblk/nblk from
- * lsb_csr_row_blocks (needed by ADAPTIVE, ignored otherwise).  If d_dot != NULL
- * the kernel also leaves sum_i xdot[i]*y[i] in d_dot[0] (two-stage, fixed
- * order; d_work must then hold lsb_hip_partials_capacity() doubles). */
+ * lsb_csr_row_blocks (needed by ADAPTIVE, ignored otherwise); d_blklanes from
+ * lsb_csr_block_lanes or NULL (lanes then follow the row count alone);
+ * flags: bit 0 = prefetch the next block, bit 1 = nontemporal stream loads.
+ * If d_dot != NULL the kernel also leaves sum_i xdot[i]*y[i] in d_dot[0]
+ * (two-stage, fixed order; d_work must then hold
+ * lsb_hip_partials_capacity() doubles). */
 int lsb_hip_spmv_csr_f64(int variant, unsigned n, const int *d_offs,
                          const int *d_cols, const double *d_vals,
-                         const int *d_rowblk, unsigned nblk,
-                         unsigned mean_row_len, const double *d_x, double *d_y,
+                         const int *d_rowblk, const unsigned char *d_blklanes,
+                         unsigned nblk, unsigned mean_row_len, unsigned flags,
+                         const double *d_x, double *d_y,
                          const double *d_xdot, double *d_dot, double *d_work,
                          void *stream);
 unsigned lsb_hip_partials_capacity(void);

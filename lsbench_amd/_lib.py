@@ -45,7 +45,7 @@ class Opts(C.Structure):
                 ("precond", C.c_int), ("spmv_variant", C.c_int),
                 ("check_every", C.c_int), ("use_graph", C.c_int),
                 ("sample_spmv", C.c_int), ("nvirt", C.c_int), ("overlap", C.c_int),
-                ("verbose", C.c_int)]
+                ("spmv_tune", C.c_int), ("spmv_grid", C.c_int), ("verbose", C.c_int)]
 
 
 class Result(C.Structure):
@@ -90,6 +90,7 @@ SIGNATURES = {
     "lsb_csr_row_slice": (_csrp, [_csrp, _u, _u]),
     "lsb_csr_partition_rows": (_i, [_csrp, _u, C.POINTER(_u)]),
     "lsb_csr_row_blocks": (_u, [_csrp, _u, C.POINTER(C.POINTER(_u))]),
+    "lsb_csr_block_lanes": (None, [_csrp, C.POINTER(_u), _u, C.POINTER(C.c_ubyte)]),
     "lsb_csr_col_hull": (None, [_csrp, C.POINTER(_u), C.POINTER(_u)]),
     "lsb_plan_exchange": (None, [_i, _i, C.POINTER(_u), C.POINTER(Xfer), C.POINTER(_i),
                                  C.POINTER(Xfer), C.POINTER(_i)]),
@@ -108,6 +109,8 @@ SIGNATURES = {
     "lsb_hip_solver_nnz_local": (C.c_ulonglong, [_vp]),
     "lsb_hip_solver_nblocks": (_u, [_vp]),
     "lsb_hip_solver_spmv_variant": (_i, [_vp]),
+    "lsb_hip_solver_spmv_flags": (_u, [_vp]),
+    "lsb_hip_solver_spmv_grid": (_u, [_vp]),
     "lsb_hip_stream": (_vp, []),
     # communicator
     "lsb_hip_comm_get_unique_id": (_i, [_vp]),
@@ -118,8 +121,8 @@ SIGNATURES = {
     "lsb_hip_comm_allreduce_sum_dev": (_i, [_vp, _i]),
     "lsb_hip_comm_barrier": (_i, []),
     # kernel-level entry points
-    "lsb_hip_spmv_csr_f64": (_i, [_i, _u, _vp, _vp, _vp, _vp, _u, _u, _vp, _vp, _vp,
-                                  _vp, _vp, _vp]),
+    "lsb_hip_spmv_csr_f64": (_i, [_i, _u, _vp, _vp, _vp, _vp, _vp, _u, _u, _u, _vp, _vp,
+                                  _vp, _vp, _vp, _vp]),
     "lsb_hip_partials_capacity": (_u, []),
     "lsb_hip_dot_f64": (_i, [_u, _vp, _vp, _vp, _vp, _vp]),
     "lsb_hip_nrm2_f64": (_i, [_u, _vp, _vp, _vp, _vp]),

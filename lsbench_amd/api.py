@@ -125,6 +125,14 @@ def lsb_csr_row_blocks(A, cap):
     return out
 
 
+def lsb_csr_block_lanes(A, rowblk):
+    rb = np.ascontiguousarray(rowblk, dtype=np.uint32)
+    out = np.zeros(len(rb) - 1, np.uint8)
+    L.load().lsb_csr_block_lanes(A.ptr, rb.ctypes.data_as(C.POINTER(C.c_uint)), len(rb) - 1,
+                                 out.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    return out
+
+
 def lsb_csr_col_hull(A):
     lo, hi = C.c_uint(), C.c_uint()
     L.load().lsb_csr_col_hull(A.ptr, C.byref(lo), C.byref(hi))
@@ -237,6 +245,14 @@ class Solver:
     @property
     def spmv_variant(self):
         return L.load().lsb_hip_solver_spmv_variant(self._h)
+
+    @property
+    def spmv_flags(self):
+        return L.load().lsb_hip_solver_spmv_flags(self._h)
+
+    @property
+    def spmv_grid(self):
+        return L.load().lsb_hip_solver_spmv_grid(self._h)
 
     def destroy(self):
         if self._h:

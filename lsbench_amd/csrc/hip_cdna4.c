@@ -67,6 +67,8 @@ void lsb_hip_opts_default(struct lsb_hip_opts *o) {
   o->sample_spmv = 0;
   o->nvirt = 1;
   o->overlap = 1;
+  o->spmv_tune = -1;
+  o->spmv_grid = 0;
   o->verbose = 0;
 }
 
@@ -84,6 +86,10 @@ static void opts_from_env(struct lsb_hip_opts *o) {
     o->use_graph = atoi(e);
   if ((e = getenv("LSBENCH_HIP_SPMV")))
     o->spmv_variant = atoi(e);
+  if ((e = getenv("LSBENCH_HIP_SPMV_TUNE")))
+    o->spmv_tune = atoi(e);
+  if ((e = getenv("LSBENCH_HIP_SPMV_GRID")))
+    o->spmv_grid = atoi(e);
   if ((e = getenv("LSBENCH_HIP_CHECK_EVERY")))
     o->check_every = atoi(e);
   if ((e = getenv("LSBENCH_HIP_VERBOSE")))
@@ -187,6 +193,8 @@ struct shard {
   unsigned row_begin, n;
   unsigned long long nnz;
   int *d_offs, *d_cols, *d_rowblk;
+  unsigned char *d_blklanes;
+  unsigned sp_flags, sp_grid; /* adaptive-SpMV flavour, picked by tune_spmv() */
   double *d_vals, *d_dinv, *d_r, *d_q, *d_pfull;
   double *d_parts_pq, *d_parts2;
   double *d_scal; /* [0] p.q   [1] r.z'  [2] r.r   (multi-shard path) */
@@ -278,8 +286,11 @@ static void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
   unsigned *rb = NULL;
   s->nblk = lsb_csr_row_blocks(&view, LSB_BLOCK_NNZ, &rb);
   s->d_rowblk = (int *)dev_upload(rb, ((size_t)s->nblk + 1) * sizeof(int));
+  unsigned char *lanes = (unsigned char *)malloc((size_t)s->nblk + 1);
+  lsb_csr_block_lanes(&view, rb, s->nblk, lanes);
+  s->d_blklanes = (unsigned char *)dev_upload(lanes, (size_t)s->nblk);
   LSB_CHK_HIP(hipStreamSynchronize(g_stream)); /* host staging is freed next */
-  free(rb), free(offs), free(cols);
+  free(rb), free(offs), free(cols), free(lanes);
 
   s->d_dinv = (double *)lsb_hip_malloc((size_t)n * sizeof(double));
   s->d_r = (double *)lsb_hip_malloc((size_t)n * sizeof(double));
@@ -316,7 +327,8 @@ static void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
 
 static void shard_free(struct shard *s) {
   lsb_hip_free(s->d_offs), lsb_hip_free(s->d_cols), lsb_hip_free(s->d_vals);
-  lsb_hip_free(s->d_rowblk), lsb_hip_free(s->d_dinv), lsb_hip_free(s->d_r);
+  lsb_hip_free(s->d_rowblk), lsb_hip_free(s->d_blklanes);
+  lsb_hip_free(s->d_dinv), lsb_hip_free(s->d_r);
   lsb_hip_free(s->d_q), lsb_hip_free(s->d_pfull), lsb_hip_free(s->d_parts_pq);
   lsb_hip_free(s->d_parts2), lsb_hip_free(s->d_st);
   free(s->recv), free(s->send);
@@ -327,6 +339,8 @@ static void plan_exchange(struct shard *s, int me, int nall, const unsigned *hul
   s->send = lsb_calloc(struct lsb_xfer, nall);
   lsb_plan_exchange(me, nall, hull, s->recv, &s->nrecv, s->send, &s->nsend);
 }
+
+static void tune_spmv(lsb_hip_solver *sv, struct shard *s);
 
 static lsb_hip_solver *solver_alloc(int nshard, const struct lsb_hip_opts *o) {
   lsb_hip_solver *sv = lsb_calloc(lsb_hip_solver, 1);
@@ -349,6 +363,9 @@ static void solver_finish_setup(lsb_hip_solver *sv) {
   LSB_CHK_HIP(hipEventCreate(&sv->ev_t0));
   LSB_CHK_HIP(hipEventCreate(&sv->ev_t1));
   sv->have_events = 1;
+  LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+  for (int i = 0; i < sv->nshard; i++)
+    tune_spmv(sv, &sv->sh[i]);
   LSB_CHK_HIP(hipStreamSynchronize(g_stream));
 }
 
@@ -460,6 +477,8 @@ unsigned long long lsb_hip_solver_nnz_local(const lsb_hip_solver *s) {
 }
 unsigned lsb_hip_solver_nblocks(const lsb_hip_solver *s) { return s->sh[0].nblk; }
 int lsb_hip_solver_spmv_variant(const lsb_hip_solver *s) { return s->sh[0].variant; }
+unsigned lsb_hip_solver_spmv_flags(const lsb_hip_solver *s) { return s->sh[0].sp_flags; }
+unsigned lsb_hip_solver_spmv_grid(const lsb_hip_solver *s) { return s->sh[0].sp_grid; }
 
 /* ------------------------------------------------------------------------ */
 /* communication steps: RCCL between processes, device copies between the     */
@@ -493,8 +512,49 @@ static void allreduce_scal(lsb_hip_solver *sv, unsigned off, unsigned cnt) {
 static void spmv_shard(struct shard *s, const double *xfull, double *y,
                        const double *xdot, double *partials, unsigned *np,
                        const struct lsb_pcg_state *st) {
-  lsb_k_spmv(s->variant, s->n, s->d_offs, s->d_cols, s->d_vals, s->d_rowblk, s->nblk,
-             s->lanes, xfull, y, xdot, partials, np, st, g_stream);
+  lsb_k_spmv(s->variant, s->n, s->d_offs, s->d_cols, s->d_vals, s->d_rowblk, s->d_blklanes,
+             s->nblk, s->lanes, s->sp_flags, s->sp_grid, xfull, y, xdot, partials, np, st,
+             g_stream);
+}
+
+/*
+ * Pick the adaptive SpMV's flavour for this operator by timing it (setup is
+ * untimed, like the reference's csr_init): {plain, prefetch, nontemporal,
+ * both}, 3 launches each after one warm-up, on the
+ * shard's own matrix with the dot product fused as in the solve.  Which one
+ * wins depends on how much of x's gather window survives in L2 next to the
+ * matrix stream: on the 10M-row 5-point operator nontemporal stream loads win
+ * by 15%, on the 7-point 256^3 one prefetch without nontemporal does.
+ */
+static void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
+  const struct lsb_hip_opts *o = &sv->o;
+  s->sp_flags = LSB_SP_PREFETCH | LSB_SP_NT;
+  s->sp_grid = o->spmv_grid > 0 ? (unsigned)o->spmv_grid : LSB_MAX_PARTIALS;
+  if (o->spmv_tune >= 0) {
+    s->sp_flags = (unsigned)o->spmv_tune & 3u;
+    return;
+  }
+  if (s->variant != LSB_SPMV_ADAPTIVE || s->nnz < 4000000ull)
+    return; /* small operators are launch-latency bound: nothing to tune */
+  float best = 1e30f;
+  unsigned bf = s->sp_flags, np;
+  for (unsigned f = 0; f < 4; f++) {
+    s->sp_flags = f;
+    spmv_shard(s, s->d_pfull, s->d_q, s->d_pfull + s->row_begin, s->d_parts_pq, &np, NULL);
+    LSB_CHK_HIP(hipEventRecord(sv->ev_t0, g_stream));
+    for (int r = 0; r < 3; r++)
+      spmv_shard(s, s->d_pfull, s->d_q, s->d_pfull + s->row_begin, s->d_parts_pq, &np, NULL);
+    LSB_CHK_HIP(hipEventRecord(sv->ev_t1, g_stream));
+    LSB_CHK_HIP(hipEventSynchronize(sv->ev_t1));
+    float ms = 0.f;
+    LSB_CHK_HIP(hipEventElapsedTime(&ms, sv->ev_t0, sv->ev_t1));
+    if (o->verbose > 1)
+      fprintf(stderr, "hip_cdna4: spmv tune flags=%u grid=%u: %.1f us\n", f, s->sp_grid,
+              ms * 1e3f / 3);
+    if (ms < best)
+      best = ms, bf = f;
+  }
+  s->sp_flags = bf;
 }
 
 /* ------------------------------------------------------------------------ */
@@ -735,8 +795,9 @@ unsigned lsb_hip_partials_capacity(void) { return 2 * LSB_MAX_PARTIALS; }
 
 int lsb_hip_spmv_csr_f64(int variant, unsigned n, const int *d_offs,
                          const int *d_cols, const double *d_vals,
-                         const int *d_rowblk, unsigned nblk,
-                         unsigned mean_row_len, const double *d_x, double *d_y,
+                         const int *d_rowblk, const unsigned char *d_blklanes,
+                         unsigned nblk, unsigned mean_row_len, unsigned flags,
+                         const double *d_x, double *d_y,
                          const double *d_xdot, double *d_dot, double *d_work,
                          void *stream) {
   if (!initialized)
@@ -752,8 +813,8 @@ int lsb_hip_spmv_csr_f64(int variant, unsigned n, const int *d_offs,
   unsigned L = pow2_ceil(mean_row_len ? mean_row_len : 1);
   L = L < 2 ? 2 : (L > 64 ? 64 : L);
   unsigned np = 0;
-  lsb_k_spmv(variant, n, d_offs, d_cols, d_vals, d_rowblk, nblk, L, d_x, d_y,
-             d_dot ? d_xdot : NULL, d_dot ? d_work : NULL, &np, NULL, stream);
+  lsb_k_spmv(variant, n, d_offs, d_cols, d_vals, d_rowblk, d_blklanes, nblk, L, flags, 0,
+             d_x, d_y, d_dot ? d_xdot : NULL, d_dot ? d_work : NULL, &np, NULL, stream);
   if (d_dot)
     lsb_k_reduce_final(d_work, np, 1, d_dot, 0, NULL, stream);
   return 0;

@@ -76,16 +76,52 @@ __device__ __forceinline__ unsigned xcd_contiguous_wg() {
 // --------------------------------------------------------------------------
 // a2-1  SpMV, adaptive row blocks.
 // rowblk[k]..rowblk[k+1] is a run of consecutive rows holding <= CAP
-// non-zeros, or a single row longer than CAP (lsb_csr_row_blocks).  A
-// workgroup walks a contiguous range of row blocks.  Short-row blocks: the
-// non-zeros are streamed (fully coalesced vals/cols, gather of x), the
-// products parked in LDS, then L = 1..64 lanes per row add them up.  A long
-// row is swept by the whole workgroup.
+// non-zeros, or a single row longer than CAP (lsb_csr_row_blocks).
+//   * short-row block: all 256 lanes stream the block's cols/vals (fully
+//     coalesced, CAP/256 loads in flight per lane), gather x, park the products
+//     in LDS; then L = blklanes[k] (1..64) lanes per row add a row's products
+//     and finish with a wavefront shuffle tree;
+//   * long row: the whole workgroup strides over it from global memory.
+// Work assignment: the row blocks are cut into 8 contiguous chunks, one per
+// XCD, and inside a chunk dealt CYCLICALLY to that XCD's workgroups.  The
+// G/8 workgroups resident on one XCD therefore sweep G/8 ADJACENT blocks at any
+// time and the window of x they gather from (a few grid lines of a stencil)
+// fits that XCD's 4 MiB L2: measured 907 -> 732 MB fetched per launch on the
+// 10M-row 5-point operator (720 MB is the minimum).  A contiguous range per
+// workgroup keeps 256 far-apart windows alive per XCD and thrashes it.
+// SP_PREFETCH: the next block's stream loads are issued before the current
+// block is reduced.  SP_NT: the once-read cols/vals stream is loaded
+// nontemporal so it does not evict x from L2.  Both are picked per operator by
+// a timing pass at solver creation (hip_cdna4.c).
 // --------------------------------------------------------------------------
-template <int CAP>
-__global__ __launch_bounds__(WG) void k_spmv_adaptive(
-    const int *__restrict__ rowblk, unsigned nblk, unsigned blk_per_wg,
-    const int *__restrict__ offs, const int *__restrict__ cols,
+enum { SP_PREFETCH = 1, SP_NT = 2 };
+
+template <int FLAGS, class T>
+__device__ __forceinline__ T stream_load(const T *p) {
+  if (FLAGS & SP_NT)
+    return __builtin_nontemporal_load(p);
+  return *p;
+}
+
+#define LSB_ISSUE_BLOCK(kk)                                                    \
+  do {                                                                         \
+    r0 = rowblk[kk], r1 = rowblk[(kk) + 1];                                    \
+    j0 = offs[r0], j1 = offs[r1];                                              \
+    if (j1 - j0 <= CAP) {                                                      \
+      _Pragma("unroll") for (int u = 0; u < U; u++) {                          \
+        const int t = (int)tid + u * WG;                                       \
+        if (t < j1 - j0) {                                                     \
+          c[u] = stream_load<FLAGS>(cols + j0 + t);                            \
+          v[u] = stream_load<FLAGS>(vals + j0 + t);                            \
+        }                                                                      \
+      }                                                                        \
+    }                                                                          \
+  } while (0)
+
+template <int CAP, int FLAGS>
+__global__ __launch_bounds__(WG, 8) void k_spmv_adaptive(
+    const int *__restrict__ rowblk, const unsigned char *__restrict__ blklanes,
+    unsigned nblk, const int *__restrict__ offs, const int *__restrict__ cols,
     const double *__restrict__ vals, const double *__restrict__ x,
     double *__restrict__ y, const double *__restrict__ xdot,
     double *__restrict__ partials, const lsb_pcg_state *__restrict__ st) {
@@ -94,78 +130,82 @@ __global__ __launch_bounds__(WG) void k_spmv_adaptive(
   __shared__ double sprod[CAP];
   __shared__ double sred[4];
   const unsigned tid = threadIdx.x;
-  const unsigned w = xcd_contiguous_wg();
-  const unsigned k0 = w * blk_per_wg;
-  const unsigned k1 = min(k0 + blk_per_wg, nblk);
+  const unsigned gx = gridDim.x / NXCD; // workgroups per XCD
+  const unsigned xcd = blockIdx.x % NXCD, slot = blockIdx.x / NXCD;
+  const unsigned chunk = (nblk + NXCD - 1) / NXCD; // row blocks per XCD
+  const unsigned kbeg = xcd * chunk, kend = min(kbeg + chunk, nblk);
   constexpr int U = CAP / WG;
   double dot = 0.0;
-
-  for (unsigned k = k0; k < k1; k++) {
-    const int r0 = rowblk[k], r1 = rowblk[k + 1];
-    const int j0 = offs[r0], j1 = offs[r1];
-    const int cnt = j1 - j0, nr = r1 - r0;
+  int c[U];
+  double v[U];
+  int r0 = 0, r1 = 0, j0 = 0, j1 = 0;
+  unsigned k = kbeg + slot;
+  if (k < kend)
+    LSB_ISSUE_BLOCK(k);
+  for (; k < kend; k += gx) {
+    const int cr0 = r0, cj0 = j0, cnt = j1 - j0, nr = r1 - r0;
     if (cnt <= CAP) {
-      // ---- stream the block's non-zeros ------------------------------
-      int c[U];
-      double v[U];
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        const int t = tid + u * WG;
-        if (t < cnt) {
-          c[u] = cols[j0 + t];
-          v[u] = vals[j0 + t];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        const int t = tid + u * WG;
+        const int t = (int)tid + u * WG;
         if (t < cnt)
           sprod[t] = v[u] * x[c[u]];
       }
+      if ((FLAGS & SP_PREFETCH) && k + gx < kend)
+        LSB_ISSUE_BLOCK(k + gx);
       __syncthreads();
       // ---- L lanes per row add the products up -----------------------
-      unsigned L = 1;
-      while (L < 64 && (unsigned)nr * (L * 2) <= WG)
-        L <<= 1;
-      const unsigned slot = tid / L, l = tid % L, slots = WG / L;
+      unsigned L;
+      if (blklanes) {
+        L = blklanes[k];
+      } else {
+        L = 1;
+        while (L < 64 && (unsigned)nr * (L * 2) <= WG)
+          L <<= 1;
+      }
+      const unsigned sl = tid / L, l = tid % L, slots = WG / L;
       for (unsigned rb = 0; rb < (unsigned)nr; rb += slots) {
-        const unsigned r = rb + slot;
+        const unsigned r = rb + sl;
         double s = 0.0;
         if (r < (unsigned)nr) {
-          const int a = offs[r0 + r] - j0, b = offs[r0 + r + 1] - j0;
+          const int a = offs[cr0 + r] - cj0, b = offs[cr0 + r + 1] - cj0;
           for (int j = a + (int)l; j < b; j += (int)L)
             s += sprod[j];
         }
         for (unsigned off = L >> 1; off > 0; off >>= 1)
           s += __shfl_xor(s, off, 64);
         if (r < (unsigned)nr && l == 0) {
-          y[r0 + r] = s;
+          y[cr0 + r] = s;
           if (xdot)
-            dot += s * xdot[r0 + r];
+            dot += s * xdot[cr0 + r];
         }
       }
       __syncthreads(); // sprod is overwritten by the next block
     } else {
-      // ---- one long row: the whole workgroup strides over it ----------
+      // ---- one long row (nr == 1): the whole workgroup strides over it --
       double s[1] = {0.0};
-      for (int j = j0 + (int)tid; j < j1; j += WG)
+      for (int j = cj0 + (int)tid; j < cj0 + cnt; j += WG)
         s[0] += vals[j] * x[cols[j]];
       wg_sum<1>(s, sred);
       if (tid == 0) {
-        y[r0] = s[0];
+        y[cr0] = s[0];
         if (xdot)
-          dot += s[0] * xdot[r0];
+          dot += s[0] * xdot[cr0];
       }
-      // rows after a long row in the same block cannot happen (nr == 1)
+      if ((FLAGS & SP_PREFETCH) && k + gx < kend)
+        LSB_ISSUE_BLOCK(k + gx);
     }
+    if (!(FLAGS & SP_PREFETCH) && k + gx < kend)
+      LSB_ISSUE_BLOCK(k + gx);
   }
   if (partials) {
     double d[1] = {dot};
     wg_sum<1>(d, sred);
     if (tid == 0)
-      partials[w] = d[0];
+      partials[blockIdx.x] = d[0];
   }
 }
+#undef LSB_ISSUE_BLOCK
 
 // --------------------------------------------------------------------------
 // a2-1  SpMV, L lanes per row (L = 2..64; L = 64 is the classic
@@ -567,7 +607,7 @@ unsigned lsb_k_blas1_grid(unsigned n) {
 
 // number of workgroups (== number of dot partials) a given SpMV launch uses
 unsigned lsb_k_spmv_grid(int variant, unsigned n, unsigned nblk,
-                         unsigned lanes_per_row) {
+                         unsigned lanes_per_row, unsigned grid_cap) {
   unsigned items;
   if (variant == LSB_SPMV_ADAPTIVE)
     items = nblk;
@@ -576,24 +616,40 @@ unsigned lsb_k_spmv_grid(int variant, unsigned n, unsigned nblk,
   else
     items = div_up(n, WG);
   unsigned g = round_up(items ? items : 1, NXCD);
-  if (g > LSB_MAX_PARTIALS)
-    g = LSB_MAX_PARTIALS; // multiple of NXCD
+  if (grid_cap == 0 || grid_cap > LSB_MAX_PARTIALS)
+    grid_cap = LSB_MAX_PARTIALS;
+  grid_cap = grid_cap / NXCD * NXCD;
+  if (grid_cap < NXCD)
+    grid_cap = NXCD;
+  if (g > grid_cap)
+    g = grid_cap;
   return g;
 }
 
 void lsb_k_spmv(int variant, unsigned n, const int *offs, const int *cols,
-                const double *vals, const int *rowblk, unsigned nblk,
-                unsigned lanes_per_row, const double *x, double *y,
-                const double *xdot, double *partials, unsigned *npartials,
+                const double *vals, const int *rowblk,
+                const unsigned char *blklanes, unsigned nblk,
+                unsigned lanes_per_row, unsigned flags, unsigned grid_cap,
+                const double *x, double *y, const double *xdot,
+                double *partials, unsigned *npartials,
                 const struct lsb_pcg_state *st, void *stream) {
   hipStream_t s = (hipStream_t)stream;
-  const unsigned g = lsb_k_spmv_grid(variant, n, nblk, lanes_per_row);
+  const unsigned g = lsb_k_spmv_grid(variant, n, nblk, lanes_per_row, grid_cap);
   if (npartials)
     *npartials = g;
   if (variant == LSB_SPMV_ADAPTIVE) {
-    const unsigned per = div_up(nblk ? nblk : 1, g);
-    k_spmv_adaptive<LSB_BLOCK_NNZ><<<g, WG, 0, s>>>(rowblk, nblk, per, offs, cols, vals,
-                                                   x, y, xdot, partials, st);
+#define LSB_ADAPTIVE(FL)                                                       \
+  case FL:                                                                     \
+    k_spmv_adaptive<LSB_BLOCK_NNZ, FL><<<g, WG, 0, s>>>(                       \
+        rowblk, blklanes, nblk, offs, cols, vals, x, y, xdot, partials, st);   \
+    break;
+    switch (flags & 3u) {
+      LSB_ADAPTIVE(0)
+      LSB_ADAPTIVE(1)
+      LSB_ADAPTIVE(2)
+      LSB_ADAPTIVE(3)
+    }
+#undef LSB_ADAPTIVE
   } else if (variant == LSB_SPMV_SUBWAVE) {
     const unsigned L = lanes_per_row;
     const unsigned slots = WG / L;

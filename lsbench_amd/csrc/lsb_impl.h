@@ -42,12 +42,17 @@ struct lsb_pcg_state {
  * for the stand-alone (non-PCG) use of a kernel; when given, a non-zero
  * st->status turns the launch into a no-op on the device. */
 void lsb_k_spmv(int variant, unsigned n, const int *offs, const int *cols,
-                const double *vals, const int *rowblk, unsigned nblk,
-                unsigned lanes_per_row, const double *x, double *y,
-                const double *xdot, double *partials, unsigned *npartials,
+                const double *vals, const int *rowblk,
+                const unsigned char *blklanes, unsigned nblk,
+                unsigned lanes_per_row, unsigned flags, unsigned grid_cap,
+                const double *x, double *y, const double *xdot,
+                double *partials, unsigned *npartials,
                 const struct lsb_pcg_state *st, void *stream);
 unsigned lsb_k_spmv_grid(int variant, unsigned n, unsigned nblk,
-                         unsigned lanes_per_row);
+                         unsigned lanes_per_row, unsigned grid_cap);
+/* flags of the adaptive SpMV (picked by the timing pass at solver creation) */
+#define LSB_SP_PREFETCH 1u
+#define LSB_SP_NT 2u
 void lsb_k_reduce_final(const double *partials, unsigned nparts, unsigned width,
                         double *out, int take_sqrt,
                         const struct lsb_pcg_state *st, void *stream);

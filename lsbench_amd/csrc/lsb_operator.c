@@ -230,3 +230,30 @@ void lsb_plan_exchange(int me, int nall, const unsigned *hull,
   }
   *nrecv = nr, *nsend = ns;
 }
+
+/*
+ * Lanes per row for each row block of the adaptive SpMV: the largest power of
+ * two that still lets all rows of the block be reduced in one pass of the
+ * 256-lane workgroup, raised so that no lane adds more than ~16 products of
+ * the block's LONGEST row (a 1500-entry row packed with 29 short ones is then
+ * reduced by 64 lanes, not by 8).  1 <= lanes <= 64.
+ */
+void lsb_csr_block_lanes(const struct csr *A, const unsigned *rowblk,
+                         unsigned nblk, unsigned char *lanes) {
+  for (unsigned k = 0; k < nblk; k++) {
+    const unsigned r0 = rowblk[k], r1 = rowblk[k + 1], nr = r1 - r0;
+    unsigned maxlen = 0;
+    for (unsigned r = r0; r < r1; r++) {
+      const unsigned len = A->offs[r + 1] - A->offs[r];
+      if (len > maxlen)
+        maxlen = len;
+    }
+    unsigned L = 1;
+    while (L < 64 && (unsigned long long)nr * (L * 2) <= 256)
+      L <<= 1;
+    unsigned want = 1;
+    while (want < 64 && want * 16 < maxlen)
+      want <<= 1;
+    lanes[k] = (unsigned char)(L > want ? L : want);
+  }
+}

@@ -145,6 +145,22 @@ def test_row_blocks_invariants(cap, matrix_path):
             assert offs[rb[k + 1] + 1] - offs[rb[k]] > cap
 
 
+def test_block_lanes():
+    thr, _ = O.powerlaw_table(1.2, 3000)
+    o, c, v = O.powerlaw(4000, thr, 5)
+    for A in (la.Matrix.from_arrays(o, c, v), la.lsbench_matrix_synth("lap2d:nx=50,ny=50")):
+        rb = la.lsb_csr_row_blocks(A, 2048).astype(np.int64)
+        L = la.lsb_csr_block_lanes(A, rb).astype(np.int64)
+        lens = np.diff(A.offs.astype(np.int64))
+        for k in range(len(rb) - 1):
+            nr, mx = rb[k + 1] - rb[k], lens[rb[k]:rb[k + 1]].max()
+            assert L[k] in (1, 2, 4, 8, 16, 32, 64)
+            assert L[k] == 64 or L[k] * 16 >= mx            # <= 16 products per lane
+            fill = max(l for l in (1, 2, 4, 8, 16, 32, 64) if l == 1 or nr * l <= 256)
+            assert L[k] >= fill                             # never fewer than one pass needs
+    assert set(la.lsb_csr_block_lanes(A, rb)) == {1}        # 5-point rows: one lane each
+
+
 @pytest.mark.parametrize("P", [1, 2, 3, 4, 8])
 def test_partition_rows_balanced_and_even(P, matrix_path):
     S = la.lsb_csr_symmetrize_upper(la.lsbench_matrix_read(matrix_path("xn3b_A_10")))

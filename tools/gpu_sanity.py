@@ -67,6 +67,7 @@ def main():
         yo = O.spmv(A.offs, A.cols, A.vals, xh)
         absb = O.spmv(A.offs, A.cols, np.abs(A.vals), np.abs(xh))
         rb = la.lsb_csr_row_blocks(A, 2048)
+        d_bl = torch.from_numpy(la.lsb_csr_block_lanes(A, rb)).to(dev)
         d_offs = torch.from_numpy(A.offs.astype(np.int32)).to(dev)
         d_cols = torch.from_numpy(A.cols.astype(np.int32)).to(dev)
         d_vals = torch.from_numpy(A.vals.copy()).to(dev)
@@ -77,8 +78,8 @@ def main():
         for variant, mean in [(1, 0), (2, 2), (2, 4), (2, 8), (2, 16), (2, 32), (2, 64), (3, 0)]:
             d_y = torch.full((n,), float("nan"), dtype=torch.float64, device=dev)
             rc = lib.lsb_hip_spmv_csr_f64(variant, n, d_offs.data_ptr(), d_cols.data_ptr(),
-                                          d_vals.data_ptr(), d_rb.data_ptr(), len(rb) - 1, mean,
-                                          d_x.data_ptr(), d_y.data_ptr(), d_x.data_ptr(),
+                                          d_vals.data_ptr(), d_rb.data_ptr(), d_bl.data_ptr(),
+                                          len(rb) - 1, mean, 3, d_x.data_ptr(), d_y.data_ptr(), d_x.data_ptr(),
                                           d_dot.data_ptr(), d_w.data_ptr(), lib.lsb_hip_stream())
             assert rc == 0
             lib.lsb_hip_sync()

@@ -1,0 +1,870 @@
+// SpMV kernel laboratory (development tool, not shipped in the library).
+// Builds a synthetic operator on the host, runs N kernel variants interleaved
+// in ONE process (cdna_hip_programming.md section 5.4 rule 24), checks each
+// against a host reference and prints median microseconds and algorithmic GB/s
+// (12*nnz + 20*n + 4 bytes per launch).
+//   hipcc --offload-arch=gfx950 -O3 tools/spmv_lab.hip -o tools/spmv_lab
+//   tools/spmv_lab lap2d 3162 | lap3d 400 | powerlaw 8000000
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#define CHK(x)                                                                 \
+  do {                                                                         \
+    hipError_t e_ = (x);                                                       \
+    if (e_ != hipSuccess) {                                                    \
+      fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); \
+      exit(1);                                                                 \
+    }                                                                          \
+  } while (0)
+
+#define WG 256
+#define NXCD 8
+
+template <int W>
+__device__ __forceinline__ void wg_sum(double (&v)[W], double *sred) {
+#pragma unroll
+  for (int k = 0; k < W; k++)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+      v[k] += __shfl_xor(v[k], off, 64);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0)
+    for (int k = 0; k < W; k++)
+      sred[wave * W + k] = v[k];
+  __syncthreads();
+  for (int k = 0; k < W; k++)
+    v[k] = (sred[0 * W + k] + sred[1 * W + k]) + (sred[2 * W + k] + sred[3 * W + k]);
+}
+
+enum { F_NOREMAP = 1, F_FAKEGATHER = 2, F_NODOT = 4, F_NOX = 8, F_CYCLIC = 16, F_NT = 32, F_PREFETCH = 64 };
+template <int FLAGS, class T> __device__ __forceinline__ T ldg(const T *p) {
+  if (FLAGS & F_NT) return __builtin_nontemporal_load(p);
+  return *p;
+}
+
+
+template <int FLAGS>
+__device__ __forceinline__ unsigned logical_wg() {
+  if (FLAGS & F_NOREMAP)
+    return blockIdx.x;
+  const unsigned b = blockIdx.x, per = gridDim.x / NXCD;
+  return (b % NXCD) * per + b / NXCD;
+}
+
+// ---- V0: the library's adaptive kernel (8 B / 4 B per lane loads) ----------
+template <int CAP, int FLAGS>
+__global__ __launch_bounds__(WG) void k_adaptive(const int *__restrict__ rowblk, unsigned nblk,
+                                                 unsigned per, const int *__restrict__ offs,
+                                                 const int *__restrict__ cols,
+                                                 const double *__restrict__ vals,
+                                                 const double *__restrict__ x,
+                                                 double *__restrict__ y,
+                                                 double *__restrict__ partials) {
+  __shared__ double sprod[CAP];
+  __shared__ double sred[4];
+  const unsigned tid = threadIdx.x, w = logical_wg<FLAGS>();
+  const unsigned k0 = w * per, k1 = min(k0 + per, nblk);
+  constexpr int U = CAP / WG;
+  double dot = 0.0;
+  for (unsigned k = k0; k < k1; k++) {
+    const int r0 = rowblk[k], r1 = rowblk[k + 1];
+    const int j0 = offs[r0], j1 = offs[r1];
+    const int cnt = j1 - j0, nr = r1 - r0;
+    if (cnt <= CAP) {
+      int c[U];
+      double v[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int t = tid + u * WG;
+        if (t < cnt) {
+          c[u] = cols[j0 + t];
+          v[u] = vals[j0 + t];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int t = tid + u * WG;
+        if (t < cnt) {
+          if (FLAGS & F_NOX)
+            sprod[t] = v[u] * (double)c[u];
+          else if (FLAGS & F_FAKEGATHER)
+            sprod[t] = v[u] * x[c[u] & 1023];
+          else
+            sprod[t] = v[u] * x[c[u]];
+        }
+      }
+      __syncthreads();
+      unsigned L = 1;
+      while (L < 64 && (unsigned)nr * (L * 2) <= WG)
+        L <<= 1;
+      const unsigned slot = tid / L, l = tid % L, slots = WG / L;
+      for (unsigned rb = 0; rb < (unsigned)nr; rb += slots) {
+        const unsigned r = rb + slot;
+        double s = 0.0;
+        if (r < (unsigned)nr) {
+          const int a = offs[r0 + r] - j0, b = offs[r0 + r + 1] - j0;
+          for (int j = a + (int)l; j < b; j += (int)L)
+            s += sprod[j];
+        }
+        for (unsigned off = L >> 1; off > 0; off >>= 1)
+          s += __shfl_xor(s, off, 64);
+        if (r < (unsigned)nr && l == 0) {
+          y[r0 + r] = s;
+          if (!(FLAGS & F_NODOT))
+            dot += s * x[r0 + r];
+        }
+      }
+      __syncthreads();
+    } else {
+      double s[1] = {0.0};
+      for (int j = j0 + (int)tid; j < j1; j += WG)
+        s[0] += vals[j] * x[cols[j]];
+      wg_sum<1>(s, sred);
+      if (tid == 0) {
+        y[r0] = s[0];
+        dot += s[0] * x[r0];
+      }
+    }
+  }
+  if (!(FLAGS & F_NODOT)) {
+    double d[1] = {dot};
+    wg_sum<1>(d, sred);
+    if (tid == 0)
+      partials[w] = d[0];
+  }
+}
+
+// ---- V1: offsets staged in LDS too; reduce phase reads no global memory -----
+// and the next block's loads are issued before the current block is reduced.
+template <int CAP, int FLAGS>
+__global__ __launch_bounds__(WG) void k_adaptive_pipe(const int *__restrict__ rowblk,
+                                                      unsigned nblk, unsigned per,
+                                                      const int *__restrict__ offs,
+                                                      const int *__restrict__ cols,
+                                                      const double *__restrict__ vals,
+                                                      const double *__restrict__ x,
+                                                      double *__restrict__ y,
+                                                      double *__restrict__ partials) {
+  __shared__ double sprod[CAP];
+  __shared__ int soffs[CAP + 1]; // a block has at most CAP rows with >=1 nnz; empty rows: fallback
+  __shared__ double sred[4];
+  const unsigned tid = threadIdx.x, w = logical_wg<FLAGS>();
+  const unsigned k0 = w * per, k1 = min(k0 + per, nblk);
+  constexpr int U = CAP / WG;
+  double dot = 0.0;
+  int c[U];
+  double v[U];
+  int r0 = 0, r1 = 0, j0 = 0, j1 = 0;
+  if (k0 < k1) {
+    r0 = rowblk[k0], r1 = rowblk[k0 + 1];
+    j0 = offs[r0], j1 = offs[r1];
+    if (j1 - j0 <= CAP) {
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int t = tid + u * WG;
+        if (t < j1 - j0) {
+          c[u] = cols[j0 + t];
+          v[u] = vals[j0 + t];
+        }
+      }
+    }
+  }
+  for (unsigned k = k0; k < k1; k++) {
+    const int cnt = j1 - j0, nr = r1 - r0;
+    const int cr0 = r0, cj0 = j0;
+    if (cnt <= CAP && nr <= CAP) {
+      // gather + park products
+      double xv[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int t = tid + u * WG;
+        if (t < cnt)
+          xv[u] = x[c[u]];
+      }
+      // row offsets of this block -> LDS (coalesced)
+      for (int t = tid; t <= nr; t += WG)
+        soffs[t] = offs[cr0 + t] - cj0;
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int t = tid + u * WG;
+        if (t < cnt)
+          sprod[t] = v[u] * xv[u];
+      }
+      // prefetch the next block's stream before reducing this one
+      if (k + 1 < k1) {
+        r0 = rowblk[k + 1], r1 = rowblk[k + 2];
+        j0 = offs[r0], j1 = offs[r1];
+        if (j1 - j0 <= CAP) {
+#pragma unroll
+          for (int u = 0; u < U; u++) {
+            const int t = tid + u * WG;
+            if (t < j1 - j0) {
+              c[u] = cols[j0 + t];
+              v[u] = vals[j0 + t];
+            }
+          }
+        }
+      }
+      __syncthreads();
+      unsigned L = 1;
+      while (L < 64 && (unsigned)nr * (L * 2) <= WG)
+        L <<= 1;
+      const unsigned slot = tid / L, l = tid % L, slots = WG / L;
+      for (unsigned rb = 0; rb < (unsigned)nr; rb += slots) {
+        const unsigned r = rb + slot;
+        double s = 0.0;
+        if (r < (unsigned)nr) {
+          const int a = soffs[r], b = soffs[r + 1];
+          for (int j = a + (int)l; j < b; j += (int)L)
+            s += sprod[j];
+        }
+        for (unsigned off = L >> 1; off > 0; off >>= 1)
+          s += __shfl_xor(s, off, 64);
+        if (r < (unsigned)nr && l == 0) {
+          y[cr0 + r] = s;
+          if (!(FLAGS & F_NODOT))
+            dot += s * x[cr0 + r];
+        }
+      }
+      __syncthreads();
+    } else {
+      double s[1] = {0.0};
+      const int ej = cj0 + cnt;
+      // long row (or a block of > CAP rows, all but one empty): generic path
+      for (int r = cr0; r < cr0 + nr; r++) {
+        s[0] = 0.0;
+        const int a = offs[r], b = offs[r + 1];
+        for (int j = a + (int)tid; j < b; j += WG)
+          s[0] += vals[j] * x[cols[j]];
+        wg_sum<1>(s, sred);
+        if (tid == 0) {
+          y[r] = s[0];
+          dot += s[0] * x[r];
+        }
+      }
+      (void)ej;
+      if (k + 1 < k1) {
+        r0 = rowblk[k + 1], r1 = rowblk[k + 2];
+        j0 = offs[r0], j1 = offs[r1];
+        if (j1 - j0 <= CAP) {
+#pragma unroll
+          for (int u = 0; u < U; u++) {
+            const int t = tid + u * WG;
+            if (t < j1 - j0) {
+              c[u] = cols[j0 + t];
+              v[u] = vals[j0 + t];
+            }
+          }
+        }
+      }
+    }
+  }
+  if (!(FLAGS & F_NODOT)) {
+    double d[1] = {dot};
+    wg_sum<1>(d, sred);
+    if (tid == 0)
+      partials[w] = d[0];
+  }
+}
+
+// ---- V2: 16 B/lane loads.  The block's nnz range is widened to a multiple of
+// 4 at both ends (cols as int4, vals as 2 x double2); the extra entries are
+// masked.  Offsets via LDS as in V1, no prefetch.
+template <int CAP, int FLAGS>
+__global__ __launch_bounds__(WG) void k_adaptive_v4(const int *__restrict__ rowblk,
+                                                    unsigned nblk, unsigned per,
+                                                    const int *__restrict__ offs,
+                                                    const int *__restrict__ cols,
+                                                    const double *__restrict__ vals,
+                                                    const double *__restrict__ x,
+                                                    double *__restrict__ y,
+                                                    double *__restrict__ partials,
+                                                    int nnz_total) {
+  __shared__ double sprod[CAP + 8];
+  __shared__ int soffs[CAP + 1];
+  __shared__ double sred[4];
+  const unsigned tid = threadIdx.x, w = logical_wg<FLAGS>();
+  const unsigned k0 = w * per, k1 = min(k0 + per, nblk);
+  constexpr int Q = (CAP / 4 + WG) / WG; // quads per thread (+1 quad of slack)
+  double dot = 0.0;
+  for (unsigned k = k0; k < k1; k++) {
+    const int r0 = rowblk[k], r1 = rowblk[k + 1];
+    const int j0 = offs[r0], j1 = offs[r1];
+    const int cnt = j1 - j0, nr = r1 - r0;
+    if (cnt <= CAP && nr <= CAP) {
+      const int ja = j0 & ~3;           // aligned start
+      const int nq = (j1 - ja + 3) / 4; // quads to fetch
+      int4 c4[Q];
+      double2 va[Q], vb[Q];
+#pragma unroll
+      for (int u = 0; u < Q; u++) {
+        const int q = tid + u * WG;
+        if (q < nq && ja + 4 * q + 4 <= ((nnz_total + 3) & ~3)) {
+          c4[u] = *(const int4 *)(cols + ja + 4 * q);
+          va[u] = *(const double2 *)(vals + ja + 4 * q);
+          vb[u] = *(const double2 *)(vals + ja + 4 * q + 2);
+        }
+      }
+      for (int t = tid; t <= nr; t += WG)
+        soffs[t] = offs[r0 + t] - j0;
+      const int sh = j0 - ja; // 0..3 leading entries to drop
+#pragma unroll
+      for (int u = 0; u < Q; u++) {
+        const int q = tid + u * WG;
+        if (q < nq) {
+          const int e = 4 * q - sh; // index of the quad's first entry in the block
+          const int cc[4] = {c4[u].x, c4[u].y, c4[u].z, c4[u].w};
+          const double vv[4] = {va[u].x, va[u].y, vb[u].x, vb[u].y};
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if (e + i >= 0 && e + i < cnt)
+              sprod[e + i] = vv[i] * x[cc[i]];
+        }
+      }
+      __syncthreads();
+      unsigned L = 1;
+      while (L < 64 && (unsigned)nr * (L * 2) <= WG)
+        L <<= 1;
+      const unsigned slot = tid / L, l = tid % L, slots = WG / L;
+      for (unsigned rb = 0; rb < (unsigned)nr; rb += slots) {
+        const unsigned r = rb + slot;
+        double s = 0.0;
+        if (r < (unsigned)nr) {
+          const int a = soffs[r], b = soffs[r + 1];
+          for (int j = a + (int)l; j < b; j += (int)L)
+            s += sprod[j];
+        }
+        for (unsigned off = L >> 1; off > 0; off >>= 1)
+          s += __shfl_xor(s, off, 64);
+        if (r < (unsigned)nr && l == 0) {
+          y[r0 + r] = s;
+          if (!(FLAGS & F_NODOT))
+            dot += s * x[r0 + r];
+        }
+      }
+      __syncthreads();
+    } else {
+      double s[1];
+      for (int r = r0; r < r1; r++) {
+        s[0] = 0.0;
+        const int a = offs[r], b = offs[r + 1];
+        for (int j = a + (int)tid; j < b; j += WG)
+          s[0] += vals[j] * x[cols[j]];
+        wg_sum<1>(s, sred);
+        if (tid == 0) {
+          y[r] = s[0];
+          dot += s[0] * x[r];
+        }
+      }
+    }
+  }
+  if (!(FLAGS & F_NODOT)) {
+    double d[1] = {dot};
+    wg_sum<1>(d, sred);
+    if (tid == 0)
+      partials[w] = d[0];
+  }
+}
+
+// ---- V3: blocks dealt CYCLICALLY to the workgroups of one XCD (the XCD's 256
+// resident workgroups then sweep 256 ADJACENT row blocks together, so the x
+// window they gather from fits the XCD's 4 MiB L2), optional register prefetch
+// of the next block's stream and nontemporal stream loads.
+template <int CAP, int FLAGS, int MINW = 8>
+__global__ __launch_bounds__(WG, MINW) void k_adaptive_cyc(const int *__restrict__ rowblk, unsigned nblk,
+                                                 unsigned per, const int *__restrict__ offs,
+                                                 const int *__restrict__ cols,
+                                                 const double *__restrict__ vals,
+                                                 const double *__restrict__ x,
+                                                 double *__restrict__ y,
+                                                 double *__restrict__ partials) {
+  __shared__ double sprod[CAP];
+  __shared__ double sred[4];
+  const unsigned tid = threadIdx.x;
+  const unsigned gx = gridDim.x / NXCD;           // workgroups per XCD
+  const unsigned xcd = blockIdx.x % NXCD, slot = blockIdx.x / NXCD;
+  const unsigned chunk = (nblk + NXCD - 1) / NXCD; // row blocks per XCD
+  const unsigned kbeg = xcd * chunk, kend = min(kbeg + chunk, nblk);
+  constexpr int U = CAP / WG;
+  double dot = 0.0;
+  int c[U];
+  double v[U];
+  unsigned k = kbeg + slot;
+  int r0 = 0, r1 = 0, j0 = 0, j1 = 0;
+#define ISSUE_WG(kk)                                                           \
+  do {                                                                         \
+    r0 = rowblk[kk], r1 = rowblk[(kk) + 1];                                    \
+    j0 = offs[r0], j1 = offs[r1];                                              \
+    if (j1 - j0 <= CAP) {                                                      \
+      _Pragma("unroll") for (int u = 0; u < U; u++) {                          \
+        const int t = tid + u * WG;                                            \
+        if (t < j1 - j0) {                                                     \
+          c[u] = ldg<FLAGS>(cols + j0 + t);                                    \
+          v[u] = ldg<FLAGS>(vals + j0 + t);                                    \
+        }                                                                      \
+      }                                                                        \
+    }                                                                          \
+  } while (0)
+  if (k < kend)
+    ISSUE_WG(k);
+  for (; k < kend; k += gx) {
+    const int cr0 = r0, cj0 = j0, cnt = j1 - j0, nr = r1 - r0;
+    if (cnt <= CAP) {
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int t = tid + u * WG;
+        if (t < cnt)
+          sprod[t] = v[u] * x[c[u]];
+      }
+      if ((FLAGS & F_PREFETCH) && k + gx < kend)
+        ISSUE_WG(k + gx);
+      __syncthreads();
+      unsigned L = 1;
+      while (L < 64 && (unsigned)nr * (L * 2) <= WG)
+        L <<= 1;
+      const unsigned sl = tid / L, l = tid % L, slots = WG / L;
+      for (unsigned rb = 0; rb < (unsigned)nr; rb += slots) {
+        const unsigned r = rb + sl;
+        double s = 0.0;
+        if (r < (unsigned)nr) {
+          const int a = offs[cr0 + r] - cj0, b = offs[cr0 + r + 1] - cj0;
+          for (int j = a + (int)l; j < b; j += (int)L)
+            s += sprod[j];
+        }
+        for (unsigned off = L >> 1; off > 0; off >>= 1)
+          s += __shfl_xor(s, off, 64);
+        if (r < (unsigned)nr && l == 0) {
+          y[cr0 + r] = s;
+          if (!(FLAGS & F_NODOT))
+            dot += s * x[cr0 + r];
+        }
+      }
+      __syncthreads();
+    } else {
+      double s[1] = {0.0};
+      for (int j = cj0 + (int)tid; j < cj0 + cnt; j += WG)
+        s[0] += vals[j] * x[cols[j]];
+      wg_sum<1>(s, sred);
+      if (tid == 0) {
+        y[cr0] = s[0];
+        dot += s[0] * x[cr0];
+      }
+      if ((FLAGS & F_PREFETCH) && k + gx < kend)
+        ISSUE_WG(k + gx);
+    }
+    if (!(FLAGS & F_PREFETCH) && k + gx < kend)
+      ISSUE_WG(k + gx);
+  }
+  if (!(FLAGS & F_NODOT)) {
+    double d[1] = {dot};
+    wg_sum<1>(d, sred);
+    if (tid == 0)
+      partials[xcd * gx + slot] = d[0];
+  }
+}
+
+// ---- V4: wave-private pipeline.  Each of the 4 wavefronts of a workgroup owns
+// CAPW LDS doubles and walks its own (cyclically dealt) row blocks of <= CAPW
+// non-zeros: no __syncthreads in the main loop, the waves never wait for each
+// other.  DS operations of one wavefront execute in order, so a wave-scope
+// fence (compiler ordering only) is all that separates the product writes from
+// the row sums.
+template <int CAPW, int FLAGS, int MINW = 8>
+__global__ __launch_bounds__(WG, MINW) void k_wave(const int *__restrict__ rowblk, unsigned nblk,
+                                                unsigned per, const int *__restrict__ offs,
+                                                const int *__restrict__ cols,
+                                                const double *__restrict__ vals,
+                                                const double *__restrict__ x,
+                                                double *__restrict__ y,
+                                                double *__restrict__ partials) {
+  __shared__ double sprod_all[4 * CAPW];
+  __shared__ double sred[4];
+  const unsigned tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  double *sprod = sprod_all + wave * CAPW;
+  const unsigned gx = gridDim.x / NXCD;
+  const unsigned xcd = blockIdx.x % NXCD, slot = blockIdx.x / NXCD;
+  const unsigned chunk = (nblk + NXCD - 1) / NXCD;
+  const unsigned kbeg = xcd * chunk, kend = min(kbeg + chunk, nblk);
+  const unsigned stride = gx * 4;
+  constexpr int U = CAPW / 64;
+  double dot = 0.0;
+  int c[U];
+  double v[U];
+  int r0 = 0, r1 = 0, j0 = 0, j1 = 0;
+#define ISSUE_WAVE(kk)                                                         \
+  do {                                                                         \
+    r0 = __builtin_amdgcn_readfirstlane(rowblk[kk]);                           \
+    r1 = __builtin_amdgcn_readfirstlane(rowblk[(kk) + 1]);                     \
+    j0 = __builtin_amdgcn_readfirstlane(offs[r0]);                             \
+    j1 = __builtin_amdgcn_readfirstlane(offs[r1]);                             \
+    if (j1 - j0 <= CAPW) {                                                     \
+      _Pragma("unroll") for (int u = 0; u < U; u++) {                          \
+        const int t = lane + u * 64;                                           \
+        if (t < j1 - j0) {                                                     \
+          c[u] = ldg<FLAGS>(cols + j0 + t);                                    \
+          v[u] = ldg<FLAGS>(vals + j0 + t);                                    \
+        }                                                                      \
+      }                                                                        \
+    }                                                                          \
+  } while (0)
+  unsigned k = kbeg + slot * 4 + wave;
+  if (k < kend)
+    ISSUE_WAVE(k);
+  for (; k < kend; k += stride) {
+    const int cr0 = r0, cj0 = j0, cnt = j1 - j0, nr = r1 - r0;
+    if (cnt <= CAPW) {
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int t = lane + u * 64;
+        if (t < cnt)
+          sprod[t] = v[u] * x[c[u]];
+      }
+      if ((FLAGS & F_PREFETCH) && k + stride < kend)
+        ISSUE_WAVE(k + stride);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      unsigned L = 1;
+      while (L < 64 && (unsigned)nr * (L * 2) <= 64)
+        L <<= 1;
+      const unsigned sl = lane / L, l = lane % L, slots = 64 / L;
+      for (unsigned rb = 0; rb < (unsigned)nr; rb += slots) {
+        const unsigned r = rb + sl;
+        double s = 0.0;
+        if (r < (unsigned)nr) {
+          const int a = offs[cr0 + r] - cj0, b = offs[cr0 + r + 1] - cj0;
+          for (int j = a + (int)l; j < b; j += (int)L)
+            s += sprod[j];
+        }
+        for (unsigned off = L >> 1; off > 0; off >>= 1)
+          s += __shfl_xor(s, off, 64);
+        if (r < (unsigned)nr && l == 0) {
+          y[cr0 + r] = s;
+          if (!(FLAGS & F_NODOT))
+            dot += s * x[cr0 + r];
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    } else {
+      // long row: this wavefront alone strides over it
+      for (int r = cr0; r < cr0 + nr; r++) {
+        double s = 0.0;
+        for (int j = offs[r] + (int)lane; j < offs[r + 1]; j += 64)
+          s += vals[j] * x[cols[j]];
+        for (int off = 32; off > 0; off >>= 1)
+          s += __shfl_xor(s, off, 64);
+        if (lane == 0) {
+          y[r] = s;
+          dot += s * x[r];
+        }
+      }
+      if ((FLAGS & F_PREFETCH) && k + stride < kend)
+        ISSUE_WAVE(k + stride);
+    }
+    if (!(FLAGS & F_PREFETCH) && k + stride < kend)
+      ISSUE_WAVE(k + stride);
+  }
+  if (!(FLAGS & F_NODOT)) {
+    double d[1] = {dot};
+    wg_sum<1>(d, sred);
+    if (tid == 0)
+      partials[xcd * gx + slot] = d[0];
+  }
+}
+
+// ---- ceiling probes ---------------------------------------------------------
+// stream: read cols+vals (16 B/lane), write one double per 5 nnz-ish (n of them)
+__global__ __launch_bounds__(WG) void k_stream_ceiling(const int4 *__restrict__ cols4,
+                                                       const double2 *__restrict__ vals2,
+                                                       size_t nq, double *__restrict__ y,
+                                                       size_t n) {
+  double acc = 0.0;
+  const size_t g = (size_t)gridDim.x * WG;
+  for (size_t q = (size_t)blockIdx.x * WG + threadIdx.x; q < nq; q += g) {
+    const int4 c = cols4[q];
+    const double2 a = vals2[2 * q], b = vals2[2 * q + 1];
+    acc += a.x * c.x + a.y * c.y + b.x * c.z + b.y * c.w;
+  }
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n; i += g)
+    y[i] = acc;
+}
+
+// ---------------------------------------------------------------------------
+struct Csr {
+  int n;
+  std::vector<int> offs, cols;
+  std::vector<double> vals;
+};
+
+static Csr lap2d(int nx, int ny) {
+  Csr A;
+  A.n = nx * ny;
+  A.offs.resize(A.n + 1);
+  A.cols.reserve((size_t)5 * A.n);
+  A.vals.reserve((size_t)5 * A.n);
+  for (int j = 0; j < ny; j++)
+    for (int i = 0; i < nx; i++) {
+      const int r = j * nx + i;
+      A.offs[r] = (int)A.cols.size();
+      if (j > 0) A.cols.push_back(r - nx), A.vals.push_back(-1);
+      if (i > 0) A.cols.push_back(r - 1), A.vals.push_back(-1);
+      A.cols.push_back(r), A.vals.push_back(4);
+      if (i + 1 < nx) A.cols.push_back(r + 1), A.vals.push_back(-1);
+      if (j + 1 < ny) A.cols.push_back(r + nx), A.vals.push_back(-1);
+    }
+  A.offs[A.n] = (int)A.cols.size();
+  return A;
+}
+
+static Csr lap3d(int nx, int ny, int nz) {
+  Csr A;
+  A.n = nx * ny * nz;
+  A.offs.resize((size_t)A.n + 1);
+  A.cols.reserve((size_t)7 * A.n);
+  A.vals.reserve((size_t)7 * A.n);
+  const int nxy = nx * ny;
+  for (int k = 0; k < nz; k++)
+    for (int j = 0; j < ny; j++)
+      for (int i = 0; i < nx; i++) {
+        const int r = (k * ny + j) * nx + i;
+        A.offs[r] = (int)A.cols.size();
+        if (k > 0) A.cols.push_back(r - nxy), A.vals.push_back(-1);
+        if (j > 0) A.cols.push_back(r - nx), A.vals.push_back(-1);
+        if (i > 0) A.cols.push_back(r - 1), A.vals.push_back(-1);
+        A.cols.push_back(r), A.vals.push_back(6);
+        if (i + 1 < nx) A.cols.push_back(r + 1), A.vals.push_back(-1);
+        if (j + 1 < ny) A.cols.push_back(r + nx), A.vals.push_back(-1);
+        if (k + 1 < nz) A.cols.push_back(r + nxy), A.vals.push_back(-1);
+      }
+  A.offs[A.n] = (int)A.cols.size();
+  return A;
+}
+
+static uint64_t mix(uint64_t s, uint64_t a, uint64_t b) {
+  uint64_t z = s + 0x9E3779B97F4A7C15ull * (a + 1) + 0xC2B2AE3D27D4EB4Full * (b + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+static Csr powerlaw(int n, double gamma, int dmax) {
+  std::vector<double> cdf(dmax);
+  double tot = 0, acc = 0;
+  for (int d = 1; d <= dmax; d++) tot += pow(d, -gamma);
+  for (int d = 1; d <= dmax; d++) acc += pow(d, -gamma) / tot, cdf[d - 1] = acc;
+  Csr A;
+  A.n = n;
+  A.offs.resize((size_t)n + 1);
+  size_t z = 0;
+  for (int r = 0; r < n; r++) {
+    A.offs[r] = (int)z;
+    const double u = (double)(mix(7, r, 0) >> 11) / 9007199254740992.0;
+    int d = (int)(std::lower_bound(cdf.begin(), cdf.end(), u) - cdf.begin()) + 1;
+    d = std::min(d, dmax);
+    z += d;
+  }
+  A.offs[n] = (int)z;
+  A.cols.resize(z);
+  A.vals.resize(z);
+#pragma omp parallel for schedule(dynamic, 4096)
+  for (int r = 0; r < n; r++) {
+    const int d = A.offs[r + 1] - A.offs[r];
+    for (int k = 0; k < d; k++) {
+      const uint64_t uk = mix(7, r, 2 * k + 1) % (uint64_t)(n - d + 1);
+      A.cols[A.offs[r] + k] = (int)(((unsigned __int128)k * n + uk) / d);
+      A.vals[A.offs[r] + k] = (double)(mix(7, r, 2 * k + 2) >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+    }
+  }
+  return A;
+}
+
+static std::vector<int> row_blocks(const Csr &A, int cap) {
+  std::vector<int> rb{0};
+  int r = 0;
+  while (r < A.n) {
+    const long lim = (long)A.offs[r] + cap;
+    int e = r + 1;
+    if (A.offs[e] <= lim)
+      e = (int)(std::upper_bound(A.offs.begin() + r + 1, A.offs.end(), (int)std::min<long>(lim, 0x7fffffff)) -
+                A.offs.begin()) - 1;
+    rb.push_back(e);
+    r = e;
+  }
+  return rb;
+}
+
+template <class T>
+static T *upload(const std::vector<T> &h) {
+  T *d;
+  CHK(hipMalloc(&d, h.size() * sizeof(T) + 64));
+  CHK(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  return d;
+}
+
+struct Variant {
+  std::string name;
+  int cap;
+  void (*launch)(const Variant &, unsigned g, unsigned per, unsigned nblk, const int *rb,
+                 const int *offs, const int *cols, const double *vals, const double *x, double *y,
+                 double *parts, int nnz);
+  unsigned maxgrid;
+  std::vector<float> us;
+  const int *d_rb = nullptr;
+  unsigned nblk = 0;
+  bool check = true;
+};
+
+#define LAUNCHER(fn, KERNEL, ...)                                                             \
+  static void fn(const Variant &v, unsigned g, unsigned per, unsigned nblk, const int *rb,    \
+                 const int *offs, const int *cols, const double *vals, const double *x,       \
+                 double *y, double *parts, int nnz) {                                         \
+    KERNEL<<<g, WG>>>(rb, nblk, per, offs, cols, vals, x, y, parts __VA_ARGS__);              \
+  }
+
+LAUNCHER(l_base2048, (k_adaptive<2048, 0>))
+LAUNCHER(l_base1024, (k_adaptive<1024, 0>))
+LAUNCHER(l_base4096, (k_adaptive<4096, 0>))
+LAUNCHER(l_noremap, (k_adaptive<2048, F_NOREMAP>))
+LAUNCHER(l_fakeg, (k_adaptive<2048, F_FAKEGATHER>))
+LAUNCHER(l_nox, (k_adaptive<2048, F_NOX>))
+LAUNCHER(l_nodot, (k_adaptive<2048, F_NODOT>))
+LAUNCHER(l_pipe2048, (k_adaptive_pipe<2048, 0>))
+LAUNCHER(l_pipe1024, (k_adaptive_pipe<1024, 0>))
+LAUNCHER(l_cyc, (k_adaptive_cyc<2048, F_CYCLIC>))
+LAUNCHER(l_cyc_pf, (k_adaptive_cyc<2048, F_CYCLIC | F_PREFETCH>))
+LAUNCHER(l_cyc_pf7, (k_adaptive_cyc<2048, F_CYCLIC | F_PREFETCH, 7>))
+LAUNCHER(l_cyc_pf6, (k_adaptive_cyc<2048, F_CYCLIC | F_PREFETCH, 6>))
+LAUNCHER(l_wave512_pf7, (k_wave<512, F_PREFETCH, 7>))
+LAUNCHER(l_wave512_pf6, (k_wave<512, F_PREFETCH, 6>))
+LAUNCHER(l_cyc_pf_nt, (k_adaptive_cyc<2048, F_CYCLIC | F_PREFETCH | F_NT>))
+LAUNCHER(l_cyc_nt, (k_adaptive_cyc<2048, F_CYCLIC | F_NT>))
+LAUNCHER(l_cyc1024_pf, (k_adaptive_cyc<1024, F_CYCLIC | F_PREFETCH>))
+LAUNCHER(l_wave512, (k_wave<512, 0>))
+LAUNCHER(l_wave512_pf, (k_wave<512, F_PREFETCH>))
+LAUNCHER(l_wave512_pf_nt, (k_wave<512, F_PREFETCH | F_NT>))
+LAUNCHER(l_wave256_pf, (k_wave<256, F_PREFETCH>))
+LAUNCHER(l_wave1024_pf, (k_wave<1024, F_PREFETCH>))
+LAUNCHER(l_v4_2048, (k_adaptive_v4<2048, 0>), , nnz)
+LAUNCHER(l_v4_1024, (k_adaptive_v4<1024, 0>), , nnz)
+LAUNCHER(l_v4_4096, (k_adaptive_v4<4096, 0>), , nnz)
+
+int main(int argc, char **argv) {
+  const std::string kind = argc > 1 ? argv[1] : "lap2d";
+  const int size = argc > 2 ? atoi(argv[2]) : 3162;
+  const int rounds = argc > 3 ? atoi(argv[3]) : 15;
+  Csr A = kind == "lap3d" ? lap3d(size, size, size)
+                          : (kind == "powerlaw" ? powerlaw(size, 1.585350372615855, 4096) : lap2d(size, size));
+  const size_t nnz = A.cols.size();
+  const double bytes = 12.0 * nnz + 20.0 * A.n + 4;
+  printf("%s %d: n=%d nnz=%zu algorithmic bytes=%.0f\n", kind.c_str(), size, A.n, nnz, bytes);
+  std::vector<double> hx(A.n), href(A.n);
+  for (int i = 0; i < A.n; i++)
+    hx[i] = (double)(mix(1, i, 0) >> 11) / 9007199254740992.0 - 0.5;
+#pragma omp parallel for
+  for (int i = 0; i < A.n; i++) {
+    double s = 0;
+    for (int j = A.offs[i]; j < A.offs[i + 1]; j++) s += A.vals[j] * hx[A.cols[j]];
+    href[i] = s;
+  }
+  int *d_offs = upload(A.offs), *d_cols = upload(A.cols);
+  double *d_vals = upload(A.vals), *d_x = upload(hx), *d_y, *d_parts;
+  CHK(hipMalloc(&d_y, (size_t)A.n * 8));
+  CHK(hipMalloc(&d_parts, 4096 * 8));
+
+  std::vector<Variant> vs = {
+      {"adaptive cap2048 g2048 (library)", 2048, l_base2048, 2048},
+      {"adaptive cap2048 g4096", 2048, l_base2048, 4096},
+      {"cyc cap2048 g2048", 2048, l_cyc, 2048},
+      {"cyc cap2048 g4096", 2048, l_cyc, 4096},
+      {"cyc+prefetch cap2048 g2048", 2048, l_cyc_pf, 2048},
+      {"cyc+prefetch cap2048 minw7 g1792", 2048, l_cyc_pf7, 1792},
+      {"cyc+prefetch cap2048 minw6 g1536", 2048, l_cyc_pf6, 1536},
+      {"wave+prefetch capw512 minw7 g1792", 512, l_wave512_pf7, 1792},
+      {"wave+prefetch capw512 minw6 g1536", 512, l_wave512_pf6, 1536},
+      {"cyc+prefetch+nt cap2048 g2048", 2048, l_cyc_pf_nt, 2048},
+      {"cyc+nt cap2048 g2048", 2048, l_cyc_nt, 2048},
+      {"cyc+prefetch cap1024 g2048", 1024, l_cyc1024_pf, 2048},
+      {"wave capw512 g2048", 512, l_wave512, 2048},
+      {"wave+prefetch capw512 g2048", 512, l_wave512_pf, 2048},
+      {"wave+prefetch+nt capw512 g2048", 512, l_wave512_pf_nt, 2048},
+      {"wave+prefetch capw256 g2048", 256, l_wave256_pf, 2048},
+      {"probe: no x gather at all", 2048, l_nox, 2048},
+  };
+  vs.back().check = false;
+  // row blocks per distinct cap
+  std::vector<std::pair<int, std::pair<int *, unsigned>>> rbs;
+  for (auto &v : vs) {
+    bool found = false;
+    for (auto &e : rbs)
+      if (e.first == v.cap) v.d_rb = e.second.first, v.nblk = e.second.second, found = true;
+    if (!found) {
+      auto rb = row_blocks(A, v.cap);
+      int *d = upload(rb);
+      rbs.push_back({v.cap, {d, (unsigned)rb.size() - 1}});
+      v.d_rb = d, v.nblk = (unsigned)rb.size() - 1;
+    }
+  }
+  hipEvent_t e0, e1;
+  CHK(hipEventCreate(&e0));
+  CHK(hipEventCreate(&e1));
+  std::vector<double> hy(A.n);
+  auto run = [&](Variant &v) {
+    unsigned g = std::min(v.maxgrid, ((v.nblk + 7) / 8) * 8);
+    unsigned per = (v.nblk + g - 1) / g;
+    v.launch(v, g, per, v.nblk, v.d_rb, d_offs, d_cols, d_vals, d_x, d_y, d_parts, (int)nnz);
+  };
+  // correctness first
+  for (auto &v : vs) {
+    CHK(hipMemset(d_y, 0xff, (size_t)A.n * 8));
+    run(v);
+    CHK(hipDeviceSynchronize());
+    if (!v.check) continue;
+    CHK(hipMemcpy(hy.data(), d_y, (size_t)A.n * 8, hipMemcpyDeviceToHost));
+    double worst = 0;
+    for (int i = 0; i < A.n; i++) {
+      const double d = fabs(hy[i] - href[i]);
+      if (!(d <= 1e-9)) worst = std::max(worst, std::isnan(d) ? 1e300 : d);
+    }
+    printf("check %-36s %s (worst %.2e)\n", v.name.c_str(), worst == 0 ? "ok" : "MISMATCH", worst);
+  }
+  // stream ceiling probe
+  std::vector<float> ceil_us;
+  for (int r = 0; r < rounds + 2; r++) {
+    for (auto &v : vs) {
+      CHK(hipEventRecord(e0));
+      run(v);
+      CHK(hipEventRecord(e1));
+      CHK(hipEventSynchronize(e1));
+      float ms;
+      CHK(hipEventElapsedTime(&ms, e0, e1));
+      if (r >= 2) v.us.push_back(ms * 1e3f);
+    }
+    CHK(hipEventRecord(e0));
+    k_stream_ceiling<<<2048, WG>>>((const int4 *)d_cols, (const double2 *)d_vals, nnz / 4, d_y, A.n);
+    CHK(hipEventRecord(e1));
+    CHK(hipEventSynchronize(e1));
+    float ms;
+    CHK(hipEventElapsedTime(&ms, e0, e1));
+    if (r >= 2) ceil_us.push_back(ms * 1e3f);
+  }
+  auto med = [](std::vector<float> v) {
+    std::sort(v.begin(), v.end());
+    return std::make_pair(v[v.size() / 2], v[0]);
+  };
+  for (auto &v : vs) {
+    auto m = med(v.us);
+    printf("%-36s median %8.1f us  min %8.1f us  => %6.0f GB/s  (%.1f%% of 8 TB/s)\n", v.name.c_str(),
+           m.first, m.second, bytes / m.first / 1e3, bytes / m.first / 1e3 / 80.0);
+  }
+  auto m = med(ceil_us);
+  const double sb = 12.0 * nnz + 8.0 * A.n;
+  printf("%-36s median %8.1f us  min %8.1f us  => %6.0f GB/s of its own %0.f bytes\n",
+         "ceiling: stream cols+vals, write y", m.first, m.second, sb / m.first / 1e3, sb);
+  return 0;
+}
