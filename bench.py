@@ -61,6 +61,11 @@ def parse():
     p.add_argument("--tol", type=float, default=1e-8)
     p.add_argument("--maxit", type=int, default=100000)
     p.add_argument("--spmv", type=int, default=0, help="LSB_SPMV_* variant (0 = auto)")
+    p.add_argument("--spmv-tune", type=int, default=-1,
+                   help="-1 = timing pass at setup picks the SpMV flavour; 0..3 force it")
+    p.add_argument("--fixed-iters", type=int, default=0,
+                   help="experiment mode: run exactly this many iterations per step "
+                        "(tol = 0); the line is marked and is NOT a solves/s figure")
     p.add_argument("--cpu-seconds", type=float, default=12.0,
                    help="budget of the CPU baseline leg (0 = skip)")
     return p.parse_args()
@@ -75,11 +80,30 @@ def read_file_matrix(path):
     return la.lsbench_matrix_read(path)
 
 
+def host_cores():
+    """CPU share of this process: affinity mask capped by the cgroup quota (the
+    GPU box shows 256 logical CPUs but grants 16)."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            parts = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    return n
+
+
 def cpu_baseline(A, gpu_iters, budget_s, is_spd):
-    """Oracle PCG (OpenMP, all cores) on a bounded number of iterations."""
+    """Oracle PCG (OpenMP, all granted cores) on a bounded number of iterations."""
     from oracle import oracle as O  # the checker, used here only as the CPU baseline
-    import numpy as np
-    cores = O.max_threads()
+    cores = host_cores()
     b = O.rhs(A.nrows)
     t = time.perf_counter()
     O.pcg_jacobi(A.offs, A.cols, A.vals, b, 0.0, 5, jacobi=is_spd, threads=cores)
@@ -145,8 +169,11 @@ def main():
         Aloc = la.lsbench_matrix_synth(spec, r0, r1)
         name = spec
     small = Aloc.nnz < 2000000
+    if a.fixed_iters > 0:
+        a.tol, a.maxit = 0.0, a.fixed_iters
     opts = la.default_opts(op_mode=la.OP_RAW, tol=a.tol, maxit=a.maxit, spmv_variant=a.spmv,
                            use_graph=1 if small else 0, sample_spmv=0 if small else 16,
+                           spmv_tune=a.spmv_tune,
                            precond=la.PRECOND_NONE if spmv_only else la.PRECOND_JACOBI)
     if world > 1:
         solver = la.Solver(Aloc, opts, row_begin=r0, n_global=n)
@@ -200,7 +227,7 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
-    if res.status != la.STATUS_CONVERGED:
+    if res.status != la.STATUS_CONVERGED and not (a.fixed_iters > 0 and res.status == la.STATUS_MAXIT):
         sys.exit("solve did not converge (status %d after %d iterations): no valid number"
                  % (res.status, res.iters))
     its = iters // max(a.steps, 1)
@@ -239,9 +266,12 @@ def main():
         "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": gbps / HBM_PEAK_GBPS, "traffic": traffic,
                      "kernel": "k_spmv_adaptive (fused p.q)", "launch_ms": spmv_avg_ms,
+                     "spmv_flags": solver.spmv_flags,
                      "algorithmic_bytes": bytes_spmv, "measured": how},
     }
-    if rank == 0 and world == 1 and a.cpu_seconds > 0:
+    if a.fixed_iters > 0:
+        line["metric"] = "EXPERIMENT_fixed_%d_iterations_per_step" % a.fixed_iters
+    if rank == 0 and world == 1 and a.cpu_seconds > 0 and a.fixed_iters == 0:
         line["cpu_baseline"] = cpu_baseline(Aloc, its, a.cpu_seconds, True)
     if rank == 0:
         print(json.dumps(line), flush=True)

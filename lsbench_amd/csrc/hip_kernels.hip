@@ -125,8 +125,6 @@ __global__ __launch_bounds__(WG, 8) void k_spmv_adaptive(
     const double *__restrict__ vals, const double *__restrict__ x,
     double *__restrict__ y, const double *__restrict__ xdot,
     double *__restrict__ partials, const lsb_pcg_state *__restrict__ st) {
-  if (st && st->status)
-    return;
   __shared__ double sprod[CAP];
   __shared__ double sred[4];
   const unsigned tid = threadIdx.x;
@@ -142,6 +140,10 @@ __global__ __launch_bounds__(WG, 8) void k_spmv_adaptive(
   unsigned k = kbeg + slot;
   if (k < kend)
     LSB_ISSUE_BLOCK(k);
+  // the "solve already finished" test rides behind the first block's loads
+  // instead of costing a memory round trip before them
+  if (st && st->status)
+    return;
   for (; k < kend; k += gx) {
     const int cr0 = r0, cj0 = j0, cnt = j1 - j0, nr = r1 - r0;
     if (cnt <= CAP) {
@@ -461,8 +463,20 @@ __global__ __launch_bounds__(WG) void k_pcg_init_state(
   }
 }
 
+// 16-byte lane loads of the BLAS-1 sweeps.  NT = nontemporal: on MI355X a
+// plain read-only stream tops out near 4.6-4.8 TB/s while the same loop with
+// nontemporal loads reads 6.1-6.2 TB/s (tools/spmv_lab.hip, "read-only" probes);
+// a 5-in/2-out sweep shaped like k_pcg_update_xr gains 27 %.
+typedef double d2v __attribute__((ext_vector_type(2)));
+template <bool NT>
+__device__ __forceinline__ d2v ld2(const d2v *p) {
+  if (NT)
+    return __builtin_nontemporal_load(p);
+  return *p;
+}
+
 // alpha = rz/pq ; x += alpha p ; r -= alpha q ; partials (r.dinv.r, r.r)
-template <bool V2>
+template <bool V2, bool NT>
 __global__ __launch_bounds__(WG) void k_pcg_update_xr(
     unsigned n, const double *__restrict__ p, const double *__restrict__ q,
     const double *__restrict__ dinv, double *__restrict__ x,
@@ -488,12 +502,11 @@ __global__ __launch_bounds__(WG) void k_pcg_update_xr(
   const size_t gsz = (size_t)gridDim.x * WG;
   if (V2) {
     const size_t n2 = n / 2;
-    const double2 *p2 = (const double2 *)p, *q2 = (const double2 *)q,
-                  *d2 = (const double2 *)dinv;
-    double2 *x2 = (double2 *)x, *r2 = (double2 *)r;
+    const d2v *p2 = (const d2v *)p, *q2 = (const d2v *)q, *d2 = (const d2v *)dinv;
+    d2v *x2 = (d2v *)x, *r2 = (d2v *)r;
     for (size_t i = gtid; i < n2; i += gsz) {
-      const double2 pv = p2[i], qv = q2[i], dv = d2[i];
-      double2 xv = x2[i], rv = r2[i];
+      const d2v pv = ld2<NT>(p2 + i), qv = ld2<NT>(q2 + i), dv = ld2<NT>(d2 + i);
+      d2v xv = ld2<NT>(x2 + i), rv = ld2<NT>(r2 + i);
       xv.x += alpha * pv.x, xv.y += alpha * pv.y;
       rv.x -= alpha * qv.x, rv.y -= alpha * qv.y;
       x2[i] = xv, r2[i] = rv;
@@ -525,7 +538,7 @@ __global__ __launch_bounds__(WG) void k_pcg_update_xr(
 }
 
 // (rz', rr) = sum partials ; stop test ; beta = rz'/rz ; p = dinv.*r + beta p
-template <bool V2>
+template <bool V2, bool NT>
 __global__ __launch_bounds__(WG) void k_pcg_update_p(
     unsigned n, const double *__restrict__ r, const double *__restrict__ dinv,
     double *__restrict__ p, lsb_pcg_state *__restrict__ st, int parity,
@@ -556,11 +569,11 @@ __global__ __launch_bounds__(WG) void k_pcg_update_p(
   const size_t gsz = (size_t)gridDim.x * WG;
   if (V2) {
     const size_t n2 = n / 2;
-    const double2 *r2 = (const double2 *)r, *d2 = (const double2 *)dinv;
-    double2 *p2 = (double2 *)p;
+    const d2v *r2 = (const d2v *)r, *d2 = (const d2v *)dinv;
+    d2v *p2 = (d2v *)p;
     for (size_t i = gtid; i < n2; i += gsz) {
-      const double2 rv = r2[i], dv = d2[i];
-      double2 pv = p2[i];
+      const d2v rv = ld2<NT>(r2 + i), dv = ld2<NT>(d2 + i);
+      d2v pv = ld2<NT>(p2 + i);
       pv.x = dv.x * rv.x + beta * pv.x;
       pv.y = dv.y * rv.y + beta * pv.y;
       p2[i] = pv;
@@ -595,7 +608,11 @@ static inline unsigned div_up(unsigned a, unsigned b) { return (a + b - 1) / b; 
 static inline unsigned round_up(unsigned a, unsigned b) { return div_up(a, b) * b; }
 static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
+static int g_blas1_nt = 1;
+
 extern "C" {
+
+void lsb_k_set_blas1_nt(int on) { g_blas1_nt = on ? 1 : 0; }
 
 unsigned lsb_k_blas1_grid(unsigned n) {
   // 16 B/lane => WG*2 elements per workgroup per trip; cap at MAX_PARTIALS
@@ -758,24 +775,34 @@ void lsb_k_pcg_update_xr(unsigned n, const double *p, const double *q,
                          double *partials2, unsigned *npartials, void *stream) {
   const unsigned g = lsb_k_blas1_grid(n);
   *npartials = g;
-  if (aligned16(p) && aligned16(q) && aligned16(dinv) && aligned16(x) && aligned16(r))
-    k_pcg_update_xr<true><<<g, WG, 0, (hipStream_t)stream>>>(n, p, q, dinv, x, r, st, parity,
-                                                             pq_parts, npq, partials2);
-  else
-    k_pcg_update_xr<false><<<g, WG, 0, (hipStream_t)stream>>>(n, p, q, dinv, x, r, st, parity,
-                                                              pq_parts, npq, partials2);
+  if (aligned16(p) && aligned16(q) && aligned16(dinv) && aligned16(x) && aligned16(r)) {
+    if (g_blas1_nt)
+      k_pcg_update_xr<true, true><<<g, WG, 0, (hipStream_t)stream>>>(
+          n, p, q, dinv, x, r, st, parity, pq_parts, npq, partials2);
+    else
+      k_pcg_update_xr<true, false><<<g, WG, 0, (hipStream_t)stream>>>(
+          n, p, q, dinv, x, r, st, parity, pq_parts, npq, partials2);
+  } else {
+    k_pcg_update_xr<false, false><<<g, WG, 0, (hipStream_t)stream>>>(
+        n, p, q, dinv, x, r, st, parity, pq_parts, npq, partials2);
+  }
 }
 
 void lsb_k_pcg_update_p(unsigned n, const double *r, const double *dinv,
                         double *p, struct lsb_pcg_state *st, int parity,
                         const double *parts2, unsigned nparts2, void *stream) {
   const unsigned g = lsb_k_blas1_grid(n);
-  if (aligned16(r) && aligned16(dinv) && aligned16(p))
-    k_pcg_update_p<true><<<g, WG, 0, (hipStream_t)stream>>>(n, r, dinv, p, st, parity, parts2,
-                                                            nparts2);
-  else
-    k_pcg_update_p<false><<<g, WG, 0, (hipStream_t)stream>>>(n, r, dinv, p, st, parity, parts2,
-                                                             nparts2);
+  if (aligned16(r) && aligned16(dinv) && aligned16(p)) {
+    if (g_blas1_nt)
+      k_pcg_update_p<true, true><<<g, WG, 0, (hipStream_t)stream>>>(n, r, dinv, p, st, parity,
+                                                                    parts2, nparts2);
+    else
+      k_pcg_update_p<true, false><<<g, WG, 0, (hipStream_t)stream>>>(n, r, dinv, p, st, parity,
+                                                                     parts2, nparts2);
+  } else {
+    k_pcg_update_p<false, false><<<g, WG, 0, (hipStream_t)stream>>>(n, r, dinv, p, st, parity,
+                                                                    parts2, nparts2);
+  }
 }
 
 } // extern "C"

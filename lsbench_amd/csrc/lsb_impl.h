@@ -86,6 +86,7 @@ void lsb_k_pcg_update_p(unsigned n, const double *r, const double *dinv,
                         double *p, struct lsb_pcg_state *st, int parity,
                         const double *parts2, unsigned nparts2, void *stream);
 unsigned lsb_k_blas1_grid(unsigned n);
+void lsb_k_set_blas1_nt(int on);
 void lsb_k_fill_index(unsigned n, unsigned first, double *v, void *stream);
 void lsb_k_vreduce(double *base, unsigned stride, unsigned nshard, unsigned off,
                    unsigned cnt, void *stream);

@@ -44,7 +44,42 @@ __device__ __forceinline__ void wg_sum(double (&v)[W], double *sred) {
     v[k] = (sred[0 * W + k] + sred[1 * W + k]) + (sred[2 * W + k] + sred[3 * W + k]);
 }
 
-enum { F_NOREMAP = 1, F_FAKEGATHER = 2, F_NODOT = 4, F_NOX = 8, F_CYCLIC = 16, F_NT = 32, F_PREFETCH = 64 };
+enum { F_NOREMAP = 1, F_FAKEGATHER = 2, F_NODOT = 4, F_NOX = 8, F_CYCLIC = 16, F_NT = 32, F_PREFETCH = 64, F_HOIST = 128 };
+
+// BLAS-1 probe shaped like k_pcg_update_xr: 5 streams in, 2 out, 16 B/lane.
+// NT bit 0: nontemporal loads, bit 1: nontemporal stores.
+typedef double lab2_d2v __attribute__((ext_vector_type(2)));
+template <int NT>
+__global__ __launch_bounds__(256) void k_blas1_probe(size_t n2, const lab2_d2v *__restrict__ p,
+                                                     const lab2_d2v *__restrict__ q,
+                                                     const lab2_d2v *__restrict__ d,
+                                                     lab2_d2v *__restrict__ x,
+                                                     lab2_d2v *__restrict__ r, double alpha,
+                                                     double *__restrict__ out) {
+  double acc = 0.0;
+  const size_t g = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += g) {
+    lab2_d2v pv, qv, dv, xv, rv;
+    if (NT & 1) {
+      pv = __builtin_nontemporal_load(p + i), qv = __builtin_nontemporal_load(q + i);
+      dv = __builtin_nontemporal_load(d + i), xv = __builtin_nontemporal_load(x + i);
+      rv = __builtin_nontemporal_load(r + i);
+    } else {
+      pv = p[i], qv = q[i], dv = d[i], xv = x[i], rv = r[i];
+    }
+    xv += alpha * pv;
+    rv -= alpha * qv;
+    if (NT & 2) {
+      __builtin_nontemporal_store(xv, x + i);
+      __builtin_nontemporal_store(rv, r + i);
+    } else {
+      x[i] = xv, r[i] = rv;
+    }
+    acc += rv.x * (dv.x * rv.x) + rv.y * (dv.y * rv.y);
+  }
+  if (acc == 123.456)
+    out[0] = acc;
+}
 template <int FLAGS, class T> __device__ __forceinline__ T ldg(const T *p) {
   if (FLAGS & F_NT) return __builtin_nontemporal_load(p);
   return *p;
@@ -326,7 +361,7 @@ __global__ __launch_bounds__(WG) void k_adaptive_v4(const int *__restrict__ rowb
 #pragma unroll
           for (int i = 0; i < 4; i++)
             if (e + i >= 0 && e + i < cnt)
-              sprod[e + i] = vv[i] * x[cc[i]];
+              sprod[e + i] = vv[i] * ((FLAGS & F_NOX) ? (double)cc[i] : x[cc[i]]);
         }
       }
       __syncthreads();
@@ -418,20 +453,52 @@ __global__ __launch_bounds__(WG, MINW) void k_adaptive_cyc(const int *__restrict
   for (; k < kend; k += gx) {
     const int cr0 = r0, cj0 = j0, cnt = j1 - j0, nr = r1 - r0;
     if (cnt <= CAP) {
+      unsigned L = 1;
+      while (L < 64 && (unsigned)nr * (L * 2) <= WG)
+        L <<= 1;
+      // F_HOIST: row offsets and the dot operand of this lane's (up to two)
+      // rows are requested together with the gathers, not after the barrier
+      const bool fast = (FLAGS & F_HOIST) && L == 1 && nr <= 2 * WG;
+      int oa0 = 0, ob0 = 0, oa1 = 0, ob1 = 0;
+      double xd0 = 0.0, xd1 = 0.0;
+      if (fast) {
+        if ((int)tid < nr) {
+          oa0 = offs[cr0 + tid] - cj0, ob0 = offs[cr0 + tid + 1] - cj0;
+          xd0 = x[cr0 + tid];
+        }
+        if ((int)tid + WG < nr) {
+          oa1 = offs[cr0 + tid + WG] - cj0, ob1 = offs[cr0 + tid + WG + 1] - cj0;
+          xd1 = x[cr0 + tid + WG];
+        }
+      }
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const int t = tid + u * WG;
-        if (t < cnt)
-          sprod[t] = v[u] * x[c[u]];
+        if (t < cnt) {
+          if (FLAGS & F_NOX)
+            sprod[t] = v[u] * (double)c[u];
+          else if (FLAGS & F_FAKEGATHER)
+            sprod[t] = v[u] * x[c[u] & 1023];
+          else
+            sprod[t] = v[u] * x[c[u]];
+        }
       }
       if ((FLAGS & F_PREFETCH) && k + gx < kend)
         ISSUE_WG(k + gx);
       __syncthreads();
-      unsigned L = 1;
-      while (L < 64 && (unsigned)nr * (L * 2) <= WG)
-        L <<= 1;
+      if (fast) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int j = oa0; j < ob0; j++)
+          s0 += sprod[j];
+        for (int j = oa1; j < ob1; j++)
+          s1 += sprod[j];
+        if ((int)tid < nr)
+          y[cr0 + tid] = s0, dot += s0 * xd0;
+        if ((int)tid + WG < nr)
+          y[cr0 + tid + WG] = s1, dot += s1 * xd1;
+      }
       const unsigned sl = tid / L, l = tid % L, slots = WG / L;
-      for (unsigned rb = 0; rb < (unsigned)nr; rb += slots) {
+      for (unsigned rb = 0; !fast && rb < (unsigned)nr; rb += slots) {
         const unsigned r = rb + sl;
         double s = 0.0;
         if (r < (unsigned)nr) {
@@ -469,6 +536,141 @@ __global__ __launch_bounds__(WG, MINW) void k_adaptive_cyc(const int *__restrict
     if (tid == 0)
       partials[xcd * gx + slot] = d[0];
   }
+}
+
+// ---- V5: V3 with 16 B/lane stream loads.  A block's nnz range [j0,j1) is
+// widened to 4-aligned [j0&~3, ...); each lane owns QPT quads of 4 consecutive
+// non-zeros (cols as int4, vals as 2 x double2).  Row blocks are built with
+// cap CAP-8 so the widened range always fits CAP.  cols/vals must be readable
+// up to the next multiple of 4 past nnz (the lab over-allocates).
+template <int CAP, int FLAGS>
+__global__ __launch_bounds__(WG, 8) void k_cyc_v4(const int *__restrict__ rowblk, unsigned nblk,
+                                                  unsigned per, const int *__restrict__ offs,
+                                                  const int *__restrict__ cols,
+                                                  const double *__restrict__ vals,
+                                                  const double *__restrict__ x,
+                                                  double *__restrict__ y,
+                                                  double *__restrict__ partials) {
+  __shared__ double sprod[CAP];
+  __shared__ double sred[4];
+  const unsigned tid = threadIdx.x;
+  const unsigned gx = gridDim.x / NXCD;
+  const unsigned xcd = blockIdx.x % NXCD, slot = blockIdx.x / NXCD;
+  const unsigned chunk = (nblk + NXCD - 1) / NXCD;
+  const unsigned kbeg = xcd * chunk, kend = min(kbeg + chunk, nblk);
+  constexpr int QPT = CAP / 4 / WG; // quads per thread
+  double dot = 0.0;
+  typedef int i4v __attribute__((ext_vector_type(4)));
+  typedef double d2v __attribute__((ext_vector_type(2)));
+  i4v c4[QPT];
+  d2v va[QPT], vb[QPT];
+  unsigned k = kbeg + slot;
+  int r0 = 0, r1 = 0, j0 = 0, j1 = 0;
+#define ISSUE_V4(kk)                                                           \
+  do {                                                                         \
+    r0 = rowblk[kk], r1 = rowblk[(kk) + 1];                                    \
+    j0 = offs[r0], j1 = offs[r1];                                              \
+    if (j1 - j0 <= CAP - 8) {                                                  \
+      const int ja_ = j0 & ~3, nq_ = (j1 - ja_ + 3) >> 2;                      \
+      _Pragma("unroll") for (int u = 0; u < QPT; u++) {                        \
+        const int q = (int)tid + u * WG;                                       \
+        if (q < nq_) {                                                         \
+          c4[u] = ldg<FLAGS>((const i4v *)(cols + ja_) + q);                   \
+          va[u] = ldg<FLAGS>((const d2v *)(vals + ja_) + 2 * q);               \
+          vb[u] = ldg<FLAGS>((const d2v *)(vals + ja_) + 2 * q + 1);           \
+        }                                                                      \
+      }                                                                        \
+    }                                                                          \
+  } while (0)
+  if (k < kend)
+    ISSUE_V4(k);
+  for (; k < kend; k += gx) {
+    const int cr0 = r0, cj0 = j0, cnt = j1 - j0, nr = r1 - r0;
+    if (cnt <= CAP - 8) {
+      const int sh = cj0 & 3, nq = (cnt + sh + 3) >> 2;
+#pragma unroll
+      for (int u = 0; u < QPT; u++) {
+        const int q = (int)tid + u * WG;
+        if (q < nq) {
+          const int e = 4 * q - sh;
+          const int cc[4] = {c4[u].x, c4[u].y, c4[u].z, c4[u].w};
+          const double vv[4] = {va[u].x, va[u].y, vb[u].x, vb[u].y};
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if (e + i >= 0 && e + i < cnt)
+              sprod[e + i] = vv[i] * ((FLAGS & F_NOX) ? (double)cc[i] : x[cc[i]]);
+        }
+      }
+      if ((FLAGS & F_PREFETCH) && k + gx < kend)
+        ISSUE_V4(k + gx);
+      __syncthreads();
+      unsigned L = 1;
+      while (L < 64 && (unsigned)nr * (L * 2) <= WG)
+        L <<= 1;
+      const unsigned sl = tid / L, l = tid % L, slots = WG / L;
+      for (unsigned rb = 0; rb < (unsigned)nr; rb += slots) {
+        const unsigned r = rb + sl;
+        double s = 0.0;
+        if (r < (unsigned)nr) {
+          const int a = offs[cr0 + r] - cj0, b = offs[cr0 + r + 1] - cj0;
+          for (int j = a + (int)l; j < b; j += (int)L)
+            s += sprod[j];
+        }
+        for (unsigned off = L >> 1; off > 0; off >>= 1)
+          s += __shfl_xor(s, off, 64);
+        if (r < (unsigned)nr && l == 0) {
+          y[cr0 + r] = s;
+          if (!(FLAGS & F_NODOT))
+            dot += s * x[cr0 + r];
+        }
+      }
+      __syncthreads();
+    } else {
+      double s[1] = {0.0};
+      for (int r = cr0; r < cr0 + nr; r++) {
+        s[0] = 0.0;
+        for (int j = offs[r] + (int)tid; j < offs[r + 1]; j += WG)
+          s[0] += vals[j] * x[cols[j]];
+        wg_sum<1>(s, sred);
+        if (tid == 0) {
+          y[r] = s[0];
+          dot += s[0] * x[r];
+        }
+      }
+      if ((FLAGS & F_PREFETCH) && k + gx < kend)
+        ISSUE_V4(k + gx);
+    }
+    if (!(FLAGS & F_PREFETCH) && k + gx < kend)
+      ISSUE_V4(k + gx);
+  }
+  if (!(FLAGS & F_NODOT)) {
+    double d[1] = {dot};
+    wg_sum<1>(d, sred);
+    if (tid == 0)
+      partials[xcd * gx + slot] = d[0];
+  }
+}
+
+// read-only ceiling: 16 B/lane loads, 4 independent streams per lane
+typedef double lab_d2v __attribute__((ext_vector_type(2)));
+template <int NT>
+__global__ __launch_bounds__(WG) void k_read_ceiling(const lab_d2v *__restrict__ p, size_t n2,
+                                                     double *__restrict__ out) {
+  double acc = 0.0;
+  const size_t g = (size_t)gridDim.x * WG;
+  size_t i = (size_t)blockIdx.x * WG + threadIdx.x;
+  for (; i + 3 * g < n2; i += 4 * g) {
+    lab_d2v a, b, c, d;
+    if (NT) {
+      a = __builtin_nontemporal_load(p + i), b = __builtin_nontemporal_load(p + i + g);
+      c = __builtin_nontemporal_load(p + i + 2 * g), d = __builtin_nontemporal_load(p + i + 3 * g);
+    } else {
+      a = p[i], b = p[i + g], c = p[i + 2 * g], d = p[i + 3 * g];
+    }
+    acc += a.x + a.y + b.x + b.y + c.x + c.y + d.x + d.y;
+  }
+  if (acc == 123.456)
+    out[0] = acc;
 }
 
 // ---- V4: wave-private pipeline.  Each of the 4 wavefronts of a workgroup owns
@@ -744,6 +946,18 @@ LAUNCHER(l_wave512_pf7, (k_wave<512, F_PREFETCH, 7>))
 LAUNCHER(l_wave512_pf6, (k_wave<512, F_PREFETCH, 6>))
 LAUNCHER(l_cyc_pf_nt, (k_adaptive_cyc<2048, F_CYCLIC | F_PREFETCH | F_NT>))
 LAUNCHER(l_cyc_nt, (k_adaptive_cyc<2048, F_CYCLIC | F_NT>))
+LAUNCHER(l_cyc_hoist, (k_adaptive_cyc<2048, F_CYCLIC | F_NT | F_PREFETCH | F_HOIST>))
+LAUNCHER(l_cyc_hoist_nopf, (k_adaptive_cyc<2048, F_CYCLIC | F_NT | F_HOIST>))
+LAUNCHER(l_cyc_hoist7, (k_adaptive_cyc<2048, F_CYCLIC | F_NT | F_PREFETCH | F_HOIST, 7>))
+LAUNCHER(l_cyc_hoist_nonT, (k_adaptive_cyc<2048, F_CYCLIC | F_PREFETCH | F_HOIST>))
+LAUNCHER(l_cyc_fake, (k_adaptive_cyc<2048, F_CYCLIC | F_NT | F_PREFETCH | F_FAKEGATHER>))
+LAUNCHER(l_cyc_nox, (k_adaptive_cyc<2048, F_CYCLIC | F_NT | F_PREFETCH | F_NOX>))
+LAUNCHER(l_cyc_nox_nodot, (k_adaptive_cyc<2048, F_CYCLIC | F_NT | F_PREFETCH | F_NOX | F_NODOT>))
+LAUNCHER(l_v4_pf_nt, (k_cyc_v4<2048, F_NT | F_PREFETCH>))
+LAUNCHER(l_v4_nt, (k_cyc_v4<2048, F_NT>))
+LAUNCHER(l_v4_pf, (k_cyc_v4<2048, F_PREFETCH>))
+LAUNCHER(l_v4_4096_pf_nt, (k_cyc_v4<4096, F_NT | F_PREFETCH>))
+LAUNCHER(l_v4_nox, (k_cyc_v4<2048, F_NT | F_PREFETCH | F_NOX>))
 LAUNCHER(l_cyc1024_pf, (k_adaptive_cyc<1024, F_CYCLIC | F_PREFETCH>))
 LAUNCHER(l_wave512, (k_wave<512, 0>))
 LAUNCHER(l_wave512_pf, (k_wave<512, F_PREFETCH>))
@@ -778,25 +992,21 @@ int main(int argc, char **argv) {
   CHK(hipMalloc(&d_parts, 4096 * 8));
 
   std::vector<Variant> vs = {
-      {"adaptive cap2048 g2048 (library)", 2048, l_base2048, 2048},
-      {"adaptive cap2048 g4096", 2048, l_base2048, 4096},
-      {"cyc cap2048 g2048", 2048, l_cyc, 2048},
-      {"cyc cap2048 g4096", 2048, l_cyc, 4096},
-      {"cyc+prefetch cap2048 g2048", 2048, l_cyc_pf, 2048},
-      {"cyc+prefetch cap2048 minw7 g1792", 2048, l_cyc_pf7, 1792},
-      {"cyc+prefetch cap2048 minw6 g1536", 2048, l_cyc_pf6, 1536},
-      {"wave+prefetch capw512 minw7 g1792", 512, l_wave512_pf7, 1792},
-      {"wave+prefetch capw512 minw6 g1536", 512, l_wave512_pf6, 1536},
-      {"cyc+prefetch+nt cap2048 g2048", 2048, l_cyc_pf_nt, 2048},
-      {"cyc+nt cap2048 g2048", 2048, l_cyc_nt, 2048},
-      {"cyc+prefetch cap1024 g2048", 1024, l_cyc1024_pf, 2048},
-      {"wave capw512 g2048", 512, l_wave512, 2048},
-      {"wave+prefetch capw512 g2048", 512, l_wave512_pf, 2048},
-      {"wave+prefetch+nt capw512 g2048", 512, l_wave512_pf_nt, 2048},
-      {"wave+prefetch capw256 g2048", 256, l_wave256_pf, 2048},
-      {"probe: no x gather at all", 2048, l_nox, 2048},
+      {"adaptive cap2048 g2048 (round-1a lib)", 2048, l_base2048, 2048},
+      {"cyc+prefetch+nt cap2048 (library)", 2048, l_cyc_pf_nt, 2048},
+      {"cyc+nt cap2048", 2048, l_cyc_nt, 2048},
+      {"cyc+prefetch cap2048", 2048, l_cyc_pf, 2048},
+      {"cyc+pf+nt+hoist", 2048, l_cyc_hoist, 2048},
+      {"cyc+nt+hoist (no prefetch)", 2048, l_cyc_hoist_nopf, 2048},
+      {"cyc+pf+nt+hoist minw7 g1792", 2048, l_cyc_hoist7, 1792},
+      {"cyc+pf+hoist (no nt)", 2048, l_cyc_hoist_nonT, 2048},
+      {"probe: cyc+pf+nt, gather from 8KB", 2048, l_cyc_fake, 2048},
+      {"probe: cyc+pf+nt, no gather", 2048, l_cyc_nox, 2048},
+      {"probe: v4 cyc+pf+nt, no gather", 2040, l_v4_nox, 2048},
+      {"probe: cyc+pf+nt, no gather, no dot", 2048, l_cyc_nox_nodot, 2048},
   };
-  vs.back().check = false;
+  for (auto &v : vs)
+    if (v.name.rfind("probe", 0) == 0) v.check = false;
   // row blocks per distinct cap
   std::vector<std::pair<int, std::pair<int *, unsigned>>> rbs;
   for (auto &v : vs) {
@@ -834,7 +1044,7 @@ int main(int argc, char **argv) {
     printf("check %-36s %s (worst %.2e)\n", v.name.c_str(), worst == 0 ? "ok" : "MISMATCH", worst);
   }
   // stream ceiling probe
-  std::vector<float> ceil_us;
+  std::vector<float> ceil_us, read_us[2];
   for (int r = 0; r < rounds + 2; r++) {
     for (auto &v : vs) {
       CHK(hipEventRecord(e0));
@@ -852,6 +1062,17 @@ int main(int argc, char **argv) {
     float ms;
     CHK(hipEventElapsedTime(&ms, e0, e1));
     if (r >= 2) ceil_us.push_back(ms * 1e3f);
+    for (int nt = 0; nt < 2; nt++) {
+      CHK(hipEventRecord(e0));
+      if (nt)
+        k_read_ceiling<1><<<2048, WG>>>((const lab_d2v *)d_vals, nnz / 2, d_parts);
+      else
+        k_read_ceiling<0><<<2048, WG>>>((const lab_d2v *)d_vals, nnz / 2, d_parts);
+      CHK(hipEventRecord(e1));
+      CHK(hipEventSynchronize(e1));
+      CHK(hipEventElapsedTime(&ms, e0, e1));
+      if (r >= 2) read_us[nt].push_back(ms * 1e3f);
+    }
   }
   auto med = [](std::vector<float> v) {
     std::sort(v.begin(), v.end());
@@ -866,5 +1087,38 @@ int main(int argc, char **argv) {
   const double sb = 12.0 * nnz + 8.0 * A.n;
   printf("%-36s median %8.1f us  min %8.1f us  => %6.0f GB/s of its own %0.f bytes\n",
          "ceiling: stream cols+vals, write y", m.first, m.second, sb / m.first / 1e3, sb);
+  {
+    // BLAS-1 probe: 5 vectors of n doubles (carved out of d_vals, which is
+    // 5n+ doubles long for the Laplacians), 2 written back
+    const size_t n2 = (size_t)A.n / 2;
+    if (nnz >= (size_t)5 * A.n - 8) {
+      lab2_d2v *b = (lab2_d2v *)d_vals;
+      for (int nt = 0; nt < 4; nt++) {
+        std::vector<float> us;
+        for (int r = 0; r < rounds + 2; r++) {
+          CHK(hipEventRecord(e0));
+          switch (nt) {
+          case 0: k_blas1_probe<0><<<2048, 256>>>(n2, b, b + n2, b + 2 * n2, b + 3 * n2, b + 4 * n2 - 8, 1e-9, d_parts); break;
+          case 1: k_blas1_probe<1><<<2048, 256>>>(n2, b, b + n2, b + 2 * n2, b + 3 * n2, b + 4 * n2 - 8, 1e-9, d_parts); break;
+          case 2: k_blas1_probe<2><<<2048, 256>>>(n2, b, b + n2, b + 2 * n2, b + 3 * n2, b + 4 * n2 - 8, 1e-9, d_parts); break;
+          default: k_blas1_probe<3><<<2048, 256>>>(n2, b, b + n2, b + 2 * n2, b + 3 * n2, b + 4 * n2 - 8, 1e-9, d_parts); break;
+          }
+          CHK(hipEventRecord(e1));
+          CHK(hipEventSynchronize(e1));
+          float ms;
+          CHK(hipEventElapsedTime(&ms, e0, e1));
+          if (r >= 2) us.push_back(ms * 1e3f);
+        }
+        auto mb = med(us);
+        printf("blas1 probe (5 in, 2 out) nt-load=%d nt-store=%d  median %8.1f us  => %6.0f GB/s of %.0f bytes\n",
+               nt & 1, nt >> 1, mb.first, 56.0 * A.n / mb.first / 1e3, 56.0 * A.n);
+      }
+    }
+  }
+  for (int nt = 0; nt < 2; nt++) {
+    auto mr = med(read_us[nt]);
+    printf("ceiling: read-only vals%s            median %8.1f us  => %6.0f GB/s of its own %.0f bytes\n",
+           nt ? " (nt)" : "     ", mr.first, 8.0 * nnz / mr.first / 1e3, 8.0 * nnz);
+  }
   return 0;
 }
