@@ -218,11 +218,15 @@ struct lsb_hip_solver {
   struct shard *sh;
   double *d_scal_all; /* nshard * SCAL_STRIDE doubles                        */
   struct lsb_hip_opts o;
-  struct lsb_pcg_state *h_st; /* pinned */
-  hipGraphExec_t gexec;
-  int graph_iters;
-  const double *graph_b;
-  double *graph_x;
+  struct lsb_pcg_state *h_st; /* pinned, 2 slots */
+  struct {
+    hipGraphExec_t exec;
+    int iters;
+    double *x;
+  } gcache[2];
+  int gnext;
+  unsigned hint_iters; /* iterations of the previous solve, 0 = none yet */
+  hipEvent_t ev_poll[2];
   hipEvent_t ev[4 * MAX_SAMPLES], ev_t0, ev_t1; /* per sample: e0 SpMV e1 e2 e3 */
   int have_events;
   double *d_tmp; /* n_here doubles: scratch for spmv_dev / jacobi sweep */
@@ -240,8 +244,12 @@ static unsigned pow2_ceil(unsigned v) {
 static void choose_spmv(struct shard *s, const struct lsb_hip_opts *o) {
   const unsigned mean = s->n ? (unsigned)((s->nnz + s->n - 1) / s->n) : 1;
   int v = o->spmv_variant;
+  /* A matrix of a few hundred thousand non-zeros is launch-latency bound: the
+   * sub-wavefront kernel has a shorter dependent-load chain (offs -> cols ->
+   * x) than the row-blocked one (rowblk -> offs -> cols -> x -> LDS -> offs)
+   * and wins 3.2 vs 5.7 us per launch on tests/xn3b_A_18.txt. */
   if (v == LSB_SPMV_AUTO)
-    v = LSB_SPMV_ADAPTIVE;
+    v = s->nnz <= 500000ull ? LSB_SPMV_SUBWAVE : LSB_SPMV_ADAPTIVE;
   s->variant = v;
   unsigned L = pow2_ceil(mean ? mean : 1);
   if (L < 2)
@@ -343,13 +351,14 @@ static void plan_exchange(struct shard *s, int me, int nall, const unsigned *hul
 }
 
 static void tune_spmv(lsb_hip_solver *sv, struct shard *s);
+static void drop_graphs(lsb_hip_solver *sv);
 
 static lsb_hip_solver *solver_alloc(int nshard, const struct lsb_hip_opts *o) {
   lsb_hip_solver *sv = lsb_calloc(lsb_hip_solver, 1);
   sv->nshard = nshard;
   sv->sh = lsb_calloc(struct shard, nshard);
   sv->o = *o;
-  LSB_CHK_HIP(hipHostMalloc((void **)&sv->h_st, sizeof(struct lsb_pcg_state), 0));
+  LSB_CHK_HIP(hipHostMalloc((void **)&sv->h_st, 2 * sizeof(struct lsb_pcg_state), 0));
   return sv;
 }
 
@@ -364,6 +373,8 @@ static void solver_finish_setup(lsb_hip_solver *sv) {
     LSB_CHK_HIP(hipEventCreate(&sv->ev[i]));
   LSB_CHK_HIP(hipEventCreate(&sv->ev_t0));
   LSB_CHK_HIP(hipEventCreate(&sv->ev_t1));
+  LSB_CHK_HIP(hipEventCreateWithFlags(&sv->ev_poll[0], hipEventDisableTiming));
+  LSB_CHK_HIP(hipEventCreateWithFlags(&sv->ev_poll[1], hipEventDisableTiming));
   sv->have_events = 1;
   LSB_CHK_HIP(hipStreamSynchronize(g_stream));
   for (int i = 0; i < sv->nshard; i++)
@@ -454,8 +465,7 @@ void lsb_hip_solver_destroy(lsb_hip_solver *sv) {
   if (!sv)
     return;
   LSB_CHK_HIP(hipStreamSynchronize(g_stream));
-  if (sv->gexec)
-    LSB_CHK_HIP(hipGraphExecDestroy(sv->gexec));
+  drop_graphs(sv);
   for (int i = 0; i < sv->nshard; i++)
     shard_free(&sv->sh[i]);
   if (sv->have_events) {
@@ -463,6 +473,8 @@ void lsb_hip_solver_destroy(lsb_hip_solver *sv) {
       LSB_CHK_HIP(hipEventDestroy(sv->ev[i]));
     LSB_CHK_HIP(hipEventDestroy(sv->ev_t0));
     LSB_CHK_HIP(hipEventDestroy(sv->ev_t1));
+    LSB_CHK_HIP(hipEventDestroy(sv->ev_poll[0]));
+    LSB_CHK_HIP(hipEventDestroy(sv->ev_poll[1]));
   }
   lsb_hip_free(sv->d_scal_all), lsb_hip_free(sv->d_tmp);
   LSB_CHK_HIP(hipHostFree(sv->h_st));
@@ -629,13 +641,15 @@ static void pcg_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int sa
 }
 
 static int auto_chunk(const lsb_hip_solver *sv) {
-  /* aim at ~2 ms of device work between two host polls */
+  /* aim at ~0.3 ms of device work per chunk (at least 8 iterations): the poll
+   * is pipelined one chunk ahead, so small chunks cost nothing while running
+   * and bound the no-op tail enqueued past convergence */
   const struct shard *s = &sv->sh[0];
   double bytes = 12.0 * (double)s->nnz + 108.0 * (double)s->n;
   double us = bytes / 4.0e6; /* 4 TB/s => bytes per microsecond */
   if (us < 6.0)
     us = 6.0;
-  int c = (int)(2000.0 / us);
+  int c = (int)(300.0 / us);
   if (c < 8)
     c = 8;
   if (c > 256)
@@ -643,54 +657,125 @@ static int auto_chunk(const lsb_hip_solver *sv) {
   return c & ~1;
 }
 
+/* hipGraph of `iters` PCG iterations writing to d_x; two cached entries (the
+ * hinted whole-solve graph and the small continuation chunk). */
+static hipGraphExec_t get_graph(lsb_hip_solver *sv, int iters, double *d_x) {
+  for (int i = 0; i < 2; i++)
+    if (sv->gcache[i].exec && sv->gcache[i].iters == iters && sv->gcache[i].x == d_x)
+      return sv->gcache[i].exec;
+  const int slot = sv->gnext;
+  sv->gnext ^= 1;
+  if (sv->gcache[slot].exec)
+    LSB_CHK_HIP(hipGraphExecDestroy(sv->gcache[slot].exec));
+  hipGraph_t g;
+  LSB_CHK_HIP(hipStreamBeginCapture(g_stream, hipStreamCaptureModeThreadLocal));
+  for (int i = 0; i < iters; i++)
+    pcg_enqueue_iter(sv, d_x, i & 1, -1);
+  LSB_CHK_HIP(hipStreamEndCapture(g_stream, &g));
+  LSB_CHK_HIP(hipGraphInstantiate(&sv->gcache[slot].exec, g, NULL, NULL, 0));
+  LSB_CHK_HIP(hipGraphDestroy(g));
+  sv->gcache[slot].iters = iters, sv->gcache[slot].x = d_x;
+  return sv->gcache[slot].exec;
+}
+
+static void drop_graphs(lsb_hip_solver *sv) {
+  for (int i = 0; i < 2; i++)
+    if (sv->gcache[i].exec) {
+      LSB_CHK_HIP(hipGraphExecDestroy(sv->gcache[i].exec));
+      sv->gcache[i].exec = NULL;
+    }
+}
+
+/*
+ * Host side of one solve.  The device decides when to stop (lsb_pcg_state);
+ * the host only has to enqueue enough iterations and look at the 64-byte state
+ * now and then:
+ *   - a solver that has solved before enqueues exactly the iteration count of
+ *     its previous solve in one go (the benchmark protocol repeats the same
+ *     solve `trials` times, src/cholmod-impl.h:44-63) and polls once;
+ *   - otherwise, and for whatever is left, chunks of `check_every` iterations
+ *     are enqueued one AHEAD of the poll, so the device never waits for the
+ *     host; iterations enqueued past convergence are no-op launches.
+ */
 int lsb_hip_solver_solve_dev(lsb_hip_solver *sv, const double *d_b, double *d_x,
                              struct lsb_hip_result *res) {
   if (!initialized)
     return 1;
   if (!sv || !d_b || !d_x)
     return 2;
-  int chunk = sv->o.check_every > 0 ? (sv->o.check_every + 1) & ~1 : auto_chunk(sv);
+  const int chunk = sv->o.check_every > 0 ? (sv->o.check_every + 1) & ~1 : auto_chunk(sv);
   const int sampling = sv->o.sample_spmv > 0;
   const int use_graph = sv->o.use_graph && !sv->multi && !sampling;
   int nsamp = 0;
+  unsigned done_iters = 0;
+  struct lsb_pcg_state *hst = sv->h_st; /* two pinned slots */
   double t0 = wall_seconds();
 
+#define ENQUEUE_ITERS(count)                                                   \
+  do {                                                                         \
+    const int cnt_ = (count);                                                  \
+    if (use_graph) {                                                           \
+      LSB_CHK_HIP(hipGraphLaunch(get_graph(sv, cnt_, d_x), g_stream));         \
+    } else {                                                                   \
+      for (int i_ = 0; i_ < cnt_; i_++) {                                      \
+        int smp_ = -1;                                                         \
+        if (sampling && nsamp < MAX_SAMPLES &&                                 \
+            ((done_iters + (unsigned)i_) % (unsigned)sv->o.sample_spmv) == 0)  \
+          smp_ = nsamp++;                                                      \
+        pcg_enqueue_iter(sv, d_x, i_ & 1, smp_);                               \
+      }                                                                        \
+    }                                                                          \
+    done_iters += (unsigned)cnt_;                                              \
+  } while (0)
+#define ENQUEUE_POLL(slot)                                                     \
+  do {                                                                         \
+    LSB_CHK_HIP(hipMemcpyAsync(&hst[slot], sv->sh[0].d_st,                     \
+                               sizeof(struct lsb_pcg_state),                   \
+                               hipMemcpyDeviceToHost, g_stream));              \
+    LSB_CHK_HIP(hipEventRecord(sv->ev_poll[slot], g_stream));                  \
+  } while (0)
+
   pcg_enqueue_init(sv, d_b, d_x);
-  if (use_graph && (!sv->gexec || sv->graph_iters != chunk || sv->graph_b != d_b ||
-                    sv->graph_x != d_x)) {
-    if (sv->gexec)
-      LSB_CHK_HIP(hipGraphExecDestroy(sv->gexec));
-    hipGraph_t g;
-    LSB_CHK_HIP(hipStreamBeginCapture(g_stream, hipStreamCaptureModeThreadLocal));
-    for (int i = 0; i < chunk; i++)
-      pcg_enqueue_iter(sv, d_x, i & 1, -1);
-    LSB_CHK_HIP(hipStreamEndCapture(g_stream, &g));
-    LSB_CHK_HIP(hipGraphInstantiate(&sv->gexec, g, NULL, NULL, 0));
-    LSB_CHK_HIP(hipGraphDestroy(g));
-    sv->graph_iters = chunk, sv->graph_b = d_b, sv->graph_x = d_x;
-  }
-  unsigned done_iters = 0;
-  for (;;) {
-    if (use_graph) {
-      LSB_CHK_HIP(hipGraphLaunch(sv->gexec, g_stream));
-    } else {
-      for (int i = 0; i < chunk; i++) {
-        int smp = -1;
-        if (sampling && nsamp < MAX_SAMPLES &&
-            ((done_iters + (unsigned)i) % (unsigned)sv->o.sample_spmv) == 0)
-          smp = nsamp++;
-        pcg_enqueue_iter(sv, d_x, i & 1, smp);
-      }
+  int fin = -1; /* slot holding the final state */
+  if (sv->hint_iters > 0) {
+    /* graphs beyond ~1k iterations cost more to build than they save */
+    int first = (int)((sv->hint_iters + 1) & ~1u);
+    while (use_graph && first > 1024)
+      first = ((first / 2) + 1) & ~1;
+    int left = (int)((sv->hint_iters + 1) & ~1u);
+    while (left > 0) {
+      const int c = left < first ? ((left + 1) & ~1) : first;
+      ENQUEUE_ITERS(c);
+      left -= c;
     }
-    done_iters += (unsigned)chunk;
-    LSB_CHK_HIP(hipMemcpyAsync(sv->h_st, sv->sh[0].d_st, sizeof(struct lsb_pcg_state),
-                               hipMemcpyDeviceToHost, g_stream));
-    LSB_CHK_HIP(hipStreamSynchronize(g_stream));
-    if (sv->h_st->status != LSB_STATUS_RUNNING)
-      break;
-    if (done_iters > sv->o.maxit + (unsigned)chunk) /* cannot happen; belt and braces */
-      errx(EXIT_FAILURE, "hip_cdna4: PCG ran past maxit without a status");
+    ENQUEUE_POLL(0);
+    LSB_CHK_HIP(hipEventSynchronize(sv->ev_poll[0]));
+    if (hst[0].status != LSB_STATUS_RUNNING)
+      fin = 0;
   }
+  if (fin < 0) {
+    int cur = 0;
+    ENQUEUE_ITERS(chunk);
+    ENQUEUE_POLL(0);
+    for (;;) {
+      ENQUEUE_ITERS(chunk); /* one chunk ahead of the poll */
+      ENQUEUE_POLL(cur ^ 1);
+      LSB_CHK_HIP(hipEventSynchronize(sv->ev_poll[cur]));
+      if (hst[cur].status != LSB_STATUS_RUNNING) {
+        fin = cur;
+        break;
+      }
+      cur ^= 1;
+      if (done_iters > sv->o.maxit + 3u * (unsigned)chunk) /* cannot happen */
+        errx(EXIT_FAILURE, "hip_cdna4: PCG ran past maxit without a status");
+    }
+    LSB_CHK_HIP(hipStreamSynchronize(g_stream)); /* drain the speculative chunk */
+  }
+#undef ENQUEUE_ITERS
+#undef ENQUEUE_POLL
+  if (fin != 0)
+    hst[0] = hst[fin];
+  sv->hint_iters = (unsigned)hst[0].iters;
   double t1 = wall_seconds();
   struct lsb_hip_result r;
   memset(&r, 0, sizeof r);
@@ -731,11 +816,8 @@ int lsb_hip_solver_solve(lsb_hip_solver *sv, const double *b, double *x,
   LSB_CHK_HIP(hipMemcpy(d_b, b, bytes, hipMemcpyHostToDevice));
   int rc = lsb_hip_solver_solve_dev(sv, d_b, d_x, res);
   LSB_CHK_HIP(hipMemcpy(x, d_x, bytes, hipMemcpyDeviceToHost));
-  /* a cached graph must not outlive the buffers it was captured with */
-  if (sv->gexec) {
-    LSB_CHK_HIP(hipGraphExecDestroy(sv->gexec));
-    sv->gexec = NULL;
-  }
+  /* cached graphs must not outlive the buffers they were captured with */
+  drop_graphs(sv);
   lsb_hip_free(d_b), lsb_hip_free(d_x);
   return rc;
 }

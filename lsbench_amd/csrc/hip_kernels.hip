@@ -221,31 +221,37 @@ __global__ __launch_bounds__(WG) void k_spmv_subwave(
     const double *__restrict__ x, double *__restrict__ y,
     const double *__restrict__ xdot, double *__restrict__ partials,
     const lsb_pcg_state *__restrict__ st) {
-  if (st && st->status)
-    return;
   __shared__ double sred[4];
   const unsigned tid = threadIdx.x, slot = tid / L, l = tid % L;
   constexpr unsigned SLOTS = WG / L;
   const unsigned w = xcd_contiguous_wg();
   const unsigned ra = min(w * rows_per_wg, n), rb = min(ra + rows_per_wg, n);
+  // the status word travels with the first row's loads (this kernel serves
+  // the small, latency-bound operators); nothing is stored before it is tested
+  const int stopped = st ? st->status : 0;
   double dot = 0.0;
   for (unsigned base = ra; base < rb; base += SLOTS) {
     const unsigned r = base + slot;
-    double s = 0.0;
+    double s = 0.0, xd = 0.0;
     if (r < rb) {
       const int j0 = offs[r], j1 = offs[r + 1];
+      if (xdot)
+        xd = xdot[r];
       for (int j = j0 + (int)l; j < j1; j += L)
         s += vals[j] * x[cols[j]];
     }
 #pragma unroll
     for (int off = L >> 1; off > 0; off >>= 1)
       s += __shfl_xor(s, off, 64);
+    if (stopped)
+      return;
     if (r < rb && l == 0) {
       y[r] = s;
-      if (xdot)
-        dot += s * xdot[r];
+      dot += s * xd;
     }
   }
+  if (stopped)
+    return;
   if (partials) {
     double d[1] = {dot};
     wg_sum<1>(d, sred);
@@ -483,51 +489,69 @@ __global__ __launch_bounds__(WG) void k_pcg_update_xr(
     double *__restrict__ r, lsb_pcg_state *__restrict__ st, int parity,
     const double *__restrict__ pq_parts, unsigned npq,
     double *__restrict__ partials2) {
-  if (st->status)
-    return;
   __shared__ double sred[8];
+  const size_t gtid = (size_t)blockIdx.x * WG + threadIdx.x;
+  const size_t gsz = (size_t)gridDim.x * WG;
+  const size_t n2 = n / 2;
+  const d2v *p2 = (const d2v *)p, *q2 = (const d2v *)q, *d2 = (const d2v *)dinv;
+  d2v *x2 = (d2v *)x, *r2 = (d2v *)r;
+  // Everything that does not depend on alpha is requested up front, so the
+  // status word, the p.q partials, r.z and this lane's first operands are ONE
+  // memory round trip, not four in a row (a small operator's sweep is nothing
+  // but these latencies).
+  const int stopped = st->status;
+  const double rz = st->rz[parity];
+  d2v pv = {0.0, 0.0}, qv = pv, dv = pv, xv = pv, rv = pv;
+  const bool first = V2 && gtid < n2;
+  if (first) {
+    pv = ld2<NT>(p2 + gtid), qv = ld2<NT>(q2 + gtid), dv = ld2<NT>(d2 + gtid);
+    xv = ld2<NT>(x2 + gtid), rv = ld2<NT>(r2 + gtid);
+  }
   double pqv[1];
   wg_sum_partials<1>(pq_parts, npq, pqv, sred);
+  if (stopped)
+    return;
   const double pq = pqv[0];
   if (!(pq != 0.0) || !isfinite(pq)) { // same decision in every workgroup
     if (blockIdx.x == 0 && threadIdx.x == 0)
       st->status = LSB_STATUS_BREAKDOWN;
     return;
   }
-  const double alpha = st->rz[parity] / pq;
+  const double alpha = rz / pq;
   if (blockIdx.x == 0 && threadIdx.x == 0)
     st->pq = pq;
   double acc[2] = {0.0, 0.0};
-  const size_t gtid = (size_t)blockIdx.x * WG + threadIdx.x;
-  const size_t gsz = (size_t)gridDim.x * WG;
   if (V2) {
-    const size_t n2 = n / 2;
-    const d2v *p2 = (const d2v *)p, *q2 = (const d2v *)q, *d2 = (const d2v *)dinv;
-    d2v *x2 = (d2v *)x, *r2 = (d2v *)r;
-    for (size_t i = gtid; i < n2; i += gsz) {
-      const d2v pv = ld2<NT>(p2 + i), qv = ld2<NT>(q2 + i), dv = ld2<NT>(d2 + i);
-      d2v xv = ld2<NT>(x2 + i), rv = ld2<NT>(r2 + i);
-      xv.x += alpha * pv.x, xv.y += alpha * pv.y;
-      rv.x -= alpha * qv.x, rv.y -= alpha * qv.y;
-      x2[i] = xv, r2[i] = rv;
-      acc[0] += rv.x * (dv.x * rv.x);
-      acc[0] += rv.y * (dv.y * rv.y);
-      acc[1] += rv.x * rv.x;
-      acc[1] += rv.y * rv.y;
+    if (first) {
+      size_t i = gtid;
+      for (;;) {
+        xv.x += alpha * pv.x, xv.y += alpha * pv.y;
+        rv.x -= alpha * qv.x, rv.y -= alpha * qv.y;
+        x2[i] = xv, r2[i] = rv;
+        acc[0] += rv.x * (dv.x * rv.x);
+        acc[0] += rv.y * (dv.y * rv.y);
+        acc[1] += rv.x * rv.x;
+        acc[1] += rv.y * rv.y;
+        i += gsz;
+        if (i >= n2)
+          break;
+        pv = ld2<NT>(p2 + i), qv = ld2<NT>(q2 + i), dv = ld2<NT>(d2 + i);
+        xv = ld2<NT>(x2 + i), rv = ld2<NT>(r2 + i);
+      }
     }
     if ((n & 1) && gtid == gsz - 1) {
       const size_t i = n - 1;
       x[i] += alpha * p[i];
-      const double rv = r[i] - alpha * q[i];
-      r[i] = rv;
-      acc[0] += rv * (dinv[i] * rv), acc[1] += rv * rv;
+      const double rs = r[i] - alpha * q[i];
+      r[i] = rs;
+      acc[0] += rs * (dinv[i] * rs), acc[1] += rs * rs;
     }
   } else {
     for (size_t i = gtid; i < n; i += gsz) {
       x[i] += alpha * p[i];
-      const double rv = r[i] - alpha * q[i];
-      r[i] = rv;
-      acc[0] += rv * (dinv[i] * rv), acc[1] += rv * rv;
+      const double rs = r[i] - alpha * q[i];
+      r[i] = rs;
+      acc[0] += rs * (dinv[i] * rs), acc[1] += rs * rs;
     }
   }
   wg_sum<2>(acc, sred);
@@ -543,14 +567,25 @@ __global__ __launch_bounds__(WG) void k_pcg_update_p(
     unsigned n, const double *__restrict__ r, const double *__restrict__ dinv,
     double *__restrict__ p, lsb_pcg_state *__restrict__ st, int parity,
     const double *__restrict__ parts2, unsigned nparts2) {
-  if (st->status)
-    return;
   __shared__ double sred[8];
+  const size_t gtid = (size_t)blockIdx.x * WG + threadIdx.x;
+  const size_t gsz = (size_t)gridDim.x * WG;
+  const size_t n2 = n / 2;
+  const d2v *r2 = (const d2v *)r, *d2 = (const d2v *)dinv;
+  d2v *p2 = (d2v *)p;
+  // as in k_pcg_update_xr: one round trip for status, scalars and operands
+  const int stopped = st->status;
+  const double rz_old = st->rz[parity], thresh2 = st->thresh2;
+  d2v rv = {0.0, 0.0}, dv = rv, pv = rv;
+  const bool first = V2 && gtid < n2;
+  if (first)
+    rv = ld2<NT>(r2 + gtid), dv = ld2<NT>(d2 + gtid), pv = ld2<NT>(p2 + gtid);
   double v[2];
   wg_sum_partials<2>(parts2, nparts2, v, sred);
+  if (stopped)
+    return;
   const double rz_new = v[0], rr = v[1];
-  const double rz_old = st->rz[parity];
-  const bool conv = rr <= st->thresh2;
+  const bool conv = rr <= thresh2;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     // only this thread touches iters/rr/rz[parity^1]/status in this launch
     const int it = st->iters + 1;
@@ -565,18 +600,18 @@ __global__ __launch_bounds__(WG) void k_pcg_update_p(
   if (conv)
     return;
   const double beta = rz_new / rz_old;
-  const size_t gtid = (size_t)blockIdx.x * WG + threadIdx.x;
-  const size_t gsz = (size_t)gridDim.x * WG;
   if (V2) {
-    const size_t n2 = n / 2;
-    const d2v *r2 = (const d2v *)r, *d2 = (const d2v *)dinv;
-    d2v *p2 = (d2v *)p;
-    for (size_t i = gtid; i < n2; i += gsz) {
-      const d2v rv = ld2<NT>(r2 + i), dv = ld2<NT>(d2 + i);
-      d2v pv = ld2<NT>(p2 + i);
-      pv.x = dv.x * rv.x + beta * pv.x;
-      pv.y = dv.y * rv.y + beta * pv.y;
-      p2[i] = pv;
+    if (first) {
+      size_t i = gtid;
+      for (;;) {
+        pv.x = dv.x * rv.x + beta * pv.x;
+        pv.y = dv.y * rv.y + beta * pv.y;
+        p2[i] = pv;
+        i += gsz;
+        if (i >= n2)
+          break;
+        rv = ld2<NT>(r2 + i), dv = ld2<NT>(d2 + i), pv = ld2<NT>(p2 + i);
+      }
     }
     if ((n & 1) && gtid == gsz - 1)
       p[n - 1] = dinv[n - 1] * r[n - 1] + beta * p[n - 1];

@@ -20,3 +20,6 @@ export TMPDIR=/tmp
 step rocprof_trace 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python3 bench.py --steps 1 --warmup 0 --cpu-seconds 0
 find "$OUT/prof" -name '*kernel_trace.csv' -size +20M -delete 2>/dev/null
 ls -laR "$OUT/prof" | tail -n 12
+step bench_cfg2 200 python bench.py --workload file:tests/golden/matrices/xn3b_A_18.txt.gz --tol 1e-12 --steps 200 --warmup 20
+step bench_lap3d 400 python bench.py --workload lap3d --steps 2 --warmup 1 --cpu-seconds 0
+step bench_powerlaw 400 python bench.py --workload powerlaw
