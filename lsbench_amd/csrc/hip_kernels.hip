@@ -184,7 +184,10 @@ __global__ __launch_bounds__(WG, 8) void k_spmv_adaptive(
       }
       __syncthreads(); // sprod is overwritten by the next block
     } else {
-      // ---- one long row (nr == 1): the whole workgroup strides over it --
+      // ---- one long row (nr == 1): the whole workgroup strides over it.
+      // Kept deliberately simple: an unrolled version of this rare path
+      // pushed the whole kernel over 64 VGPRs into scratch and cost the
+      // common path 70 % (tests/test_build_resources.py guards that).
       double s[1] = {0.0};
       for (int j = cj0 + (int)tid; j < cj0 + cnt; j += WG)
         s[0] += vals[j] * x[cols[j]];
