@@ -121,6 +121,37 @@ def cpu_baseline(A, gpu_iters, budget_s, is_spd):
                       % (done, dt, per_iter * 1e3, gpu_iters)}
 
 
+def cpu_direct_baseline(A, trials=100):
+    """Stand-in for the reference's CHOLMOD protocol (src/cholmod-impl.h:34-71:
+    factor once untimed, `trials` warm-up + `trials` timed solves with the
+    cached factor), with SciPy's SuperLU because CHOLMOD is not installable
+    here.  Small file matrices only; 1 core."""
+    try:
+        import numpy as np
+        import scipy.sparse as sp
+        import scipy.sparse.linalg as sla
+    except ImportError:
+        return None
+    n = A.nrows
+    S = sp.csc_matrix(sp.csr_matrix((A.vals, A.cols.astype(np.int64), A.offs.astype(np.int64)),
+                                    shape=(n, n)))
+    b = np.arange(n, dtype=np.float64)
+    t = time.perf_counter()
+    lu = sla.splu(S, permc_spec="MMD_AT_PLUS_A", options=dict(SymmetricMode=True))
+    t_factor = time.perf_counter() - t
+    for _ in range(trials):
+        lu.solve(b)
+    t = time.perf_counter()
+    for _ in range(trials):
+        x = lu.solve(b)
+    dt = time.perf_counter() - t
+    return {"value": trials / dt, "unit": "solves/s", "cores": 1, "kind": "stand-in",
+            "sample": "SuperLU (scipy %s) factor once (%.1f ms, untimed) + %d solves with the "
+                      "cached factor in %.3f s; relres %.1e" % (
+                          __import__("scipy").__version__, t_factor * 1e3, trials, dt,
+                          float(np.linalg.norm(b - S @ x) / np.linalg.norm(b)))}
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -273,6 +304,8 @@ def main():
         line["metric"] = "EXPERIMENT_fixed_%d_iterations_per_step" % a.fixed_iters
     if rank == 0 and world == 1 and a.cpu_seconds > 0 and a.fixed_iters == 0:
         line["cpu_baseline"] = cpu_baseline(Aloc, its, a.cpu_seconds, True)
+        if a.workload.startswith("file:"):
+            line["cpu_direct_baseline"] = cpu_direct_baseline(Aloc)
     if rank == 0:
         print(json.dumps(line), flush=True)
     solver.destroy()

@@ -83,6 +83,10 @@ int hip_cdna4_bench(double *x, struct csr *A, const double *r,
 enum { LSB_OP_CHOLMOD_UPPER = 0, /* S = triu(A)+triu(A,1)^T (default)      */
        LSB_OP_RAW = 1 };         /* the CSR exactly as handed in            */
 enum { LSB_PRECOND_JACOBI = 0, LSB_PRECOND_NONE = 1 };
+enum { LSB_KRYLOV_PCG = 0,    /* preconditioned CG (symmetric operators)    */
+       LSB_KRYLOV_GMRES = 1 };/* restarted GMRES(m), right-preconditioned,
+                                 for LSB_OP_RAW / unsymmetric operators;
+                                 single shard only in this round            */
 enum { LSB_SPMV_AUTO = 0,     /* pick by mean row length                    */
        LSB_SPMV_ADAPTIVE = 1, /* row-blocked: LDS-streamed short rows +
                                  wavefront-per-row long rows                */
@@ -107,6 +111,8 @@ struct lsb_hip_opts {
                         fastest; >= 0: force flags (bit 0 prefetch, bit 1
                         nontemporal)                                   [-1] */
   int spmv_grid;     /* workgroup cap of the SpMV launch, 0 = tuned     [0] */
+  int krylov;        /* LSB_KRYLOV_*                                  [PCG] */
+  int restart;       /* GMRES restart length m, 1..32                  [30] */
   int verbose;
 };
 

@@ -18,6 +18,7 @@ UNIQUE_ID_BYTES = 128
 SOLVER_HIP = 6
 OP_CHOLMOD_UPPER, OP_RAW = 0, 1
 PRECOND_JACOBI, PRECOND_NONE = 0, 1
+KRYLOV_PCG, KRYLOV_GMRES = 0, 1
 SPMV_AUTO, SPMV_ADAPTIVE, SPMV_SUBWAVE, SPMV_SCALAR = 0, 1, 2, 3
 STATUS_RUNNING, STATUS_CONVERGED, STATUS_BREAKDOWN, STATUS_MAXIT = 0, 1, 2, 3
 
@@ -45,7 +46,8 @@ class Opts(C.Structure):
                 ("precond", C.c_int), ("spmv_variant", C.c_int),
                 ("check_every", C.c_int), ("use_graph", C.c_int),
                 ("sample_spmv", C.c_int), ("nvirt", C.c_int), ("overlap", C.c_int),
-                ("spmv_tune", C.c_int), ("spmv_grid", C.c_int), ("verbose", C.c_int)]
+                ("spmv_tune", C.c_int), ("spmv_grid", C.c_int), ("krylov", C.c_int),
+                ("restart", C.c_int), ("verbose", C.c_int)]
 
 
 class Result(C.Structure):

@@ -69,6 +69,8 @@ void lsb_hip_opts_default(struct lsb_hip_opts *o) {
   o->overlap = 1;
   o->spmv_tune = -1;
   o->spmv_grid = 0;
+  o->krylov = LSB_KRYLOV_PCG;
+  o->restart = 30;
   o->verbose = 0;
 }
 
@@ -86,6 +88,10 @@ static void opts_from_env(struct lsb_hip_opts *o) {
     o->use_graph = atoi(e);
   if ((e = getenv("LSBENCH_HIP_SPMV")))
     o->spmv_variant = atoi(e);
+  if ((e = getenv("LSBENCH_HIP_KRYLOV")))
+    o->krylov = strcasecmp(e, "gmres") == 0 ? LSB_KRYLOV_GMRES : LSB_KRYLOV_PCG;
+  if ((e = getenv("LSBENCH_HIP_RESTART")))
+    o->restart = atoi(e);
   if ((e = getenv("LSBENCH_HIP_SPMV_TUNE")))
     o->spmv_tune = atoi(e);
   if ((e = getenv("LSBENCH_HIP_SPMV_GRID")))
@@ -226,6 +232,11 @@ struct lsb_hip_solver {
   } gcache[2];
   int gnext;
   unsigned hint_iters; /* iterations of the previous solve, 0 = none yet */
+  /* GMRES workspace (allocated on first use) */
+  double *gm_V, *gm_h, *gm_parts, *gm_ax;
+  struct lsb_gmres_state *gm_st, *gm_hst;
+  size_t gm_ld;
+  int gm_m;
   hipEvent_t ev_poll[2];
   hipEvent_t ev[4 * MAX_SAMPLES], ev_t0, ev_t1; /* per sample: e0 SpMV e1 e2 e3 */
   int have_events;
@@ -477,6 +488,10 @@ void lsb_hip_solver_destroy(lsb_hip_solver *sv) {
     LSB_CHK_HIP(hipEventDestroy(sv->ev_poll[1]));
   }
   lsb_hip_free(sv->d_scal_all), lsb_hip_free(sv->d_tmp);
+  lsb_hip_free(sv->gm_V), lsb_hip_free(sv->gm_h), lsb_hip_free(sv->gm_parts);
+  lsb_hip_free(sv->gm_ax), lsb_hip_free(sv->gm_st);
+  if (sv->gm_hst)
+    LSB_CHK_HIP(hipHostFree(sv->gm_hst));
   LSB_CHK_HIP(hipHostFree(sv->h_st));
   free(sv->sh), free(sv);
 }
@@ -697,12 +712,97 @@ static void drop_graphs(lsb_hip_solver *sv) {
  *     are enqueued one AHEAD of the poll, so the device never waits for the
  *     host; iterations enqueued past convergence are no-op launches.
  */
+/*
+ * Restarted GMRES(m), right Jacobi preconditioning, x0 = 0 (SURVEY.md section 8
+ * a2-6; kernels in hip_gmres.hip).  One restart cycle = up to m inner steps of
+ *   z = D^-1 v_j ; w = Op z ; h = V^T w ; w -= V h ; (again: CGS2) ; Givens
+ * enqueued in one go; the device closes the cycle early when the residual
+ * estimate |g_{j+1}| <= tol ||b||; the host polls the state once per cycle.
+ */
+static int gmres_solve_dev(lsb_hip_solver *sv, const double *d_b, double *d_x,
+                           struct lsb_hip_result *res) {
+  if (sv->multi)
+    errx(EXIT_FAILURE, "hip_cdna4: GMRES runs on a single shard only (round 1)");
+  struct shard *s = &sv->sh[0];
+  const unsigned n = s->n;
+  int m = sv->o.restart;
+  if (m < 1)
+    m = 1;
+  if (m > LSB_GMRES_MAX_RESTART)
+    m = LSB_GMRES_MAX_RESTART;
+  if (!sv->gm_V || sv->gm_m != m) {
+    lsb_hip_free(sv->gm_V);
+    sv->gm_ld = ((size_t)n + 1) & ~(size_t)1;
+    sv->gm_V = (double *)lsb_hip_malloc((size_t)(m + 1) * sv->gm_ld * sizeof(double));
+    sv->gm_m = m;
+    if (!sv->gm_h) {
+      sv->gm_h = (double *)lsb_hip_malloc(2 * (LSB_GMRES_MAX_RESTART + 1) * sizeof(double));
+      sv->gm_parts = (double *)lsb_hip_malloc((size_t)LSB_GMRES_PARTIALS *
+                                              (LSB_GMRES_MAX_RESTART + 1) * sizeof(double));
+      sv->gm_ax = (double *)lsb_hip_malloc((size_t)n * sizeof(double));
+      sv->gm_st = (struct lsb_gmres_state *)lsb_hip_malloc(sizeof(struct lsb_gmres_state));
+      LSB_CHK_HIP(hipHostMalloc((void **)&sv->gm_hst, sizeof(struct lsb_gmres_state), 0));
+    }
+  }
+  double *V = sv->gm_V, *h = sv->gm_h, *parts = sv->gm_parts;
+  const size_t ld = sv->gm_ld;
+  struct lsb_gmres_state *st = sv->gm_st;
+  const unsigned g = lsb_k_gm_grid(n);
+  double *z = s->d_pfull + s->row_begin; /* the vector the SpMV gathers from */
+  const double t0 = wall_seconds();
+
+  LSB_CHK_HIP(hipMemsetAsync(st, 0, sizeof *st, g_stream));
+  LSB_CHK_HIP(hipMemsetAsync(d_x, 0, (size_t)n * sizeof(double), g_stream));
+  LSB_CHK_HIP(hipMemsetAsync(sv->gm_ax, 0, (size_t)n * sizeof(double), g_stream));
+  for (int cycle = 0;; cycle++) {
+    if (cycle > 0) { /* ax = Op x for the restart residual */
+      LSB_CHK_HIP(hipMemcpyAsync(z, d_x, (size_t)n * sizeof(double),
+                                 hipMemcpyDeviceToDevice, g_stream));
+      spmv_shard(s, s->d_pfull, sv->gm_ax, NULL, NULL, NULL, NULL);
+    }
+    lsb_k_gm_resid(n, d_b, sv->gm_ax, V, parts, st, g_stream);
+    lsb_k_gm_begin(st, parts, g, sv->o.tol, (int)sv->o.maxit, m, cycle == 0, g_stream);
+    for (int j = 0; j < m; j++) {
+      double *vj = V + (size_t)j * ld, *w = V + (size_t)(j + 1) * ld;
+      /* v_j = (r or w) / norm ; z = D^-1 v_j */
+      lsb_k_gm_scale_prec(n, vj, vj, s->d_dinv, z, st, g_stream);
+      spmv_shard(s, s->d_pfull, w, NULL, NULL, NULL, NULL);
+      lsb_k_gm_multidot(n, V, ld, j + 1, w, parts, h, 0, st, g_stream);
+      lsb_k_gm_update_w(n, V, ld, j + 1, h, w, parts, st, g_stream);
+      /* second Gram-Schmidt pass (CGS2): h2 = V^T w ; w -= V h2 ; h = h + h2 */
+      double *h2 = h + LSB_GMRES_MAX_RESTART + 1;
+      lsb_k_gm_multidot(n, V, ld, j + 1, w, parts, h2, 0, st, g_stream);
+      lsb_k_gm_update_w(n, V, ld, j + 1, h2, w, parts, st, g_stream);
+      lsb_k_gm_hess(st, j, h, h2, parts, g, g_stream);
+    }
+    lsb_k_gm_finish_cycle(n, V, ld, s->d_dinv, d_x, st, g_stream);
+    LSB_CHK_HIP(hipMemcpyAsync(sv->gm_hst, st, sizeof *st, hipMemcpyDeviceToHost, g_stream));
+    LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+    if (sv->gm_hst->status != LSB_STATUS_RUNNING)
+      break;
+    if ((unsigned)cycle > sv->o.maxit + 2u)
+      errx(EXIT_FAILURE, "hip_cdna4: GMRES ran past maxit without a status");
+  }
+  struct lsb_hip_result r;
+  memset(&r, 0, sizeof r);
+  r.iters = (unsigned)sv->gm_hst->iters;
+  r.status = sv->gm_hst->status;
+  r.relres = sv->gm_hst->bnorm > 0.0 ? sv->gm_hst->resid / sv->gm_hst->bnorm : 0.0;
+  r.seconds = wall_seconds() - t0;
+  if (res)
+    *res = r;
+  g_last = r;
+  return 0;
+}
+
 int lsb_hip_solver_solve_dev(lsb_hip_solver *sv, const double *d_b, double *d_x,
                              struct lsb_hip_result *res) {
   if (!initialized)
     return 1;
   if (!sv || !d_b || !d_x)
     return 2;
+  if (sv->o.krylov == LSB_KRYLOV_GMRES)
+    return gmres_solve_dev(sv, d_b, d_x, res);
   const int chunk = sv->o.check_every > 0 ? (sv->o.check_every + 1) & ~1 : auto_chunk(sv);
   const int sampling = sv->o.sample_spmv > 0;
   const int use_graph = sv->o.use_graph && !sv->multi && !sampling;

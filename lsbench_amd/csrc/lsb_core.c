@@ -18,7 +18,7 @@
  * deliberate differences: --ordering/--precision/--verbose/--trials accept
  * "--flag value" as well as "--flag=value" (the reference segfaults on the
  * first form), --help prints the program name, and
- * --tol/--maxit/--operator/--nvirt are new.
+ * --tol/--maxit/--operator/--nvirt/--krylov/--restart are new.
  */
 #define _GNU_SOURCE
 #include "lsb_impl.h"
@@ -77,6 +77,8 @@ static void usage(const char *prog) {
   printf("  --maxit <N>          (hip) iteration cap, default 20000\n");
   printf("  --operator <upper|raw> (hip) upper = CHOLMOD's triu-mirrored matrix\n");
   printf("  --nvirt <P>          (hip) P row-range shards on one device (test)\n");
+  printf("  --krylov <cg|gmres>  (hip) Krylov method; gmres for --operator raw\n");
+  printf("  --restart <M>        (hip) GMRES restart length, 1..32, default 30\n");
   printf("  --help\n");
 }
 
@@ -87,7 +89,8 @@ struct lsbench *lsbench_init(int argc, char *argv[]) {
       {"verbose", required_argument, 0, 50},  {"trials", required_argument, 0, 60},
       {"help", no_argument, 0, 70},           {"tol", required_argument, 0, 80},
       {"maxit", required_argument, 0, 81},    {"operator", required_argument, 0, 82},
-      {"nvirt", required_argument, 0, 83},    {0, 0, 0, 0}};
+      {"nvirt", required_argument, 0, 83},    {"krylov", required_argument, 0, 84},
+      {"restart", required_argument, 0, 85},  {0, 0, 0, 0}};
 
   /* zero-filled => solver 0 (CUSOLVER), ordering 0 (RCM), FP64: the
    * reference's de-facto defaults (src/lsbench.c:95-96) */
@@ -135,6 +138,12 @@ struct lsbench *lsbench_init(int argc, char *argv[]) {
       break;
     case 83:
       o.nvirt = atoi(optarg);
+      break;
+    case 84:
+      o.krylov = strcasecmp(optarg, "gmres") == 0 ? LSB_KRYLOV_GMRES : LSB_KRYLOV_PCG;
+      break;
+    case 85:
+      o.restart = atoi(optarg);
       break;
     default:
       usage(argv[0]);

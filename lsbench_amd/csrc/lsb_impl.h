@@ -31,6 +31,17 @@ struct lsb_pcg_state {
   int pad;
 };
 
+/* ---- device-side GMRES(m) scalars ----------------------------------------- */
+#define LSB_GMRES_MAX_RESTART 32
+#define LSB_GMRES_PARTIALS 512
+struct lsb_gmres_state {
+  double bnorm, thresh, beta, resid, hnorm;
+  double g[LSB_GMRES_MAX_RESTART + 1];
+  double cs[LSB_GMRES_MAX_RESTART], sn[LSB_GMRES_MAX_RESTART], y[LSB_GMRES_MAX_RESTART];
+  double R[LSB_GMRES_MAX_RESTART * LSB_GMRES_MAX_RESTART]; /* R[i*MAX + j] */
+  int iters, status, maxit, restart, jlast, cycle_open;
+};
+
 /* Upper bound on per-launch partial sums any reduction kernel writes; the
  * consumer kernels re-reduce them in fixed order (deterministic). */
 #define LSB_MAX_PARTIALS 2048
@@ -90,6 +101,25 @@ void lsb_k_set_blas1_nt(int on);
 void lsb_k_fill_index(unsigned n, unsigned first, double *v, void *stream);
 void lsb_k_vreduce(double *base, unsigned stride, unsigned nshard, unsigned off,
                    unsigned cnt, void *stream);
+
+/* GMRES launchers (hip_gmres.hip) */
+unsigned lsb_k_gm_grid(unsigned n);
+void lsb_k_gm_resid(unsigned n, const double *b, const double *ax, double *v0,
+                    double *partials, const struct lsb_gmres_state *st, void *stream);
+void lsb_k_gm_begin(struct lsb_gmres_state *st, const double *partials, unsigned nparts,
+                    double tol, int maxit, int restart, int first, void *stream);
+void lsb_k_gm_scale_prec(unsigned n, const double *w, double *v, const double *dinv, double *z,
+                         const struct lsb_gmres_state *st, void *stream);
+void lsb_k_gm_multidot(unsigned n, const double *V, size_t ld, int cnt, const double *w,
+                       double *partials, double *h, int accumulate,
+                       const struct lsb_gmres_state *st, void *stream);
+void lsb_k_gm_update_w(unsigned n, const double *V, size_t ld, int cnt, const double *h,
+                       double *w, double *partials, const struct lsb_gmres_state *st,
+                       void *stream);
+void lsb_k_gm_hess(struct lsb_gmres_state *st, int j, const double *h, const double *h2,
+                   const double *partials, unsigned nparts, void *stream);
+void lsb_k_gm_finish_cycle(unsigned n, const double *V, size_t ld, const double *dinv, double *x,
+                           struct lsb_gmres_state *st, void *stream);
 
 /* ---- backend internals shared between hip_cdna4.c and hip_comm.c -------- */
 void *lsb_hip_stream(void);

@@ -337,6 +337,128 @@ done:
   return status;
 }
 
+/*
+ * Restarted GMRES(m), right Jacobi preconditioning, x0 = 0, Arnoldi by
+ * classical Gram-Schmidt applied twice, Givens rotations; stop when the
+ * residual estimate |g_{j+1}| <= tol*||b||, counted in inner steps -- the rules
+ * of lsbench_amd/csrc/hip_gmres.hip, stated sequentially.  Textbook (Saad,
+ * Iterative Methods, Alg. 6.9 + 9.5); no reference source exists.
+ * status: 1 converged, 2 breakdown, 3 maxit.
+ */
+int orc_gmres_jacobi(uint64_t n, const uint64_t *offs, const uint32_t *cols,
+                     const double *vals, const double *b, double *x, double tol,
+                     uint32_t maxit, uint32_t restart, uint32_t *iters_out,
+                     double *relres_out) {
+  const uint32_t m = restart < 1 ? 1 : restart;
+  double *V = (double *)malloc((size_t)(m + 1) * n * sizeof(double));
+  double *z = (double *)malloc(n * sizeof(double));
+  double *ax = (double *)calloc(n, sizeof(double));
+  double *dinv = (double *)malloc(n * sizeof(double));
+  double *R = (double *)calloc((size_t)m * m, sizeof(double));
+  double *g = (double *)calloc(m + 1, sizeof(double));
+  double *cs = (double *)calloc(m, sizeof(double)), *sn = (double *)calloc(m, sizeof(double));
+  double *h = (double *)calloc(m + 2, sizeof(double)), *y = (double *)calloc(m, sizeof(double));
+  for (uint64_t i = 0; i < n; i++) {
+    double d = 0.0;
+    for (uint64_t j = offs[i]; j < offs[i + 1]; j++)
+      if (cols[j] == i)
+        d = vals[j];
+    dinv[i] = d != 0.0 ? 1.0 / d : 0.0;
+    x[i] = 0.0;
+  }
+  int status = 0;
+  uint32_t it = 0;
+  double bnorm = 0.0, resid = 0.0, thresh = 0.0;
+  for (int cycle = 0; status == 0; cycle++) {
+    if (cycle > 0)
+      orc_spmv(n, offs, cols, vals, x, ax);
+    double rr = 0.0;
+    for (uint64_t i = 0; i < n; i++) {
+      V[i] = b[i] - ax[i];
+      rr += V[i] * V[i];
+    }
+    const double beta = sqrt(rr);
+    if (cycle == 0)
+      bnorm = beta, thresh = tol * beta;
+    resid = beta;
+    if (beta <= thresh || beta == 0.0) {
+      status = 1;
+      break;
+    }
+    if (it >= maxit) {
+      status = 3;
+      break;
+    }
+    memset(g, 0, (m + 1) * sizeof(double));
+    g[0] = beta;
+    double hnorm = beta;
+    uint32_t jlast = 0;
+    for (uint32_t j = 0; j < m && status == 0; j++) {
+      double *vj = V + (size_t)j * n, *w = V + (size_t)(j + 1) * n;
+      for (uint64_t i = 0; i < n; i++) {
+        vj[i] /= hnorm;
+        z[i] = dinv[i] * vj[i];
+      }
+      orc_spmv(n, offs, cols, vals, z, w);
+      for (uint32_t k = 0; k <= j; k++)
+        h[k] = 0.0;
+      for (int pass = 0; pass < 2; pass++) { /* CGS2 */
+        double hp[64];
+        for (uint32_t k = 0; k <= j; k++)
+          hp[k] = orc_dot(n, V + (size_t)k * n, w);
+        for (uint32_t k = 0; k <= j; k++) {
+          const double *vk = V + (size_t)k * n;
+          for (uint64_t i = 0; i < n; i++)
+            w[i] -= hp[k] * vk[i];
+          h[k] += hp[k];
+        }
+      }
+      hnorm = sqrt(orc_dot(n, w, w));
+      h[j + 1] = hnorm;
+      for (uint32_t i = 0; i < j; i++) {
+        const double t = cs[i] * h[i] + sn[i] * h[i + 1];
+        h[i + 1] = -sn[i] * h[i] + cs[i] * h[i + 1];
+        h[i] = t;
+      }
+      const double a = h[j], bb = h[j + 1], d = sqrt(a * a + bb * bb);
+      double c = 1.0, s = 0.0;
+      if (d != 0.0)
+        c = a / d, s = bb / d;
+      cs[j] = c, sn[j] = s;
+      h[j] = d;
+      for (uint32_t i = 0; i <= j; i++)
+        R[(size_t)i * m + j] = h[i];
+      g[j + 1] = -s * g[j];
+      g[j] = c * g[j];
+      resid = fabs(g[j + 1]);
+      jlast = j + 1;
+      it++;
+      if (d == 0.0)
+        status = 2;
+      else if (resid <= thresh || hnorm == 0.0)
+        status = 1;
+      else if (it >= maxit)
+        status = 3;
+    }
+    for (int i = (int)jlast - 1; i >= 0; i--) {
+      double s = g[i];
+      for (uint32_t k = i + 1; k < jlast; k++)
+        s -= R[(size_t)i * m + k] * y[k];
+      y[i] = R[(size_t)i * m + i] != 0.0 ? s / R[(size_t)i * m + i] : 0.0;
+    }
+    for (uint64_t i = 0; i < n; i++) {
+      double s = 0.0;
+      for (uint32_t k = 0; k < jlast; k++)
+        s += y[k] * V[(size_t)k * n + i];
+      x[i] += dinv[i] * s;
+    }
+  }
+  *iters_out = it;
+  *relres_out = bnorm > 0.0 ? resid / bnorm : 0.0;
+  free(V), free(z), free(ax), free(dinv), free(R), free(g), free(cs), free(sn), free(h), free(y);
+  return status;
+}
+
 /* ---------------------------------------------------------------------- */
 /* Synthetic operators of BASELINE.json configs 3-5, stated independently    */
 /* of the product generator (lsbench_amd/csrc/lsb_synth.c).  Definitions in  */
