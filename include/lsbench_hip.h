@@ -111,6 +111,8 @@ struct lsb_hip_opts {
                         fastest; >= 0: force flags (bit 0 prefetch, bit 1
                         nontemporal)                                   [-1] */
   int spmv_grid;     /* workgroup cap of the SpMV launch, 0 = tuned     [0] */
+  int reorder;       /* 1: solve P S P^T with P = reverse Cuthill-McKee, permute
+                        b, un-permute x (single shard)                  [0] */
   int krylov;        /* LSB_KRYLOV_*                                  [PCG] */
   int restart;       /* GMRES restart length m, 1..32                  [30] */
   int verbose;
@@ -163,6 +165,14 @@ unsigned lsb_csr_row_blocks(const struct csr *A, unsigned cap,
  * rows of each block; lanes[] holds nblk entries. */
 void lsb_csr_block_lanes(const struct csr *A, const unsigned *rowblk,
                          unsigned nblk, unsigned char *lanes);
+/* Reverse Cuthill-McKee ordering of a structurally symmetric CSR:
+ * perm[new] = old (cf. the host permutation Q of src/cusparse.c:67-85).
+ * Returns 0, or 2 on allocation failure. */
+int lsb_csr_rcm(const struct csr *S, unsigned *perm);
+/* P S P^T for perm[new] = old, as a new 0-based CSR (src/cusparse.c:87-97). */
+struct csr *lsb_csr_permute_sym(const struct csr *S, const unsigned *perm);
+/* max |row - col| over the stored entries */
+unsigned lsb_csr_bandwidth(const struct csr *S);
 /* [lo,hi) column range referenced by A (0-based). */
 void lsb_csr_col_hull(const struct csr *A, unsigned *lo, unsigned *hi);
 /* One contiguous range [offset, offset+count) (in doubles) of the exchanged

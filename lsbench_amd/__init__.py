@@ -10,7 +10,8 @@ from ._lib import (KRYLOV_GMRES, KRYLOV_PCG, LsbenchHipError, OP_CHOLMOD_UPPER, 
                    STATUS_MAXIT, STATUS_RUNNING)
 from .api import (Matrix, Solver, default_opts, hip_cdna4_bench,
                   hip_cdna4_finalize, hip_cdna4_init, last_result,
-                  lsb_csr_block_lanes, lsb_csr_col_hull, lsb_csr_copy_base0, lsb_csr_partition_rows,
+                  lsb_csr_bandwidth, lsb_csr_block_lanes, lsb_csr_col_hull,
+                  lsb_csr_permute_sym, lsb_csr_rcm, lsb_csr_copy_base0, lsb_csr_partition_rows,
                   lsb_plan_exchange,
                   lsb_csr_row_blocks, lsb_csr_row_slice,
                   lsb_csr_symmetrize_upper, lsbench_matrix_read,

@@ -46,7 +46,8 @@ class Opts(C.Structure):
                 ("precond", C.c_int), ("spmv_variant", C.c_int),
                 ("check_every", C.c_int), ("use_graph", C.c_int),
                 ("sample_spmv", C.c_int), ("nvirt", C.c_int), ("overlap", C.c_int),
-                ("spmv_tune", C.c_int), ("spmv_grid", C.c_int), ("krylov", C.c_int),
+                ("spmv_tune", C.c_int), ("spmv_grid", C.c_int), ("reorder", C.c_int),
+                ("krylov", C.c_int),
                 ("restart", C.c_int), ("verbose", C.c_int)]
 
 
@@ -93,6 +94,9 @@ SIGNATURES = {
     "lsb_csr_partition_rows": (_i, [_csrp, _u, C.POINTER(_u)]),
     "lsb_csr_row_blocks": (_u, [_csrp, _u, C.POINTER(C.POINTER(_u))]),
     "lsb_csr_block_lanes": (None, [_csrp, C.POINTER(_u), _u, C.POINTER(C.c_ubyte)]),
+    "lsb_csr_rcm": (_i, [_csrp, C.POINTER(_u)]),
+    "lsb_csr_permute_sym": (_csrp, [_csrp, C.POINTER(_u)]),
+    "lsb_csr_bandwidth": (_u, [_csrp]),
     "lsb_csr_col_hull": (None, [_csrp, C.POINTER(_u), C.POINTER(_u)]),
     "lsb_plan_exchange": (None, [_i, _i, C.POINTER(_u), C.POINTER(Xfer), C.POINTER(_i),
                                  C.POINTER(Xfer), C.POINTER(_i)]),

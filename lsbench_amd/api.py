@@ -133,6 +133,21 @@ def lsb_csr_block_lanes(A, rowblk):
     return out
 
 
+def lsb_csr_rcm(A):
+    perm = np.zeros(A.nrows, np.uint32)
+    L.check(L.load().lsb_csr_rcm(A.ptr, perm.ctypes.data_as(C.POINTER(C.c_uint))), "rcm")
+    return perm
+
+
+def lsb_csr_permute_sym(A, perm):
+    perm = np.ascontiguousarray(perm, dtype=np.uint32)
+    return Matrix(L.load().lsb_csr_permute_sym(A.ptr, perm.ctypes.data_as(C.POINTER(C.c_uint))))
+
+
+def lsb_csr_bandwidth(A):
+    return int(L.load().lsb_csr_bandwidth(A.ptr))
+
+
 def lsb_csr_col_hull(A):
     lo, hi = C.c_uint(), C.c_uint()
     L.load().lsb_csr_col_hull(A.ptr, C.byref(lo), C.byref(hi))

@@ -69,6 +69,7 @@ void lsb_hip_opts_default(struct lsb_hip_opts *o) {
   o->overlap = 1;
   o->spmv_tune = -1;
   o->spmv_grid = 0;
+  o->reorder = 0;
   o->krylov = LSB_KRYLOV_PCG;
   o->restart = 30;
   o->verbose = 0;
@@ -88,6 +89,8 @@ static void opts_from_env(struct lsb_hip_opts *o) {
     o->use_graph = atoi(e);
   if ((e = getenv("LSBENCH_HIP_SPMV")))
     o->spmv_variant = atoi(e);
+  if ((e = getenv("LSBENCH_HIP_REORDER")))
+    o->reorder = atoi(e);
   if ((e = getenv("LSBENCH_HIP_KRYLOV")))
     o->krylov = strcasecmp(e, "gmres") == 0 ? LSB_KRYLOV_GMRES : LSB_KRYLOV_PCG;
   if ((e = getenv("LSBENCH_HIP_RESTART")))
@@ -232,6 +235,9 @@ struct lsb_hip_solver {
   } gcache[2];
   int gnext;
   unsigned hint_iters; /* iterations of the previous solve, 0 = none yet */
+  /* reordering: d_perm[new] = old; b and x are permuted through d_bp / d_xp */
+  int *d_perm;
+  double *d_bp, *d_xp;
   /* GMRES workspace (allocated on first use) */
   double *gm_V, *gm_h, *gm_parts, *gm_ax;
   struct lsb_gmres_state *gm_st, *gm_hst;
@@ -409,6 +415,23 @@ lsb_hip_solver *lsb_hip_solver_create(const struct csr *A,
   if ((unsigned)P > S->nrows / 2)
     P = 1;
   lsb_hip_solver *sv = solver_alloc(P, &o);
+  if (o.reorder) {
+    /* Q = RCM(S); S <- Q S Q^T (src/cusparse.c:67-97) */
+    unsigned *perm = (unsigned *)malloc((size_t)S->nrows * sizeof(unsigned));
+    if (!perm || lsb_csr_rcm(S, perm))
+      errx(EXIT_FAILURE, "hip_cdna4: out of memory computing the RCM ordering");
+    struct csr *Sp = lsb_csr_permute_sym(S, perm);
+    if (o.verbose)
+      fprintf(stderr, "hip_cdna4: RCM bandwidth %u -> %u\n", lsb_csr_bandwidth(S),
+              lsb_csr_bandwidth(Sp));
+    lsbench_matrix_free(S);
+    S = Sp;
+    sv->d_perm = (int *)dev_upload(perm, (size_t)S->nrows * sizeof(int));
+    LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+    free(perm);
+    sv->d_bp = (double *)lsb_hip_malloc((size_t)S->nrows * sizeof(double));
+    sv->d_xp = (double *)lsb_hip_malloc((size_t)S->nrows * sizeof(double));
+  }
   sv->n_glob = sv->n_here = S->nrows, sv->row_first = 0;
   sv->dist = 0, sv->multi = P > 1;
   unsigned *bounds = lsb_calloc(unsigned, (size_t)P + 1);
@@ -488,6 +511,7 @@ void lsb_hip_solver_destroy(lsb_hip_solver *sv) {
     LSB_CHK_HIP(hipEventDestroy(sv->ev_poll[1]));
   }
   lsb_hip_free(sv->d_scal_all), lsb_hip_free(sv->d_tmp);
+  lsb_hip_free(sv->d_perm), lsb_hip_free(sv->d_bp), lsb_hip_free(sv->d_xp);
   lsb_hip_free(sv->gm_V), lsb_hip_free(sv->gm_h), lsb_hip_free(sv->gm_parts);
   lsb_hip_free(sv->gm_ax), lsb_hip_free(sv->gm_st);
   if (sv->gm_hst)
@@ -795,12 +819,27 @@ static int gmres_solve_dev(lsb_hip_solver *sv, const double *d_b, double *d_x,
   return 0;
 }
 
+static int solve_core(lsb_hip_solver *sv, const double *d_b, double *d_x,
+                      struct lsb_hip_result *res);
+
 int lsb_hip_solver_solve_dev(lsb_hip_solver *sv, const double *d_b, double *d_x,
                              struct lsb_hip_result *res) {
   if (!initialized)
     return 1;
   if (!sv || !d_b || !d_x)
     return 2;
+  if (!sv->d_perm)
+    return solve_core(sv, d_b, d_x, res);
+  /* b' = Q b ; solve Q S Q^T x' = b' ; x = Q^T x'   (src/cusparse.c:177,204) */
+  lsb_k_perm_gather(sv->n_here, sv->d_perm, d_b, sv->d_bp, g_stream);
+  const int rc = solve_core(sv, sv->d_bp, sv->d_xp, res);
+  lsb_k_perm_scatter(sv->n_here, sv->d_perm, sv->d_xp, d_x, g_stream);
+  LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+  return rc;
+}
+
+static int solve_core(lsb_hip_solver *sv, const double *d_b, double *d_x,
+                      struct lsb_hip_result *res) {
   if (sv->o.krylov == LSB_KRYLOV_GMRES)
     return gmres_solve_dev(sv, d_b, d_x, res);
   const int chunk = sv->o.check_every > 0 ? (sv->o.check_every + 1) & ~1 : auto_chunk(sv);
@@ -928,6 +967,11 @@ int lsb_hip_solver_spmv_dev(lsb_hip_solver *sv, const double *d_x, double *d_y) 
     return 1;
   if (!sv || !d_x || !d_y)
     return 2;
+  double *d_yout = NULL;
+  if (sv->d_perm) { /* y = Q^T (Q S Q^T) Q x */
+    lsb_k_perm_gather(sv->n_here, sv->d_perm, d_x, sv->d_bp, g_stream);
+    d_x = sv->d_bp, d_yout = d_y, d_y = sv->d_xp;
+  }
   for (int i = 0; i < sv->nshard; i++) {
     struct shard *s = &sv->sh[i];
     LSB_CHK_HIP(hipMemcpyAsync(s->d_pfull + s->row_begin, d_x + (s->row_begin - sv->row_first),
@@ -940,6 +984,8 @@ int lsb_hip_solver_spmv_dev(lsb_hip_solver *sv, const double *d_x, double *d_y) 
     struct shard *s = &sv->sh[i];
     spmv_shard(s, s->d_pfull, d_y + (s->row_begin - sv->row_first), NULL, NULL, NULL, NULL);
   }
+  if (d_yout)
+    lsb_k_perm_scatter(sv->n_here, sv->d_perm, d_y, d_yout, g_stream);
   LSB_CHK_HIP(hipStreamSynchronize(g_stream));
   return 0;
 }

@@ -392,6 +392,21 @@ __global__ __launch_bounds__(WG) void k_jacobi_sweep(
     x[i] += w * dinv[i] * (b[i] - ax[i]);
 }
 
+// dst[i] = src[perm[i]]  /  dst[perm[i]] = src[i]   (reordering, perm[new] = old)
+__global__ __launch_bounds__(WG) void k_perm_gather(unsigned n, const int *__restrict__ perm,
+                                                    const double *__restrict__ src,
+                                                    double *__restrict__ dst) {
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n; i += (size_t)gridDim.x * WG)
+    dst[i] = src[perm[i]];
+}
+
+__global__ __launch_bounds__(WG) void k_perm_scatter(unsigned n, const int *__restrict__ perm,
+                                                     const double *__restrict__ src,
+                                                     double *__restrict__ dst) {
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n; i += (size_t)gridDim.x * WG)
+    dst[perm[i]] = src[i];
+}
+
 __global__ __launch_bounds__(WG) void k_fill_index(unsigned n, unsigned first,
                                                    double *__restrict__ v) {
   for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n;
@@ -783,6 +798,16 @@ void lsb_k_jacobi_sweep(unsigned n, double w, const double *dinv,
 void lsb_k_vreduce(double *base, unsigned stride, unsigned nshard, unsigned off,
                    unsigned cnt, void *stream) {
   k_vreduce<<<1, 64, 0, (hipStream_t)stream>>>(base, stride, nshard, off, cnt);
+}
+
+void lsb_k_perm_gather(unsigned n, const int *perm, const double *src, double *dst,
+                       void *stream) {
+  k_perm_gather<<<ew_grid(n), WG, 0, (hipStream_t)stream>>>(n, perm, src, dst);
+}
+
+void lsb_k_perm_scatter(unsigned n, const int *perm, const double *src, double *dst,
+                        void *stream) {
+  k_perm_scatter<<<ew_grid(n), WG, 0, (hipStream_t)stream>>>(n, perm, src, dst);
 }
 
 void lsb_k_fill_index(unsigned n, unsigned first, double *v, void *stream) {

@@ -79,6 +79,9 @@ static void usage(const char *prog) {
   printf("  --nvirt <P>          (hip) P row-range shards on one device (test)\n");
   printf("  --krylov <cg|gmres>  (hip) Krylov method; gmres for --operator raw\n");
   printf("  --restart <M>        (hip) GMRES restart length, 1..32, default 30\n");
+  printf("  --reorder            (hip) solve the RCM-permuted operator (any --ordering\n");
+  printf("                       value maps to RCM; off by default because the reference's\n");
+  printf("                       zero-filled default ordering IS RCM, src/lsbench.c:95)\n");
   printf("  --help\n");
 }
 
@@ -90,7 +93,8 @@ struct lsbench *lsbench_init(int argc, char *argv[]) {
       {"help", no_argument, 0, 70},           {"tol", required_argument, 0, 80},
       {"maxit", required_argument, 0, 81},    {"operator", required_argument, 0, 82},
       {"nvirt", required_argument, 0, 83},    {"krylov", required_argument, 0, 84},
-      {"restart", required_argument, 0, 85},  {0, 0, 0, 0}};
+      {"restart", required_argument, 0, 85},  {"reorder", no_argument, 0, 86},
+      {0, 0, 0, 0}};
 
   /* zero-filled => solver 0 (CUSOLVER), ordering 0 (RCM), FP64: the
    * reference's de-facto defaults (src/lsbench.c:95-96) */
@@ -144,6 +148,9 @@ struct lsbench *lsbench_init(int argc, char *argv[]) {
       break;
     case 85:
       o.restart = atoi(optarg);
+      break;
+    case 86:
+      o.reorder = 1;
       break;
     default:
       usage(argv[0]);

@@ -99,6 +99,10 @@ void lsb_k_pcg_update_p(unsigned n, const double *r, const double *dinv,
 unsigned lsb_k_blas1_grid(unsigned n);
 void lsb_k_set_blas1_nt(int on);
 void lsb_k_fill_index(unsigned n, unsigned first, double *v, void *stream);
+void lsb_k_perm_gather(unsigned n, const int *perm, const double *src, double *dst,
+                       void *stream);
+void lsb_k_perm_scatter(unsigned n, const int *perm, const double *src, double *dst,
+                        void *stream);
 void lsb_k_vreduce(double *base, unsigned stride, unsigned nshard, unsigned off,
                    unsigned cnt, void *stream);
 

@@ -257,3 +257,151 @@ void lsb_csr_block_lanes(const struct csr *A, const unsigned *rowblk,
     lanes[k] = (unsigned char)(L > want ? L : want);
   }
 }
+
+/* ------------------------------------------------------------------------ */
+/* Reordering.  The reference's cuSOLVER     */
+/* backend computes a host permutation Q (src/cusparse.c:67-85), applies it    */
+/* symmetrically (:87-97), permutes the right-hand side (:177) and un-permutes */
+/* x (:204).  Same semantics here, with our own reverse Cuthill-McKee: it      */
+/* shrinks the band, which is what the SpMV's x-window-in-L2 design and the    */
+/* neighbour-only halo exchange feed on.                                       */
+/* ------------------------------------------------------------------------ */
+
+struct deg_node {
+  unsigned deg, id;
+};
+
+static int deg_cmp(const void *a, const void *b) {
+  const struct deg_node *x = (const struct deg_node *)a, *y = (const struct deg_node *)b;
+  if (x->deg != y->deg)
+    return x->deg < y->deg ? -1 : 1;
+  return x->id < y->id ? -1 : (x->id > y->id);
+}
+
+/* BFS from `start` over the unvisited part; appends to order[*pos...]; returns
+ * the last level's first node and the eccentricity through *depth */
+static unsigned bfs_component(const struct csr *S, unsigned start, unsigned char *seen,
+                              unsigned *order, unsigned *pos, struct deg_node *tmp,
+                              unsigned *depth) {
+  unsigned head = *pos, level_end, last_level_first = start, d = 0;
+  order[(*pos)++] = start;
+  seen[start] = 1;
+  level_end = *pos;
+  while (head < *pos) {
+    if (head == level_end) {
+      level_end = *pos;
+      last_level_first = order[head];
+      d++;
+    }
+    const unsigned u = order[head++];
+    unsigned k = 0;
+    for (unsigned j = S->offs[u]; j < S->offs[u + 1]; j++) {
+      const unsigned v = S->cols[j] - S->base;
+      if (v < S->nrows && !seen[v]) {
+        seen[v] = 1;
+        tmp[k].id = v, tmp[k].deg = S->offs[v + 1] - S->offs[v], k++;
+      }
+    }
+    if (k > 1)
+      qsort(tmp, k, sizeof *tmp, deg_cmp); /* Cuthill-McKee: by increasing degree */
+    for (unsigned i = 0; i < k; i++)
+      order[(*pos)++] = tmp[i].id;
+  }
+  *depth = d;
+  return last_level_first;
+}
+
+/*
+ * Reverse Cuthill-McKee of the pattern of S (assumed structurally symmetric,
+ * as the operator built by lsb_csr_symmetrize_upper is).  perm[new] = old.
+ * Every connected component starts from a pseudo-peripheral node (George-Liu:
+ * repeat BFS from the far end while the eccentricity grows).
+ */
+int lsb_csr_rcm(const struct csr *S, unsigned *perm) {
+  const unsigned n = S->nrows;
+  unsigned char *seen = (unsigned char *)calloc(n ? n : 1, 1);
+  unsigned char *scratch_seen = (unsigned char *)malloc(n ? n : 1);
+  unsigned *scratch = (unsigned *)malloc((size_t)(n ? n : 1) * sizeof(unsigned));
+  unsigned maxdeg = 1;
+  for (unsigned i = 0; i < n; i++)
+    if (S->offs[i + 1] - S->offs[i] > maxdeg)
+      maxdeg = S->offs[i + 1] - S->offs[i];
+  struct deg_node *tmp = (struct deg_node *)malloc((size_t)maxdeg * sizeof *tmp);
+  if (!seen || !scratch_seen || !scratch || !tmp)
+    return 2;
+  unsigned pos = 0;
+  for (unsigned root = 0; root < n; root++) {
+    if (seen[root])
+      continue;
+    /* pseudo-peripheral start inside this component */
+    unsigned start = root, best_depth = 0;
+    for (int trial = 0; trial < 8; trial++) {
+      memcpy(scratch_seen, seen, n);
+      unsigned p = 0, depth = 0;
+      const unsigned far = bfs_component(S, start, scratch_seen, scratch, &p, tmp, &depth);
+      if (trial > 0 && depth <= best_depth)
+        break;
+      best_depth = depth;
+      /* among the last level prefer the smallest degree: `far` is the first
+       * node of that level, which the degree sort put first among its peers */
+      start = far;
+    }
+    unsigned depth;
+    bfs_component(S, start, seen, perm, &pos, tmp, &depth);
+  }
+  for (unsigned i = 0; i < n / 2; i++) { /* reverse */
+    const unsigned t = perm[i];
+    perm[i] = perm[n - 1 - i], perm[n - 1 - i] = t;
+  }
+  free(seen), free(scratch_seen), free(scratch), free(tmp);
+  return pos == n ? 0 : 2;
+}
+
+/* B = P S P^T with perm[new] = old: row new of B is row perm[new] of S with
+ * columns renumbered by the inverse permutation and re-sorted.  0-based out. */
+struct csr *lsb_csr_permute_sym(const struct csr *S, const unsigned *perm) {
+  const unsigned n = S->nrows;
+  unsigned *inv = (unsigned *)malloc((size_t)(n ? n : 1) * sizeof(unsigned));
+  for (unsigned i = 0; i < n; i++)
+    inv[perm[i]] = i;
+  struct csr *B = csr_alloc(n, S->offs[n]);
+  unsigned long long acc = 0;
+  for (unsigned i = 0; i < n; i++) {
+    B->offs[i] = (unsigned)acc;
+    acc += S->offs[perm[i] + 1] - S->offs[perm[i]];
+  }
+  B->offs[n] = (unsigned)acc;
+  unsigned maxlen = 1;
+  for (unsigned i = 0; i < n; i++)
+    if (B->offs[i + 1] - B->offs[i] > maxlen)
+      maxlen = B->offs[i + 1] - B->offs[i];
+#pragma omp parallel
+  {
+    struct deg_node *row = (struct deg_node *)malloc((size_t)maxlen * sizeof *row);
+#pragma omp for schedule(static)
+    for (long long ii = 0; ii < (long long)n; ii++) {
+      const unsigned i = (unsigned)ii, src = perm[i], j0 = S->offs[src];
+      const unsigned len = S->offs[src + 1] - j0, d0 = B->offs[i];
+      for (unsigned k = 0; k < len; k++)
+        row[k].deg = inv[S->cols[j0 + k] - S->base], row[k].id = k; /* (new col, slot) */
+      qsort(row, len, sizeof *row, deg_cmp);
+      for (unsigned k = 0; k < len; k++)
+        B->cols[d0 + k] = row[k].deg, B->vals[d0 + k] = S->vals[j0 + row[k].id];
+    }
+    free(row);
+  }
+  free(inv);
+  return B;
+}
+
+/* max |i - j| over the stored entries */
+unsigned lsb_csr_bandwidth(const struct csr *S) {
+  unsigned bw = 0;
+  for (unsigned i = 0; i < S->nrows; i++)
+    for (unsigned j = S->offs[i]; j < S->offs[i + 1]; j++) {
+      const unsigned c = S->cols[j] - S->base, d = c > i ? c - i : i - c;
+      if (d > bw)
+        bw = d;
+    }
+  return bw;
+}
