@@ -157,6 +157,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # LSB_BENCH_FORCE_DIST=1 drives the multi-rank code path (process group, RCCL
+    # communicator, distributed solver constructor) with a single rank -- the
+    # only way to rehearse it on a one-GPU box
+    dist_on = world > 1 or os.environ.get("LSB_BENCH_FORCE_DIST") == "1"
+    if dist_on:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
@@ -166,7 +173,7 @@ def main():
     lib = la._lib.load()
     if la.hip_cdna4_init() != 0:
         sys.exit("hip_cdna4_init failed: no MI355X visible (there is no CPU path)")
-    if world > 1:
+    if dist_on:
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local))
         idb = ctypes.create_string_buffer(la._lib.UNIQUE_ID_BYTES)
@@ -185,7 +192,7 @@ def main():
         A = la.lsb_csr_symmetrize_upper(Afile)  # the operator CHOLMOD factorises
         n = A.nrows
         name = os.path.basename(a.workload[5:])
-        if world > 1:
+        if dist_on:
             b = la.lsb_csr_partition_rows(A, world)
             r0, r1 = int(b[rank]), int(b[rank + 1])
             Aloc = la.lsb_csr_row_slice(A, r0, r1)
@@ -206,7 +213,7 @@ def main():
                            use_graph=1 if small else 0, sample_spmv=0 if small else 16,
                            spmv_tune=a.spmv_tune,
                            precond=la.PRECOND_NONE if spmv_only else la.PRECOND_JACOBI)
-    if world > 1:
+    if dist_on:
         solver = la.Solver(Aloc, opts, row_begin=r0, n_global=n)
     else:
         solver = la.Solver(Aloc, opts)
@@ -217,7 +224,7 @@ def main():
     t_setup = time.perf_counter() - t_setup
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -254,7 +261,7 @@ def main():
         spmv_n += res.spmv_samples
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
@@ -278,7 +285,7 @@ def main():
     except OSError:
         pass
     n_tot_nnz = nnz_loc
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([float(nnz_loc)], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt)
         n_tot_nnz = int(tt.item())
@@ -309,7 +316,7 @@ def main():
     if rank == 0:
         print(json.dumps(line), flush=True)
     solver.destroy()
-    if world > 1:
+    if dist_on:
         lib.lsb_hip_comm_destroy()
         dist.destroy_process_group()
 
