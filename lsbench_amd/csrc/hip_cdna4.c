@@ -235,6 +235,7 @@ struct lsb_hip_solver {
   } gcache[2];
   int gnext;
   unsigned hint_iters; /* iterations of the previous solve, 0 = none yet */
+  unsigned agree_nnz, agree_n; /* distributed: largest shard, identical on all ranks */
   /* reordering: d_perm[new] = old; b and x are permuted through d_bp / d_xp */
   int *d_perm;
   double *d_bp, *d_xp;
@@ -469,6 +470,20 @@ lsb_hip_solver *lsb_hip_solver_create_dist(const struct csr *A_rows,
   unsigned mine[4] = {row_begin, A_rows->nrows, sv->sh[0].col_lo, sv->sh[0].col_hi};
   unsigned *hull = lsb_calloc(unsigned, 4 * (size_t)P);
   lsb_hip_comm_allgather_u32(mine, 4, hull);
+  /* every rank must enqueue the SAME number of iterations between polls (the
+   * collectives inside have to pair up), so the chunk size is derived from
+   * numbers all ranks agree on: the largest shard */
+  {
+    unsigned nz = (unsigned)sv->sh[0].nnz, *allnz = lsb_calloc(unsigned, (size_t)P);
+    lsb_hip_comm_allgather_u32(&nz, 1, allnz);
+    for (int q = 0; q < P; q++) {
+      if (allnz[q] > sv->agree_nnz)
+        sv->agree_nnz = allnz[q];
+      if (hull[4 * q + 1] > sv->agree_n)
+        sv->agree_n = hull[4 * q + 1];
+    }
+    free(allnz);
+  }
   /* sanity: the shards must tile [0, n_global) in rank order */
   unsigned expect = 0;
   int full = 1, equal = 1;
@@ -685,6 +700,8 @@ static int auto_chunk(const lsb_hip_solver *sv) {
    * and bound the no-op tail enqueued past convergence */
   const struct shard *s = &sv->sh[0];
   double bytes = 12.0 * (double)s->nnz + 108.0 * (double)s->n;
+  if (sv->dist) /* must not depend on this rank's own shard size */
+    bytes = 12.0 * (double)sv->agree_nnz + 108.0 * (double)sv->agree_n;
   double us = bytes / 4.0e6; /* 4 TB/s => bytes per microsecond */
   if (us < 6.0)
     us = 6.0;

@@ -365,3 +365,33 @@ def test_driver_binary_end_to_end(hip, matrix_path):
                         "--operator", "raw", "--tol", "1e-8", "--trials=2"],
                        capture_output=True, text=True)
     assert r.returncode == 0 and "===hip_cdna4:" in r.stdout
+
+
+def test_edge_inputs_through_the_driver(hip, tmp_path):
+    """1x1 system, a missing diagonal (Jacobi cannot be built: hard error like the
+    reference's chk_* macros, src/cusparse.c:8-31), trials=0, --reorder."""
+    drv = os.path.join(ROOT, "lsbench_amd", "csrc", "driver")
+    one = tmp_path / "one.txt"
+    one.write_text("1 1\n1 1 4.0\n")
+    r = subprocess.run([drv, "--solver", "hip", "--matrix", str(one), "--trials=2", "--verbose", "2"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and "x[0] = 0" in r.stdout           # b_0 = 0 -> x = 0, 0 iterations
+    nodiag = tmp_path / "nodiag.txt"
+    nodiag.write_text("3 0\n0 0 2.0\n0 1 1.0\n1 0 1.0\n")        # row 1 has no diagonal
+    r = subprocess.run([drv, "--solver", "hip", "--matrix", str(nodiag), "--trials=1"],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "no non-zero diagonal" in r.stderr
+    m = os.path.join(GOLD, "matrices", "I1_05x05.txt")
+    r = subprocess.run([drv, "--solver", "hip", "--matrix", m, "--trials=0"], capture_output=True, text=True)
+    assert r.returncode == 0 and "===matrix" in r.stdout           # protocol with zero trials
+    r = subprocess.run([drv, "--solver", "hip", "--matrix", m, "--trials=2", "--reorder", "--verbose", "2"],
+                       capture_output=True, text=True)
+    x = [float(l.split("=")[1]) for l in r.stdout.splitlines() if l.startswith("x[")]
+    assert r.returncode == 0 and np.allclose(x, [0, 1 / 2, 2 / 3, 3 / 4, 4 / 5], rtol=1e-15)
+    r = subprocess.run([drv, "--solver", "hip", "--matrix", "synth:lap2d:nx=64,ny=64", "--operator", "raw",
+                        "--krylov", "gmres", "--restart", "20", "--tol", "1e-9", "--trials=1"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and "===hip_cdna4:" in r.stdout
+    f = r.stdout.splitlines()[r.stdout.splitlines().index(
+        "===hip_cdna4:iterations,relres,status,tol,solves_per_sec,nshards===") + 1].split(",")
+    assert int(f[2]) == 1 and float(f[1]) <= 1e-9

@@ -44,7 +44,7 @@ __device__ __forceinline__ void wg_sum(double (&v)[W], double *sred) {
     v[k] = (sred[0 * W + k] + sred[1 * W + k]) + (sred[2 * W + k] + sred[3 * W + k]);
 }
 
-enum { F_NOREMAP = 1, F_FAKEGATHER = 2, F_NODOT = 4, F_NOX = 8, F_CYCLIC = 16, F_NT = 32, F_PREFETCH = 64, F_HOIST = 128 };
+enum { F_NOREMAP = 1, F_FAKEGATHER = 2, F_NODOT = 4, F_NOX = 8, F_CYCLIC = 16, F_NT = 32, F_PREFETCH = 64, F_HOIST = 128, F_TWOROW = 256, F_ROWCAP = 512 };
 
 // BLAS-1 probe shaped like k_pcg_update_xr: 5 streams in, 2 out, 16 B/lane.
 // NT bit 0: nontemporal loads, bit 1: nontemporal stores.
@@ -458,10 +458,10 @@ __global__ __launch_bounds__(WG, MINW) void k_adaptive_cyc(const int *__restrict
         L <<= 1;
       // F_HOIST: row offsets and the dot operand of this lane's (up to two)
       // rows are requested together with the gathers, not after the barrier
-      const bool fast = (FLAGS & F_HOIST) && L == 1 && nr <= 2 * WG;
+      const bool fast = (FLAGS & (F_HOIST | F_TWOROW)) && L == 1 && nr <= 2 * WG;
       int oa0 = 0, ob0 = 0, oa1 = 0, ob1 = 0;
       double xd0 = 0.0, xd1 = 0.0;
-      if (fast) {
+      if (fast && (FLAGS & F_HOIST)) {
         if ((int)tid < nr) {
           oa0 = offs[cr0 + tid] - cj0, ob0 = offs[cr0 + tid + 1] - cj0;
           xd0 = x[cr0 + tid];
@@ -486,6 +486,16 @@ __global__ __launch_bounds__(WG, MINW) void k_adaptive_cyc(const int *__restrict
       if ((FLAGS & F_PREFETCH) && k + gx < kend)
         ISSUE_WG(k + gx);
       __syncthreads();
+      if (fast && (FLAGS & F_TWOROW)) { // both rows of this lane in ONE pass
+        if ((int)tid < nr) {
+          oa0 = offs[cr0 + tid] - cj0, ob0 = offs[cr0 + tid + 1] - cj0;
+          xd0 = x[cr0 + tid];
+        }
+        if ((int)tid + WG < nr) {
+          oa1 = offs[cr0 + tid + WG] - cj0, ob1 = offs[cr0 + tid + WG + 1] - cj0;
+          xd1 = x[cr0 + tid + WG];
+        }
+      }
       if (fast) {
         double s0 = 0.0, s1 = 0.0;
         for (int j = oa0; j < ob0; j++)
@@ -889,12 +899,15 @@ static Csr powerlaw(int n, double gamma, int dmax) {
 static std::vector<int> row_blocks(const Csr &A, int cap) {
   std::vector<int> rb{0};
   int r = 0;
+  int rowcap = 0x7fffffff;
+  if (cap < 0) rowcap = -cap, cap = 2048;
   while (r < A.n) {
     const long lim = (long)A.offs[r] + cap;
     int e = r + 1;
     if (A.offs[e] <= lim)
       e = (int)(std::upper_bound(A.offs.begin() + r + 1, A.offs.end(), (int)std::min<long>(lim, 0x7fffffff)) -
                 A.offs.begin()) - 1;
+    if (e - r > rowcap) e = r + rowcap;
     rb.push_back(e);
     r = e;
   }
@@ -946,6 +959,8 @@ LAUNCHER(l_wave512_pf7, (k_wave<512, F_PREFETCH, 7>))
 LAUNCHER(l_wave512_pf6, (k_wave<512, F_PREFETCH, 6>))
 LAUNCHER(l_cyc_pf_nt, (k_adaptive_cyc<2048, F_CYCLIC | F_PREFETCH | F_NT>))
 LAUNCHER(l_cyc_nt, (k_adaptive_cyc<2048, F_CYCLIC | F_NT>))
+LAUNCHER(l_cyc_two, (k_adaptive_cyc<2048, F_CYCLIC | F_NT | F_PREFETCH | F_TWOROW>))
+LAUNCHER(l_cyc_two_nont, (k_adaptive_cyc<2048, F_CYCLIC | F_PREFETCH | F_TWOROW>))
 LAUNCHER(l_cyc_hoist, (k_adaptive_cyc<2048, F_CYCLIC | F_NT | F_PREFETCH | F_HOIST>))
 LAUNCHER(l_cyc_hoist_nopf, (k_adaptive_cyc<2048, F_CYCLIC | F_NT | F_HOIST>))
 LAUNCHER(l_cyc_hoist7, (k_adaptive_cyc<2048, F_CYCLIC | F_NT | F_PREFETCH | F_HOIST, 7>))
@@ -996,10 +1011,10 @@ int main(int argc, char **argv) {
       {"cyc+prefetch+nt cap2048 (library)", 2048, l_cyc_pf_nt, 2048},
       {"cyc+nt cap2048", 2048, l_cyc_nt, 2048},
       {"cyc+prefetch cap2048", 2048, l_cyc_pf, 2048},
-      {"cyc+pf+nt+hoist", 2048, l_cyc_hoist, 2048},
-      {"cyc+nt+hoist (no prefetch)", 2048, l_cyc_hoist_nopf, 2048},
-      {"cyc+pf+nt+hoist minw7 g1792", 2048, l_cyc_hoist7, 1792},
-      {"cyc+pf+hoist (no nt)", 2048, l_cyc_hoist_nonT, 2048},
+      {"cyc+pf+nt+tworow", 2048, l_cyc_two, 2048},
+      {"cyc+pf+tworow (no nt)", 2048, l_cyc_two_nont, 2048},
+      {"cyc+pf+nt rows<=256 per block", -256, l_cyc_pf_nt, 2048},
+      {"cyc+pf rows<=256 per block", -256, l_cyc_pf, 2048},
       {"probe: cyc+pf+nt, gather from 8KB", 2048, l_cyc_fake, 2048},
       {"probe: cyc+pf+nt, no gather", 2048, l_cyc_nox, 2048},
       {"probe: v4 cyc+pf+nt, no gather", 2040, l_v4_nox, 2048},
