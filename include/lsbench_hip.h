@@ -106,7 +106,6 @@ struct lsb_hip_opts {
   int sample_spmv;   /* HIP-event-time every Nth SpMV launch (0=off)   [0]  */
   int nvirt;         /* >1: split into that many row-range shards on ONE
                         device, exchanging by device copies (test mode) [1] */
-  int overlap;       /* overlap halo exchange with interior rows        [1] */
   int spmv_tune;     /* -1: time the SpMV flavours at creation and keep the
                         fastest; >= 0: force flags (bit 0 prefetch, bit 1
                         nontemporal)                                   [-1] */

@@ -66,7 +66,6 @@ void lsb_hip_opts_default(struct lsb_hip_opts *o) {
   o->use_graph = 1;
   o->sample_spmv = 0;
   o->nvirt = 1;
-  o->overlap = 1;
   o->spmv_tune = -1;
   o->spmv_grid = 0;
   o->reorder = 0;
