@@ -91,7 +91,9 @@ enum { LSB_SPMV_AUTO = 0,     /* pick by mean row length                    */
        LSB_SPMV_ADAPTIVE = 1, /* row-blocked: LDS-streamed short rows +
                                  wavefront-per-row long rows                */
        LSB_SPMV_SUBWAVE = 2,  /* 2..64 lanes per row, shuffle reduction     */
-       LSB_SPMV_SCALAR = 3 }; /* one lane per row (test/debug baseline)     */
+       LSB_SPMV_SCALAR = 3,   /* one lane per row (test/debug baseline)     */
+       LSB_SPMV_PANEL = 4 };  /* column panels with an L2-resident x window,
+                                 for scattered rows (solver handle only)    */
 enum { LSB_STATUS_RUNNING = 0, LSB_STATUS_CONVERGED = 1,
        LSB_STATUS_BREAKDOWN = 2, LSB_STATUS_MAXIT = 3 };
 
@@ -172,6 +174,20 @@ int lsb_csr_rcm(const struct csr *S, unsigned *perm);
 struct csr *lsb_csr_permute_sym(const struct csr *S, const unsigned *perm);
 /* max |row - col| over the stored entries */
 unsigned lsb_csr_bandwidth(const struct csr *S);
+/* Column-panel form of a CSR (for scattered operators): the (row, panel) pairs
+ * of panel-major order as the rows of one CSR.  See lsb_csr_panelize. */
+struct lsb_panel_csr {
+  unsigned npanels, width, npairs, nrows;
+  unsigned *pair_begin; /* npanels+1: first pair of each panel            */
+  unsigned *pair_row;   /* npairs: original row of each pair              */
+  unsigned *offs;       /* npairs+1 into cols/vals                        */
+  unsigned *cols;       /* 0-based global column ids, panel-major copy    */
+  double *vals;
+};
+struct lsb_panel_csr *lsb_csr_panelize(const struct csr *A, unsigned width);
+void lsb_panel_csr_free(struct lsb_panel_csr *P);
+/* mean |col - (row + row_begin)| over a sample of the rows */
+double lsb_csr_mean_scatter(const struct csr *A, unsigned row_begin);
 /* [lo,hi) column range referenced by A (0-based). */
 void lsb_csr_col_hull(const struct csr *A, unsigned *lo, unsigned *hi);
 /* One contiguous range [offset, offset+count) (in doubles) of the exchanged

@@ -5,7 +5,7 @@ this package is the ctypes binding the tests and bench.py drive it through.
 """
 from . import _lib
 from ._lib import (KRYLOV_GMRES, KRYLOV_PCG, LsbenchHipError, OP_CHOLMOD_UPPER, OP_RAW, PRECOND_JACOBI,
-                   PRECOND_NONE, SPMV_ADAPTIVE, SPMV_AUTO, SPMV_SCALAR,
+                   PRECOND_NONE, SPMV_ADAPTIVE, SPMV_AUTO, SPMV_PANEL, SPMV_SCALAR,
                    SPMV_SUBWAVE, STATUS_BREAKDOWN, STATUS_CONVERGED,
                    STATUS_MAXIT, STATUS_RUNNING)
 from .api import (Matrix, Solver, default_opts, hip_cdna4_bench,

@@ -19,7 +19,7 @@ SOLVER_HIP = 6
 OP_CHOLMOD_UPPER, OP_RAW = 0, 1
 PRECOND_JACOBI, PRECOND_NONE = 0, 1
 KRYLOV_PCG, KRYLOV_GMRES = 0, 1
-SPMV_AUTO, SPMV_ADAPTIVE, SPMV_SUBWAVE, SPMV_SCALAR = 0, 1, 2, 3
+SPMV_AUTO, SPMV_ADAPTIVE, SPMV_SUBWAVE, SPMV_SCALAR, SPMV_PANEL = 0, 1, 2, 3, 4
 STATUS_RUNNING, STATUS_CONVERGED, STATUS_BREAKDOWN, STATUS_MAXIT = 0, 1, 2, 3
 
 
@@ -56,6 +56,14 @@ class Result(C.Structure):
     _fields_ = [("iters", C.c_uint), ("status", C.c_int), ("relres", C.c_double),
                 ("seconds", C.c_double), ("spmv_ms", C.c_double),
                 ("spmv_samples", C.c_uint)]
+
+
+class PanelCsr(C.Structure):
+    """struct lsb_panel_csr."""
+    _fields_ = [("npanels", C.c_uint), ("width", C.c_uint), ("npairs", C.c_uint),
+                ("nrows", C.c_uint), ("pair_begin", C.POINTER(C.c_uint)),
+                ("pair_row", C.POINTER(C.c_uint)), ("offs", C.POINTER(C.c_uint)),
+                ("cols", C.POINTER(C.c_uint)), ("vals", C.POINTER(C.c_double))]
 
 
 class Xfer(C.Structure):
@@ -97,6 +105,9 @@ SIGNATURES = {
     "lsb_csr_rcm": (_i, [_csrp, C.POINTER(_u)]),
     "lsb_csr_permute_sym": (_csrp, [_csrp, C.POINTER(_u)]),
     "lsb_csr_bandwidth": (_u, [_csrp]),
+    "lsb_csr_panelize": (C.POINTER(PanelCsr), [_csrp, _u]),
+    "lsb_panel_csr_free": (None, [C.POINTER(PanelCsr)]),
+    "lsb_csr_mean_scatter": (_d, [_csrp, _u]),
     "lsb_csr_col_hull": (None, [_csrp, C.POINTER(_u), C.POINTER(_u)]),
     "lsb_plan_exchange": (None, [_i, _i, C.POINTER(_u), C.POINTER(Xfer), C.POINTER(_i),
                                  C.POINTER(Xfer), C.POINTER(_i)]),

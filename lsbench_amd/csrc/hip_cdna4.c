@@ -212,6 +212,12 @@ struct shard {
   unsigned nblk, lanes;
   int variant;
   unsigned col_lo, col_hi; /* column hull referenced by the shard's rows */
+  /* column-panel form (LSB_SPMV_PANEL), built for scattered operators only */
+  unsigned pn;       /* panels, 0 = not built */
+  unsigned *h_pblk;  /* pn+1: first row block of each panel */
+  int *pd_offs, *pd_cols, *pd_rowmap, *pd_rowblk;
+  unsigned char *pd_blklanes;
+  double *pd_vals;
   struct lsb_xfer *recv, *send;
   int nrecv, nsend;
 };
@@ -267,6 +273,8 @@ static void choose_spmv(struct shard *s, const struct lsb_hip_opts *o) {
    * and wins 3.2 vs 5.7 us per launch on tests/xn3b_A_18.txt. */
   if (v == LSB_SPMV_AUTO)
     v = s->nnz <= 500000ull ? LSB_SPMV_SUBWAVE : LSB_SPMV_ADAPTIVE;
+  if (v == LSB_SPMV_PANEL && !s->pn)
+    v = LSB_SPMV_ADAPTIVE; /* the operator did not qualify for panels */
   s->variant = v;
   unsigned L = pow2_ceil(mean ? mean : 1);
   if (L < 2)
@@ -274,6 +282,47 @@ static void choose_spmv(struct shard *s, const struct lsb_hip_opts *o) {
   if (L > 64)
     L = 64;
   s->lanes = L;
+}
+
+static void *dev_upload(const void *h, size_t bytes);
+
+/* Column-panel form of the shard (lsb_csr_panelize) + its row blocks, one run
+ * of blocks per panel so that a launch never crosses a panel. */
+static void shard_build_panels(struct shard *s, const struct csr *view, unsigned width) {
+  struct lsb_panel_csr *P = lsb_csr_panelize(view, width);
+  const unsigned np = P->npanels;
+  s->h_pblk = lsb_calloc(unsigned, (size_t)np + 1);
+  size_t cap = (size_t)P->offs[P->npairs] / LSB_BLOCK_NNZ * 2 + 4 * (size_t)np + 16, nb = 0;
+  unsigned *rball = (unsigned *)malloc((cap + 1) * sizeof(unsigned));
+  unsigned char *lanes = (unsigned char *)malloc(cap + 1);
+  for (unsigned p = 0; p < np; p++) {
+    const unsigned b0 = P->pair_begin[p], cnt = P->pair_begin[p + 1] - b0;
+    s->h_pblk[p] = (unsigned)nb;
+    if (cnt == 0)
+      continue;
+    struct csr sub = {cnt, 0, P->offs + b0, NULL, NULL};
+    unsigned *rb = NULL;
+    const unsigned k = lsb_csr_row_blocks(&sub, LSB_BLOCK_NNZ, &rb);
+    if (nb + k + 1 > cap)
+      errx(EXIT_FAILURE, "hip_cdna4: panel row-block estimate too small");
+    lsb_csr_block_lanes(&sub, rb, k, lanes + nb);
+    for (unsigned i = 0; i <= k; i++)
+      rball[nb + i] = rb[i] + b0; /* the last entry is the next panel's first */
+    nb += k;
+    free(rb);
+  }
+  s->h_pblk[np] = (unsigned)nb;
+  rball[nb] = P->npairs;
+  s->pn = np;
+  s->pd_offs = (int *)dev_upload(P->offs, ((size_t)P->npairs + 1) * sizeof(int));
+  s->pd_cols = (int *)dev_upload(P->cols, (size_t)P->offs[P->npairs] * sizeof(int));
+  s->pd_vals = (double *)dev_upload(P->vals, (size_t)P->offs[P->npairs] * sizeof(double));
+  s->pd_rowmap = (int *)dev_upload(P->pair_row, (size_t)P->npairs * sizeof(int));
+  s->pd_rowblk = (int *)dev_upload(rball, (nb + 1) * sizeof(int));
+  s->pd_blklanes = (unsigned char *)dev_upload(lanes, nb ? nb : 1);
+  LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+  free(rball), free(lanes);
+  lsb_panel_csr_free(P);
 }
 
 /* Upload rows [r0,r1) of the 0-based operator `S` (global column ids) as one
@@ -316,6 +365,18 @@ static void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
   unsigned char *lanes = (unsigned char *)malloc((size_t)s->nblk + 1);
   lsb_csr_block_lanes(&view, rb, s->nblk, lanes);
   s->d_blklanes = (unsigned char *)dev_upload(lanes, (size_t)s->nblk);
+  /* Scattered rows (mean |col-row| in the millions, x far beyond L2): also
+   * build the column-panel form; tune_spmv() keeps whichever is faster. */
+  {
+    struct csr gview = {n, 0, (unsigned *)offs, (unsigned *)cols, (double *)(S->vals + j0)};
+    const char *e = getenv("LSBENCH_HIP_PANEL_COLS");
+    const unsigned width = e ? (unsigned)strtoul(e, NULL, 10) : 262144u; /* 2 MiB of x */
+    const int forced = o->spmv_variant == LSB_SPMV_PANEL;
+    const int scattered = s->nnz > 4000000ull && (double)(hi - lo) * 8.0 > 16.0e6 &&
+                          lsb_csr_mean_scatter(&gview, row_begin) > 1.0e6;
+    if (width && (forced || (o->spmv_variant == LSB_SPMV_AUTO && scattered)))
+      shard_build_panels(s, &gview, width);
+  }
   LSB_CHK_HIP(hipStreamSynchronize(g_stream)); /* host staging is freed next */
   free(rb), free(offs), free(cols), free(lanes);
 
@@ -358,6 +419,9 @@ static void shard_free(struct shard *s) {
   lsb_hip_free(s->d_dinv), lsb_hip_free(s->d_r);
   lsb_hip_free(s->d_q), lsb_hip_free(s->d_pfull), lsb_hip_free(s->d_parts_pq);
   lsb_hip_free(s->d_parts2), lsb_hip_free(s->d_st);
+  lsb_hip_free(s->pd_offs), lsb_hip_free(s->pd_cols), lsb_hip_free(s->pd_vals);
+  lsb_hip_free(s->pd_rowmap), lsb_hip_free(s->pd_rowblk), lsb_hip_free(s->pd_blklanes);
+  free(s->h_pblk);
   free(s->recv), free(s->send);
 }
 
@@ -579,9 +643,24 @@ static void allreduce_scal(lsb_hip_solver *sv, unsigned off, unsigned cnt) {
 static void spmv_shard(struct shard *s, const double *xfull, double *y,
                        const double *xdot, double *partials, unsigned *np,
                        const struct lsb_pcg_state *st) {
+  if (s->variant == LSB_SPMV_PANEL) {
+    /* y = 0, then one launch per column panel accumulates into it: inside a
+     * launch every XCD gathers from the same 2 MiB slice of x, out of its L2 */
+    LSB_CHK_HIP(hipMemsetAsync(y, 0, (size_t)s->n * sizeof(double), g_stream));
+    for (unsigned p = 0; p < s->pn; p++) {
+      const unsigned b0 = s->h_pblk[p], nb = s->h_pblk[p + 1] - b0;
+      if (nb)
+        lsb_k_spmv(LSB_SPMV_ADAPTIVE, s->n, s->pd_offs, s->pd_cols, s->pd_vals,
+                   s->pd_rowblk + b0, s->pd_blklanes + b0, nb, s->lanes, s->sp_flags,
+                   s->sp_grid, xfull, y, NULL, NULL, NULL, st, s->pd_rowmap, g_stream);
+    }
+    if (partials)
+      lsb_k_dot(s->n, y, xdot, partials, np, g_stream);
+    return;
+  }
   lsb_k_spmv(s->variant, s->n, s->d_offs, s->d_cols, s->d_vals, s->d_rowblk, s->d_blklanes,
              s->nblk, s->lanes, s->sp_flags, s->sp_grid, xfull, y, xdot, partials, np, st,
-             g_stream);
+             NULL, g_stream);
 }
 
 /*
@@ -601,26 +680,34 @@ static void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
     s->sp_flags = (unsigned)o->spmv_tune & 3u;
     return;
   }
-  if (s->variant != LSB_SPMV_ADAPTIVE || s->nnz < 4000000ull)
+  if ((s->variant != LSB_SPMV_ADAPTIVE && s->variant != LSB_SPMV_PANEL) ||
+      s->nnz < 4000000ull)
     return; /* small operators are launch-latency bound: nothing to tune */
   float best = 1e30f;
   unsigned bf = s->sp_flags, np;
-  for (unsigned f = 0; f < 4; f++) {
-    s->sp_flags = f;
-    spmv_shard(s, s->d_pfull, s->d_q, s->d_pfull + s->row_begin, s->d_parts_pq, &np, NULL);
-    LSB_CHK_HIP(hipEventRecord(sv->ev_t0, g_stream));
-    for (int r = 0; r < 3; r++)
+  int bv = s->variant;
+  const int nvar = (s->pn && o->spmv_variant == LSB_SPMV_AUTO) ? 2 : 1;
+  for (int vi = 0; vi < nvar; vi++) {
+    if (nvar == 2)
+      s->variant = vi ? LSB_SPMV_PANEL : LSB_SPMV_ADAPTIVE;
+    for (unsigned f = 0; f < 4; f++) {
+      s->sp_flags = f;
       spmv_shard(s, s->d_pfull, s->d_q, s->d_pfull + s->row_begin, s->d_parts_pq, &np, NULL);
-    LSB_CHK_HIP(hipEventRecord(sv->ev_t1, g_stream));
-    LSB_CHK_HIP(hipEventSynchronize(sv->ev_t1));
-    float ms = 0.f;
-    LSB_CHK_HIP(hipEventElapsedTime(&ms, sv->ev_t0, sv->ev_t1));
-    if (o->verbose > 1)
-      fprintf(stderr, "hip_cdna4: spmv tune flags=%u grid=%u: %.1f us\n", f, s->sp_grid,
-              ms * 1e3f / 3);
-    if (ms < best)
-      best = ms, bf = f;
+      LSB_CHK_HIP(hipEventRecord(sv->ev_t0, g_stream));
+      for (int r = 0; r < 3; r++)
+        spmv_shard(s, s->d_pfull, s->d_q, s->d_pfull + s->row_begin, s->d_parts_pq, &np, NULL);
+      LSB_CHK_HIP(hipEventRecord(sv->ev_t1, g_stream));
+      LSB_CHK_HIP(hipEventSynchronize(sv->ev_t1));
+      float ms = 0.f;
+      LSB_CHK_HIP(hipEventElapsedTime(&ms, sv->ev_t0, sv->ev_t1));
+      if (o->verbose > 1)
+        fprintf(stderr, "hip_cdna4: spmv tune variant=%d flags=%u: %.1f us\n", s->variant, f,
+                ms * 1e3f / 3);
+      if (ms < best)
+        best = ms, bf = f, bv = s->variant;
+    }
   }
+  s->variant = bv;
   s->sp_flags = bf;
 }
 
@@ -1070,7 +1157,7 @@ int lsb_hip_spmv_csr_f64(int variant, unsigned n, const int *d_offs,
   L = L < 2 ? 2 : (L > 64 ? 64 : L);
   unsigned np = 0;
   lsb_k_spmv(variant, n, d_offs, d_cols, d_vals, d_rowblk, d_blklanes, nblk, L, flags, 0,
-             d_x, d_y, d_dot ? d_xdot : NULL, d_dot ? d_work : NULL, &np, NULL, stream);
+             d_x, d_y, d_dot ? d_xdot : NULL, d_dot ? d_work : NULL, &np, NULL, NULL, stream);
   if (d_dot)
     lsb_k_reduce_final(d_work, np, 1, d_dot, 0, NULL, stream);
   return 0;

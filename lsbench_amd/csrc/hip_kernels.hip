@@ -124,7 +124,11 @@ __global__ __launch_bounds__(WG, 8) void k_spmv_adaptive(
     unsigned nblk, const int *__restrict__ offs, const int *__restrict__ cols,
     const double *__restrict__ vals, const double *__restrict__ x,
     double *__restrict__ y, const double *__restrict__ xdot,
-    double *__restrict__ partials, const lsb_pcg_state *__restrict__ st) {
+    double *__restrict__ partials, const lsb_pcg_state *__restrict__ st,
+    const int *__restrict__ rowmap) {
+  // rowmap != NULL: column-panel mode -- the CSR's rows are (row, panel) pairs,
+  // row r of it accumulates into y[rowmap[r]] (one launch per panel, so a y
+  // entry is touched by one lane per launch; lsb_csr_panelize)
   __shared__ double sprod[CAP];
   __shared__ double sred[4];
   const unsigned tid = threadIdx.x;
@@ -177,9 +181,13 @@ __global__ __launch_bounds__(WG, 8) void k_spmv_adaptive(
         for (unsigned off = L >> 1; off > 0; off >>= 1)
           s += __shfl_xor(s, off, 64);
         if (r < (unsigned)nr && l == 0) {
-          y[cr0 + r] = s;
-          if (xdot)
-            dot += s * xdot[cr0 + r];
+          if (rowmap) {
+            y[rowmap[cr0 + r]] += s;
+          } else {
+            y[cr0 + r] = s;
+            if (xdot)
+              dot += s * xdot[cr0 + r];
+          }
         }
       }
       __syncthreads(); // sprod is overwritten by the next block
@@ -193,9 +201,13 @@ __global__ __launch_bounds__(WG, 8) void k_spmv_adaptive(
         s[0] += vals[j] * x[cols[j]];
       wg_sum<1>(s, sred);
       if (tid == 0) {
-        y[cr0] = s[0];
-        if (xdot)
-          dot += s[0] * xdot[cr0];
+        if (rowmap) {
+          y[rowmap[cr0]] += s[0];
+        } else {
+          y[cr0] = s[0];
+          if (xdot)
+            dot += s[0] * xdot[cr0];
+        }
       }
       if ((FLAGS & SP_PREFETCH) && k + gx < kend)
         LSB_ISSUE_BLOCK(k + gx);
@@ -702,7 +714,7 @@ void lsb_k_spmv(int variant, unsigned n, const int *offs, const int *cols,
                 unsigned lanes_per_row, unsigned flags, unsigned grid_cap,
                 const double *x, double *y, const double *xdot,
                 double *partials, unsigned *npartials,
-                const struct lsb_pcg_state *st, void *stream) {
+                const struct lsb_pcg_state *st, const int *rowmap, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   const unsigned g = lsb_k_spmv_grid(variant, n, nblk, lanes_per_row, grid_cap);
   if (npartials)
@@ -711,7 +723,8 @@ void lsb_k_spmv(int variant, unsigned n, const int *offs, const int *cols,
 #define LSB_ADAPTIVE(FL)                                                       \
   case FL:                                                                     \
     k_spmv_adaptive<LSB_BLOCK_NNZ, FL><<<g, WG, 0, s>>>(                       \
-        rowblk, blklanes, nblk, offs, cols, vals, x, y, xdot, partials, st);   \
+        rowblk, blklanes, nblk, offs, cols, vals, x, y, xdot, partials, st,    \
+        rowmap);                                                               \
     break;
     switch (flags & 3u) {
       LSB_ADAPTIVE(0)

@@ -58,7 +58,7 @@ void lsb_k_spmv(int variant, unsigned n, const int *offs, const int *cols,
                 unsigned lanes_per_row, unsigned flags, unsigned grid_cap,
                 const double *x, double *y, const double *xdot,
                 double *partials, unsigned *npartials,
-                const struct lsb_pcg_state *st, void *stream);
+                const struct lsb_pcg_state *st, const int *rowmap, void *stream);
 unsigned lsb_k_spmv_grid(int variant, unsigned n, unsigned nblk,
                          unsigned lanes_per_row, unsigned grid_cap);
 /* flags of the adaptive SpMV (picked by the timing pass at solver creation) */

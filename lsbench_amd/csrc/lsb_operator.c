@@ -405,3 +405,93 @@ unsigned lsb_csr_bandwidth(const struct csr *S) {
     }
   return bw;
 }
+
+/* ------------------------------------------------------------------------ */
+/* Column-panel form of a CSR for operators whose rows scatter over the whole */
+/* column range (power-law / unordered matrices).  The gather x[col] of such  */
+/* a row touches one cache line per non-zero; with x far larger than an XCD's */
+/* 4 MiB L2 every one of them comes from beyond L2.  Cutting the columns into */
+/* panels of `width` (x panel = 8*width bytes, L2-resident) and sweeping the   */
+/* matrix panel by panel turns them into L2 hits at the price of re-visiting   */
+/* y once per (row, panel) pair.  Layout: one CSR whose "rows" are those       */
+/* pairs, panel-major, rows ascending inside a panel:                          */
+/*   pair_row[npairs]   original row of each pair                              */
+/*   offs[npairs+1]     into cols/vals (a permuted copy of the operator)       */
+/*   pair_begin[np+1]   first pair of each panel                               */
+/* ------------------------------------------------------------------------ */
+struct lsb_panel_csr *lsb_csr_panelize(const struct csr *A, unsigned width) {
+  if (!A || width == 0)
+    return NULL;
+  const unsigned n = A->nrows, base = A->base;
+  unsigned lo, hi;
+  lsb_csr_col_hull(A, &lo, &hi);
+  const unsigned np = hi ? (hi - 1) / width + 1 : 1;
+  unsigned long long *pairs = lsb_calloc(unsigned long long, (size_t)np + 1);
+  unsigned long long *nnzp = lsb_calloc(unsigned long long, (size_t)np + 1);
+  for (unsigned i = 0; i < n; i++) {
+    unsigned last = 0xFFFFFFFFu;
+    for (unsigned j = A->offs[i]; j < A->offs[i + 1]; j++) {
+      const unsigned p = (A->cols[j] - base) / width;
+      nnzp[p + 1]++;
+      if (p != last)
+        pairs[p + 1]++, last = p;
+    }
+  }
+  for (unsigned p = 0; p < np; p++)
+    pairs[p + 1] += pairs[p], nnzp[p + 1] += nnzp[p];
+  const unsigned long long npairs = pairs[np], nnz = nnzp[np];
+  if (npairs > 0x7FFFFFFEull || nnz > 0x7FFFFFFEull)
+    errx(EXIT_FAILURE, "panel CSR too large for 32-bit indices");
+  struct lsb_panel_csr *P = lsb_calloc(struct lsb_panel_csr, 1);
+  P->npanels = np, P->width = width, P->npairs = (unsigned)npairs, P->nrows = n;
+  P->pair_begin = lsb_calloc(unsigned, (size_t)np + 1);
+  P->pair_row = (unsigned *)malloc((size_t)(npairs ? npairs : 1) * sizeof(unsigned));
+  P->offs = (unsigned *)malloc(((size_t)npairs + 1) * sizeof(unsigned));
+  P->cols = (unsigned *)malloc((size_t)(nnz ? nnz : 1) * sizeof(unsigned));
+  P->vals = (double *)malloc((size_t)(nnz ? nnz : 1) * sizeof(double));
+  if (!P->pair_row || !P->offs || !P->cols || !P->vals)
+    errx(EXIT_FAILURE, "out of host memory for the panel CSR");
+  unsigned *pc = (unsigned *)malloc((size_t)np * sizeof(unsigned)); /* pair cursor */
+  unsigned *zc = (unsigned *)malloc((size_t)np * sizeof(unsigned)); /* nnz cursor  */
+  for (unsigned p = 0; p < np; p++)
+    P->pair_begin[p] = pc[p] = (unsigned)pairs[p], zc[p] = (unsigned)nnzp[p];
+  P->pair_begin[np] = (unsigned)npairs;
+  for (unsigned i = 0; i < n; i++) {
+    unsigned last = 0xFFFFFFFFu;
+    for (unsigned j = A->offs[i]; j < A->offs[i + 1]; j++) {
+      const unsigned c = A->cols[j] - base, p = c / width;
+      if (p != last) {
+        P->pair_row[pc[p]] = i;
+        P->offs[pc[p]] = zc[p];
+        pc[p]++, last = p;
+      }
+      P->cols[zc[p]] = c, P->vals[zc[p]] = A->vals[j];
+      zc[p]++;
+    }
+  }
+  P->offs[npairs] = (unsigned)nnz;
+  free(pairs), free(nnzp), free(pc), free(zc);
+  return P;
+}
+
+void lsb_panel_csr_free(struct lsb_panel_csr *P) {
+  if (!P)
+    return;
+  free(P->pair_begin), free(P->pair_row), free(P->offs), free(P->cols), free(P->vals);
+  free(P);
+}
+
+/* mean |col - row| over a sample of the rows: how far the gather of a row
+ * strays from the diagonal (banded: ~bandwidth; scattered: ~n/3) */
+double lsb_csr_mean_scatter(const struct csr *A, unsigned row_begin) {
+  const unsigned n = A->nrows, step = n > 4096 ? n / 4096 : 1;
+  double sum = 0.0;
+  unsigned long long cnt = 0;
+  for (unsigned i = 0; i < n; i += step)
+    for (unsigned j = A->offs[i]; j < A->offs[i + 1]; j++) {
+      const double c = (double)(A->cols[j] - A->base), r = (double)i + row_begin;
+      sum += c > r ? c - r : r - c;
+      cnt++;
+    }
+  return cnt ? sum / (double)cnt : 0.0;
+}

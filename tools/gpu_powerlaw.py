@@ -14,9 +14,9 @@ for n in [int(a) for a in sys.argv[1:]] or [2000000, 8000000]:
     print("n=%d nnz=%d mean=%.1f max=%d rows>2048: %d (%.1f%% of nnz) rows>256: %d (%.1f%% of nnz)" % (
         n, A.nnz, lens.mean(), lens.max(), (lens > 2048).sum(), 100 * lens[lens > 2048].sum() / A.nnz,
         (lens > 256).sum(), 100 * lens[lens > 256].sum() / A.nnz))
-    for variant, tune in [(1, 0), (1, 1), (1, 2), (1, 3), (2, 0)]:
+    for variant, tune in [(1, 0), (1, 3), (2, 0), (4, 0), (4, 1), (4, 2), (4, 3), (0, -1)]:
         o = la.default_opts(op_mode=la.OP_RAW, precond=la.PRECOND_NONE, spmv_variant=variant, spmv_tune=tune)
         s = la.Solver(A, o)
         ms = s.time_spmv(3, 10)
-        print("  variant=%d flags=%d: %.1f us => %.0f GB/s (%.1f%%)" % (variant, tune, ms * 1e3, B / ms / 1e6, B / ms / 1e6 / 80))
+        print("  variant=%d(->%d) flags=%d(->%d): %.1f us => %.0f GB/s (%.1f%%)" % (variant, s.spmv_variant, tune, s.spmv_flags, ms * 1e3, B / ms / 1e6, B / ms / 1e6 / 80))
         s.destroy()

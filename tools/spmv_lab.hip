@@ -44,7 +44,7 @@ __device__ __forceinline__ void wg_sum(double (&v)[W], double *sred) {
     v[k] = (sred[0 * W + k] + sred[1 * W + k]) + (sred[2 * W + k] + sred[3 * W + k]);
 }
 
-enum { F_NOREMAP = 1, F_FAKEGATHER = 2, F_NODOT = 4, F_NOX = 8, F_CYCLIC = 16, F_NT = 32, F_PREFETCH = 64, F_HOIST = 128, F_TWOROW = 256, F_ROWCAP = 512 };
+enum { F_NOREMAP = 1, F_FAKEGATHER = 2, F_NODOT = 4, F_NOX = 8, F_CYCLIC = 16, F_NT = 32, F_PREFETCH = 64, F_HOIST = 128, F_TWOROW = 256, F_ROWCAP = 512, F_PERIOD = 1024 };
 
 // BLAS-1 probe shaped like k_pcg_update_xr: 5 streams in, 2 out, 16 B/lane.
 // NT bit 0: nontemporal loads, bit 1: nontemporal stores.
@@ -426,17 +426,31 @@ __global__ __launch_bounds__(WG, MINW) void k_adaptive_cyc(const int *__restrict
   const unsigned tid = threadIdx.x;
   const unsigned gx = gridDim.x / NXCD;           // workgroups per XCD
   const unsigned xcd = blockIdx.x % NXCD, slot = blockIdx.x / NXCD;
-  const unsigned chunk = (nblk + NXCD - 1) / NXCD; // row blocks per XCD
-  const unsigned kbeg = xcd * chunk, kend = min(kbeg + chunk, nblk);
+  // contiguous mode: XCD c owns blocks [c*chunk, (c+1)*chunk).  F_PERIOD: the
+  // block sequence is cut into periods of T = `per` blocks (one stencil plane,
+  // i.e. the matrix bandwidth) and XCD c owns the c-th eighth of EVERY period,
+  // so the +-bandwidth neighbours of its blocks are its own blocks one period
+  // away: reuse distance T/8 blocks instead of T.
+  const unsigned T = (FLAGS & F_PERIOD) ? per : nblk;
+  const unsigned sg = (T + NXCD - 1) / NXCD;      // blocks per XCD per period
+  const unsigned nper = (nblk + T - 1) / T;
+  const unsigned kend = nper * sg;                // virtual index space of this XCD
   constexpr int U = CAP / WG;
   double dot = 0.0;
   int c[U];
   double v[U];
-  unsigned k = kbeg + slot;
+  unsigned k = slot;
+  unsigned kb = 0; // actual block id of the block in flight
   int r0 = 0, r1 = 0, j0 = 0, j1 = 0;
 #define ISSUE_WG(kk)                                                           \
   do {                                                                         \
-    r0 = rowblk[kk], r1 = rowblk[(kk) + 1];                                    \
+    const unsigned pos_ = xcd * sg + (kk) % sg;                                \
+    kb = ((kk) / sg) * T + pos_;                                               \
+    if (pos_ >= T || kb >= nblk) {                                             \
+      r0 = r1 = j0 = j1 = 0;                                                   \
+      break;                                                                   \
+    }                                                                          \
+    r0 = rowblk[kb], r1 = rowblk[kb + 1];                                      \
     j0 = offs[r0], j1 = offs[r1];                                              \
     if (j1 - j0 <= CAP) {                                                      \
       _Pragma("unroll") for (int u = 0; u < U; u++) {                          \
@@ -959,6 +973,8 @@ LAUNCHER(l_wave512_pf7, (k_wave<512, F_PREFETCH, 7>))
 LAUNCHER(l_wave512_pf6, (k_wave<512, F_PREFETCH, 6>))
 LAUNCHER(l_cyc_pf_nt, (k_adaptive_cyc<2048, F_CYCLIC | F_PREFETCH | F_NT>))
 LAUNCHER(l_cyc_nt, (k_adaptive_cyc<2048, F_CYCLIC | F_NT>))
+LAUNCHER(l_cyc_period, (k_adaptive_cyc<2048, F_CYCLIC | F_NT | F_PREFETCH | F_PERIOD>))
+LAUNCHER(l_cyc_period_nont, (k_adaptive_cyc<2048, F_CYCLIC | F_PREFETCH | F_PERIOD>))
 LAUNCHER(l_cyc_two, (k_adaptive_cyc<2048, F_CYCLIC | F_NT | F_PREFETCH | F_TWOROW>))
 LAUNCHER(l_cyc_two_nont, (k_adaptive_cyc<2048, F_CYCLIC | F_PREFETCH | F_TWOROW>))
 LAUNCHER(l_cyc_hoist, (k_adaptive_cyc<2048, F_CYCLIC | F_NT | F_PREFETCH | F_HOIST>))
@@ -1011,10 +1027,8 @@ int main(int argc, char **argv) {
       {"cyc+prefetch+nt cap2048 (library)", 2048, l_cyc_pf_nt, 2048},
       {"cyc+nt cap2048", 2048, l_cyc_nt, 2048},
       {"cyc+prefetch cap2048", 2048, l_cyc_pf, 2048},
-      {"cyc+pf+nt+tworow", 2048, l_cyc_two, 2048},
-      {"cyc+pf+tworow (no nt)", 2048, l_cyc_two_nont, 2048},
-      {"cyc+pf+nt rows<=256 per block", -256, l_cyc_pf_nt, 2048},
-      {"cyc+pf rows<=256 per block", -256, l_cyc_pf, 2048},
+      {"cyc+pf+nt PERIOD=bandwidth", 2048, l_cyc_period, 2048},
+      {"cyc+pf PERIOD=bandwidth (no nt)", 2048, l_cyc_period_nont, 2048},
       {"probe: cyc+pf+nt, gather from 8KB", 2048, l_cyc_fake, 2048},
       {"probe: cyc+pf+nt, no gather", 2048, l_cyc_nox, 2048},
       {"probe: v4 cyc+pf+nt, no gather", 2040, l_v4_nox, 2048},
@@ -1039,9 +1053,17 @@ int main(int argc, char **argv) {
   CHK(hipEventCreate(&e0));
   CHK(hipEventCreate(&e1));
   std::vector<double> hy(A.n);
+  long bw = 0;
+  for (int i = 0; i < A.n; i += 97)
+    for (int j = A.offs[i]; j < A.offs[i + 1]; j++) bw = std::max<long>(bw, labs((long)A.cols[j] - i));
+  printf("bandwidth (sampled) = %ld rows\n", bw);
   auto run = [&](Variant &v) {
     unsigned g = std::min(v.maxgrid, ((v.nblk + 7) / 8) * 8);
     unsigned per = (v.nblk + g - 1) / g;
+    if (v.name.find("PERIOD") != std::string::npos) {
+      const double rows_per_blk = (double)A.n / v.nblk;
+      per = (unsigned)std::max(8.0, std::round(bw / rows_per_blk));
+    }
     v.launch(v, g, per, v.nblk, v.d_rb, d_offs, d_cols, d_vals, d_x, d_y, d_parts, (int)nnz);
   };
   // correctness first
