@@ -61,6 +61,9 @@ def parse():
     p.add_argument("--tol", type=float, default=1e-8)
     p.add_argument("--maxit", type=int, default=100000)
     p.add_argument("--spmv", type=int, default=0, help="LSB_SPMV_* variant (0 = auto)")
+    p.add_argument("--krylov", default="auto", choices=["cg", "cg1", "auto"],
+                   help="cg = classic PCG; cg1 = single-reduction PCG (2 launches, 1 reduction "
+                        "per iteration); auto = cg1 when the operator spans several GPUs")
     p.add_argument("--spmv-tune", type=int, default=-1,
                    help="-1 = timing pass at setup picks the SpMV flavour; 0..3 force it")
     p.add_argument("--fixed-iters", type=int, default=0,
@@ -212,6 +215,8 @@ def main():
     opts = la.default_opts(op_mode=la.OP_RAW, tol=a.tol, maxit=a.maxit, spmv_variant=a.spmv,
                            use_graph=1 if small else 0, sample_spmv=0 if small else 16,
                            spmv_tune=a.spmv_tune,
+                           krylov={"cg": la.KRYLOV_PCG, "cg1": la.KRYLOV_PCG1,
+                                   "auto": la.KRYLOV_AUTO}[a.krylov],
                            precond=la.PRECOND_NONE if spmv_only else la.PRECOND_JACOBI)
     if dist_on:
         solver = la.Solver(Aloc, opts, row_begin=r0, n_global=n)
@@ -295,7 +300,9 @@ def main():
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not a.workload.startswith("file:") else "reference tests/ matrix",
-        "config": {"workload": name, "rows": n, "nnz": n_tot_nnz, "solver": "PCG+Jacobi",
+        "config": {"workload": name, "rows": n, "nnz": n_tot_nnz,
+                   "solver": "PCG+Jacobi" + (" (single-reduction form)" if (
+                       a.krylov == "cg1" or (a.krylov == "auto" and world > 1)) else ""),
                    "tol": a.tol, "rhs": "b_i=i", "partition": "row-range x%d" % world,
                    "iterations_per_solve": its, "relres": res.relres},
         "iterations_per_sec": iters / dt,

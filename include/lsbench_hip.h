@@ -84,9 +84,15 @@ enum { LSB_OP_CHOLMOD_UPPER = 0, /* S = triu(A)+triu(A,1)^T (default)      */
        LSB_OP_RAW = 1 };         /* the CSR exactly as handed in            */
 enum { LSB_PRECOND_JACOBI = 0, LSB_PRECOND_NONE = 1 };
 enum { LSB_KRYLOV_PCG = 0,    /* preconditioned CG (symmetric operators)    */
-       LSB_KRYLOV_GMRES = 1 };/* restarted GMRES(m), right-preconditioned,
+       LSB_KRYLOV_GMRES = 1,  /* restarted GMRES(m), right-preconditioned,
                                  for LSB_OP_RAW / unsymmetric operators;
                                  single shard only in this round            */
+       LSB_KRYLOV_PCG1 = 2,   /* single-reduction CG (Chronopoulos-Gear): the
+                                 same iterates with 2 launches and 1 global
+                                 reduction per iteration instead of 3 and 2 */
+       LSB_KRYLOV_AUTO = 3 }; /* PCG1 when the operator is spread over several
+                                 shards (one collective less per iteration),
+                                 PCG otherwise                              */
 enum { LSB_SPMV_AUTO = 0,     /* pick by mean row length                    */
        LSB_SPMV_ADAPTIVE = 1, /* row-blocked: LDS-streamed short rows +
                                  wavefront-per-row long rows                */

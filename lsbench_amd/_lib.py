@@ -18,7 +18,7 @@ UNIQUE_ID_BYTES = 128
 SOLVER_HIP = 6
 OP_CHOLMOD_UPPER, OP_RAW = 0, 1
 PRECOND_JACOBI, PRECOND_NONE = 0, 1
-KRYLOV_PCG, KRYLOV_GMRES = 0, 1
+KRYLOV_PCG, KRYLOV_GMRES, KRYLOV_PCG1, KRYLOV_AUTO = 0, 1, 2, 3
 SPMV_AUTO, SPMV_ADAPTIVE, SPMV_SUBWAVE, SPMV_SCALAR, SPMV_PANEL = 0, 1, 2, 3, 4
 STATUS_RUNNING, STATUS_CONVERGED, STATUS_BREAKDOWN, STATUS_MAXIT = 0, 1, 2, 3
 

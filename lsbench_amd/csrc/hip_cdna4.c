@@ -91,7 +91,10 @@ static void opts_from_env(struct lsb_hip_opts *o) {
   if ((e = getenv("LSBENCH_HIP_REORDER")))
     o->reorder = atoi(e);
   if ((e = getenv("LSBENCH_HIP_KRYLOV")))
-    o->krylov = strcasecmp(e, "gmres") == 0 ? LSB_KRYLOV_GMRES : LSB_KRYLOV_PCG;
+    o->krylov = strcasecmp(e, "gmres") == 0  ? LSB_KRYLOV_GMRES
+                : strcasecmp(e, "cg1") == 0  ? LSB_KRYLOV_PCG1
+                : strcasecmp(e, "auto") == 0 ? LSB_KRYLOV_AUTO
+                                             : LSB_KRYLOV_PCG;
   if ((e = getenv("LSBENCH_HIP_RESTART")))
     o->restart = atoi(e);
   if ((e = getenv("LSBENCH_HIP_SPMV_TUNE")))
@@ -206,6 +209,8 @@ struct shard {
   unsigned char *d_blklanes;
   unsigned sp_flags, sp_grid; /* adaptive-SpMV flavour, picked by tune_spmv() */
   double *d_vals, *d_dinv, *d_r, *d_q, *d_pfull;
+  double *d_p1, *d_s1; /* single-reduction CG: p and s = S p (pfull then holds u) */
+  unsigned npq, np2;   /* partial counts of the SpMV / sweep launches */
   double *d_parts_pq, *d_parts2;
   double *d_scal; /* [0] p.q   [1] r.z'  [2] r.r   (multi-shard path) */
   struct lsb_pcg_state *d_st;
@@ -386,7 +391,9 @@ static void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
   s->d_pfull = (double *)lsb_hip_malloc((size_t)n_glob * sizeof(double));
   LSB_CHK_HIP(hipMemsetAsync(s->d_pfull, 0, (size_t)n_glob * sizeof(double), g_stream));
   s->d_parts_pq = (double *)lsb_hip_malloc(LSB_MAX_PARTIALS * sizeof(double));
-  s->d_parts2 = (double *)lsb_hip_malloc(2 * LSB_MAX_PARTIALS * sizeof(double));
+  /* two buffers: k_cg1_update reads the previous launch's partials while
+   * writing its own */
+  s->d_parts2 = (double *)lsb_hip_malloc(4 * LSB_MAX_PARTIALS * sizeof(double));
   s->d_st = (struct lsb_pcg_state *)lsb_hip_malloc(sizeof(struct lsb_pcg_state));
   LSB_CHK_HIP(hipMemsetAsync(s->d_st, 0, sizeof(struct lsb_pcg_state), g_stream));
   choose_spmv(s, o);
@@ -418,6 +425,7 @@ static void shard_free(struct shard *s) {
   lsb_hip_free(s->d_rowblk), lsb_hip_free(s->d_blklanes);
   lsb_hip_free(s->d_dinv), lsb_hip_free(s->d_r);
   lsb_hip_free(s->d_q), lsb_hip_free(s->d_pfull), lsb_hip_free(s->d_parts_pq);
+  lsb_hip_free(s->d_p1), lsb_hip_free(s->d_s1);
   lsb_hip_free(s->d_parts2), lsb_hip_free(s->d_st);
   lsb_hip_free(s->pd_offs), lsb_hip_free(s->pd_cols), lsb_hip_free(s->pd_vals);
   lsb_hip_free(s->pd_rowmap), lsb_hip_free(s->pd_rowblk), lsb_hip_free(s->pd_blklanes);
@@ -714,7 +722,15 @@ static void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
 /* ------------------------------------------------------------------------ */
 /* PCG                                                                       */
 /* ------------------------------------------------------------------------ */
+static int use_cg1(const lsb_hip_solver *sv);
+static void cg1_enqueue_init(lsb_hip_solver *sv, const double *d_b, double *d_x);
+static void cg1_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int sample);
+
 static void pcg_enqueue_init(lsb_hip_solver *sv, const double *d_b, double *d_x) {
+  if (use_cg1(sv)) {
+    cg1_enqueue_init(sv, d_b, d_x);
+    return;
+  }
   unsigned np2 = 0;
   for (int i = 0; i < sv->nshard; i++) {
     struct shard *s = &sv->sh[i];
@@ -738,6 +754,10 @@ static void pcg_enqueue_init(lsb_hip_solver *sv, const double *d_b, double *d_x)
 /* One PCG iteration, enqueued.  sample >= 0: bracket the SpMV of shard 0 with
  * events 4*sample .. 4*sample+3. */
 static void pcg_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int sample) {
+  if (use_cg1(sv)) {
+    cg1_enqueue_iter(sv, d_x, parity, sample);
+    return;
+  }
   unsigned npq = 0, np2 = 0;
   if (sv->multi)
     exchange_p(sv);
@@ -778,6 +798,88 @@ static void pcg_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int sa
                        sv->multi ? s->d_scal + 1 : s->d_parts2, sv->multi ? 1u : np2,
                        g_stream);
   }
+}
+
+/* ---- single-reduction CG (LSB_KRYLOV_PCG1): see k_cg1_update -------------- */
+static int use_cg1(const lsb_hip_solver *sv) {
+  if (sv->o.krylov == LSB_KRYLOV_PCG1)
+    return 1;
+  if (sv->o.krylov != LSB_KRYLOV_AUTO)
+    return 0;
+  /* measured on one GPU: no gain for small operators (tests/xn3b_A_18.txt: 390 vs
+   * 400 solves/s, the fused sweep is as long as the two it replaces) and +6 % time
+   * on the 10M-row operator (96 n vs 88 n bytes); what it saves is a collective */
+  return sv->multi;
+}
+
+static void cg1_enqueue_init(lsb_hip_solver *sv, const double *d_b, double *d_x) {
+  for (int i = 0; i < sv->nshard; i++) {
+    struct shard *s = &sv->sh[i];
+    const size_t o = s->row_begin - sv->row_first, bytes = (size_t)s->n * sizeof(double);
+    if (!s->d_p1) {
+      s->d_p1 = (double *)lsb_hip_malloc(bytes);
+      s->d_s1 = (double *)lsb_hip_malloc(bytes);
+    }
+    /* x = 0, r = b, u = D^-1 b (into the gather vector), partials (r.u, b.b) */
+    lsb_k_pcg_init(s->n, d_b + o, s->d_dinv, d_x + o, s->d_r, s->d_pfull + s->row_begin,
+                   s->d_parts2, &s->np2, g_stream);
+    LSB_CHK_HIP(hipMemsetAsync(s->d_p1, 0, bytes, g_stream));
+    LSB_CHK_HIP(hipMemsetAsync(s->d_s1, 0, bytes, g_stream));
+    if (sv->multi)
+      lsb_k_reduce_final(s->d_parts2, s->np2, 2, s->d_scal + 1, 0, NULL, g_stream);
+  }
+  if (sv->multi)
+    allreduce_scal(sv, 1, 2);
+  for (int i = 0; i < sv->nshard; i++) {
+    struct shard *s = &sv->sh[i];
+    if (sv->multi)
+      lsb_k_pcg_init_state(s->d_st, s->d_scal + 1, 1, sv->o.tol, (int)sv->o.maxit, g_stream);
+    else
+      lsb_k_pcg_init_state(s->d_st, s->d_parts2, s->np2, sv->o.tol, (int)sv->o.maxit, g_stream);
+  }
+  if (sv->multi)
+    exchange_p(sv);
+  for (int i = 0; i < sv->nshard; i++) { /* w = S u, partials w.u */
+    struct shard *s = &sv->sh[i];
+    spmv_shard(s, s->d_pfull, s->d_q, s->d_pfull + s->row_begin, s->d_parts_pq, &s->npq, s->d_st);
+    if (sv->multi)
+      lsb_k_reduce_final(s->d_parts_pq, s->npq, 1, s->d_scal + 0, 0, s->d_st, g_stream);
+  }
+  if (sv->multi)
+    allreduce_scal(sv, 0, 1);
+}
+
+static void cg1_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int sample) {
+  for (int i = 0; i < sv->nshard; i++) {
+    struct shard *s = &sv->sh[i];
+    const size_t o = s->row_begin - sv->row_first;
+    double *gr_in = s->d_parts2 + (size_t)parity * 2 * LSB_MAX_PARTIALS;
+    double *gr_out = s->d_parts2 + (size_t)(parity ^ 1) * 2 * LSB_MAX_PARTIALS;
+    unsigned np2 = 0;
+    lsb_k_cg1_update(s->n, s->d_pfull + s->row_begin, s->d_q, s->d_dinv, s->d_p1, s->d_s1,
+                     d_x + o, s->d_r, s->d_st, parity, sv->multi ? s->d_scal + 1 : gr_in,
+                     sv->multi ? 1u : s->np2, sv->multi ? s->d_scal : s->d_parts_pq,
+                     sv->multi ? 1u : s->npq, gr_out, &np2, g_stream);
+    if (sv->multi)
+      lsb_k_reduce_final(gr_out, np2, 2, s->d_scal + 1, 0, s->d_st, g_stream);
+  }
+  if (sv->multi)
+    exchange_p(sv);
+  for (int i = 0; i < sv->nshard; i++) {
+    struct shard *s = &sv->sh[i];
+    if (i == 0 && sample >= 0)
+      LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample], g_stream));
+    spmv_shard(s, s->d_pfull, s->d_q, s->d_pfull + s->row_begin, s->d_parts_pq, &s->npq, s->d_st);
+    if (i == 0 && sample >= 0) {
+      LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 1], g_stream));
+      LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 2], g_stream));
+      LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 3], g_stream));
+    }
+    if (sv->multi)
+      lsb_k_reduce_final(s->d_parts_pq, s->npq, 1, s->d_scal + 0, 0, s->d_st, g_stream);
+  }
+  if (sv->multi)
+    allreduce_scal(sv, 0, 3); /* w.u, r.u, r.r in ONE collective */
 }
 
 static int auto_chunk(const lsb_hip_solver *sv) {
@@ -1018,6 +1120,26 @@ static int solve_core(lsb_hip_solver *sv, const double *d_b, double *d_x,
   if (fin != 0)
     hst[0] = hst[fin];
   sv->hint_iters = (unsigned)hst[0].iters;
+  if (use_cg1(sv) && hst[0].status == LSB_STATUS_MAXIT && hst[0].iters > 0) {
+    /* The single-reduction form learns r.r of an update one launch later, and
+     * the launch after the maxit-th update is a no-op: fetch it from that
+     * update's partial sums so that relres (and "converged exactly at maxit")
+     * are reported like the classic form does. */
+    double rr = 0.0;
+    for (int i = 0; i < sv->nshard; i++) {
+      struct shard *s = &sv->sh[i];
+      double *last = s->d_parts2 + (size_t)(hst[0].iters & 1) * 2 * LSB_MAX_PARTIALS;
+      lsb_k_reduce_final(last, s->np2, 2, s->d_scal + 1, 0, NULL, g_stream);
+    }
+    if (sv->multi)
+      allreduce_scal(sv, 1, 2);
+    LSB_CHK_HIP(hipMemcpyAsync(&rr, sv->sh[0].d_scal + 2, sizeof rr, hipMemcpyDeviceToHost,
+                               g_stream));
+    LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+    hst[0].rr = rr;
+    if (rr <= hst[0].thresh2)
+      hst[0].status = LSB_STATUS_CONVERGED;
+  }
   double t1 = wall_seconds();
   struct lsb_hip_result r;
   memset(&r, 0, sizeof r);

@@ -487,6 +487,7 @@ __global__ __launch_bounds__(WG) void k_pcg_init_state(
   if (threadIdx.x == 0) {
     st->rz[0] = v[0];
     st->rz[1] = 0.0;
+    st->alpha[0] = st->alpha[1] = 0.0; // "no previous step" marker of k_cg1_update
     st->bb = v[1];
     st->thresh2 = tol * tol * v[1];
     st->rr = v[1];
@@ -648,6 +649,125 @@ __global__ __launch_bounds__(WG) void k_pcg_update_p(
   } else {
     for (size_t i = gtid; i < n; i += gsz)
       p[i] = dinv[i] * r[i] + beta * p[i];
+  }
+}
+
+// --------------------------------------------------------------------------
+// Single-reduction CG (Chronopoulos & Gear 1989), LSB_KRYLOV_PCG1: the same
+// Krylov iterates as PCG in exact arithmetic, arranged so that an iteration is
+// TWO launches and ONE global reduction instead of three and two:
+//     [this kernel]  beta = g'/g ; alpha = g' / (d - beta g'/alpha)
+//                    p = u + beta p ; s = w + beta s ; x += alpha p ; r -= alpha s
+//                    u = D^-1 r ; partials (g'' = r.u, r.r)
+//     [SpMV]         w = S u ; partials d = w.u         (the fused-dot SpMV)
+// with g' = r.u and r.r taken from this kernel's own previous launch and
+// d = w.u from the SpMV in between.  For launch-latency-bound operators that is
+// 2/3 of the launches; across GPUs it is one all-reduce (3 doubles) per
+// iteration instead of two.  Costs one more vector (s) and 96 n instead of 88 n
+// bytes per iteration, so the large single-GPU case keeps the classic form.
+// --------------------------------------------------------------------------
+template <bool V2, bool NT>
+__global__ __launch_bounds__(WG) void k_cg1_update(
+    unsigned n, double *__restrict__ u, const double *__restrict__ w,
+    const double *__restrict__ dinv, double *__restrict__ p, double *__restrict__ sv,
+    double *__restrict__ x, double *__restrict__ r, lsb_pcg_state *__restrict__ st,
+    int parity, const double *__restrict__ parts_gr, unsigned ngr,
+    const double *__restrict__ parts_d, unsigned nd, double *__restrict__ partials2) {
+  __shared__ double sred[8];
+  const size_t gtid = (size_t)blockIdx.x * WG + threadIdx.x;
+  const size_t gsz = (size_t)gridDim.x * WG;
+  const size_t n2 = n / 2;
+  const int stopped = st->status;
+  const double g_old = st->rz[parity], a_old = st->alpha[parity], thresh2 = st->thresh2;
+  d2v *u2 = (d2v *)u, *p2 = (d2v *)p, *s2 = (d2v *)sv, *x2 = (d2v *)x, *r2 = (d2v *)r;
+  const d2v *w2 = (const d2v *)w, *d2 = (const d2v *)dinv;
+  d2v uv = {0.0, 0.0}, wv = uv, dv = uv, pv = uv, sw = uv, xv = uv, rv = uv;
+  const bool first = V2 && gtid < n2;
+  if (first) {
+    uv = ld2<NT>(u2 + gtid), wv = ld2<NT>(w2 + gtid), dv = ld2<NT>(d2 + gtid);
+    pv = ld2<NT>(p2 + gtid), sw = ld2<NT>(s2 + gtid), xv = ld2<NT>(x2 + gtid);
+    rv = ld2<NT>(r2 + gtid);
+  }
+  double gr[2], dd[1];
+  wg_sum_partials<2>(parts_gr, ngr, gr, sred);
+  wg_sum_partials<1>(parts_d, nd, dd, sred);
+  if (stopped)
+    return;
+  const double g_new = gr[0], rr = gr[1], delta = dd[0];
+  const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
+  if (rr <= thresh2) { // r of the previous update already meets the tolerance
+    if (leader)
+      st->status = LSB_STATUS_CONVERGED, st->rr = rr;
+    return;
+  }
+  double beta = 0.0, alpha;
+  if (a_old == 0.0) { // first iteration of the solve (k_pcg_init_state zeroes alpha)
+    alpha = g_new / delta;
+  } else {
+    beta = g_new / g_old;
+    alpha = g_new / (delta - beta * g_new / a_old);
+  }
+  if (!isfinite(alpha) || alpha == 0.0) { // same decision in every workgroup
+    if (leader)
+      st->status = LSB_STATUS_BREAKDOWN;
+    return;
+  }
+  if (leader) {
+    const int it = st->iters + 1;
+    st->iters = it;
+    st->rr = rr;
+    st->pq = delta;
+    st->rz[parity ^ 1] = g_new;
+    st->alpha[parity ^ 1] = alpha;
+    if (it >= st->maxit)
+      st->status = LSB_STATUS_MAXIT; // this update still happens; later launches are no-ops
+  }
+  double acc[2] = {0.0, 0.0};
+  if (V2) {
+    if (first) {
+      size_t i = gtid;
+      for (;;) {
+        pv.x = uv.x + beta * pv.x, pv.y = uv.y + beta * pv.y;
+        sw.x = wv.x + beta * sw.x, sw.y = wv.y + beta * sw.y;
+        xv.x += alpha * pv.x, xv.y += alpha * pv.y;
+        rv.x -= alpha * sw.x, rv.y -= alpha * sw.y;
+        uv.x = dv.x * rv.x, uv.y = dv.y * rv.y;
+        p2[i] = pv, s2[i] = sw, x2[i] = xv, r2[i] = rv, u2[i] = uv;
+        acc[0] += rv.x * uv.x;
+        acc[0] += rv.y * uv.y;
+        acc[1] += rv.x * rv.x;
+        acc[1] += rv.y * rv.y;
+        i += gsz;
+        if (i >= n2)
+          break;
+        uv = ld2<NT>(u2 + i), wv = ld2<NT>(w2 + i), dv = ld2<NT>(d2 + i);
+        pv = ld2<NT>(p2 + i), sw = ld2<NT>(s2 + i), xv = ld2<NT>(x2 + i);
+        rv = ld2<NT>(r2 + i);
+      }
+    }
+    if ((n & 1) && gtid == gsz - 1) {
+      const size_t i = n - 1;
+      const double pi = u[i] + beta * p[i], si = w[i] + beta * sv[i];
+      p[i] = pi, sv[i] = si;
+      x[i] += alpha * pi;
+      const double ri = r[i] - alpha * si, ui = dinv[i] * ri;
+      r[i] = ri, u[i] = ui;
+      acc[0] += ri * ui, acc[1] += ri * ri;
+    }
+  } else {
+    for (size_t i = gtid; i < n; i += gsz) {
+      const double pi = u[i] + beta * p[i], si = w[i] + beta * sv[i];
+      p[i] = pi, sv[i] = si;
+      x[i] += alpha * pi;
+      const double ri = r[i] - alpha * si, ui = dinv[i] * ri;
+      r[i] = ri, u[i] = ui;
+      acc[0] += ri * ui, acc[1] += ri * ri;
+    }
+  }
+  wg_sum<2>(acc, sred);
+  if (threadIdx.x == 0) {
+    partials2[2 * blockIdx.x + 0] = acc[0];
+    partials2[2 * blockIdx.x + 1] = acc[1];
   }
 }
 
@@ -861,6 +981,27 @@ void lsb_k_pcg_update_xr(unsigned n, const double *p, const double *q,
   } else {
     k_pcg_update_xr<false, false><<<g, WG, 0, (hipStream_t)stream>>>(
         n, p, q, dinv, x, r, st, parity, pq_parts, npq, partials2);
+  }
+}
+
+void lsb_k_cg1_update(unsigned n, double *u, const double *w, const double *dinv, double *p,
+                      double *s, double *x, double *r, struct lsb_pcg_state *st, int parity,
+                      const double *parts_gr, unsigned ngr, const double *parts_d, unsigned nd,
+                      double *partials2, unsigned *npartials, void *stream) {
+  const unsigned g = lsb_k_blas1_grid(n);
+  *npartials = g;
+  hipStream_t hs = (hipStream_t)stream;
+  if (aligned16(u) && aligned16(w) && aligned16(dinv) && aligned16(p) && aligned16(s) &&
+      aligned16(x) && aligned16(r)) {
+    if (g_blas1_nt)
+      k_cg1_update<true, true><<<g, WG, 0, hs>>>(n, u, w, dinv, p, s, x, r, st, parity, parts_gr,
+                                                 ngr, parts_d, nd, partials2);
+    else
+      k_cg1_update<true, false><<<g, WG, 0, hs>>>(n, u, w, dinv, p, s, x, r, st, parity,
+                                                  parts_gr, ngr, parts_d, nd, partials2);
+  } else {
+    k_cg1_update<false, false><<<g, WG, 0, hs>>>(n, u, w, dinv, p, s, x, r, st, parity, parts_gr,
+                                                 ngr, parts_d, nd, partials2);
   }
 }
 

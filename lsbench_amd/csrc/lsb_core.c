@@ -77,7 +77,7 @@ static void usage(const char *prog) {
   printf("  --maxit <N>          (hip) iteration cap, default 20000\n");
   printf("  --operator <upper|raw> (hip) upper = CHOLMOD's triu-mirrored matrix\n");
   printf("  --nvirt <P>          (hip) P row-range shards on one device (test)\n");
-  printf("  --krylov <cg|gmres>  (hip) Krylov method; gmres for --operator raw\n");
+  printf("  --krylov <cg|cg1|auto|gmres> (hip) cg1 = single-reduction CG, gmres for --operator raw\n");
   printf("  --restart <M>        (hip) GMRES restart length, 1..32, default 30\n");
   printf("  --reorder            (hip) solve the RCM-permuted operator (any --ordering\n");
   printf("                       value maps to RCM; off by default because the reference's\n");
@@ -144,7 +144,10 @@ struct lsbench *lsbench_init(int argc, char *argv[]) {
       o.nvirt = atoi(optarg);
       break;
     case 84:
-      o.krylov = strcasecmp(optarg, "gmres") == 0 ? LSB_KRYLOV_GMRES : LSB_KRYLOV_PCG;
+      o.krylov = strcasecmp(optarg, "gmres") == 0  ? LSB_KRYLOV_GMRES
+                 : strcasecmp(optarg, "cg1") == 0  ? LSB_KRYLOV_PCG1
+                 : strcasecmp(optarg, "auto") == 0 ? LSB_KRYLOV_AUTO
+                                                   : LSB_KRYLOV_PCG;
       break;
     case 85:
       o.restart = atoi(optarg);

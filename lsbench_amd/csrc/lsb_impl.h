@@ -25,6 +25,7 @@ struct lsb_pcg_state {
   double thresh2;  /* tol^2 * b.b                                            */
   double rr;       /* r.r after the last completed iteration                 */
   double pq;       /* p.q of the last completed iteration (diagnostic)       */
+  double alpha[2]; /* single-reduction CG: step length, parity-buffered      */
   int iters;       /* completed iterations                                   */
   int status;      /* LSB_STATUS_*; != 0 makes every later kernel a no-op    */
   int maxit;
@@ -96,6 +97,10 @@ void lsb_k_pcg_update_xr(unsigned n, const double *p, const double *q,
 void lsb_k_pcg_update_p(unsigned n, const double *r, const double *dinv,
                         double *p, struct lsb_pcg_state *st, int parity,
                         const double *parts2, unsigned nparts2, void *stream);
+void lsb_k_cg1_update(unsigned n, double *u, const double *w, const double *dinv, double *p,
+                      double *s, double *x, double *r, struct lsb_pcg_state *st, int parity,
+                      const double *parts_gr, unsigned ngr, const double *parts_d, unsigned nd,
+                      double *partials2, unsigned *npartials, void *stream);
 unsigned lsb_k_blas1_grid(unsigned n);
 void lsb_k_set_blas1_nt(int on);
 void lsb_k_fill_index(unsigned n, unsigned first, double *v, void *stream);

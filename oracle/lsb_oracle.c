@@ -338,6 +338,71 @@ done:
 }
 
 /*
+ * Single-reduction CG (Chronopoulos & Gear 1989), Jacobi-preconditioned,
+ * x0 = 0 -- the recurrences of k_cg1_update in lsbench_amd/csrc/hip_kernels.hip,
+ * stated sequentially:
+ *   r = b; u = D^-1 r; w = A u; g = r.u; d = w.u
+ *   repeat: stop if r.r <= tol^2 b.b
+ *           beta = g/g_old (0 first); alpha = g / (d - beta g/alpha_old) (g/d first)
+ *           p = u + beta p; s = w + beta s; x += alpha p; r -= alpha s
+ *           u = D^-1 r; w = A u; g_old = g; g = r.u; d = w.u
+ * Same iterates as orc_pcg_jacobi in exact arithmetic.
+ */
+int orc_pcg1_jacobi(uint64_t n, const uint64_t *offs, const uint32_t *cols,
+                    const double *vals, const double *b, double *x, double tol,
+                    uint32_t maxit, uint32_t *iters_out, double *relres_out) {
+  double *r = (double *)malloc(n * sizeof(double)), *u = (double *)malloc(n * sizeof(double));
+  double *w = (double *)malloc(n * sizeof(double)), *p = (double *)calloc(n, sizeof(double));
+  double *s = (double *)calloc(n, sizeof(double)), *dinv = (double *)malloc(n * sizeof(double));
+  for (uint64_t i = 0; i < n; i++) {
+    double d = 0.0;
+    for (uint64_t j = offs[i]; j < offs[i + 1]; j++)
+      if (cols[j] == i)
+        d = vals[j];
+    dinv[i] = d != 0.0 ? 1.0 / d : 0.0;
+    x[i] = 0.0, r[i] = b[i], u[i] = dinv[i] * b[i];
+  }
+  orc_spmv(n, offs, cols, vals, u, w);
+  double g = orc_dot(n, r, u), d = orc_dot(n, w, u), rr = orc_dot(n, r, r);
+  const double bb = rr, thresh2 = tol * tol * bb;
+  double g_old = 0.0, a_old = 0.0;
+  int status = bb == 0.0 ? 1 : (maxit == 0 ? 3 : 0);
+  uint32_t it = 0;
+  while (status == 0) {
+    if (rr <= thresh2) {
+      status = 1;
+      break;
+    }
+    double beta = 0.0, alpha;
+    if (a_old == 0.0)
+      alpha = g / d;
+    else
+      beta = g / g_old, alpha = g / (d - beta * g / a_old);
+    if (!isfinite(alpha) || alpha == 0.0) {
+      status = 2;
+      break;
+    }
+    for (uint64_t i = 0; i < n; i++) {
+      p[i] = u[i] + beta * p[i];
+      s[i] = w[i] + beta * s[i];
+      x[i] += alpha * p[i];
+      r[i] -= alpha * s[i];
+      u[i] = dinv[i] * r[i];
+    }
+    it++;
+    g_old = g, a_old = alpha;
+    orc_spmv(n, offs, cols, vals, u, w);
+    g = orc_dot(n, r, u), d = orc_dot(n, w, u), rr = orc_dot(n, r, r);
+    if (it >= maxit && rr > thresh2)
+      status = 3;
+  }
+  *iters_out = it;
+  *relres_out = bb > 0.0 ? sqrt(rr / bb) : 0.0;
+  free(r), free(u), free(w), free(p), free(s), free(dinv);
+  return status;
+}
+
+/*
  * Restarted GMRES(m), right Jacobi preconditioning, x0 = 0, Arnoldi by
  * classical Gram-Schmidt applied twice, Givens rotations; stop when the
  * residual estimate |g_{j+1}| <= tol*||b||, counted in inner steps -- the rules

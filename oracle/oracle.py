@@ -164,6 +164,24 @@ def pcg_jacobi(offs, cols, vals, b, tol=1e-12, maxit=20000, jacobi=True, threads
     return x, it.value, rel.value, st
 
 
+def pcg1_jacobi(offs, cols, vals, b, tol=1e-12, maxit=20000):
+    """Single-reduction (Chronopoulos-Gear) Jacobi-PCG, sequential.
+    Returns (x, iters, relres, status)."""
+    L = lib()
+    L.orc_set_threads(1)
+    n = len(offs) - 1
+    x = np.zeros(n, np.float64)
+    it, rel = C.c_uint32(), C.c_double()
+    L.orc_pcg1_jacobi.restype = C.c_int
+    L.orc_pcg1_jacobi.argtypes = [C.c_uint64, _u64p, _u32p, _f64p, _f64p, _f64p, C.c_double,
+                                  C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
+    st = L.orc_pcg1_jacobi(n, _as64(offs), np.ascontiguousarray(cols, np.uint32),
+                           np.ascontiguousarray(vals, np.float64),
+                           np.ascontiguousarray(b, np.float64), x, tol, maxit,
+                           C.byref(it), C.byref(rel))
+    return x, it.value, rel.value, st
+
+
 def gmres_jacobi(offs, cols, vals, b, tol=1e-10, maxit=20000, restart=30):
     """Restarted GMRES(m) with right Jacobi preconditioning (sequential).
     Returns (x, inner iterations, relres estimate, status)."""
