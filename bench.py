@@ -172,17 +172,25 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
                      "--nproc-per-node %d" % (a.gpus, a.gpus))
         a.gpus = world
-    torch.cuda.set_device(local)
+    # rehearsal switches (tests/test_dist_gpu.py): several ranks on ONE device, gloo
+    # for torch.distributed; the library's own collectives then run on a test
+    # double of RCCL that is LD_PRELOADed by the test
+    torch.cuda.set_device(0 if os.environ.get("LSB_BENCH_ONE_GPU") == "1" else local)
+    backend = os.environ.get("LSB_BENCH_BACKEND", "nccl")
     lib = la._lib.load()
     if la.hip_cdna4_init() != 0:
         sys.exit("hip_cdna4_init failed: no MI355X visible (there is no CPU path)")
     if dist_on:
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         idb = ctypes.create_string_buffer(la._lib.UNIQUE_ID_BYTES)
         if rank == 0:
             lib.lsb_hip_comm_get_unique_id(idb)
-        t = torch.frombuffer(bytearray(idb.raw), dtype=torch.uint8).cuda()
+        t = torch.frombuffer(bytearray(idb.raw), dtype=torch.uint8).clone()
+        t = t.cuda() if backend == "nccl" else t
         dist.broadcast(t, 0)
         idb = ctypes.create_string_buffer(bytes(t.cpu().tolist()), la._lib.UNIQUE_ID_BYTES)
         la._lib.check(lib.lsb_hip_comm_init_rank(idb, world, rank), "comm_init_rank")
@@ -267,7 +275,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist_on:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
     if res.status != la.STATUS_CONVERGED and not (a.fixed_iters > 0 and res.status == la.STATUS_MAXIT):
@@ -291,7 +299,8 @@ def main():
         pass
     n_tot_nnz = nnz_loc
     if dist_on:
-        tt = torch.tensor([float(nnz_loc)], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([float(nnz_loc)], dtype=torch.float64,
+                          device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt)
         n_tot_nnz = int(tt.item())
     bytes_iter = 12 * n_tot_nnz + 20 * n + 136 * n  # unfused-PCG accounting, SURVEY 8(d)

@@ -1,0 +1,85 @@
+"""The multi-PROCESS path on ONE GPU.  RCCL refuses two ranks on a device, so
+the ranks talk through tests/fake_rccl (a shared-memory test double preloaded in
+front of librccl): everything of the product runs for real -- per-rank shard
+generation, lsb_hip_solver_create_dist, the exchange plan, hip_comm.c's call
+sequence, the identical control flow on every rank, the HIP kernels -- only the
+transport under the nccl* symbols is replaced.  A mismatch in the sequence of
+collectives between ranks shows up as a barrier time-out there, not as a hung
+node in the 8-GPU bench."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+FAKE = os.path.join(ROOT, "tests", "fake_rccl")
+
+
+def _env():
+    subprocess.run(["make", "-s", "-C", FAKE], check=True)
+    env = dict(os.environ)
+    env["LD_PRELOAD"] = os.path.join(FAKE, "libfake_rccl.so")
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    return env
+
+
+def _run(world, args, port):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(port)] + args
+    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    return r
+
+
+@pytest.mark.parametrize("world,spec,krylov", [(2, "lap2d:nx=240,ny=180", "cg"),
+                                               (3, "lap3d:nx=30,ny=28,nz=26", "cg1"),
+                                               (4, "lap2d:nx=150,ny=400", "auto")])
+def test_multi_process_solve_matches_oracle(world, spec, krylov, tmp_path):
+    import lsbench_amd as la
+    _run(world, [os.path.join(ROOT, "tests", "dist_gpu_worker.py"), spec, str(tmp_path), krylov, "1e-10"],
+         29600 + world)
+    A = la.lsbench_matrix_synth(spec)
+    b = O.rhs(A.nrows)
+    xo, ito, relo, sto = O.pcg_jacobi(A.offs, A.cols, A.vals, b, 1e-10)
+    metas = [np.load(tmp_path / ("m%d.npy" % r)) for r in range(world)]
+    x = np.concatenate([np.load(tmp_path / ("x%d.npy" % r)) for r in range(world)])
+    y = np.concatenate([np.load(tmp_path / ("y%d.npy" % r)) for r in range(world)])
+    assert [int(m[4]) for m in metas] == sorted(int(m[4]) for m in metas) and int(metas[-1][5]) == A.nrows
+    assert all(m[1] == 1 and m[3] == 1 for m in metas)                  # converged, twice
+    assert len({int(m[0]) for m in metas}) == 1 and len({int(m[2]) for m in metas}) == 1
+    assert abs(int(metas[0][0]) - ito) <= 2 and int(metas[0][2]) == int(metas[0][0])
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-8
+    v = np.sin(np.arange(A.nrows, dtype=np.float64))
+    assert np.allclose(y, O.spmv(A.offs, A.cols, A.vals, v), rtol=1e-12, atol=1e-12)
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's N > 1 branch end to end (gloo for torch.distributed, the test
+    double for the library's collectives): same iteration count as N = 1."""
+    common = ["--workload", "lap2d:nx=700,ny=500", "--tol", "1e-8", "--steps", "2", "--warmup", "1",
+              "--cpu-seconds", "0"]
+    env = _env()
+    env["LSB_BENCH_BACKEND"] = "gloo"
+    env["LSB_BENCH_ONE_GPU"] = "1"
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common,
+                        capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    one = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29655", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2"] + common
+    r2 = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, (r2.stdout[-1500:], r2.stderr[-3000:])
+    lines = [l for l in r2.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                              # rank 0 only
+    two = json.loads(lines[0])
+    assert two["n_gpus"] == 2 and two["config"]["partition"] == "row-range x2"
+    assert abs(two["config"]["iterations_per_solve"] - one["config"]["iterations_per_solve"]) <= 2
+    assert two["config"]["relres"] <= 1e-8 and "single-reduction" in two["config"]["solver"]
+    assert two["config"]["nnz"] == one["config"]["nnz"]
