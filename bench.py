@@ -64,6 +64,8 @@ def parse():
     p.add_argument("--krylov", default="auto", choices=["cg", "cg1", "auto"],
                    help="cg = classic PCG; cg1 = single-reduction PCG (2 launches, 1 reduction "
                         "per iteration); auto = cg1 when the operator spans several GPUs")
+    p.add_argument("--overlap", type=int, default=0,
+                   help="N>1: 1 = halo exchange on its own stream behind the interior rows")
     p.add_argument("--spmv-tune", type=int, default=-1,
                    help="-1 = timing pass at setup picks the SpMV flavour; 0..3 force it")
     p.add_argument("--fixed-iters", type=int, default=0,
@@ -222,7 +224,7 @@ def main():
         a.tol, a.maxit = 0.0, a.fixed_iters
     opts = la.default_opts(op_mode=la.OP_RAW, tol=a.tol, maxit=a.maxit, spmv_variant=a.spmv,
                            use_graph=1 if small else 0, sample_spmv=0 if small else 16,
-                           spmv_tune=a.spmv_tune,
+                           spmv_tune=a.spmv_tune, overlap=a.overlap,
                            krylov={"cg": la.KRYLOV_PCG, "cg1": la.KRYLOV_PCG1,
                                    "auto": la.KRYLOV_AUTO}[a.krylov],
                            precond=la.PRECOND_NONE if spmv_only else la.PRECOND_JACOBI)

@@ -114,6 +114,9 @@ struct lsb_hip_opts {
   int sample_spmv;   /* HIP-event-time every Nth SpMV launch (0=off)   [0]  */
   int nvirt;         /* >1: split into that many row-range shards on ONE
                         device, exchanging by device copies (test mode) [1] */
+  int overlap;       /* multi-shard: run the halo exchange on its own stream
+                        behind the rows that need no halo (costs two
+                        extra launches per iteration)                   [0] */
   int spmv_tune;     /* -1: time the SpMV flavours at creation and keep the
                         fastest; >= 0: force flags (bit 0 prefetch, bit 1
                         nontemporal)                                   [-1] */
@@ -266,6 +269,8 @@ int lsb_hip_solver_spmv_variant(const lsb_hip_solver *s);
  * bit 1 nontemporal) and the workgroup cap of the SpMV launch. */
 unsigned lsb_hip_solver_spmv_flags(const lsb_hip_solver *s);
 unsigned lsb_hip_solver_spmv_grid(const lsb_hip_solver *s);
+/* 1 when the halo exchange of this solver runs behind its interior rows. */
+int lsb_hip_solver_overlaps(const lsb_hip_solver *s);
 /* hipStream_t of the backend (as void*), for callers that time with events. */
 void *lsb_hip_stream(void);
 

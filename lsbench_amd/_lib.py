@@ -45,7 +45,7 @@ class Opts(C.Structure):
     _fields_ = [("tol", C.c_double), ("maxit", C.c_uint), ("op_mode", C.c_int),
                 ("precond", C.c_int), ("spmv_variant", C.c_int),
                 ("check_every", C.c_int), ("use_graph", C.c_int),
-                ("sample_spmv", C.c_int), ("nvirt", C.c_int),
+                ("sample_spmv", C.c_int), ("nvirt", C.c_int), ("overlap", C.c_int),
                 ("spmv_tune", C.c_int), ("spmv_grid", C.c_int), ("reorder", C.c_int),
                 ("krylov", C.c_int),
                 ("restart", C.c_int), ("verbose", C.c_int)]
@@ -128,6 +128,7 @@ SIGNATURES = {
     "lsb_hip_solver_spmv_variant": (_i, [_vp]),
     "lsb_hip_solver_spmv_flags": (_u, [_vp]),
     "lsb_hip_solver_spmv_grid": (_u, [_vp]),
+    "lsb_hip_solver_overlaps": (_i, [_vp]),
     "lsb_hip_stream": (_vp, []),
     # communicator
     "lsb_hip_comm_get_unique_id": (_i, [_vp]),

@@ -269,6 +269,11 @@ class Solver:
     def spmv_grid(self):
         return L.load().lsb_hip_solver_spmv_grid(self._h)
 
+    @property
+    def overlaps(self):
+        """True when the halo exchange runs behind the interior rows."""
+        return bool(L.load().lsb_hip_solver_overlaps(self._h))
+
     def destroy(self):
         if self._h:
             L.load().lsb_hip_solver_destroy(self._h)

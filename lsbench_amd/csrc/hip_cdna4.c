@@ -44,7 +44,7 @@
 /* backend globals (reference style: file statics, src/cusparse.c:33-36)     */
 /* ------------------------------------------------------------------------ */
 static int initialized = 0;
-static hipStream_t g_stream = 0;
+static hipStream_t g_stream = 0, g_comm_stream = 0; /* compute / halo exchange */
 static struct lsb_hip_opts g_opts;
 static int g_opts_set = 0;
 static struct lsb_hip_result g_last;
@@ -66,6 +66,7 @@ void lsb_hip_opts_default(struct lsb_hip_opts *o) {
   o->use_graph = 1;
   o->sample_spmv = 0;
   o->nvirt = 1;
+  o->overlap = 0; /* measured: the split costs ~18 us per iteration, DESIGN.md section 6 */
   o->spmv_tune = -1;
   o->spmv_grid = 0;
   o->reorder = 0;
@@ -88,6 +89,8 @@ static void opts_from_env(struct lsb_hip_opts *o) {
     o->use_graph = atoi(e);
   if ((e = getenv("LSBENCH_HIP_SPMV")))
     o->spmv_variant = atoi(e);
+  if ((e = getenv("LSBENCH_HIP_OVERLAP")))
+    o->overlap = atoi(e);
   if ((e = getenv("LSBENCH_HIP_REORDER")))
     o->reorder = atoi(e);
   if ((e = getenv("LSBENCH_HIP_KRYLOV")))
@@ -146,6 +149,7 @@ int hip_cdna4_init(void) {
   if (e)
     LSB_CHK_HIP(hipSetDevice(atoi(e)));
   LSB_CHK_HIP(hipStreamCreate(&g_stream)); /* cf. src/cusparse.c:142 */
+  LSB_CHK_HIP(hipStreamCreate(&g_comm_stream));
   struct lsb_hip_opts o;
   lsb_hip_get_opts(&o);
   initialized = 1;
@@ -157,7 +161,8 @@ int hip_cdna4_finalize(void) {
     return 1;
   LSB_CHK_HIP(hipStreamSynchronize(g_stream));
   LSB_CHK_HIP(hipStreamDestroy(g_stream));
-  g_stream = 0;
+  LSB_CHK_HIP(hipStreamDestroy(g_comm_stream));
+  g_stream = 0, g_comm_stream = 0;
   initialized = 0;
   return 0;
 }
@@ -211,6 +216,10 @@ struct shard {
   double *d_vals, *d_dinv, *d_r, *d_q, *d_pfull;
   double *d_p1, *d_s1; /* single-reduction CG: p and s = S p (pfull then holds u) */
   unsigned npq, np2;   /* partial counts of the SpMV / sweep launches */
+  /* rows that reference other shards' columns sit in row blocks [0,ov_b1) and
+   * [ov_b2,nblk); the blocks in between need no halo (0,0 = not separable) */
+  unsigned ov_b1, ov_b2;
+  int ov_ok;
   double *d_parts_pq, *d_parts2;
   double *d_scal; /* [0] p.q   [1] r.z'  [2] r.r   (multi-shard path) */
   struct lsb_pcg_state *d_st;
@@ -254,7 +263,7 @@ struct lsb_hip_solver {
   struct lsb_gmres_state *gm_st, *gm_hst;
   size_t gm_ld;
   int gm_m;
-  hipEvent_t ev_poll[2];
+  hipEvent_t ev_poll[2], ev_vec, ev_halo;
   hipEvent_t ev[4 * MAX_SAMPLES], ev_t0, ev_t1; /* per sample: e0 SpMV e1 e2 e3 */
   int have_events;
   double *d_tmp; /* n_here doubles: scratch for spmv_dev / jacobi sweep */
@@ -370,6 +379,28 @@ static void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
   unsigned char *lanes = (unsigned char *)malloc((size_t)s->nblk + 1);
   lsb_csr_block_lanes(&view, rb, s->nblk, lanes);
   s->d_blklanes = (unsigned char *)dev_upload(lanes, (size_t)s->nblk);
+  /* Which row blocks touch columns owned by other shards?  Under row-range
+   * partitioning of a banded operator they are a prefix and a suffix; the
+   * blocks in between can start before the halo has arrived. */
+  {
+    const int row_end = (int)(row_begin + n);
+    unsigned b1 = 0, b2 = s->nblk;
+    int ok = 1;
+    unsigned char *ext = (unsigned char *)calloc(s->nblk ? s->nblk : 1, 1);
+    for (unsigned k = 0; k < s->nblk; k++)
+      for (unsigned r = rb[k]; r < rb[k + 1] && !ext[k]; r++)
+        if (offs[r + 1] > offs[r] &&
+            (cols[offs[r]] < (int)row_begin || cols[offs[r + 1] - 1] >= row_end))
+          ext[k] = 1;
+    while (b1 < s->nblk && ext[b1])
+      b1++;
+    while (b2 > b1 && ext[b2 - 1])
+      b2--;
+    for (unsigned k = b1; k < b2; k++)
+      ok &= !ext[k];
+    free(ext);
+    s->ov_ok = ok && b2 > b1, s->ov_b1 = b1, s->ov_b2 = b2;
+  }
   /* Scattered rows (mean |col-row| in the millions, x far beyond L2): also
    * build the column-panel form; tune_spmv() keeps whichever is faster. */
   {
@@ -390,7 +421,7 @@ static void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
   s->d_q = (double *)lsb_hip_malloc((size_t)n * sizeof(double));
   s->d_pfull = (double *)lsb_hip_malloc((size_t)n_glob * sizeof(double));
   LSB_CHK_HIP(hipMemsetAsync(s->d_pfull, 0, (size_t)n_glob * sizeof(double), g_stream));
-  s->d_parts_pq = (double *)lsb_hip_malloc(LSB_MAX_PARTIALS * sizeof(double));
+  s->d_parts_pq = (double *)lsb_hip_malloc(3 * LSB_MAX_PARTIALS * sizeof(double));
   /* two buffers: k_cg1_update reads the previous launch's partials while
    * writing its own */
   s->d_parts2 = (double *)lsb_hip_malloc(4 * LSB_MAX_PARTIALS * sizeof(double));
@@ -464,6 +495,8 @@ static void solver_finish_setup(lsb_hip_solver *sv) {
   LSB_CHK_HIP(hipEventCreate(&sv->ev_t1));
   LSB_CHK_HIP(hipEventCreateWithFlags(&sv->ev_poll[0], hipEventDisableTiming));
   LSB_CHK_HIP(hipEventCreateWithFlags(&sv->ev_poll[1], hipEventDisableTiming));
+  LSB_CHK_HIP(hipEventCreateWithFlags(&sv->ev_vec, hipEventDisableTiming));
+  LSB_CHK_HIP(hipEventCreateWithFlags(&sv->ev_halo, hipEventDisableTiming));
   sv->have_events = 1;
   LSB_CHK_HIP(hipStreamSynchronize(g_stream));
   for (int i = 0; i < sv->nshard; i++)
@@ -595,6 +628,8 @@ void lsb_hip_solver_destroy(lsb_hip_solver *sv) {
     LSB_CHK_HIP(hipEventDestroy(sv->ev_t1));
     LSB_CHK_HIP(hipEventDestroy(sv->ev_poll[0]));
     LSB_CHK_HIP(hipEventDestroy(sv->ev_poll[1]));
+    LSB_CHK_HIP(hipEventDestroy(sv->ev_vec));
+    LSB_CHK_HIP(hipEventDestroy(sv->ev_halo));
   }
   lsb_hip_free(sv->d_scal_all), lsb_hip_free(sv->d_tmp);
   lsb_hip_free(sv->d_perm), lsb_hip_free(sv->d_bp), lsb_hip_free(sv->d_xp);
@@ -618,15 +653,17 @@ unsigned lsb_hip_solver_nblocks(const lsb_hip_solver *s) { return s->sh[0].nblk;
 int lsb_hip_solver_spmv_variant(const lsb_hip_solver *s) { return s->sh[0].variant; }
 unsigned lsb_hip_solver_spmv_flags(const lsb_hip_solver *s) { return s->sh[0].sp_flags; }
 unsigned lsb_hip_solver_spmv_grid(const lsb_hip_solver *s) { return s->sh[0].sp_grid; }
+static int can_overlap(const lsb_hip_solver *sv);
+int lsb_hip_solver_overlaps(const lsb_hip_solver *s) { return can_overlap(s); }
 
 /* ------------------------------------------------------------------------ */
 /* communication steps: RCCL between processes, device copies between the     */
 /* virtual shards of one process                                              */
 /* ------------------------------------------------------------------------ */
-static void exchange_p(lsb_hip_solver *sv) {
+static void exchange_on(lsb_hip_solver *sv, hipStream_t stream) {
   if (sv->dist) {
     struct shard *s = &sv->sh[0];
-    lsb_hip_comm_exchange(s->d_pfull, s->send, s->nsend, s->recv, s->nrecv, g_stream);
+    lsb_hip_comm_exchange(s->d_pfull, s->send, s->nsend, s->recv, s->nrecv, stream);
     return;
   }
   for (int i = 0; i < sv->nshard; i++) {
@@ -636,10 +673,12 @@ static void exchange_p(lsb_hip_solver *sv) {
       LSB_CHK_HIP(hipMemcpyAsync(s->d_pfull + x->offset,
                                  sv->sh[x->peer].d_pfull + x->offset,
                                  x->count * sizeof(double), hipMemcpyDeviceToDevice,
-                                 g_stream));
+                                 stream));
     }
   }
 }
+
+static void exchange_p(lsb_hip_solver *sv) { exchange_on(sv, g_stream); }
 
 static void allreduce_scal(lsb_hip_solver *sv, unsigned off, unsigned cnt) {
   if (sv->dist)
@@ -669,6 +708,74 @@ static void spmv_shard(struct shard *s, const double *xfull, double *y,
   lsb_k_spmv(s->variant, s->n, s->d_offs, s->d_cols, s->d_vals, s->d_rowblk, s->d_blklanes,
              s->nblk, s->lanes, s->sp_flags, s->sp_grid, xfull, y, xdot, partials, np, st,
              NULL, g_stream);
+}
+
+/*
+ * Exchange + SpMV of one iteration with the halo transfer hidden behind the
+ * rows that do not need it: the exchange runs on its
+ * own stream as soon as the vector is final, the interior row blocks start at
+ * once on the compute stream, the boundary blocks wait for the halo.  Three
+ * launches of the same kernel on sub-ranges of the row blocks; their partial
+ * sums land in consecutive regions of the shard's partial buffer.
+ */
+static int can_overlap(const lsb_hip_solver *sv) {
+  if (!sv->multi || !sv->o.overlap)
+    return 0;
+  for (int i = 0; i < sv->nshard; i++)
+    if (!sv->sh[i].ov_ok || sv->sh[i].variant != LSB_SPMV_ADAPTIVE)
+      return 0;
+  return 1;
+}
+
+static void spmv_range(struct shard *s, unsigned b0, unsigned b1, double *y, double *partials,
+                       unsigned *np, const struct lsb_pcg_state *st) {
+  *np = 0;
+  if (b1 > b0)
+    lsb_k_spmv(LSB_SPMV_ADAPTIVE, s->n, s->d_offs, s->d_cols, s->d_vals, s->d_rowblk + b0,
+               s->d_blklanes + b0, b1 - b0, s->lanes, s->sp_flags, s->sp_grid, s->d_pfull, y,
+               s->d_pfull + s->row_begin, partials, np, st, NULL, g_stream);
+}
+
+static void exchange_and_spmv(lsb_hip_solver *sv, int sample) {
+  if (!can_overlap(sv)) {
+    exchange_p(sv);
+    for (int i = 0; i < sv->nshard; i++) {
+      struct shard *s = &sv->sh[i];
+      if (i == 0 && sample >= 0)
+        LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample], g_stream));
+      spmv_shard(s, s->d_pfull, s->d_q, s->d_pfull + s->row_begin, s->d_parts_pq, &s->npq, s->d_st);
+      if (i == 0 && sample >= 0) {
+        LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 1], g_stream));
+        LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 2], g_stream));
+        LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 3], g_stream));
+      }
+    }
+    return;
+  }
+  LSB_CHK_HIP(hipEventRecord(sv->ev_vec, g_stream));            /* the vector is final   */
+  LSB_CHK_HIP(hipStreamWaitEvent(g_comm_stream, sv->ev_vec, 0));
+  exchange_on(sv, g_comm_stream);
+  LSB_CHK_HIP(hipEventRecord(sv->ev_halo, g_comm_stream));      /* the halo has landed   */
+  if (sample >= 0)
+    LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample], g_stream));
+  unsigned na, nb, nc;
+  for (int i = 0; i < sv->nshard; i++) {                         /* interior: no halo     */
+    struct shard *s = &sv->sh[i];
+    spmv_range(s, s->ov_b1, s->ov_b2, s->d_q, s->d_parts_pq, &na, s->d_st);
+    s->npq = na;
+  }
+  LSB_CHK_HIP(hipStreamWaitEvent(g_stream, sv->ev_halo, 0));
+  for (int i = 0; i < sv->nshard; i++) {                         /* boundary rows         */
+    struct shard *s = &sv->sh[i];
+    spmv_range(s, 0, s->ov_b1, s->d_q, s->d_parts_pq + s->npq, &nb, s->d_st);
+    spmv_range(s, s->ov_b2, s->nblk, s->d_q, s->d_parts_pq + s->npq + nb, &nc, s->d_st);
+    s->npq += nb + nc;
+  }
+  if (sample >= 0) {
+    LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 1], g_stream));
+    LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 2], g_stream));
+    LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 3], g_stream));
+  }
 }
 
 /*
@@ -759,9 +866,14 @@ static void pcg_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int sa
     return;
   }
   unsigned npq = 0, np2 = 0;
-  if (sv->multi)
-    exchange_p(sv);
-  for (int i = 0; i < sv->nshard; i++) {
+  if (sv->multi) {
+    exchange_and_spmv(sv, sample);
+    for (int i = 0; i < sv->nshard; i++) {
+      struct shard *s = &sv->sh[i];
+      lsb_k_reduce_final(s->d_parts_pq, s->npq, 1, s->d_scal + 0, 0, s->d_st, g_stream);
+    }
+  }
+  for (int i = 0; i < sv->nshard && !sv->multi; i++) {
     struct shard *s = &sv->sh[i];
     if (i == 0 && sample >= 0)
       LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample], g_stream));
@@ -776,8 +888,6 @@ static void pcg_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int sa
       LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 2], g_stream));
       LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 3], g_stream));
     }
-    if (sv->multi)
-      lsb_k_reduce_final(s->d_parts_pq, npq, 1, s->d_scal + 0, 0, s->d_st, g_stream);
   }
   if (sv->multi)
     allreduce_scal(sv, 0, 1);
@@ -838,10 +948,11 @@ static void cg1_enqueue_init(lsb_hip_solver *sv, const double *d_b, double *d_x)
       lsb_k_pcg_init_state(s->d_st, s->d_parts2, s->np2, sv->o.tol, (int)sv->o.maxit, g_stream);
   }
   if (sv->multi)
-    exchange_p(sv);
-  for (int i = 0; i < sv->nshard; i++) { /* w = S u, partials w.u */
+    exchange_and_spmv(sv, -1); /* w = S u, partials w.u */
+  for (int i = 0; i < sv->nshard; i++) {
     struct shard *s = &sv->sh[i];
-    spmv_shard(s, s->d_pfull, s->d_q, s->d_pfull + s->row_begin, s->d_parts_pq, &s->npq, s->d_st);
+    if (!sv->multi)
+      spmv_shard(s, s->d_pfull, s->d_q, s->d_pfull + s->row_begin, s->d_parts_pq, &s->npq, s->d_st);
     if (sv->multi)
       lsb_k_reduce_final(s->d_parts_pq, s->npq, 1, s->d_scal + 0, 0, s->d_st, g_stream);
   }
@@ -864,18 +975,20 @@ static void cg1_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int sa
       lsb_k_reduce_final(gr_out, np2, 2, s->d_scal + 1, 0, s->d_st, g_stream);
   }
   if (sv->multi)
-    exchange_p(sv);
+    exchange_and_spmv(sv, sample);
   for (int i = 0; i < sv->nshard; i++) {
     struct shard *s = &sv->sh[i];
-    if (i == 0 && sample >= 0)
-      LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample], g_stream));
-    spmv_shard(s, s->d_pfull, s->d_q, s->d_pfull + s->row_begin, s->d_parts_pq, &s->npq, s->d_st);
-    if (i == 0 && sample >= 0) {
-      LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 1], g_stream));
-      LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 2], g_stream));
-      LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 3], g_stream));
-    }
-    if (sv->multi)
+    if (!sv->multi) {
+      if (sample >= 0)
+        LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample], g_stream));
+      spmv_shard(s, s->d_pfull, s->d_q, s->d_pfull + s->row_begin, s->d_parts_pq, &s->npq,
+                 s->d_st);
+      if (sample >= 0) {
+        LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 1], g_stream));
+        LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 2], g_stream));
+        LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 3], g_stream));
+      }
+    } else
       lsb_k_reduce_final(s->d_parts_pq, s->npq, 1, s->d_scal + 0, 0, s->d_st, g_stream);
   }
   if (sv->multi)

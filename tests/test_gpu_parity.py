@@ -307,6 +307,40 @@ def test_virtual_shards_reproduce_single_shard(hip, nvirt, matrix_path, golden_x
     sp.destroy()
 
 
+@pytest.mark.parametrize("krylov", ["PCG", "PCG1"])
+@pytest.mark.parametrize("nvirt", [2, 3, 5])
+def test_halo_exchange_behind_interior_rows(hip, nvirt, krylov):
+    """Multi-shard iteration with the exchange on its own stream and the SpMV
+    split into interior / boundary row blocks against the
+    sequential exchange-then-SpMV order and the oracle."""
+    kr = getattr(hip, "KRYLOV_" + krylov)
+    L = hip.lsbench_matrix_synth("lap2d:nx=300,ny=200")
+    offs, cols, vals = O.lap2d(300, 200)
+    b = O.rhs(L.nrows)
+    xo, ito, _, sto = O.pcg_jacobi(offs, cols, vals, b, tol=1e-10)
+    assert sto == 1
+    out = {}
+    for ov in (0, 1):
+        s = hip.Solver(L, hip.default_opts(op_mode=hip.OP_RAW, nvirt=nvirt, overlap=ov, tol=1e-10,
+                                           krylov=kr, spmv_variant=hip.SPMV_ADAPTIVE))
+        assert s.overlaps == bool(ov)
+        out[ov] = s.solve(b)
+        s.destroy()
+    (x0, r0), (x1, r1) = out[0], out[1]
+    assert r0.status == 1 and r1.status == 1
+    assert abs(int(r1.iters) - int(r0.iters)) <= 2 and abs(int(r1.iters) - ito) <= 4
+    assert np.linalg.norm(x1 - x0) / np.linalg.norm(x0) <= 1e-9
+    assert np.linalg.norm(x1 - xo) / np.linalg.norm(xo) <= 1e-8
+    # an operator whose halo rows are not a prefix+suffix of the row blocks
+    # falls back to the sequential order on its own
+    A = hip.lsbench_matrix_synth("powerlaw:n=20000,avg=8,max=64,seed=3")
+    s = hip.Solver(A, hip.default_opts(op_mode=hip.OP_RAW, nvirt=nvirt, maxit=5,
+                                       precond=hip.PRECOND_NONE,
+                                       spmv_variant=hip.SPMV_ADAPTIVE))
+    assert not s.overlaps
+    s.destroy()
+
+
 def test_single_rank_communicator_and_dist_create(hip, matrix_path):
     """RCCL with one rank: unique id, init, all-reduce, barrier, and the
     distributed constructor on the full row range == the plain constructor."""
