@@ -101,7 +101,12 @@ enum { LSB_SPMV_AUTO = 0,     /* pick by mean row length                    */
        LSB_SPMV_PANEL = 4 };  /* column panels with an L2-resident x window,
                                  for scattered rows (solver handle only)    */
 enum { LSB_STATUS_RUNNING = 0, LSB_STATUS_CONVERGED = 1,
-       LSB_STATUS_BREAKDOWN = 2, LSB_STATUS_MAXIT = 3 };
+       LSB_STATUS_BREAKDOWN = 2, LSB_STATUS_MAXIT = 3,
+       LSB_STATUS_COMM = 4 /* a peer never arrived (direct xGMI path) */ };
+/* how sharded solves communicate */
+enum { LSB_COMM_AUTO = 0,  /* direct xGMI stores where they validate and win */
+       LSB_COMM_RCCL = 1,  /* RCCL send/recv + all-reduce                    */
+       LSB_COMM_P2P = 2 }; /* direct xGMI stores, or fail                    */
 
 struct lsb_hip_opts {
   double tol;        /* stop when ||r||_2 <= tol*||b||_2            [1e-12] */
@@ -114,6 +119,7 @@ struct lsb_hip_opts {
   int sample_spmv;   /* HIP-event-time every Nth SpMV launch (0=off)   [0]  */
   int nvirt;         /* >1: split into that many row-range shards on ONE
                         device, exchanging by device copies (test mode) [1] */
+  int comm;          /* LSB_COMM_*                                      [0] */
   int overlap;       /* multi-shard: run the halo exchange on its own stream
                         behind the rows that need no halo (costs two
                         extra launches per iteration)                   [0] */
@@ -271,6 +277,11 @@ unsigned lsb_hip_solver_spmv_flags(const lsb_hip_solver *s);
 unsigned lsb_hip_solver_spmv_grid(const lsb_hip_solver *s);
 /* 1 when the halo exchange of this solver runs behind its interior rows. */
 int lsb_hip_solver_overlaps(const lsb_hip_solver *s);
+/* 0 one shard; 1 RCCL (device copies between virtual shards); 2 direct xGMI
+ * stores for the all-reduces; 3 for the halo exchange as well.  p2p_us/rccl_us
+ * (may be NULL): what one exchange + all-reduce cost each way in the
+ * creation-time self-test, 0 if it did not run. */
+int lsb_hip_solver_comm(const lsb_hip_solver *s, double *p2p_us, double *rccl_us);
 /* hipStream_t of the backend (as void*), for callers that time with events. */
 void *lsb_hip_stream(void);
 

@@ -21,6 +21,8 @@ PRECOND_JACOBI, PRECOND_NONE = 0, 1
 KRYLOV_PCG, KRYLOV_GMRES, KRYLOV_PCG1, KRYLOV_AUTO = 0, 1, 2, 3
 SPMV_AUTO, SPMV_ADAPTIVE, SPMV_SUBWAVE, SPMV_SCALAR, SPMV_PANEL = 0, 1, 2, 3, 4
 STATUS_RUNNING, STATUS_CONVERGED, STATUS_BREAKDOWN, STATUS_MAXIT = 0, 1, 2, 3
+STATUS_COMM = 4
+COMM_AUTO, COMM_RCCL, COMM_P2P = 0, 1, 2
 
 
 class LsbenchHipError(RuntimeError):
@@ -45,7 +47,7 @@ class Opts(C.Structure):
     _fields_ = [("tol", C.c_double), ("maxit", C.c_uint), ("op_mode", C.c_int),
                 ("precond", C.c_int), ("spmv_variant", C.c_int),
                 ("check_every", C.c_int), ("use_graph", C.c_int),
-                ("sample_spmv", C.c_int), ("nvirt", C.c_int), ("overlap", C.c_int),
+                ("sample_spmv", C.c_int), ("nvirt", C.c_int), ("comm", C.c_int), ("overlap", C.c_int),
                 ("spmv_tune", C.c_int), ("spmv_grid", C.c_int), ("reorder", C.c_int),
                 ("krylov", C.c_int),
                 ("restart", C.c_int), ("verbose", C.c_int)]
@@ -129,6 +131,7 @@ SIGNATURES = {
     "lsb_hip_solver_spmv_flags": (_u, [_vp]),
     "lsb_hip_solver_spmv_grid": (_u, [_vp]),
     "lsb_hip_solver_overlaps": (_i, [_vp]),
+    "lsb_hip_solver_comm": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "lsb_hip_stream": (_vp, []),
     # communicator
     "lsb_hip_comm_get_unique_id": (_i, [_vp]),

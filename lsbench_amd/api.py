@@ -270,6 +270,16 @@ class Solver:
         return L.load().lsb_hip_solver_spmv_grid(self._h)
 
     @property
+    def comm(self):
+        """(mode, p2p_us, rccl_us): mode 0 = one shard, 1 = RCCL / device copies,
+        2 = direct xGMI stores for the all-reduces, 3 = and for the halos; the
+        two times are the creation-time self-test's cost of one exchange +
+        all-reduce each way (0 when it did not run)."""
+        a, b = C.c_double(), C.c_double()
+        m = L.load().lsb_hip_solver_comm(self._h, C.byref(a), C.byref(b))
+        return m, a.value, b.value
+
+    @property
     def overlaps(self):
         """True when the halo exchange runs behind the interior rows."""
         return bool(L.load().lsb_hip_solver_overlaps(self._h))

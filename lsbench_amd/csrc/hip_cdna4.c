@@ -66,6 +66,7 @@ void lsb_hip_opts_default(struct lsb_hip_opts *o) {
   o->use_graph = 1;
   o->sample_spmv = 0;
   o->nvirt = 1;
+  o->comm = LSB_COMM_AUTO;
   o->overlap = 0; /* measured: the split costs ~18 us per iteration, DESIGN.md section 6 */
   o->spmv_tune = -1;
   o->spmv_grid = 0;
@@ -89,6 +90,8 @@ static void opts_from_env(struct lsb_hip_opts *o) {
     o->use_graph = atoi(e);
   if ((e = getenv("LSBENCH_HIP_SPMV")))
     o->spmv_variant = atoi(e);
+  if ((e = getenv("LSBENCH_HIP_COMM")))
+    o->comm = !strcmp(e, "rccl") ? LSB_COMM_RCCL : !strcmp(e, "p2p") ? LSB_COMM_P2P : LSB_COMM_AUTO;
   if ((e = getenv("LSBENCH_HIP_OVERLAP")))
     o->overlap = atoi(e);
   if ((e = getenv("LSBENCH_HIP_REORDER")))
@@ -267,6 +270,11 @@ struct lsb_hip_solver {
   hipEvent_t ev[4 * MAX_SAMPLES], ev_t0, ev_t1; /* per sample: e0 SpMV e1 e2 e3 */
   int have_events;
   double *d_tmp; /* n_here doubles: scratch for spmv_dev / jacobi sweep */
+  /* direct xGMI path (hip_p2p.hip), one context per shard; p2p_on: used for
+   * the all-reduces, p2p_halo: also for the halo exchange */
+  struct lsb_p2p **p2p;
+  int p2p_on, p2p_halo;
+  double p2p_us, rccl_us; /* self-test: one exchange + all-reduce, each way */
 };
 
 static unsigned pow2_ceil(unsigned v) {
@@ -471,6 +479,9 @@ static void plan_exchange(struct shard *s, int me, int nall, const unsigned *hul
 }
 
 static void tune_spmv(lsb_hip_solver *sv, struct shard *s);
+static void p2p_setup(lsb_hip_solver *sv);
+static void exchange_p(lsb_hip_solver *sv);
+static void allreduce_scal(lsb_hip_solver *sv, unsigned off, unsigned cnt);
 static void drop_graphs(lsb_hip_solver *sv);
 
 static lsb_hip_solver *solver_alloc(int nshard, const struct lsb_hip_opts *o) {
@@ -501,6 +512,141 @@ static void solver_finish_setup(lsb_hip_solver *sv) {
   LSB_CHK_HIP(hipStreamSynchronize(g_stream));
   for (int i = 0; i < sv->nshard; i++)
     tune_spmv(sv, &sv->sh[i]);
+  LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+  p2p_setup(sv);
+}
+
+/*
+ * Direct xGMI path: build it, prove it, time it, and only then use it.
+ *   dist:    collective.  Every rank runs P2P_ROUNDS rounds of {pattern ->
+ *            exchange -> check the halos bit by bit -> all-reduce of three
+ *            known values -> check the sums}, then times 100 x {exchange +
+ *            all-reduce} on this path and on RCCL.  The path is kept when
+ *            EVERY rank saw zero mismatches, no time-out, and (comm = auto) a
+ *            faster loop; the decision is taken on all-gathered numbers, so
+ *            all ranks take the same one.
+ *   virtual: only on request (comm = p2p), for the one-GPU tests of the
+ *            kernels; device copies remain the default there.
+ */
+#define P2P_ROUNDS 24
+#define P2P_TIMED 100
+static void p2p_rounds(lsb_hip_solver *sv, int rounds, int check, unsigned *d_bad) {
+  for (int t = 0; t < rounds; t++) {
+    for (int i = 0; i < sv->nshard && check; i++)
+      lsb_p2p_test_pattern(sv->sh[i].d_pfull, sv->sh[i].row_begin, sv->sh[i].n, (unsigned)t,
+                           g_stream);
+    exchange_p(sv);
+    for (int i = 0; i < sv->nshard && check; i++) {
+      struct shard *s = &sv->sh[i];
+      for (int k = 0; k < s->nrecv && sv->p2p_halo; k++)
+        lsb_p2p_test_check_range(s->d_pfull, s->recv[k].offset, s->recv[k].count, (unsigned)t,
+                                 d_bad, g_stream);
+      lsb_p2p_test_setvals(s->d_scal, sv->dist ? lsb_hip_comm_rank() : i, (unsigned)t, g_stream);
+    }
+    allreduce_scal(sv, 0, 3);
+    for (int i = 0; i < sv->nshard && check; i++)
+      lsb_p2p_test_checkvals(sv->sh[i].d_scal, sv->dist ? lsb_hip_comm_size() : sv->nshard,
+                             (unsigned)t, d_bad, g_stream);
+  }
+}
+
+static float timed_rounds(lsb_hip_solver *sv) {
+  float ms = 0;
+  if (sv->dist)
+    lsb_hip_comm_barrier();
+  p2p_rounds(sv, 8, 0, NULL);
+  LSB_CHK_HIP(hipEventRecord(sv->ev_t0, g_stream));
+  p2p_rounds(sv, P2P_TIMED, 0, NULL);
+  LSB_CHK_HIP(hipEventRecord(sv->ev_t1, g_stream));
+  LSB_CHK_HIP(hipEventSynchronize(sv->ev_t1));
+  LSB_CHK_HIP(hipEventElapsedTime(&ms, sv->ev_t0, sv->ev_t1));
+  return ms * 1e3f / P2P_TIMED;
+}
+
+static void p2p_setup(lsb_hip_solver *sv) {
+  if (!sv->multi || sv->o.comm == LSB_COMM_RCCL || (!sv->dist && sv->o.comm != LSB_COMM_P2P))
+    return;
+  const int P = sv->dist ? lsb_hip_comm_size() : 1;
+  sv->p2p = lsb_calloc(struct lsb_p2p *, sv->nshard);
+  int ok;
+  if (sv->dist) {
+    struct shard *s = &sv->sh[0];
+    sv->p2p[0] = lsb_p2p_create_dist(s->recv, s->nrecv, s->send, s->nsend);
+    ok = sv->p2p[0] != NULL;
+  } else {
+    struct lsb_xfer **rv = lsb_calloc(struct lsb_xfer *, sv->nshard),
+                    **sd = lsb_calloc(struct lsb_xfer *, sv->nshard);
+    int *nr = lsb_calloc(int, sv->nshard), *ns = lsb_calloc(int, sv->nshard);
+    for (int i = 0; i < sv->nshard; i++)
+      rv[i] = sv->sh[i].recv, sd[i] = sv->sh[i].send, nr[i] = sv->sh[i].nrecv,
+      ns[i] = sv->sh[i].nsend;
+    ok = lsb_p2p_create_virtual(sv->p2p, sv->nshard, rv, nr, sd, ns) == 0;
+    free(rv), free(sd), free(nr), free(ns);
+  }
+  unsigned mine[3] = {(unsigned)ok, 0, 0}, *all = lsb_calloc(unsigned, 3 * (size_t)P);
+#define AGREE() (sv->dist ? (void)lsb_hip_comm_allgather_u32(mine, 3, all) : (void)memcpy(all, mine, sizeof mine))
+  AGREE();
+  for (int q = 0; q < P; q++)
+    ok &= all[3 * q] != 0;
+  if (ok) {
+    unsigned *d_bad = (unsigned *)lsb_hip_malloc(sizeof(unsigned)), bad = 0;
+    LSB_CHK_HIP(hipMemsetAsync(d_bad, 0, sizeof(unsigned), g_stream));
+    for (int i = 0; i < sv->nshard; i++)
+      LSB_CHK_HIP(hipMemsetAsync(sv->sh[i].d_st, 0, sizeof(struct lsb_pcg_state), g_stream));
+    sv->p2p_on = 1, sv->p2p_halo = lsb_p2p_has_halo(sv->p2p[0]);
+    if (sv->dist)
+      lsb_hip_comm_barrier();
+    p2p_rounds(sv, P2P_ROUNDS, 1, d_bad);
+    LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+    lsb_hip_memcpy_d2h(&bad, d_bad, sizeof(unsigned));
+    for (int i = 0; i < sv->nshard; i++) {
+      struct lsb_pcg_state hst;
+      lsb_hip_memcpy_d2h(&hst, sv->sh[i].d_st, sizeof hst);
+      bad += hst.status != 0;
+    }
+    lsb_hip_free(d_bad);
+    mine[0] = bad == 0;
+    AGREE(); /* nobody times a path somebody saw fail */
+    for (int q = 0; q < P; q++)
+      ok &= all[3 * q] != 0;
+    for (int i = 0; i < sv->nshard; i++)
+      LSB_CHK_HIP(hipMemsetAsync(sv->sh[i].d_st, 0, sizeof(struct lsb_pcg_state), g_stream));
+    if (ok) {
+      sv->p2p_us = timed_rounds(sv);
+      const int halo = sv->p2p_halo;
+      sv->p2p_on = sv->p2p_halo = 0;
+      sv->rccl_us = timed_rounds(sv);
+      sv->p2p_on = 1, sv->p2p_halo = halo;
+    }
+    mine[0] = (unsigned)ok, mine[1] = (unsigned)(sv->p2p_us * 1e3),
+    mine[2] = (unsigned)(sv->rccl_us * 1e3);
+    AGREE();
+    unsigned tp = 0, tr = 0;
+    for (int q = 0; q < P; q++) {
+      tp = all[3 * q + 1] > tp ? all[3 * q + 1] : tp;
+      tr = all[3 * q + 2] > tr ? all[3 * q + 2] : tr;
+    }
+    if (sv->o.comm == LSB_COMM_AUTO && tp >= tr)
+      ok = 0;
+    if (sv->o.verbose)
+      fprintf(stderr, "hip_cdna4: direct xGMI path %s: %u mismatches here, exchange+all-reduce "
+                      "%.1f us vs %.1f us over RCCL -> %s\n",
+              lsb_p2p_has_halo(sv->p2p[0]) ? "(halos + all-reduce)" : "(all-reduce only)", bad,
+              tp * 1e-3, tr * 1e-3, ok ? "used" : "not used");
+  }
+#undef AGREE
+  free(all);
+  if (!ok) {
+    if (sv->o.comm == LSB_COMM_P2P)
+      errx(EXIT_FAILURE, "hip_cdna4: comm = p2p requested, but the direct xGMI path is not "
+                         "available or failed its self-test");
+    sv->p2p_on = sv->p2p_halo = 0;
+    for (int i = 0; i < sv->nshard; i++)
+      lsb_p2p_destroy(sv->p2p[i]);
+    free(sv->p2p), sv->p2p = NULL;
+  }
+  for (int i = 0; i < sv->nshard; i++)
+    LSB_CHK_HIP(hipMemsetAsync(sv->sh[i].d_st, 0, sizeof(struct lsb_pcg_state), g_stream));
   LSB_CHK_HIP(hipStreamSynchronize(g_stream));
 }
 
@@ -619,6 +765,13 @@ void lsb_hip_solver_destroy(lsb_hip_solver *sv) {
     return;
   LSB_CHK_HIP(hipStreamSynchronize(g_stream));
   drop_graphs(sv);
+  if (sv->p2p) {
+    if (sv->dist) /* no peer may still be storing into a mailbox that goes away */
+      lsb_hip_comm_barrier();
+    for (int i = 0; i < sv->nshard; i++)
+      lsb_p2p_destroy(sv->p2p[i]);
+    free(sv->p2p);
+  }
   for (int i = 0; i < sv->nshard; i++)
     shard_free(&sv->sh[i]);
   if (sv->have_events) {
@@ -655,6 +808,13 @@ unsigned lsb_hip_solver_spmv_flags(const lsb_hip_solver *s) { return s->sh[0].sp
 unsigned lsb_hip_solver_spmv_grid(const lsb_hip_solver *s) { return s->sh[0].sp_grid; }
 static int can_overlap(const lsb_hip_solver *sv);
 int lsb_hip_solver_overlaps(const lsb_hip_solver *s) { return can_overlap(s); }
+int lsb_hip_solver_comm(const lsb_hip_solver *s, double *p2p_us, double *rccl_us) {
+  if (p2p_us)
+    *p2p_us = s->p2p_us;
+  if (rccl_us)
+    *rccl_us = s->rccl_us;
+  return !s->multi ? 0 : !s->p2p_on ? 1 : s->p2p_halo ? 3 : 2;
+}
 
 /* ------------------------------------------------------------------------ */
 /* communication steps: RCCL between processes, device copies between the     */
@@ -678,13 +838,62 @@ static void exchange_on(lsb_hip_solver *sv, hipStream_t stream) {
   }
 }
 
-static void exchange_p(lsb_hip_solver *sv) { exchange_on(sv, g_stream); }
+/* 1: communicate although no solve is running (the device state's status is
+ * whatever the last solve left there) */
+static int g_ar_nostate;
+static void exchange_p(lsb_hip_solver *sv) {
+  if (sv->p2p_halo) { /* all sends before any wait: virtual shards share a stream */
+    for (int i = 0; i < sv->nshard; i++)
+      lsb_p2p_send(sv->p2p[i], sv->sh[i].d_pfull, g_ar_nostate ? NULL : sv->sh[i].d_st, g_stream);
+    for (int i = 0; i < sv->nshard; i++)
+      lsb_p2p_recv(sv->p2p[i], sv->sh[i].d_pfull, g_ar_nostate ? NULL : sv->sh[i].d_st, g_stream);
+    return;
+  }
+  exchange_on(sv, g_stream);
+}
+
+/* d_scal[off .. off+cnt) <- sum over shards; with the direct path the shard's
+ * own partial sums (parts, nparts x width) can be folded into the same launch:
+ * then d_scal[off .. off+width) need not have been reduced beforehand */
+static void allreduce_parts(lsb_hip_solver *sv, unsigned off, unsigned cnt, unsigned width) {
+  for (int ph = 1; ph <= 2; ph++)
+    for (int i = 0; i < sv->nshard; i++) {
+      struct shard *s = &sv->sh[i];
+      const double *parts = width ? s->d_parts_pq : NULL;
+      struct lsb_pcg_state *st = g_ar_nostate ? NULL : s->d_st;
+      if (sv->nshard == 1) {
+        if (ph == 1)
+          lsb_p2p_allreduce(sv->p2p[i], parts, s->npq, width, s->d_scal + off + width,
+                            cnt - width, s->d_scal + off, st, 3, g_stream);
+      } else
+        lsb_p2p_allreduce(sv->p2p[i], parts, s->npq, width, s->d_scal + off + width, cnt - width,
+                          s->d_scal + off, st, ph, g_stream);
+    }
+}
 
 static void allreduce_scal(lsb_hip_solver *sv, unsigned off, unsigned cnt) {
+  if (sv->p2p_on) {
+    allreduce_parts(sv, off, cnt, 0);
+    return;
+  }
   if (sv->dist)
     lsb_hip_comm_allreduce_stream(sv->sh[0].d_scal + off, (int)cnt, g_stream);
   else if (sv->nshard > 1)
     lsb_k_vreduce(sv->d_scal_all, SCAL_STRIDE, (unsigned)sv->nshard, off, cnt, g_stream);
+}
+
+/* d_scal[0] <- all-reduced sum of the SpMV's dot partials; d_scal[1..cnt) are
+ * all-reduced along with it */
+static void allreduce_pq(lsb_hip_solver *sv, unsigned cnt) {
+  if (sv->p2p_on) {
+    allreduce_parts(sv, 0, cnt, 1);
+    return;
+  }
+  for (int i = 0; i < sv->nshard; i++) {
+    struct shard *s = &sv->sh[i];
+    lsb_k_reduce_final(s->d_parts_pq, s->npq, 1, s->d_scal + 0, 0, s->d_st, g_stream);
+  }
+  allreduce_scal(sv, 0, cnt);
 }
 
 static void spmv_shard(struct shard *s, const double *xfull, double *y,
@@ -752,10 +961,15 @@ static void exchange_and_spmv(lsb_hip_solver *sv, int sample) {
     }
     return;
   }
-  LSB_CHK_HIP(hipEventRecord(sv->ev_vec, g_stream));            /* the vector is final   */
-  LSB_CHK_HIP(hipStreamWaitEvent(g_comm_stream, sv->ev_vec, 0));
-  exchange_on(sv, g_comm_stream);
-  LSB_CHK_HIP(hipEventRecord(sv->ev_halo, g_comm_stream));      /* the halo has landed   */
+  if (sv->p2p_halo) { /* direct stores to the peers: no second stream needed */
+    for (int i = 0; i < sv->nshard; i++)
+      lsb_p2p_send(sv->p2p[i], sv->sh[i].d_pfull, sv->sh[i].d_st, g_stream);
+  } else {
+    LSB_CHK_HIP(hipEventRecord(sv->ev_vec, g_stream));          /* the vector is final   */
+    LSB_CHK_HIP(hipStreamWaitEvent(g_comm_stream, sv->ev_vec, 0));
+    exchange_on(sv, g_comm_stream);
+    LSB_CHK_HIP(hipEventRecord(sv->ev_halo, g_comm_stream));    /* the halo has landed   */
+  }
   if (sample >= 0)
     LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample], g_stream));
   unsigned na, nb, nc;
@@ -764,7 +978,11 @@ static void exchange_and_spmv(lsb_hip_solver *sv, int sample) {
     spmv_range(s, s->ov_b1, s->ov_b2, s->d_q, s->d_parts_pq, &na, s->d_st);
     s->npq = na;
   }
-  LSB_CHK_HIP(hipStreamWaitEvent(g_stream, sv->ev_halo, 0));
+  if (sv->p2p_halo) {
+    for (int i = 0; i < sv->nshard; i++)
+      lsb_p2p_recv(sv->p2p[i], sv->sh[i].d_pfull, sv->sh[i].d_st, g_stream);
+  } else
+    LSB_CHK_HIP(hipStreamWaitEvent(g_stream, sv->ev_halo, 0));
   for (int i = 0; i < sv->nshard; i++) {                         /* boundary rows         */
     struct shard *s = &sv->sh[i];
     spmv_range(s, 0, s->ov_b1, s->d_q, s->d_parts_pq + s->npq, &nb, s->d_st);
@@ -847,8 +1065,11 @@ static void pcg_enqueue_init(lsb_hip_solver *sv, const double *d_b, double *d_x)
     if (sv->multi)
       lsb_k_reduce_final(s->d_parts2, np2, 2, s->d_scal + 1, 0, NULL, g_stream);
   }
-  if (sv->multi)
+  if (sv->multi) {
+    g_ar_nostate = 1; /* the device state still holds the previous solve's status */
     allreduce_scal(sv, 1, 2);
+    g_ar_nostate = 0;
+  }
   for (int i = 0; i < sv->nshard; i++) {
     struct shard *s = &sv->sh[i];
     if (sv->multi)
@@ -868,10 +1089,7 @@ static void pcg_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int sa
   unsigned npq = 0, np2 = 0;
   if (sv->multi) {
     exchange_and_spmv(sv, sample);
-    for (int i = 0; i < sv->nshard; i++) {
-      struct shard *s = &sv->sh[i];
-      lsb_k_reduce_final(s->d_parts_pq, s->npq, 1, s->d_scal + 0, 0, s->d_st, g_stream);
-    }
+    allreduce_pq(sv, 1);
   }
   for (int i = 0; i < sv->nshard && !sv->multi; i++) {
     struct shard *s = &sv->sh[i];
@@ -889,8 +1107,6 @@ static void pcg_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int sa
       LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 3], g_stream));
     }
   }
-  if (sv->multi)
-    allreduce_scal(sv, 0, 1);
   for (int i = 0; i < sv->nshard; i++) {
     struct shard *s = &sv->sh[i];
     const size_t o = s->row_begin - sv->row_first;
@@ -938,8 +1154,11 @@ static void cg1_enqueue_init(lsb_hip_solver *sv, const double *d_b, double *d_x)
     if (sv->multi)
       lsb_k_reduce_final(s->d_parts2, s->np2, 2, s->d_scal + 1, 0, NULL, g_stream);
   }
-  if (sv->multi)
+  if (sv->multi) {
+    g_ar_nostate = 1; /* the device state still holds the previous solve's status */
     allreduce_scal(sv, 1, 2);
+    g_ar_nostate = 0;
+  }
   for (int i = 0; i < sv->nshard; i++) {
     struct shard *s = &sv->sh[i];
     if (sv->multi)
@@ -953,11 +1172,9 @@ static void cg1_enqueue_init(lsb_hip_solver *sv, const double *d_b, double *d_x)
     struct shard *s = &sv->sh[i];
     if (!sv->multi)
       spmv_shard(s, s->d_pfull, s->d_q, s->d_pfull + s->row_begin, s->d_parts_pq, &s->npq, s->d_st);
-    if (sv->multi)
-      lsb_k_reduce_final(s->d_parts_pq, s->npq, 1, s->d_scal + 0, 0, s->d_st, g_stream);
   }
   if (sv->multi)
-    allreduce_scal(sv, 0, 1);
+    allreduce_pq(sv, 1);
 }
 
 static void cg1_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int sample) {
@@ -988,11 +1205,10 @@ static void cg1_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int sa
         LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 2], g_stream));
         LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 3], g_stream));
       }
-    } else
-      lsb_k_reduce_final(s->d_parts_pq, s->npq, 1, s->d_scal + 0, 0, s->d_st, g_stream);
+    }
   }
   if (sv->multi)
-    allreduce_scal(sv, 0, 3); /* w.u, r.u, r.r in ONE collective */
+    allreduce_pq(sv, 3); /* w.u, r.u, r.r in ONE collective */
 }
 
 static int auto_chunk(const lsb_hip_solver *sv) {
@@ -1140,6 +1356,39 @@ static int gmres_solve_dev(lsb_hip_solver *sv, const double *d_b, double *d_x,
 static int solve_core(lsb_hip_solver *sv, const double *d_b, double *d_x,
                       struct lsb_hip_result *res);
 
+/* ||b - S x|| / ||b|| of a finished multi-shard solve, communicating WITHOUT
+ * the direct xGMI path; overwrites the search-direction and q vectors. */
+static double true_relres(lsb_hip_solver *sv, const double *d_b, const double *d_x) {
+  static const double minus_one = -1.0;
+  const int on = sv->p2p_on, halo = sv->p2p_halo;
+  double rr = 0.0;
+  sv->p2p_on = sv->p2p_halo = 0;
+  for (int i = 0; i < sv->nshard; i++) {
+    struct shard *s = &sv->sh[i];
+    const size_t o = s->row_begin - sv->row_first;
+    LSB_CHK_HIP(hipMemcpyAsync(s->d_pfull + s->row_begin, d_x + o, (size_t)s->n * sizeof(double),
+                               hipMemcpyDeviceToDevice, g_stream));
+    LSB_CHK_HIP(hipMemcpyAsync(s->d_scal + 5, &minus_one, sizeof(double), hipMemcpyHostToDevice,
+                               g_stream));
+  }
+  exchange_p(sv);
+  for (int i = 0; i < sv->nshard; i++) {
+    struct shard *s = &sv->sh[i];
+    const size_t o = s->row_begin - sv->row_first;
+    unsigned np = 0;
+    spmv_shard(s, s->d_pfull, s->d_q, s->d_pfull + s->row_begin, s->d_parts_pq, &s->npq, NULL);
+    lsb_k_axpy(s->n, s->d_scal + 5, d_b + o, s->d_q, g_stream); /* q = S x - b */
+    lsb_k_dot(s->n, s->d_q, s->d_q, s->d_parts_pq, &np, g_stream);
+    lsb_k_reduce_final(s->d_parts_pq, np, 1, s->d_scal + 4, 0, NULL, g_stream);
+  }
+  allreduce_scal(sv, 4, 1);
+  LSB_CHK_HIP(hipMemcpyAsync(&rr, sv->sh[0].d_scal + 4, sizeof rr, hipMemcpyDeviceToHost,
+                             g_stream));
+  LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+  sv->p2p_on = on, sv->p2p_halo = halo;
+  return sv->h_st->bb > 0.0 ? sqrt(rr / sv->h_st->bb) : 0.0;
+}
+
 int lsb_hip_solver_solve_dev(lsb_hip_solver *sv, const double *d_b, double *d_x,
                              struct lsb_hip_result *res) {
   if (!initialized)
@@ -1232,6 +1481,9 @@ static int solve_core(lsb_hip_solver *sv, const double *d_b, double *d_x,
 #undef ENQUEUE_POLL
   if (fin != 0)
     hst[0] = hst[fin];
+  if (hst[0].status == LSB_STATUS_COMM)
+    errx(EXIT_FAILURE, "hip_cdna4: a peer did not arrive within the time-out of the direct "
+                       "xGMI path (LSBENCH_HIP_P2P_TIMEOUT_MS); iteration %d", hst[0].iters);
   sv->hint_iters = (unsigned)hst[0].iters;
   if (use_cg1(sv) && hst[0].status == LSB_STATUS_MAXIT && hst[0].iters > 0) {
     /* The single-reduction form learns r.r of an update one launch later, and
@@ -1244,8 +1496,10 @@ static int solve_core(lsb_hip_solver *sv, const double *d_b, double *d_x,
       double *last = s->d_parts2 + (size_t)(hst[0].iters & 1) * 2 * LSB_MAX_PARTIALS;
       lsb_k_reduce_final(last, s->np2, 2, s->d_scal + 1, 0, NULL, g_stream);
     }
+    g_ar_nostate = 1;
     if (sv->multi)
       allreduce_scal(sv, 1, 2);
+    g_ar_nostate = 0;
     LSB_CHK_HIP(hipMemcpyAsync(&rr, sv->sh[0].d_scal + 2, sizeof rr, hipMemcpyDeviceToHost,
                                g_stream));
     LSB_CHK_HIP(hipStreamSynchronize(g_stream));
@@ -1275,6 +1529,20 @@ static int solve_core(lsb_hip_solver *sv, const double *d_b, double *d_x,
     }
     r.spmv_ms = used ? tot / used : 0.0;
     r.spmv_samples = (unsigned)used;
+  }
+  if (sv->p2p_on) {
+    /* The direct path passed its self-test, but a solve is only reported if
+     * the residual b - S x, recomputed with the exchange and the all-reduce
+     * going through RCCL (device copies between virtual shards), agrees with
+     * the recurrence; otherwise: say so, drop the path, solve again. */
+    const double tr = true_relres(sv, d_b, d_x);
+    if (!(tr <= 100.0 * fmax(r.relres, sv->o.tol) + 1e-9)) {
+      fprintf(stderr, "hip_cdna4: WARNING: true residual %.3e after a solve over the direct xGMI "
+                      "path (recurrence: %.3e); falling back to RCCL and solving again\n",
+              tr, r.relres);
+      sv->p2p_on = sv->p2p_halo = 0, sv->hint_iters = 0;
+      return solve_core(sv, d_b, d_x, res);
+    }
   }
   if (res)
     *res = r;
@@ -1316,8 +1584,10 @@ int lsb_hip_solver_spmv_dev(lsb_hip_solver *sv, const double *d_x, double *d_y) 
                                (size_t)s->n * sizeof(double), hipMemcpyDeviceToDevice,
                                g_stream));
   }
+  g_ar_nostate = 1;
   if (sv->multi)
     exchange_p(sv);
+  g_ar_nostate = 0;
   for (int i = 0; i < sv->nshard; i++) {
     struct shard *s = &sv->sh[i];
     spmv_shard(s, s->d_pfull, d_y + (s->row_begin - sv->row_first), NULL, NULL, NULL, NULL);

@@ -1,0 +1,493 @@
+// Direct xGMI path of the HIP backend: the two
+// communication steps of a sharded Krylov iteration -- the halo exchange in
+// front of the SpMV and the all-reduce of 1-3 dot products -- done by plain
+// stores into the peers' memory instead of RCCL calls.
+//
+// Why: with the operator split over 8 GPUs an iteration is ~30 us of kernels,
+// and an RCCL collective of 8-24 bytes costs about as much again (launch,
+// ring/tree protocol, two hops).  MI355X's xGMI is a full point-to-point mesh
+// and every GPU can store into every other GPU's HBM, so a few bytes travel
+// in ONE hop: each rank owns a MAILBOX (fine-grained device memory, opened by
+// all peers through HIP IPC handles) and
+//   send       copies the rows a peer's shard references into that peer's
+//              mailbox, then sets the peer's flag for this rank to the epoch;
+//   recv       waits for the flags of the ranks it receives from, copies the
+//              halos out of the mailbox into its full-length vector;
+//   allreduce  reduces this rank's per-workgroup partial sums, stores the 1-3
+//              results into slot [epoch&1][rank] of EVERY mailbox, waits for
+//              all R slots of its own mailbox and adds them in rank order (the
+//              same order on every rank: all ranks get identical bits, which
+//              the convergence test needs).
+// Flags are monotonically increasing epochs, so nothing is ever reset; slot
+// reuse is safe because an all-reduce separates two successive exchanges and
+// all-reduce k+2 cannot start anywhere before every rank has left k.
+// Every wait is bounded (wall_clock64): a peer that never arrives turns into
+// st->status = LSB_STATUS_COMM -- later kernels no-op, the host reports it --
+// never into a hung wave.
+//
+// Memory model: payload stores, system-scope release fence, flag store
+// (system scope) on the producer; system-scope flag loads, acquire fence and
+// system-scope payload loads on the consumer -- the HSA rules for fine-grained
+// memory shared between agents.  hip_cdna4.c does not trust this blindly: at
+// solver creation it runs patterns through both this path and RCCL and keeps
+// this one only if it was bit-exact AND faster on every rank.
+//
+// The reference has no counterpart (it is single-process, SURVEY.md section
+// 2.2); the RCCL path in hip_comm.c stays the default wherever this one is not
+// available (no IPC, no peer access) or not faster.
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include "lsb_impl.h"
+
+#define P2P_MAX_RANKS 64
+#define P2P_AR_BYTES 4096u   // 2 parities x 64 ranks x 32 B
+#define P2P_FLAG_BYTES 4096u // 64 ranks x one 64-B line
+#define P2P_HEADER (P2P_AR_BYTES + P2P_FLAG_BYTES)
+#define P2P_NONE 0xFFFFFFFFu
+#define P2P_WG 256
+
+typedef unsigned long long u64;
+
+struct p2p_send_ent {
+  double *dst;   // region in the RECEIVER's mailbox
+  u64 *flag;     // the receiver's flag for this rank
+  size_t src_off, count;
+  unsigned wgs, first_wg;
+};
+struct p2p_recv_ent {
+  const double *src; // region in MY mailbox
+  const u64 *flag;   // my flag for the sending rank
+  size_t dst_off, count;
+  unsigned wgs, first_wg;
+};
+
+struct lsb_p2p {
+  int R, me, virt, halo;
+  u64 epoch_x, epoch_r;
+  long long timeout_ticks;
+  char *mbox;
+  size_t mbox_bytes;
+  unsigned region_off[P2P_MAX_RANKS]; // doubles from the halo base, per source
+  char *peer[P2P_MAX_RANKS];
+  int opened[P2P_MAX_RANKS];
+  char **d_peer;
+  p2p_send_ent *d_send;
+  p2p_recv_ent *d_recv;
+  unsigned *d_counters;
+  int nsend, nrecv;
+  unsigned send_grid, recv_grid;
+};
+
+// --------------------------------------------------------------------------
+__device__ __forceinline__ u64 ld_sys(const u64 *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ double ld_sys(const double *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// true when *flag reached `epoch` before the deadline
+__device__ __forceinline__ bool wait_flag(const u64 *flag, u64 epoch, long long timeout) {
+  const long long t0 = wall_clock64();
+  while (ld_sys(flag) != epoch) {
+    __builtin_amdgcn_s_sleep(1);
+    if (wall_clock64() - t0 > timeout)
+      return false;
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(P2P_WG) void k_p2p_send(const p2p_send_ent *__restrict__ ents,
+                                                     int nent, const double *__restrict__ full,
+                                                     u64 epoch, unsigned *__restrict__ counters,
+                                                     const lsb_pcg_state *__restrict__ st) {
+  if (st && st->status)
+    return;
+  int e = 0;
+  while (e + 1 < nent && blockIdx.x >= ents[e + 1].first_wg)
+    e++;
+  const p2p_send_ent en = ents[e];
+  const unsigned part = blockIdx.x - en.first_wg;
+  const size_t per = (en.count + en.wgs - 1) / en.wgs;
+  const size_t lo = (size_t)part * per, hi = lo + per < en.count ? lo + per : en.count;
+  const double *src = full + en.src_off;
+  for (size_t i = lo + threadIdx.x; i < hi; i += P2P_WG)
+    en.dst[i] = src[i];
+  __threadfence_system(); // this thread's stores have reached the peer
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned old =
+        __hip_atomic_fetch_add(&counters[e], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if ((old + 1) % en.wgs == 0) // the last workgroup of this entry raises the flag
+      __hip_atomic_store(en.flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+__global__ __launch_bounds__(P2P_WG) void k_p2p_recv(const p2p_recv_ent *__restrict__ ents,
+                                                     int nent, double *__restrict__ full,
+                                                     u64 epoch, lsb_pcg_state *__restrict__ st,
+                                                     long long timeout) {
+  if (st && st->status)
+    return;
+  __shared__ int ok;
+  int e = 0;
+  while (e + 1 < nent && blockIdx.x >= ents[e + 1].first_wg)
+    e++;
+  const p2p_recv_ent en = ents[e];
+  if (threadIdx.x == 0)
+    ok = wait_flag(en.flag, epoch, timeout) ? 1 : 0;
+  __syncthreads();
+  if (!ok) {
+    if (threadIdx.x == 0 && st)
+      __hip_atomic_store(&st->status, (int)LSB_STATUS_COMM, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  const unsigned part = blockIdx.x - en.first_wg;
+  const size_t per = (en.count + en.wgs - 1) / en.wgs;
+  const size_t lo = (size_t)part * per, hi = lo + per < en.count ? lo + per : en.count;
+  double *dst = full + en.dst_off;
+  for (size_t i = lo + threadIdx.x; i < hi; i += P2P_WG)
+    dst[i] = ld_sys(en.src + i);
+}
+
+// slot of rank r, parity b, inside a mailbox: 3 doubles + the epoch
+__device__ __forceinline__ char *ar_slot(char *mbox, unsigned b, int r) {
+  return mbox + ((size_t)b * P2P_MAX_RANKS + (size_t)r) * 32;
+}
+
+__global__ __launch_bounds__(P2P_WG) void k_p2p_allreduce(
+    const double *__restrict__ parts, unsigned nparts, unsigned width,
+    const double *extra, unsigned nextra, double *out, // may alias
+    char *const *__restrict__ peer, int R, int me, u64 epoch, lsb_pcg_state *__restrict__ st,
+    int phases, long long timeout) {
+  if (st && st->status)
+    return;
+  __shared__ double sred[P2P_WG / 64];
+  __shared__ double sval[3];
+  const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const unsigned nvals = width + nextra, b = (unsigned)(epoch & 1);
+  if (phases & 1) {
+    for (unsigned k = 0; k < width; k++) { // my partial sums, fixed order
+      double v = 0.0;
+      for (unsigned i = tid; i < nparts; i += P2P_WG)
+        v += parts[(size_t)i * width + k];
+      for (int off = 32; off > 0; off >>= 1)
+        v += __shfl_xor(v, off, 64);
+      if (lane == 0)
+        sred[wave] = v;
+      __syncthreads();
+      if (tid == 0) {
+        double s = 0.0;
+        for (unsigned w = 0; w < P2P_WG / 64; w++)
+          s += sred[w];
+        sval[k] = s;
+      }
+      __syncthreads();
+    }
+    if (tid < nextra)
+      sval[width + tid] = extra[tid];
+    __syncthreads();
+    if (tid < (unsigned)R) { // lane r serves peer r (own mailbox included)
+      double *slot = (double *)ar_slot(peer[tid], b, me);
+      for (unsigned k = 0; k < nvals; k++)
+        slot[k] = sval[k];
+      __threadfence_system();
+      __hip_atomic_store((u64 *)(slot + 3), epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  if ((phases & 2) && wave == 0) {
+    const double *slot = (const double *)ar_slot(peer[me], b, lane < (unsigned)R ? (int)lane : 0);
+    bool ok = true;
+    if (lane < (unsigned)R)
+      ok = wait_flag((const u64 *)(slot + 3), epoch, timeout);
+    if (!__all(ok)) {
+      if (lane == 0 && st)
+        __hip_atomic_store(&st->status, (int)LSB_STATUS_COMM, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    for (unsigned k = 0; k < nvals; k++) {
+      const double a = lane < (unsigned)R ? ld_sys(slot + k) : 0.0;
+      double s = 0.0;
+      for (int r = 0; r < R; r++) // rank order: identical bits on every rank
+        s += __shfl(a, r, 64);
+      if (lane == 0)
+        out[k] = s;
+    }
+  }
+}
+
+// ---- self-test helpers ------------------------------------------------------
+__device__ __forceinline__ double pattern(u64 g, unsigned round) {
+  return (double)((g * 1315423911ull + (u64)round * 2654435761ull + 12345ull) & 0xFFFFFFFFFFFFull);
+}
+__global__ void k_p2p_pattern(double *v, size_t n, size_t goff, unsigned round) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    v[goff + i] = pattern(goff + i, round);
+}
+__global__ void k_p2p_check_range(const double *full, size_t goff, size_t n, unsigned round,
+                                  unsigned *bad) {
+  unsigned mine = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    mine += full[goff + i] != pattern(goff + i, round);
+  if (mine)
+    atomicAdd(bad, mine);
+}
+__global__ void k_p2p_setvals(double *v, int me, unsigned round) {
+  v[0] = (double)((me + 1) * (round + 1));
+  v[1] = (double)((me + 1) * (round + 7)) * 0.5;
+  v[2] = (double)(me + 1);
+}
+__global__ void k_p2p_checkvals(const double *v, int R, unsigned round, unsigned *bad) {
+  const double t = 0.5 * R * (R + 1);
+  if (v[0] != t * (round + 1) || v[1] != t * (round + 7) * 0.5 || v[2] != t)
+    atomicAdd(bad, 1u);
+}
+
+// ---- host side --------------------------------------------------------------
+static unsigned wgs_for(size_t count) {
+  size_t w = (count + 4095) / 4096;
+  return (unsigned)(w < 1 ? 1 : (w > 16 ? 16 : w));
+}
+
+static struct lsb_p2p *p2p_alloc(int R, int me, int virt, const struct lsb_xfer *recv, int nrecv,
+                                 const struct lsb_xfer *send, int nsend) {
+  if (R > P2P_MAX_RANKS)
+    return NULL;
+  struct lsb_p2p *p = (struct lsb_p2p *)calloc(1, sizeof *p);
+  p->R = R, p->me = me, p->virt = virt;
+  const char *e = getenv("LSBENCH_HIP_P2P_TIMEOUT_MS");
+  int dev = 0, khz = 100000;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0)
+    khz = 100000, (void)hipGetLastError();
+  p->timeout_ticks = (e ? atoll(e) : 10000) * (long long)khz; // wall_clock64 ticks per ms
+  for (int q = 0; q < R; q++)
+    p->region_off[q] = P2P_NONE;
+  size_t doubles = 0;
+  p->halo = !(nsend == 1 && send[0].peer == -1); // not the all-gather plan
+  for (int i = 0; i < nrecv && p->halo; i++) {
+    p->region_off[recv[i].peer] = (unsigned)doubles;
+    doubles += (recv[i].count + 31) & ~(size_t)31;
+    if (doubles > (size_t)8 << 20) // 64 MiB of halos: leave that to RCCL
+      p->halo = 0;
+  }
+  if (!p->halo) {
+    doubles = 0;
+    for (int q = 0; q < R; q++)
+      p->region_off[q] = P2P_NONE;
+  }
+  p->mbox_bytes = P2P_HEADER + doubles * sizeof(double) + 256;
+  if (hipExtMallocWithFlags((void **)&p->mbox, p->mbox_bytes, hipDeviceMallocFinegrained) !=
+      hipSuccess) {
+    (void)hipGetLastError();
+    free(p);
+    return NULL;
+  }
+  if (hipMemset(p->mbox, 0, p->mbox_bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(p->mbox);
+    free(p);
+    return NULL;
+  }
+  p->peer[me] = p->mbox;
+  return p;
+}
+
+// peer[] and tab[q*R + src] (region offsets of rank q) known: build the tables
+static int p2p_connect(struct lsb_p2p *p, const unsigned *tab, const unsigned *halo_ok,
+                       const struct lsb_xfer *recv, int nrecv, const struct lsb_xfer *send,
+                       int nsend) {
+  const int R = p->R, me = p->me;
+  for (int q = 0; q < R; q++)
+    p->halo &= halo_ok[q] != 0;
+  if (hipMalloc((void **)&p->d_peer, sizeof(char *) * R) != hipSuccess ||
+      hipMemcpy(p->d_peer, p->peer, sizeof(char *) * R, hipMemcpyHostToDevice) != hipSuccess)
+    return 1;
+  if (!p->halo)
+    return 0;
+  p2p_send_ent hs[P2P_MAX_RANKS];
+  p2p_recv_ent hr[P2P_MAX_RANKS];
+  unsigned g = 0;
+  for (int i = 0; i < nsend; i++) {
+    const int q = send[i].peer;
+    const unsigned off = tab[(size_t)q * R + me];
+    if (off == P2P_NONE)
+      return 2; // the receiver does not expect what the plan sends
+    hs[i].dst = (double *)(p->peer[q] + P2P_HEADER) + off;
+    hs[i].flag = (u64 *)(p->peer[q] + P2P_AR_BYTES + 64 * (size_t)me);
+    hs[i].src_off = send[i].offset, hs[i].count = send[i].count;
+    hs[i].wgs = wgs_for(send[i].count), hs[i].first_wg = g;
+    g += hs[i].wgs;
+  }
+  p->send_grid = g, p->nsend = nsend;
+  g = 0;
+  for (int i = 0; i < nrecv; i++) {
+    const int q = recv[i].peer;
+    hr[i].src = (const double *)(p->mbox + P2P_HEADER) + p->region_off[q];
+    hr[i].flag = (const u64 *)(p->mbox + P2P_AR_BYTES + 64 * (size_t)q);
+    hr[i].dst_off = recv[i].offset, hr[i].count = recv[i].count;
+    hr[i].wgs = wgs_for(recv[i].count), hr[i].first_wg = g;
+    g += hr[i].wgs;
+  }
+  p->recv_grid = g, p->nrecv = nrecv;
+  if (hipMalloc((void **)&p->d_send, sizeof(p2p_send_ent) * (nsend ? nsend : 1)) != hipSuccess ||
+      hipMalloc((void **)&p->d_recv, sizeof(p2p_recv_ent) * (nrecv ? nrecv : 1)) != hipSuccess ||
+      hipMalloc((void **)&p->d_counters, sizeof(unsigned) * P2P_MAX_RANKS) != hipSuccess)
+    return 1;
+  if (hipMemcpy(p->d_send, hs, sizeof(p2p_send_ent) * nsend, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(p->d_recv, hr, sizeof(p2p_recv_ent) * nrecv, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemset(p->d_counters, 0, sizeof(unsigned) * P2P_MAX_RANKS) != hipSuccess)
+    return 1;
+  return 0;
+}
+
+extern "C" void lsb_p2p_destroy(struct lsb_p2p *p) {
+  if (!p)
+    return;
+  for (int q = 0; q < p->R; q++)
+    if (p->opened[q])
+      (void)hipIpcCloseMemHandle(p->peer[q]);
+  (void)hipFree(p->d_peer), (void)hipFree(p->d_send), (void)hipFree(p->d_recv);
+  (void)hipFree(p->d_counters), (void)hipFree(p->mbox);
+  (void)hipGetLastError();
+  free(p);
+}
+
+/* One process per GPU.  Collective over the RCCL communicator (the handles and
+ * region tables travel by lsb_hip_comm_allgather_u32).  Returns NULL when the
+ * path is unavailable HERE; the caller still has to agree with its peers. */
+extern "C" struct lsb_p2p *lsb_p2p_create_dist(const struct lsb_xfer *recv, int nrecv,
+                                               const struct lsb_xfer *send, int nsend) {
+  const int R = lsb_hip_comm_size(), me = lsb_hip_comm_rank();
+  struct lsb_p2p *p = p2p_alloc(R, me, 0, recv, nrecv, send, nsend);
+  /* every rank takes part in the all-gather, whatever happened locally */
+  const unsigned W = 16 + 2 + P2P_MAX_RANKS;
+  unsigned mine[16 + 2 + P2P_MAX_RANKS];
+  memset(mine, 0, sizeof mine);
+  hipIpcMemHandle_t h;
+  int ok = p != NULL;
+  if (ok && hipIpcGetMemHandle(&h, p->mbox) != hipSuccess)
+    ok = 0, (void)hipGetLastError();
+  if (ok) {
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle is 64 bytes");
+    memcpy(mine, &h, 64);
+    mine[16] = 1, mine[17] = (unsigned)p->halo;
+    for (int q = 0; q < R; q++)
+      mine[18 + q] = p->region_off[q];
+  }
+  unsigned *all = (unsigned *)calloc((size_t)W * R, sizeof(unsigned));
+  lsb_hip_comm_allgather_u32(mine, W, all);
+  for (int q = 0; q < R; q++)
+    ok &= all[(size_t)q * W + 16] != 0;
+  for (int q = 0; q < R && ok; q++) {
+    if (q == me)
+      continue;
+    hipIpcMemHandle_t hq;
+    memcpy(&hq, all + (size_t)q * W, 64);
+    void *ptr = NULL;
+    if (hipIpcOpenMemHandle(&ptr, hq, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+      (void)hipGetLastError();
+      ok = 0;
+      break;
+    }
+    p->peer[q] = (char *)ptr, p->opened[q] = 1;
+  }
+  if (ok) {
+    unsigned tab[P2P_MAX_RANKS * P2P_MAX_RANKS], halo_ok[P2P_MAX_RANKS];
+    for (int q = 0; q < R; q++) {
+      halo_ok[q] = all[(size_t)q * W + 17];
+      for (int s = 0; s < R; s++)
+        tab[(size_t)q * R + s] = all[(size_t)q * W + 18 + s];
+    }
+    ok = p2p_connect(p, tab, halo_ok, recv, nrecv, send, nsend) == 0;
+  }
+  free(all);
+  if (!ok) {
+    lsb_p2p_destroy(p);
+    return NULL;
+  }
+  return p;
+}
+
+/* n shards on ONE device (test mode): mailboxes are ordinary local pointers. */
+extern "C" int lsb_p2p_create_virtual(struct lsb_p2p **out, int n, struct lsb_xfer *const *recv,
+                                      const int *nrecv, struct lsb_xfer *const *send,
+                                      const int *nsend) {
+  if (n > P2P_MAX_RANKS)
+    return 1;
+  unsigned tab[P2P_MAX_RANKS * P2P_MAX_RANKS], halo_ok[P2P_MAX_RANKS];
+  for (int s = 0; s < n; s++) {
+    out[s] = p2p_alloc(n, s, 1, recv[s], nrecv[s], send[s], nsend[s]);
+    if (!out[s])
+      return 1;
+    halo_ok[s] = (unsigned)out[s]->halo;
+    for (int q = 0; q < n; q++)
+      tab[(size_t)s * n + q] = out[s]->region_off[q];
+  }
+  for (int s = 0; s < n; s++) {
+    for (int q = 0; q < n; q++)
+      out[s]->peer[q] = out[q]->mbox;
+    if (p2p_connect(out[s], tab, halo_ok, recv[s], nrecv[s], send[s], nsend[s]))
+      return 1;
+  }
+  return 0;
+}
+
+extern "C" int lsb_p2p_has_halo(const struct lsb_p2p *p) { return p && p->halo; }
+
+extern "C" void lsb_p2p_send(struct lsb_p2p *p, const double *d_full,
+                             const struct lsb_pcg_state *st, void *stream) {
+  p->epoch_x++;
+  if (p->nsend)
+    k_p2p_send<<<p->send_grid, P2P_WG, 0, (hipStream_t)stream>>>(p->d_send, p->nsend, d_full,
+                                                                 p->epoch_x, p->d_counters, st);
+}
+
+extern "C" void lsb_p2p_recv(struct lsb_p2p *p, double *d_full, struct lsb_pcg_state *st,
+                             void *stream) {
+  if (p->nrecv)
+    k_p2p_recv<<<p->recv_grid, P2P_WG, 0, (hipStream_t)stream>>>(p->d_recv, p->nrecv, d_full,
+                                                                 p->epoch_x, st, p->timeout_ticks);
+}
+
+/* out[0..width+nextra) = sum over ranks of {column sums of parts[nparts][width],
+ * extra[0..nextra)}; phases: 1 = contribute, 2 = collect, 3 = both (one rank
+ * per process); out may alias extra. */
+extern "C" void lsb_p2p_allreduce(struct lsb_p2p *p, const double *parts, unsigned nparts,
+                                  unsigned width, const double *extra, unsigned nextra,
+                                  double *out, struct lsb_pcg_state *st, int phases,
+                                  void *stream) {
+  if (width + nextra > 3)
+    errx(EXIT_FAILURE, "lsb_p2p_allreduce: at most 3 values");
+  if (phases & 1)
+    p->epoch_r++;
+  k_p2p_allreduce<<<1, P2P_WG, 0, (hipStream_t)stream>>>(parts, nparts, width, extra, nextra, out,
+                                                         p->d_peer, p->R, p->me, p->epoch_r, st,
+                                                         phases, p->timeout_ticks);
+}
+
+/* self-test pieces (hip_cdna4.c drives them) */
+extern "C" void lsb_p2p_test_pattern(double *d_full, size_t goff, size_t n, unsigned round,
+                                     void *stream) {
+  if (n)
+    k_p2p_pattern<<<64, 256, 0, (hipStream_t)stream>>>(d_full, n, goff, round);
+}
+extern "C" void lsb_p2p_test_check_range(const double *d_full, size_t goff, size_t n,
+                                         unsigned round, unsigned *d_bad, void *stream) {
+  if (n)
+    k_p2p_check_range<<<64, 256, 0, (hipStream_t)stream>>>(d_full, goff, n, round, d_bad);
+}
+extern "C" void lsb_p2p_test_setvals(double *d_v, int me, unsigned round, void *stream) {
+  k_p2p_setvals<<<1, 1, 0, (hipStream_t)stream>>>(d_v, me, round);
+}
+extern "C" void lsb_p2p_test_checkvals(const double *d_v, int R, unsigned round, unsigned *d_bad,
+                                       void *stream) {
+  k_p2p_checkvals<<<1, 1, 0, (hipStream_t)stream>>>(d_v, R, round, d_bad);
+}

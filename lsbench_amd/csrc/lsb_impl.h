@@ -130,6 +130,27 @@ void lsb_k_gm_hess(struct lsb_gmres_state *st, int j, const double *h, const dou
 void lsb_k_gm_finish_cycle(unsigned n, const double *V, size_t ld, const double *dinv, double *x,
                            struct lsb_gmres_state *st, void *stream);
 
+/* ---- direct xGMI path (hip_p2p.hip) ---------------------------------------- */
+struct lsb_p2p;
+struct lsb_p2p *lsb_p2p_create_dist(const struct lsb_xfer *recv, int nrecv,
+                                    const struct lsb_xfer *send, int nsend);
+int lsb_p2p_create_virtual(struct lsb_p2p **out, int n, struct lsb_xfer *const *recv,
+                           const int *nrecv, struct lsb_xfer *const *send, const int *nsend);
+void lsb_p2p_destroy(struct lsb_p2p *p);
+int lsb_p2p_has_halo(const struct lsb_p2p *p);
+void lsb_p2p_send(struct lsb_p2p *p, const double *d_full, const struct lsb_pcg_state *st,
+                  void *stream);
+void lsb_p2p_recv(struct lsb_p2p *p, double *d_full, struct lsb_pcg_state *st, void *stream);
+void lsb_p2p_allreduce(struct lsb_p2p *p, const double *parts, unsigned nparts, unsigned width,
+                       const double *extra, unsigned nextra, double *out,
+                       struct lsb_pcg_state *st, int phases, void *stream);
+void lsb_p2p_test_pattern(double *d_full, size_t goff, size_t n, unsigned round, void *stream);
+void lsb_p2p_test_check_range(const double *d_full, size_t goff, size_t n, unsigned round,
+                              unsigned *d_bad, void *stream);
+void lsb_p2p_test_setvals(double *d_v, int me, unsigned round, void *stream);
+void lsb_p2p_test_checkvals(const double *d_v, int R, unsigned round, unsigned *d_bad,
+                            void *stream);
+
 /* ---- backend internals shared between hip_cdna4.c and hip_comm.c -------- */
 void *lsb_hip_stream(void);
 int lsb_hip_is_initialized(void);

@@ -16,6 +16,9 @@ import lsbench_amd as la  # noqa: E402
 
 def main():
     spec, outdir, krylov, tol = sys.argv[1], sys.argv[2], sys.argv[3], float(sys.argv[4])
+    comm = {"auto": la.COMM_AUTO, "rccl": la.COMM_RCCL, "p2p": la.COMM_P2P}[
+        sys.argv[5] if len(sys.argv) > 5 else "auto"]
+    overlap = int(sys.argv[6]) if len(sys.argv) > 6 else 0
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
@@ -33,8 +36,10 @@ def main():
     r1 = (n * (rank + 1) // world) & ~1 if rank + 1 < world else n
     A = la.lsbench_matrix_synth(spec, r0, r1)
     kry = {"cg": la.KRYLOV_PCG, "cg1": la.KRYLOV_PCG1, "auto": la.KRYLOV_AUTO}[krylov]
-    s = la.Solver(A, la.default_opts(op_mode=la.OP_RAW, tol=tol, krylov=kry, maxit=50000),
+    s = la.Solver(A, la.default_opts(op_mode=la.OP_RAW, tol=tol, krylov=kry, maxit=50000, comm=comm,
+                                     overlap=overlap, spmv_variant=la.SPMV_ADAPTIVE if overlap else 0),
                   row_begin=r0, n_global=n)
+    mode, p2p_us, rccl_us = s.comm
     d_b = torch.arange(r0, r1, dtype=torch.float64, device="cuda")
     d_x = torch.zeros(r1 - r0, dtype=torch.float64, device="cuda")
     res = s.solve_dev(d_b, d_x)
@@ -46,7 +51,11 @@ def main():
     np.save(os.path.join(outdir, "x%d.npy" % rank), d_x.cpu().numpy())
     np.save(os.path.join(outdir, "y%d.npy" % rank), d_y.cpu().numpy())
     np.save(os.path.join(outdir, "m%d.npy" % rank),
-            np.array([res.iters, res.status, res2.iters, res2.status, r0, r1], dtype=np.int64))
+            np.array([res.iters, res.status, res2.iters, res2.status, r0, r1, mode,
+                      int(s.overlaps)], dtype=np.int64))
+    if rank == 0:
+        print("comm mode %d: direct %.1f us, rccl double %.1f us per exchange+all-reduce"
+              % (mode, p2p_us, rccl_us), flush=True)
     s.destroy()
     lib.lsb_hip_comm_destroy()
     dist.destroy_process_group()

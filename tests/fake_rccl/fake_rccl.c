@@ -24,6 +24,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
 #include <time.h>
 #include <unistd.h>
 
@@ -123,6 +124,14 @@ ncclResult_t ncclCommInitRank(ncclComm_t *out, int nranks, ncclUniqueId id, int 
       sched_yield();
       if (now_s() - t0 > FAKE_TIMEOUT_S)
         die("rank 0 never created the segment");
+    }
+    struct stat sb; /* mapping it before rank 0 has sized it would SIGBUS on first touch */
+    for (;;) {
+      if (fstat(fd, &sb) == 0 && (size_t)sb.st_size >= c->bytes)
+        break;
+      sched_yield();
+      if (now_s() - t0 > FAKE_TIMEOUT_S)
+        die("rank 0 never sized the segment");
     }
   }
   void *m = MAP_FAILED;

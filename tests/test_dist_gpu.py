@@ -37,13 +37,19 @@ def _run(world, args, port):
     return r
 
 
-@pytest.mark.parametrize("world,spec,krylov", [(2, "lap2d:nx=240,ny=180", "cg"),
-                                               (3, "lap3d:nx=30,ny=28,nz=26", "cg1"),
-                                               (4, "lap2d:nx=150,ny=400", "auto")])
-def test_multi_process_solve_matches_oracle(world, spec, krylov, tmp_path):
+@pytest.mark.parametrize("world,spec,krylov,comm,overlap", [
+    (2, "lap2d:nx=240,ny=180", "cg", "rccl", 0),
+    (3, "lap3d:nx=30,ny=28,nz=26", "cg1", "rccl", 0),
+    (4, "lap2d:nx=150,ny=400", "auto", "rccl", 1),
+    # the direct path: mailboxes opened through HIP IPC between the processes
+    (2, "lap2d:nx=240,ny=180", "cg", "p2p", 0),
+    (3, "lap3d:nx=30,ny=28,nz=26", "cg1", "p2p", 0),
+    (4, "lap2d:nx=150,ny=400", "auto", "p2p", 1),
+    (2, "lap2d:nx=300,ny=300", "auto", "auto", 0)])
+def test_multi_process_solve_matches_oracle(world, spec, krylov, comm, overlap, tmp_path):
     import lsbench_amd as la
-    _run(world, [os.path.join(ROOT, "tests", "dist_gpu_worker.py"), spec, str(tmp_path), krylov, "1e-10"],
-         29600 + world)
+    _run(world, [os.path.join(ROOT, "tests", "dist_gpu_worker.py"), spec, str(tmp_path), krylov, "1e-10",
+                 comm, str(overlap)], 29600 + world)
     A = la.lsbench_matrix_synth(spec)
     b = O.rhs(A.nrows)
     xo, ito, relo, sto = O.pcg_jacobi(A.offs, A.cols, A.vals, b, 1e-10)
@@ -52,6 +58,10 @@ def test_multi_process_solve_matches_oracle(world, spec, krylov, tmp_path):
     y = np.concatenate([np.load(tmp_path / ("y%d.npy" % r)) for r in range(world)])
     assert [int(m[4]) for m in metas] == sorted(int(m[4]) for m in metas) and int(metas[-1][5]) == A.nrows
     assert all(m[1] == 1 and m[3] == 1 for m in metas)                  # converged, twice
+    assert len({int(m[6]) for m in metas}) == 1                         # every rank took the same path
+    if comm != "auto":
+        assert int(metas[0][6]) == {"rccl": 1, "p2p": 3}[comm]
+    assert all(int(m[7]) == overlap for m in metas)
     assert len({int(m[0]) for m in metas}) == 1 and len({int(m[2]) for m in metas}) == 1
     assert abs(int(metas[0][0]) - ito) <= 2 and int(metas[0][2]) == int(metas[0][0])
     assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-8

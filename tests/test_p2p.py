@@ -1,0 +1,67 @@
+"""The direct xGMI path (lsbench_amd/csrc/hip_p2p.hip) on ONE GPU: the shards
+of one process own a mailbox each and exchange halos / all-reduce dot products
+by stores into each other's mailboxes -- the kernels, flags, epochs and tables
+of the 8-GPU path, minus the IPC mapping (tests/test_dist_gpu.py covers that
+between processes).  Oracle: the sequential Jacobi-PCG of oracle/lsb_oracle.c."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("krylov", ["PCG", "PCG1"])
+@pytest.mark.parametrize("nvirt,overlap", [(2, 0), (3, 1), (8, 0), (5, 1)])
+def test_direct_path_between_virtual_shards(hip, nvirt, overlap, krylov):
+    L = hip.lsbench_matrix_synth("lap2d:nx=300,ny=200")
+    offs, cols, vals = O.lap2d(300, 200)
+    b = O.rhs(L.nrows)
+    xo, ito, _, sto = O.pcg_jacobi(offs, cols, vals, b, tol=1e-10)
+    s = hip.Solver(L, hip.default_opts(op_mode=hip.OP_RAW, nvirt=nvirt, overlap=overlap, tol=1e-10,
+                                       krylov=getattr(hip, "KRYLOV_" + krylov), comm=hip.COMM_P2P,
+                                       spmv_variant=hip.SPMV_ADAPTIVE))
+    assert s.comm[0] == 3 and s.overlaps == bool(overlap)
+    x, r = s.solve(b)
+    x2, r2 = s.solve(b)                       # hint path, epochs keep counting
+    s.destroy()
+    assert r.status == 1 and abs(int(r.iters) - ito) <= 4 and r2.iters == r.iters
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-8
+    assert np.array_equal(x, x2)
+
+
+def test_direct_path_3d_and_golden(hip, matrix_path, golden_x):
+    # 3D stencil: halos of one plane (several workgroups per halo)
+    L = hip.lsbench_matrix_synth("lap3d:nx=70,ny=70,nz=40")
+    offs, cols, vals = O.lap3d(70, 70, 40)
+    b = O.rhs(L.nrows)
+    xo, ito, _, _ = O.pcg_jacobi(offs, cols, vals, b, tol=1e-10)
+    s = hip.Solver(L, hip.default_opts(op_mode=hip.OP_RAW, nvirt=4, tol=1e-10, comm=hip.COMM_P2P))
+    assert s.comm[0] == 3
+    x, r = s.solve(b)
+    s.destroy()
+    assert r.status == 1 and abs(int(r.iters) - ito) <= 3
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-8
+    # a reference matrix (unstructured: every shard references every other)
+    A = hip.lsbench_matrix_read(matrix_path("xn3b_A_12"))
+    s = hip.Solver(A, hip.default_opts(nvirt=3, comm=hip.COMM_P2P))
+    x, r = s.solve(O.rhs(A.nrows))
+    mode = s.comm[0]
+    s.destroy()
+    xg = golden_x("xn3b_A_12")
+    assert mode in (2, 3) and r.status == 1
+    assert np.linalg.norm(x - xg) / np.linalg.norm(xg) <= 1e-10
+
+
+def test_maxit_and_scattered_operator(hip):
+    # MAXIT in the single-reduction form: the residual fix-up all-reduces after
+    # the device state has left RUNNING
+    L = hip.lsbench_matrix_synth("lap2d:nx=200,ny=200")
+    s = hip.Solver(L, hip.default_opts(op_mode=hip.OP_RAW, nvirt=2, maxit=23, comm=hip.COMM_P2P,
+                                       krylov=hip.KRYLOV_PCG1))
+    x, r = s.solve(O.rhs(L.nrows))
+    s.destroy()
+    offs, cols, vals = O.lap2d(200, 200)
+    xo, ito, relo, sto = O.pcg1_jacobi(offs, cols, vals, O.rhs(L.nrows), tol=1e-12, maxit=23)
+    assert r.status == hip.STATUS_MAXIT and r.iters == 23 and sto == 3
+    assert abs(r.relres - relo) <= 1e-6 * relo

@@ -44,7 +44,12 @@ __device__ __forceinline__ void wg_sum(double (&v)[W], double *sred) {
     v[k] = (sred[0 * W + k] + sred[1 * W + k]) + (sred[2 * W + k] + sred[3 * W + k]);
 }
 
-enum { F_NOREMAP = 1, F_FAKEGATHER = 2, F_NODOT = 4, F_NOX = 8, F_CYCLIC = 16, F_NT = 32, F_PREFETCH = 64, F_HOIST = 128, F_TWOROW = 256, F_ROWCAP = 512, F_PERIOD = 1024 };
+enum { F_NOREMAP = 1, F_FAKEGATHER = 2, F_NODOT = 4, F_NOX = 8, F_CYCLIC = 16, F_NT = 32, F_PREFETCH = 64, F_HOIST = 128, F_TWOROW = 256, F_ROWCAP = 512, F_PERIOD = 1024, F_C16 = 2048, F_C16W = 4096 };
+// F_C16: `cols` points at int16 deltas relative to the block's first row.
+// F_C16W: `cols` points at uint16 codes, 2 bits window + 14 bits offset; the
+// four window bases of block b are g_wbase[4b..4b+3] (passed through `per`'s
+// neighbour argument wbase).
+__device__ const int *g_wbase;
 
 // BLAS-1 probe shaped like k_pcg_update_xr: 5 streams in, 2 out, 16 B/lane.
 // NT bit 0: nontemporal loads, bit 1: nontemporal stores.
@@ -452,11 +457,22 @@ __global__ __launch_bounds__(WG, MINW) void k_adaptive_cyc(const int *__restrict
     }                                                                          \
     r0 = rowblk[kb], r1 = rowblk[kb + 1];                                      \
     j0 = offs[r0], j1 = offs[r1];                                              \
+    int wb0_ = 0, wb1_ = 0, wb2_ = 0, wb3_ = 0;                                \
+    if (FLAGS & F_C16W)                                                        \
+      wb0_ = g_wbase[4 * kb], wb1_ = g_wbase[4 * kb + 1], wb2_ = g_wbase[4 * kb + 2], wb3_ = g_wbase[4 * kb + 3]; \
     if (j1 - j0 <= CAP) {                                                      \
       _Pragma("unroll") for (int u = 0; u < U; u++) {                          \
         const int t = tid + u * WG;                                            \
         if (t < j1 - j0) {                                                     \
-          c[u] = ldg<FLAGS>(cols + j0 + t);                                    \
+          if (FLAGS & F_C16)                                                   \
+            c[u] = r0 + (int)ldg<FLAGS>((const short *)cols + j0 + t);         \
+          else if (FLAGS & F_C16W) {                                           \
+            const unsigned code_ = ldg<FLAGS>((const unsigned short *)cols + j0 + t); \
+            const unsigned w_ = code_ >> 14;                                   \
+            const int lo_ = (w_ & 1) ? wb1_ : wb0_, hi_ = (w_ & 1) ? wb3_ : wb2_; \
+            c[u] = ((w_ & 2) ? hi_ : lo_) + (int)(code_ & 16383u);             \
+          } else                                                               \
+            c[u] = ldg<FLAGS>(cols + j0 + t);                                  \
           v[u] = ldg<FLAGS>(vals + j0 + t);                                    \
         }                                                                      \
       }                                                                        \
@@ -973,6 +989,10 @@ LAUNCHER(l_wave512_pf7, (k_wave<512, F_PREFETCH, 7>))
 LAUNCHER(l_wave512_pf6, (k_wave<512, F_PREFETCH, 6>))
 LAUNCHER(l_cyc_pf_nt, (k_adaptive_cyc<2048, F_CYCLIC | F_PREFETCH | F_NT>))
 LAUNCHER(l_cyc_nt, (k_adaptive_cyc<2048, F_CYCLIC | F_NT>))
+LAUNCHER(l_c16, (k_adaptive_cyc<2048, F_CYCLIC | F_NT | F_PREFETCH | F_C16>))
+LAUNCHER(l_c16_nopf, (k_adaptive_cyc<2048, F_CYCLIC | F_NT | F_C16>))
+LAUNCHER(l_c16w, (k_adaptive_cyc<2048, F_CYCLIC | F_NT | F_PREFETCH | F_C16W>))
+LAUNCHER(l_c16w_nopf, (k_adaptive_cyc<2048, F_CYCLIC | F_NT | F_C16W>))
 LAUNCHER(l_cyc_period, (k_adaptive_cyc<2048, F_CYCLIC | F_NT | F_PREFETCH | F_PERIOD>))
 LAUNCHER(l_cyc_period_nont, (k_adaptive_cyc<2048, F_CYCLIC | F_PREFETCH | F_PERIOD>))
 LAUNCHER(l_cyc_two, (k_adaptive_cyc<2048, F_CYCLIC | F_NT | F_PREFETCH | F_TWOROW>))
@@ -1026,6 +1046,10 @@ int main(int argc, char **argv) {
       {"adaptive cap2048 g2048 (round-1a lib)", 2048, l_base2048, 2048},
       {"cyc+prefetch+nt cap2048 (library)", 2048, l_cyc_pf_nt, 2048},
       {"cyc+nt cap2048", 2048, l_cyc_nt, 2048},
+      {"C16 cyc+pf+nt (int16 row-relative cols)", 2048, l_c16, 2048},
+      {"C16 cyc+nt", 2048, l_c16_nopf, 2048},
+      {"C16W cyc+pf+nt (4 windows x 14 bit)", 2048, l_c16w, 2048},
+      {"C16W cyc+nt", 2048, l_c16w_nopf, 2048},
       {"cyc+prefetch cap2048", 2048, l_cyc_pf, 2048},
       {"cyc+pf+nt PERIOD=bandwidth", 2048, l_cyc_period, 2048},
       {"cyc+pf PERIOD=bandwidth (no nt)", 2048, l_cyc_period_nont, 2048},
@@ -1049,6 +1073,44 @@ int main(int argc, char **argv) {
       v.d_rb = d, v.nblk = (unsigned)rb.size() - 1;
     }
   }
+  // 16-bit column encodings over the cap-2048 row blocks
+  short *d_c16 = nullptr;
+  unsigned short *d_c16w = nullptr;
+  {
+    auto rb = row_blocks(A, 2048);
+    const unsigned nb = (unsigned)rb.size() - 1;
+    std::vector<short> c16(nnz + 8);
+    std::vector<unsigned short> c16w(nnz + 8);
+    std::vector<int> wbase(4 * (size_t)nb, 0);
+    bool ok16 = true, okw = true;
+    for (unsigned b = 0; b < nb; b++) {
+      const int r0 = rb[b], j0 = A.offs[rb[b]], j1 = A.offs[rb[b + 1]];
+      std::vector<int> cs(A.cols.begin() + j0, A.cols.begin() + j1);
+      std::sort(cs.begin(), cs.end());
+      int nw = 0, base[4] = {0, 0, 0, 0};
+      for (int c : cs)
+        if (nw == 0 || c - base[nw - 1] >= 16384) {
+          if (nw == 4) { okw = false; break; }
+          base[nw++] = c;
+        }
+      for (int w = 0; w < 4; w++) wbase[4 * (size_t)b + w] = base[w < nw ? w : 0];
+      for (int j = j0; j < j1; j++) {
+        const int d = A.cols[j] - r0;
+        if (d < -32768 || d > 32767) ok16 = false;
+        c16[j] = (short)d;
+        int w = nw - 1;
+        while (w > 0 && A.cols[j] < base[w]) w--;
+        c16w[j] = (unsigned short)((w << 14) | (A.cols[j] - base[w]));
+      }
+    }
+    printf("16-bit column codes: row-relative %s, 4-window %s\n", ok16 ? "fits" : "DOES NOT FIT", okw ? "fits" : "DOES NOT FIT");
+    if (ok16) d_c16 = upload(c16);
+    if (okw) {
+      d_c16w = upload(c16w);
+      int *d_wb = upload(wbase);
+      CHK(hipMemcpyToSymbol(HIP_SYMBOL(g_wbase), &d_wb, sizeof(d_wb)));
+    }
+  }
   hipEvent_t e0, e1;
   CHK(hipEventCreate(&e0));
   CHK(hipEventCreate(&e1));
@@ -1064,7 +1126,11 @@ int main(int argc, char **argv) {
       const double rows_per_blk = (double)A.n / v.nblk;
       per = (unsigned)std::max(8.0, std::round(bw / rows_per_blk));
     }
-    v.launch(v, g, per, v.nblk, v.d_rb, d_offs, d_cols, d_vals, d_x, d_y, d_parts, (int)nnz);
+    const int *cp = d_cols;
+    if (v.name.rfind("C16W", 0) == 0) cp = (const int *)d_c16w;
+    else if (v.name.rfind("C16", 0) == 0) cp = (const int *)d_c16;
+    if (v.name.rfind("C16", 0) == 0 && !cp) return;
+    v.launch(v, g, per, v.nblk, v.d_rb, d_offs, cp, d_vals, d_x, d_y, d_parts, (int)nnz);
   };
   // correctness first
   for (auto &v : vs) {
@@ -1072,6 +1138,7 @@ int main(int argc, char **argv) {
     run(v);
     CHK(hipDeviceSynchronize());
     if (!v.check) continue;
+    if (v.name.rfind("C16W", 0) == 0 ? !d_c16w : (v.name.rfind("C16", 0) == 0 && !d_c16)) { v.check = false; continue; }
     CHK(hipMemcpy(hy.data(), d_y, (size_t)A.n * 8, hipMemcpyDeviceToHost));
     double worst = 0;
     for (int i = 0; i < A.n; i++) {
