@@ -64,6 +64,9 @@ def parse():
     p.add_argument("--krylov", default="auto", choices=["cg", "cg1", "auto"],
                    help="cg = classic PCG; cg1 = single-reduction PCG (2 launches, 1 reduction "
                         "per iteration); auto = cg1 when the operator spans several GPUs")
+    p.add_argument("--comm", default="auto", choices=["auto", "rccl", "p2p"],
+                   help="N>1: auto = direct xGMI stores where they pass the self-test and beat "
+                        "RCCL; rccl / p2p force one")
     p.add_argument("--overlap", type=int, default=0,
                    help="N>1: 1 = halo exchange on its own stream behind the interior rows")
     p.add_argument("--spmv-tune", type=int, default=-1,
@@ -225,6 +228,7 @@ def main():
     opts = la.default_opts(op_mode=la.OP_RAW, tol=a.tol, maxit=a.maxit, spmv_variant=a.spmv,
                            use_graph=1 if small else 0, sample_spmv=0 if small else 16,
                            spmv_tune=a.spmv_tune, overlap=a.overlap,
+                           comm={"auto": la.COMM_AUTO, "rccl": la.COMM_RCCL, "p2p": la.COMM_P2P}[a.comm],
                            krylov={"cg": la.KRYLOV_PCG, "cg1": la.KRYLOV_PCG1,
                                    "auto": la.KRYLOV_AUTO}[a.krylov],
                            precond=la.PRECOND_NONE if spmv_only else la.PRECOND_JACOBI)
@@ -319,6 +323,8 @@ def main():
         "iterations_per_sec": iters / dt,
         "pcg_iteration_GBps": bytes_iter * iters / dt / 1e9,
         "setup_seconds": t_setup,
+        "comm": dict(zip(("mode", "selftest_direct_us", "selftest_rccl_us"), solver.comm),
+                     modes="0 one shard, 1 RCCL, 2 direct xGMI all-reduce, 3 direct xGMI halos too"),
         "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": gbps / HBM_PEAK_GBPS, "traffic": traffic,
                      "kernel": "k_spmv_adaptive (fused p.q)", "launch_ms": spmv_avg_ms,

@@ -219,6 +219,8 @@ struct shard {
   double *d_vals, *d_dinv, *d_r, *d_q, *d_pfull;
   double *d_p1, *d_s1; /* single-reduction CG: p and s = S p (pfull then holds u) */
   unsigned npq, np2;   /* partial counts of the SpMV / sweep launches */
+  const double *ar2_parts; /* sweep partials the next all-reduce folds in */
+  unsigned ar2_n, ar2_width;
   /* rows that reference other shards' columns sit in row blocks [0,ov_b1) and
    * [ov_b2,nblk); the blocks in between need no halo (0,0 = not separable) */
   unsigned ov_b1, ov_b2;
@@ -842,6 +844,11 @@ static void exchange_on(lsb_hip_solver *sv, hipStream_t stream) {
  * whatever the last solve left there) */
 static int g_ar_nostate;
 static void exchange_p(lsb_hip_solver *sv) {
+  if (sv->p2p_halo && sv->dist) { /* peers are other GPUs: both roles in one launch */
+    lsb_p2p_sendrecv(sv->p2p[0], sv->sh[0].d_pfull, g_ar_nostate ? NULL : sv->sh[0].d_st,
+                     g_stream);
+    return;
+  }
   if (sv->p2p_halo) { /* all sends before any wait: virtual shards share a stream */
     for (int i = 0; i < sv->nshard; i++)
       lsb_p2p_send(sv->p2p[i], sv->sh[i].d_pfull, g_ar_nostate ? NULL : sv->sh[i].d_st, g_stream);
@@ -852,28 +859,31 @@ static void exchange_p(lsb_hip_solver *sv) {
   exchange_on(sv, g_stream);
 }
 
-/* d_scal[off .. off+cnt) <- sum over shards; with the direct path the shard's
- * own partial sums (parts, nparts x width) can be folded into the same launch:
- * then d_scal[off .. off+width) need not have been reduced beforehand */
-static void allreduce_parts(lsb_hip_solver *sv, unsigned off, unsigned cnt, unsigned width) {
+/* d_scal[off .. off+cnt) <- sum over shards.  With the direct path the
+ * shard's own partial sums are folded into the same launch: the first `width`
+ * values come from the SpMV's dot partials, the next s->ar2_width from the
+ * array the sweep kernel left in s->ar2_parts, and only the rest must already
+ * sit, reduced, in d_scal. */
+static void allreduce_parts(lsb_hip_solver *sv, unsigned off, unsigned cnt, unsigned width,
+                            int with2) {
   for (int ph = 1; ph <= 2; ph++)
     for (int i = 0; i < sv->nshard; i++) {
       struct shard *s = &sv->sh[i];
       const double *parts = width ? s->d_parts_pq : NULL;
+      const unsigned w2 = with2 ? s->ar2_width : 0;
       struct lsb_pcg_state *st = g_ar_nostate ? NULL : s->d_st;
-      if (sv->nshard == 1) {
-        if (ph == 1)
-          lsb_p2p_allreduce(sv->p2p[i], parts, s->npq, width, s->d_scal + off + width,
-                            cnt - width, s->d_scal + off, st, 3, g_stream);
-      } else
-        lsb_p2p_allreduce(sv->p2p[i], parts, s->npq, width, s->d_scal + off + width, cnt - width,
-                          s->d_scal + off, st, ph, g_stream);
+      const int phases = sv->nshard == 1 ? 3 : ph;
+      if (sv->nshard == 1 && ph == 2)
+        continue;
+      lsb_p2p_allreduce(sv->p2p[i], parts, s->npq, width, s->ar2_parts, s->ar2_n, w2,
+                        s->d_scal + off + width + w2, cnt - width - w2, s->d_scal + off, st,
+                        phases, g_stream);
     }
 }
 
 static void allreduce_scal(lsb_hip_solver *sv, unsigned off, unsigned cnt) {
   if (sv->p2p_on) {
-    allreduce_parts(sv, off, cnt, 0);
+    allreduce_parts(sv, off, cnt, 0, 0);
     return;
   }
   if (sv->dist)
@@ -884,9 +894,9 @@ static void allreduce_scal(lsb_hip_solver *sv, unsigned off, unsigned cnt) {
 
 /* d_scal[0] <- all-reduced sum of the SpMV's dot partials; d_scal[1..cnt) are
  * all-reduced along with it */
-static void allreduce_pq(lsb_hip_solver *sv, unsigned cnt) {
+static void allreduce_pq(lsb_hip_solver *sv, unsigned cnt, int with2) {
   if (sv->p2p_on) {
-    allreduce_parts(sv, 0, cnt, 1);
+    allreduce_parts(sv, 0, cnt, 1, with2);
     return;
   }
   for (int i = 0; i < sv->nshard; i++) {
@@ -1089,7 +1099,7 @@ static void pcg_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int sa
   unsigned npq = 0, np2 = 0;
   if (sv->multi) {
     exchange_and_spmv(sv, sample);
-    allreduce_pq(sv, 1);
+    allreduce_pq(sv, 1, 0);
   }
   for (int i = 0; i < sv->nshard && !sv->multi; i++) {
     struct shard *s = &sv->sh[i];
@@ -1174,7 +1184,7 @@ static void cg1_enqueue_init(lsb_hip_solver *sv, const double *d_b, double *d_x)
       spmv_shard(s, s->d_pfull, s->d_q, s->d_pfull + s->row_begin, s->d_parts_pq, &s->npq, s->d_st);
   }
   if (sv->multi)
-    allreduce_pq(sv, 1);
+    allreduce_pq(sv, 1, 0);
 }
 
 static void cg1_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int sample) {
@@ -1188,7 +1198,8 @@ static void cg1_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int sa
                      d_x + o, s->d_r, s->d_st, parity, sv->multi ? s->d_scal + 1 : gr_in,
                      sv->multi ? 1u : s->np2, sv->multi ? s->d_scal : s->d_parts_pq,
                      sv->multi ? 1u : s->npq, gr_out, &np2, g_stream);
-    if (sv->multi)
+    s->ar2_parts = gr_out, s->ar2_n = np2, s->ar2_width = 2;
+    if (sv->multi && !sv->p2p_on) /* the direct all-reduce reduces these itself */
       lsb_k_reduce_final(gr_out, np2, 2, s->d_scal + 1, 0, s->d_st, g_stream);
   }
   if (sv->multi)
@@ -1208,7 +1219,7 @@ static void cg1_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int sa
     }
   }
   if (sv->multi)
-    allreduce_pq(sv, 3); /* w.u, r.u, r.r in ONE collective */
+    allreduce_pq(sv, 3, 1); /* w.u, r.u, r.r in ONE collective */
 }
 
 static int auto_chunk(const lsb_hip_solver *sv) {

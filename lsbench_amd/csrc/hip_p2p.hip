@@ -98,17 +98,14 @@ __device__ __forceinline__ bool wait_flag(const u64 *flag, u64 epoch, long long 
   return true;
 }
 
-__global__ __launch_bounds__(P2P_WG) void k_p2p_send(const p2p_send_ent *__restrict__ ents,
-                                                     int nent, const double *__restrict__ full,
-                                                     u64 epoch, unsigned *__restrict__ counters,
-                                                     const lsb_pcg_state *__restrict__ st) {
-  if (st && st->status)
-    return;
+__device__ __forceinline__ void p2p_send_body(const p2p_send_ent *__restrict__ ents, int nent,
+                                              unsigned blk, const double *__restrict__ full,
+                                              u64 epoch, unsigned *__restrict__ counters) {
   int e = 0;
-  while (e + 1 < nent && blockIdx.x >= ents[e + 1].first_wg)
+  while (e + 1 < nent && blk >= ents[e + 1].first_wg)
     e++;
   const p2p_send_ent en = ents[e];
-  const unsigned part = blockIdx.x - en.first_wg;
+  const unsigned part = blk - en.first_wg;
   const size_t per = (en.count + en.wgs - 1) / en.wgs;
   const size_t lo = (size_t)part * per, hi = lo + per < en.count ? lo + per : en.count;
   const double *src = full + en.src_off;
@@ -124,15 +121,12 @@ __global__ __launch_bounds__(P2P_WG) void k_p2p_send(const p2p_send_ent *__restr
   }
 }
 
-__global__ __launch_bounds__(P2P_WG) void k_p2p_recv(const p2p_recv_ent *__restrict__ ents,
-                                                     int nent, double *__restrict__ full,
-                                                     u64 epoch, lsb_pcg_state *__restrict__ st,
-                                                     long long timeout) {
-  if (st && st->status)
-    return;
+__device__ __forceinline__ void p2p_recv_body(const p2p_recv_ent *__restrict__ ents, int nent,
+                                              unsigned blk, double *__restrict__ full, u64 epoch,
+                                              lsb_pcg_state *__restrict__ st, long long timeout) {
   __shared__ int ok;
   int e = 0;
-  while (e + 1 < nent && blockIdx.x >= ents[e + 1].first_wg)
+  while (e + 1 < nent && blk >= ents[e + 1].first_wg)
     e++;
   const p2p_recv_ent en = ents[e];
   if (threadIdx.x == 0)
@@ -145,12 +139,46 @@ __global__ __launch_bounds__(P2P_WG) void k_p2p_recv(const p2p_recv_ent *__restr
     return;
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-  const unsigned part = blockIdx.x - en.first_wg;
+  const unsigned part = blk - en.first_wg;
   const size_t per = (en.count + en.wgs - 1) / en.wgs;
   const size_t lo = (size_t)part * per, hi = lo + per < en.count ? lo + per : en.count;
   double *dst = full + en.dst_off;
   for (size_t i = lo + threadIdx.x; i < hi; i += P2P_WG)
     dst[i] = ld_sys(en.src + i);
+}
+
+__global__ __launch_bounds__(P2P_WG) void k_p2p_send(const p2p_send_ent *__restrict__ ents,
+                                                     int nent, const double *__restrict__ full,
+                                                     u64 epoch, unsigned *__restrict__ counters,
+                                                     const lsb_pcg_state *__restrict__ st) {
+  if (st && st->status)
+    return;
+  p2p_send_body(ents, nent, blockIdx.x, full, epoch, counters);
+}
+
+__global__ __launch_bounds__(P2P_WG) void k_p2p_recv(const p2p_recv_ent *__restrict__ ents,
+                                                     int nent, double *__restrict__ full,
+                                                     u64 epoch, lsb_pcg_state *__restrict__ st,
+                                                     long long timeout) {
+  if (st && st->status)
+    return;
+  p2p_recv_body(ents, nent, blockIdx.x, full, epoch, st, timeout);
+}
+
+// One process per GPU: both roles in ONE launch (the workgroups that wait and
+// the ones that send are all resident at once; what a waiter waits for comes
+// from another GPU).  Sends read rows this rank owns, receives write rows it
+// does not, so the two roles never touch the same element of `full`.
+__global__ __launch_bounds__(P2P_WG) void k_p2p_sendrecv(
+    const p2p_send_ent *__restrict__ sends, int nsend, unsigned send_grid,
+    const p2p_recv_ent *__restrict__ recvs, int nrecv, double *full, u64 epoch,
+    unsigned *__restrict__ counters, lsb_pcg_state *__restrict__ st, long long timeout) {
+  if (st && st->status)
+    return;
+  if (blockIdx.x < send_grid)
+    p2p_send_body(sends, nsend, blockIdx.x, full, epoch, counters);
+  else
+    p2p_recv_body(recvs, nrecv, blockIdx.x - send_grid, full, epoch, st, timeout);
 }
 
 // slot of rank r, parity b, inside a mailbox: 3 doubles + the epoch
@@ -160,7 +188,8 @@ __device__ __forceinline__ char *ar_slot(char *mbox, unsigned b, int r) {
 
 __global__ __launch_bounds__(P2P_WG) void k_p2p_allreduce(
     const double *__restrict__ parts, unsigned nparts, unsigned width,
-    const double *extra, unsigned nextra, double *out, // may alias
+    const double *__restrict__ parts2, unsigned nparts2, unsigned width2,
+    const double *extra, unsigned nextra, double *out, // extra and out may alias
     char *const *__restrict__ peer, int R, int me, u64 epoch, lsb_pcg_state *__restrict__ st,
     int phases, long long timeout) {
   if (st && st->status)
@@ -168,12 +197,16 @@ __global__ __launch_bounds__(P2P_WG) void k_p2p_allreduce(
   __shared__ double sred[P2P_WG / 64];
   __shared__ double sval[3];
   const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const unsigned nvals = width + nextra, b = (unsigned)(epoch & 1);
+  const unsigned nvals = width + width2 + nextra, b = (unsigned)(epoch & 1);
   if (phases & 1) {
-    for (unsigned k = 0; k < width; k++) { // my partial sums, fixed order
+    for (unsigned k = 0; k < width + width2; k++) { // my partial sums, fixed order
+      const bool first = k < width;
+      const double *pp = first ? parts : parts2;
+      const unsigned np = first ? nparts : nparts2, w = first ? width : width2,
+                     c = first ? k : k - width;
       double v = 0.0;
-      for (unsigned i = tid; i < nparts; i += P2P_WG)
-        v += parts[(size_t)i * width + k];
+      for (unsigned i = tid; i < np; i += P2P_WG)
+        v += pp[(size_t)i * w + c];
       for (int off = 32; off > 0; off >>= 1)
         v += __shfl_xor(v, off, 64);
       if (lane == 0)
@@ -181,14 +214,14 @@ __global__ __launch_bounds__(P2P_WG) void k_p2p_allreduce(
       __syncthreads();
       if (tid == 0) {
         double s = 0.0;
-        for (unsigned w = 0; w < P2P_WG / 64; w++)
-          s += sred[w];
+        for (unsigned q = 0; q < P2P_WG / 64; q++)
+          s += sred[q];
         sval[k] = s;
       }
       __syncthreads();
     }
     if (tid < nextra)
-      sval[width + tid] = extra[tid];
+      sval[width + width2 + tid] = extra[tid];
     __syncthreads();
     if (tid < (unsigned)R) { // lane r serves peer r (own mailbox included)
       double *slot = (double *)ar_slot(peer[tid], b, me);
@@ -457,20 +490,34 @@ extern "C" void lsb_p2p_recv(struct lsb_p2p *p, double *d_full, struct lsb_pcg_s
                                                                  p->epoch_x, st, p->timeout_ticks);
 }
 
-/* out[0..width+nextra) = sum over ranks of {column sums of parts[nparts][width],
- * extra[0..nextra)}; phases: 1 = contribute, 2 = collect, 3 = both (one rank
- * per process); out may alias extra. */
+/* send + recv in one launch; only where the peers are other processes */
+extern "C" void lsb_p2p_sendrecv(struct lsb_p2p *p, double *d_full, struct lsb_pcg_state *st,
+                                 void *stream) {
+  if (p->virt)
+    errx(EXIT_FAILURE, "lsb_p2p_sendrecv between shards of one stream would wait on itself");
+  p->epoch_x++;
+  if (p->send_grid + p->recv_grid)
+    k_p2p_sendrecv<<<p->send_grid + p->recv_grid, P2P_WG, 0, (hipStream_t)stream>>>(
+        p->d_send, p->nsend, p->send_grid, p->d_recv, p->nrecv, d_full, p->epoch_x,
+        p->d_counters, st, p->timeout_ticks);
+}
+
+/* out[0..width+width2+nextra) = sum over ranks of {column sums of
+ * parts[nparts][width], column sums of parts2[nparts2][width2], extra[0..nextra)};
+ * phases: 1 = contribute, 2 = collect, 3 = both (one rank per process); out may
+ * alias extra. */
 extern "C" void lsb_p2p_allreduce(struct lsb_p2p *p, const double *parts, unsigned nparts,
-                                  unsigned width, const double *extra, unsigned nextra,
+                                  unsigned width, const double *parts2, unsigned nparts2,
+                                  unsigned width2, const double *extra, unsigned nextra,
                                   double *out, struct lsb_pcg_state *st, int phases,
                                   void *stream) {
-  if (width + nextra > 3)
+  if (width + width2 + nextra > 3)
     errx(EXIT_FAILURE, "lsb_p2p_allreduce: at most 3 values");
   if (phases & 1)
     p->epoch_r++;
-  k_p2p_allreduce<<<1, P2P_WG, 0, (hipStream_t)stream>>>(parts, nparts, width, extra, nextra, out,
-                                                         p->d_peer, p->R, p->me, p->epoch_r, st,
-                                                         phases, p->timeout_ticks);
+  k_p2p_allreduce<<<1, P2P_WG, 0, (hipStream_t)stream>>>(
+      parts, nparts, width, parts2, nparts2, width2, extra, nextra, out, p->d_peer, p->R, p->me,
+      p->epoch_r, st, phases, p->timeout_ticks);
 }
 
 /* self-test pieces (hip_cdna4.c drives them) */

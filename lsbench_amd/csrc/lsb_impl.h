@@ -141,7 +141,9 @@ int lsb_p2p_has_halo(const struct lsb_p2p *p);
 void lsb_p2p_send(struct lsb_p2p *p, const double *d_full, const struct lsb_pcg_state *st,
                   void *stream);
 void lsb_p2p_recv(struct lsb_p2p *p, double *d_full, struct lsb_pcg_state *st, void *stream);
+void lsb_p2p_sendrecv(struct lsb_p2p *p, double *d_full, struct lsb_pcg_state *st, void *stream);
 void lsb_p2p_allreduce(struct lsb_p2p *p, const double *parts, unsigned nparts, unsigned width,
+                       const double *parts2, unsigned nparts2, unsigned width2,
                        const double *extra, unsigned nextra, double *out,
                        struct lsb_pcg_state *st, int phases, void *stream);
 void lsb_p2p_test_pattern(double *d_full, size_t goff, size_t n, unsigned round, void *stream);

@@ -12,15 +12,15 @@ A = hip.lsbench_matrix_synth(spec)
 b = np.arange(A.nrows, dtype=np.float64)
 for nv in (1, 2, 8):
     for kr in (hip.KRYLOV_PCG, hip.KRYLOV_PCG1):
-        for ov in (0, 1):
-            if nv == 1 and ov:
+        for ov, cm in ((0, 0), (1, 0), (0, 2), (1, 2)):
+            if nv == 1 and (ov or cm):
                 continue
             s = hip.Solver(A, hip.default_opts(op_mode=hip.OP_RAW, nvirt=nv, overlap=ov, tol=1e-30,
-                                               maxit=600, krylov=kr))
+                                               maxit=600, krylov=kr, comm=cm))
             s.solve(b)
             t = time.perf_counter()
             x, r = s.solve(b)
             dt = time.perf_counter() - t
-            print(f"{spec} nvirt={nv} krylov={kr} overlap={ov} overlaps={s.overlaps} "
+            print(f"{spec} nvirt={nv} krylov={kr} overlap={ov} comm={s.comm} "
                   f"iters={r.iters} us/iter={dt / r.iters * 1e6:.1f}", flush=True)
             s.destroy()
