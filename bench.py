@@ -67,8 +67,9 @@ def parse():
     p.add_argument("--comm", default="auto", choices=["auto", "rccl", "p2p"],
                    help="N>1: auto = direct xGMI stores where they pass the self-test and beat "
                         "RCCL; rccl / p2p force one")
-    p.add_argument("--overlap", type=int, default=0,
-                   help="N>1: 1 = halo exchange on its own stream behind the interior rows")
+    p.add_argument("--overlap", type=int, default=-1,
+                   help="N>1: 1 = interior rows of the SpMV run while the halo is in flight; "
+                        "-1 = only where a halo is >= 64 Ki doubles")
     p.add_argument("--spmv-tune", type=int, default=-1,
                    help="-1 = timing pass at setup picks the SpMV flavour; 0..3 force it")
     p.add_argument("--fixed-iters", type=int, default=0,

@@ -120,9 +120,9 @@ struct lsb_hip_opts {
   int nvirt;         /* >1: split into that many row-range shards on ONE
                         device, exchanging by device copies (test mode) [1] */
   int comm;          /* LSB_COMM_*                                      [0] */
-  int overlap;       /* multi-shard: run the halo exchange on its own stream
-                        behind the rows that need no halo (costs two
-                        extra launches per iteration)                   [0] */
+  int overlap;       /* multi-shard: start the SpMV's interior rows while the
+                        halo is in flight; 1 on, 0 off, -1 = on when some
+                        halo is >= 64 Ki doubles (the split costs launches) [-1] */
   int spmv_tune;     /* -1: time the SpMV flavours at creation and keep the
                         fastest; >= 0: force flags (bit 0 prefetch, bit 1
                         nontemporal)                                   [-1] */

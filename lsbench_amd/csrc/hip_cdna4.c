@@ -67,7 +67,7 @@ void lsb_hip_opts_default(struct lsb_hip_opts *o) {
   o->sample_spmv = 0;
   o->nvirt = 1;
   o->comm = LSB_COMM_AUTO;
-  o->overlap = 0; /* measured: the split costs ~18 us per iteration, DESIGN.md section 6 */
+  o->overlap = -1; /* on where the halos are large enough to pay for the split, DESIGN.md section 6 */
   o->spmv_tune = -1;
   o->spmv_grid = 0;
   o->reorder = 0;
@@ -260,6 +260,7 @@ struct lsb_hip_solver {
   int gnext;
   unsigned hint_iters; /* iterations of the previous solve, 0 = none yet */
   unsigned agree_nnz, agree_n; /* distributed: largest shard, identical on all ranks */
+  unsigned agree_halo;         /* largest halo (doubles) any shard receives from one peer */
   /* reordering: d_perm[new] = old; b and x are permuted through d_bp / d_xp */
   int *d_perm;
   double *d_bp, *d_xp;
@@ -695,8 +696,12 @@ lsb_hip_solver *lsb_hip_solver_create(const struct csr *A,
     hull[4 * q] = bounds[q], hull[4 * q + 1] = bounds[q + 1] - bounds[q];
     hull[4 * q + 2] = sv->sh[q].col_lo, hull[4 * q + 3] = sv->sh[q].col_hi;
   }
-  for (int q = 0; q < P; q++)
+  for (int q = 0; q < P; q++) {
     plan_exchange(&sv->sh[q], q, P, hull);
+    for (int k = 0; k < sv->sh[q].nrecv; k++)
+      if (sv->sh[q].recv[k].count > sv->agree_halo)
+        sv->agree_halo = (unsigned)sv->sh[q].recv[k].count;
+  }
   free(hull), free(bounds);
   lsbench_matrix_free(S);
   solver_finish_setup(sv);
@@ -758,6 +763,17 @@ lsb_hip_solver *lsb_hip_solver_create_dist(const struct csr *A_rows,
     sv->sh[0].nrecv = 0;
   }
   free(hull);
+  {
+    unsigned h = 0, *allh = lsb_calloc(unsigned, (size_t)P);
+    for (int k = 0; k < sv->sh[0].nrecv; k++)
+      if (sv->sh[0].recv[k].count > h)
+        h = (unsigned)sv->sh[0].recv[k].count;
+    lsb_hip_comm_allgather_u32(&h, 1, allh);
+    for (int q = 0; q < P; q++)
+      if (allh[q] > sv->agree_halo)
+        sv->agree_halo = allh[q];
+    free(allh);
+  }
   solver_finish_setup(sv);
   return sv;
 }
@@ -943,6 +959,12 @@ static int can_overlap(const lsb_hip_solver *sv) {
   for (int i = 0; i < sv->nshard; i++)
     if (!sv->sh[i].ov_ok || sv->sh[i].variant != LSB_SPMV_ADAPTIVE)
       return 0;
+  /* auto: the split SpMV costs 2 launches (direct path) or 2 launches and two
+   * cross-stream events (RCCL), 6-20 us; a halo of >= 64 Ki doubles takes
+   * longer than that on one xGMI link.  agree_halo is the largest halo of ANY
+   * rank, so every rank takes the same branch. */
+  if (sv->o.overlap < 0)
+    return sv->agree_halo >= 65536u;
   return 1;
 }
 

@@ -65,3 +65,21 @@ def test_maxit_and_scattered_operator(hip):
     xo, ito, relo, sto = O.pcg1_jacobi(offs, cols, vals, O.rhs(L.nrows), tol=1e-12, maxit=23)
     assert r.status == hip.STATUS_MAXIT and r.iters == 23 and sto == 3
     assert abs(r.relres - relo) <= 1e-6 * relo
+
+
+def test_overlap_is_automatic_for_large_halos(hip):
+    """opts.overlap = -1 (default): split the SpMV only where a halo is at least
+    64 Ki doubles."""
+    big = hip.lsbench_matrix_synth("lap3d:nx=260,ny=260,nz=8")      # plane = 67600 rows
+    small = hip.lsbench_matrix_synth("lap3d:nx=100,ny=100,nz=54")   # plane = 10000 rows
+    for A, want in ((big, True), (small, False)):
+        s = hip.Solver(A, hip.default_opts(op_mode=hip.OP_RAW, nvirt=2, maxit=40, tol=1e-30,
+                                           spmv_variant=hip.SPMV_ADAPTIVE))
+        assert s.overlaps == want
+        x, r = s.solve(O.rhs(A.nrows))
+        s.destroy()
+        s1 = hip.Solver(A, hip.default_opts(op_mode=hip.OP_RAW, maxit=40, tol=1e-30))
+        x1, r1 = s1.solve(O.rhs(A.nrows))
+        s1.destroy()
+        assert r.iters == r1.iters == 40
+        assert np.linalg.norm(x - x1) / np.linalg.norm(x1) <= 1e-11
