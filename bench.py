@@ -290,6 +290,16 @@ def main():
                  % (res.status, res.iters))
     its = iters // max(a.steps, 1)
 
+    # ---- outside the timed region: ||b - S x|| / ||b|| recomputed from x ----
+    d_y = torch.empty_like(d_x)
+    solver.spmv_dev(d_x, d_y)
+    sq = torch.stack([((d_b - d_y) ** 2).sum(), (d_b ** 2).sum()])
+    if dist_on:
+        sq = sq.to("cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(sq)
+    true_relres = float((sq[0] / sq[1]).sqrt())
+    del d_y
+
     # ---- dominant kernel: SpMV, HIP events on the library's stream ---------
     if spmv_n:
         spmv_avg_ms = spmv_ms / spmv_n  # sampled inside the timed solves
@@ -320,7 +330,8 @@ def main():
                    "solver": "PCG+Jacobi" + (" (single-reduction form)" if (
                        a.krylov == "cg1" or (a.krylov == "auto" and world > 1)) else ""),
                    "tol": a.tol, "rhs": "b_i=i", "partition": "row-range x%d" % world,
-                   "iterations_per_solve": its, "relres": res.relres},
+                   "iterations_per_solve": its, "relres": res.relres,
+                   "true_relres": true_relres},
         "iterations_per_sec": iters / dt,
         "pcg_iteration_GBps": bytes_iter * iters / dt / 1e9,
         "setup_seconds": t_setup,
