@@ -511,6 +511,16 @@ __device__ __forceinline__ d2v ld2(const d2v *p) {
     return __builtin_nontemporal_load(p);
   return *p;
 }
+// Stores of vectors nobody reads before the NEXT sweep (x; in the single-
+// reduction form also p, s, r): nontemporal, so that they do not sit as dirty
+// lines in L2 / Infinity Cache while the SpMV that follows streams the matrix.
+template <bool NT>
+__device__ __forceinline__ void st2(d2v *p, d2v v) {
+  if (NT)
+    __builtin_nontemporal_store(v, p);
+  else
+    *p = v;
+}
 
 // alpha = rz/pq ; x += alpha p ; r -= alpha q ; partials (r.dinv.r, r.r)
 template <bool V2, bool NT>
@@ -558,7 +568,7 @@ __global__ __launch_bounds__(WG) void k_pcg_update_xr(
       for (;;) {
         xv.x += alpha * pv.x, xv.y += alpha * pv.y;
         rv.x -= alpha * qv.x, rv.y -= alpha * qv.y;
-        x2[i] = xv, r2[i] = rv;
+        st2<NT>(x2 + i, xv), r2[i] = rv;
         acc[0] += rv.x * (dv.x * rv.x);
         acc[0] += rv.y * (dv.y * rv.y);
         acc[1] += rv.x * rv.x;
@@ -732,7 +742,8 @@ __global__ __launch_bounds__(WG) void k_cg1_update(
         xv.x += alpha * pv.x, xv.y += alpha * pv.y;
         rv.x -= alpha * sw.x, rv.y -= alpha * sw.y;
         uv.x = dv.x * rv.x, uv.y = dv.y * rv.y;
-        p2[i] = pv, s2[i] = sw, x2[i] = xv, r2[i] = rv, u2[i] = uv;
+        st2<NT>(p2 + i, pv), st2<NT>(s2 + i, sw), st2<NT>(x2 + i, xv), st2<NT>(r2 + i, rv);
+        u2[i] = uv;
         acc[0] += rv.x * uv.x;
         acc[0] += rv.y * uv.y;
         acc[1] += rv.x * rv.x;
