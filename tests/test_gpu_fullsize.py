@@ -70,6 +70,18 @@ def test_lap2d_10m_rows(hip):
     res2 = s.solve_dev(d_b, d_x)
     assert res2.iters == res.iters and np.array_equal(d_x.cpu().numpy(), xs)  # deterministic
     s.destroy()
+    # the sharded forms at full size: 8 row-range shards on the one device, the
+    # multi-GPU defaults (single-reduction PCG), both transports; 60 iterations
+    xo1, it1, rel1, _ = O.pcg1_jacobi(A.offs, A.cols, A.vals, b, 0.0, 60)
+    for comm in (hip.COMM_RCCL, hip.COMM_P2P):
+        sp = hip.Solver(A, hip.default_opts(op_mode=hip.OP_RAW, tol=0.0, maxit=60, nvirt=8, comm=comm,
+                                            krylov=hip.KRYLOV_AUTO))
+        assert sp.comm[0] == (1 if comm == hip.COMM_RCCL else 3)
+        xp, rp = sp.solve(b)
+        sp.destroy()
+        assert rp.iters == 60 and rp.status == hip.STATUS_MAXIT
+        assert np.linalg.norm(xp - xo1) / np.linalg.norm(xo1) <= 1e-10
+        assert abs(rp.relres - rel1) <= 1e-9 * rel1
 
 
 def test_powerlaw_8m_rows_spmv(hip):
