@@ -339,7 +339,10 @@ def main():
                      modes="0 one shard, 1 RCCL, 2 direct xGMI all-reduce, 3 direct xGMI halos too"),
         "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": gbps / HBM_PEAK_GBPS, "traffic": traffic,
-                     "kernel": "k_spmv_adaptive (fused p.q)", "launch_ms": spmv_avg_ms,
+                     "kernel": {la.SPMV_ADAPTIVE: "k_spmv_adaptive", la.SPMV_SUBWAVE: "k_spmv_subwave",
+                                la.SPMV_SCALAR: "k_spmv_scalar", la.SPMV_PANEL: "k_spmv_adaptive (panels)",
+                                la.SPMV_SELL: "k_spmv_sell"}.get(solver.spmv_variant, "?") + " (fused p.q)",
+                     "launch_ms": spmv_avg_ms,
                      "spmv_flags": solver.spmv_flags,
                      "algorithmic_bytes": bytes_spmv, "measured": how},
     }

@@ -98,8 +98,11 @@ enum { LSB_SPMV_AUTO = 0,     /* pick by mean row length                    */
                                  wavefront-per-row long rows                */
        LSB_SPMV_SUBWAVE = 2,  /* 2..64 lanes per row, shuffle reduction     */
        LSB_SPMV_SCALAR = 3,   /* one lane per row (test/debug baseline)     */
-       LSB_SPMV_PANEL = 4 };  /* column panels with an L2-resident x window,
+       LSB_SPMV_PANEL = 4,    /* column panels with an L2-resident x window,
                                  for scattered rows (solver handle only)    */
+       LSB_SPMV_SELL = 5 };   /* sliced-ELL copy of the rows (lsb_csr_sellize):
+                                 128-row slices stored column-major, two rows
+                                 per lane, no LDS; for near-uniform row lengths */
 enum { LSB_STATUS_RUNNING = 0, LSB_STATUS_CONVERGED = 1,
        LSB_STATUS_BREAKDOWN = 2, LSB_STATUS_MAXIT = 3,
        LSB_STATUS_COMM = 4 /* a peer never arrived (direct xGMI path) */ };
@@ -201,6 +204,25 @@ struct lsb_panel_csr {
 };
 struct lsb_panel_csr *lsb_csr_panelize(const struct csr *A, unsigned width);
 void lsb_panel_csr_free(struct lsb_panel_csr *P);
+/* Sliced-ELL copy of a CSR for LSB_SPMV_SELL: rows in slices of LSB_SELL_ROWS,
+ * every slice padded to its longest row and stored column-major (entry j of
+ * row 128s+i at sptr[s] + 128j + i), so that a wavefront's lane l reads the
+ * j-th entries of rows 2l and 2l+1 as one int2 / double2.  Padding entries
+ * carry value 0 and the row's last column (a column the row references anyway).
+ * cols are 0-based whatever A->base is. */
+#define LSB_SELL_ROWS 128
+struct lsb_sell {
+  unsigned nrows, nslice;
+  unsigned long long stored; /* entries incl. padding = sptr[nslice]        */
+  unsigned *sptr;            /* nslice+1                                    */
+  int *cols;                 /* stored (+ LSB_SELL_ROWS slack)              */
+  double *vals;
+};
+/* entries a sliced-ELL copy of A would store (to decide before building it) */
+unsigned long long lsb_csr_sell_stored(const struct csr *A);
+/* NULL when the copy would not fit 32-bit offsets */
+struct lsb_sell *lsb_csr_sellize(const struct csr *A);
+void lsb_sell_free(struct lsb_sell *S);
 /* mean |col - (row + row_begin)| over a sample of the rows */
 double lsb_csr_mean_scatter(const struct csr *A, unsigned row_begin);
 /* [lo,hi) column range referenced by A (0-based). */
@@ -314,6 +336,8 @@ int lsb_hip_comm_barrier(void);
  * If d_dot != NULL the kernel also leaves sum_i xdot[i]*y[i] in d_dot[0]
  * (two-stage, fixed order; d_work must then hold
  * lsb_hip_partials_capacity() doubles). */
+/* LSB_SPMV_SELL: pass the device copies of lsb_sell's sptr as d_offs, cols as
+ * d_cols, vals as d_vals and nslice as nblk (d_rowblk, d_blklanes unused). */
 int lsb_hip_spmv_csr_f64(int variant, unsigned n, const int *d_offs,
                          const int *d_cols, const double *d_vals,
                          const int *d_rowblk, const unsigned char *d_blklanes,

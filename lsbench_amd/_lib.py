@@ -19,7 +19,8 @@ SOLVER_HIP = 6
 OP_CHOLMOD_UPPER, OP_RAW = 0, 1
 PRECOND_JACOBI, PRECOND_NONE = 0, 1
 KRYLOV_PCG, KRYLOV_GMRES, KRYLOV_PCG1, KRYLOV_AUTO = 0, 1, 2, 3
-SPMV_AUTO, SPMV_ADAPTIVE, SPMV_SUBWAVE, SPMV_SCALAR, SPMV_PANEL = 0, 1, 2, 3, 4
+SPMV_AUTO, SPMV_ADAPTIVE, SPMV_SUBWAVE, SPMV_SCALAR, SPMV_PANEL, SPMV_SELL = 0, 1, 2, 3, 4, 5
+SELL_ROWS = 128
 STATUS_RUNNING, STATUS_CONVERGED, STATUS_BREAKDOWN, STATUS_MAXIT = 0, 1, 2, 3
 STATUS_COMM = 4
 COMM_AUTO, COMM_RCCL, COMM_P2P = 0, 1, 2
@@ -68,6 +69,13 @@ class PanelCsr(C.Structure):
                 ("cols", C.POINTER(C.c_uint)), ("vals", C.POINTER(C.c_double))]
 
 
+class Sell(C.Structure):
+    """struct lsb_sell."""
+    _fields_ = [("nrows", C.c_uint), ("nslice", C.c_uint), ("stored", C.c_ulonglong),
+                ("sptr", C.POINTER(C.c_uint)), ("cols", C.POINTER(C.c_int)),
+                ("vals", C.POINTER(C.c_double))]
+
+
 class Xfer(C.Structure):
     """struct lsb_xfer."""
     _fields_ = [("peer", C.c_int), ("offset", C.c_size_t), ("count", C.c_size_t)]
@@ -109,6 +117,9 @@ SIGNATURES = {
     "lsb_csr_bandwidth": (_u, [_csrp]),
     "lsb_csr_panelize": (C.POINTER(PanelCsr), [_csrp, _u]),
     "lsb_panel_csr_free": (None, [C.POINTER(PanelCsr)]),
+    "lsb_csr_sell_stored": (C.c_ulonglong, [_csrp]),
+    "lsb_csr_sellize": (C.POINTER(Sell), [_csrp]),
+    "lsb_sell_free": (None, [C.POINTER(Sell)]),
     "lsb_csr_mean_scatter": (_d, [_csrp, _u]),
     "lsb_csr_col_hull": (None, [_csrp, C.POINTER(_u), C.POINTER(_u)]),
     "lsb_plan_exchange": (None, [_i, _i, C.POINTER(_u), C.POINTER(Xfer), C.POINTER(_i),

@@ -133,6 +133,21 @@ def lsb_csr_block_lanes(A, rowblk):
     return out
 
 
+def lsb_csr_sellize(A):
+    """(sptr, cols, vals) of the sliced-ELL copy, as numpy arrays (copies)."""
+    lib = L.load()
+    p = lib.lsb_csr_sellize(A.ptr)
+    if not p:
+        raise L.LsbenchHipError("sliced-ELL copy does not fit 32-bit offsets")
+    S = p.contents
+    sptr = np.ctypeslib.as_array(S.sptr, (S.nslice + 1,)).copy()
+    cols = np.ctypeslib.as_array(S.cols, (S.stored,)).copy()
+    vals = np.ctypeslib.as_array(S.vals, (S.stored,)).copy()
+    assert int(lib.lsb_csr_sell_stored(A.ptr)) == int(S.stored) == int(sptr[-1])
+    lib.lsb_sell_free(p)
+    return sptr, cols, vals
+
+
 def lsb_csr_rcm(A):
     perm = np.zeros(A.nrows, np.uint32)
     L.check(L.load().lsb_csr_rcm(A.ptr, perm.ctypes.data_as(C.POINTER(C.c_uint))), "rcm")

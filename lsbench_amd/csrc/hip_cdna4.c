@@ -225,6 +225,13 @@ struct shard {
    * [ov_b2,nblk); the blocks in between need no halo (0,0 = not separable) */
   unsigned ov_b1, ov_b2;
   int ov_ok;
+  /* sliced-ELL copy (LSB_SPMV_SELL), built when padding stays under 1/8; the
+   * same prefix/interior/suffix split in slices */
+  unsigned *d_sptr;
+  int *d_scols;
+  double *d_svals;
+  unsigned nslice, ov_s1, ov_s2;
+  int ov_sok;
   double *d_parts_pq, *d_parts2;
   double *d_scal; /* [0] p.q   [1] r.z'  [2] r.r   (multi-shard path) */
   struct lsb_pcg_state *d_st;
@@ -300,6 +307,8 @@ static void choose_spmv(struct shard *s, const struct lsb_hip_opts *o) {
     v = s->nnz <= 500000ull ? LSB_SPMV_SUBWAVE : LSB_SPMV_ADAPTIVE;
   if (v == LSB_SPMV_PANEL && !s->pn)
     v = LSB_SPMV_ADAPTIVE; /* the operator did not qualify for panels */
+  if (v == LSB_SPMV_SELL && !s->d_sptr)
+    v = LSB_SPMV_ADAPTIVE; /* no sliced-ELL copy (32-bit offsets exceeded) */
   s->variant = v;
   unsigned L = pow2_ceil(mean ? mean : 1);
   if (L < 2)
@@ -424,6 +433,41 @@ static void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
     if (width && (forced || (o->spmv_variant == LSB_SPMV_AUTO && scattered)))
       shard_build_panels(s, &gview, width);
   }
+  /* Near-uniform row lengths (stencils, meshes): also keep a sliced-ELL copy;
+   * tune_spmv() keeps whichever kernel is faster on this shard. */
+  {
+    struct csr gview = {n, 0, (unsigned *)offs, (unsigned *)cols, (double *)(S->vals + j0)};
+    const int forced = o->spmv_variant == LSB_SPMV_SELL;
+    const unsigned long long stored = (forced || s->nnz >= 4000000ull) ? lsb_csr_sell_stored(&gview) : 0;
+    struct lsb_sell *E = NULL;
+    if (stored && (forced || (o->spmv_variant == LSB_SPMV_AUTO && stored <= s->nnz + s->nnz / 8)))
+      E = lsb_csr_sellize(&gview);
+    if (E) {
+      s->nslice = E->nslice;
+      s->d_sptr = (unsigned *)dev_upload(E->sptr, ((size_t)E->nslice + 1) * sizeof(unsigned));
+      s->d_scols = (int *)dev_upload(E->cols, ((size_t)E->stored + LSB_SELL_ROWS) * sizeof(int));
+      s->d_svals = (double *)dev_upload(E->vals, ((size_t)E->stored + LSB_SELL_ROWS) * sizeof(double));
+      const int row_end = (int)(row_begin + n);
+      unsigned s1 = 0, s2 = E->nslice;
+      int ok = 1;
+      unsigned char *ext = (unsigned char *)calloc(E->nslice ? E->nslice : 1, 1);
+      for (unsigned k = 0; k < E->nslice; k++)
+        for (unsigned r = k * LSB_SELL_ROWS; r < n && r < (k + 1) * LSB_SELL_ROWS && !ext[k]; r++)
+          if (offs[r + 1] > offs[r] &&
+              (cols[offs[r]] < (int)row_begin || cols[offs[r + 1] - 1] >= row_end))
+            ext[k] = 1;
+      while (s1 < E->nslice && ext[s1])
+        s1++;
+      while (s2 > s1 && ext[s2 - 1])
+        s2--;
+      for (unsigned k = s1; k < s2; k++)
+        ok &= !ext[k];
+      free(ext);
+      s->ov_sok = ok && s2 > s1, s->ov_s1 = s1, s->ov_s2 = s2;
+      LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+      lsb_sell_free(E);
+    }
+  }
   LSB_CHK_HIP(hipStreamSynchronize(g_stream)); /* host staging is freed next */
   free(rb), free(offs), free(cols), free(lanes);
 
@@ -471,6 +515,7 @@ static void shard_free(struct shard *s) {
   lsb_hip_free(s->d_parts2), lsb_hip_free(s->d_st);
   lsb_hip_free(s->pd_offs), lsb_hip_free(s->pd_cols), lsb_hip_free(s->pd_vals);
   lsb_hip_free(s->pd_rowmap), lsb_hip_free(s->pd_rowblk), lsb_hip_free(s->pd_blklanes);
+  lsb_hip_free(s->d_sptr), lsb_hip_free(s->d_scols), lsb_hip_free(s->d_svals);
   free(s->h_pblk);
   free(s->recv), free(s->send);
 }
@@ -940,6 +985,12 @@ static void spmv_shard(struct shard *s, const double *xfull, double *y,
       lsb_k_dot(s->n, y, xdot, partials, np, g_stream);
     return;
   }
+  if (s->variant == LSB_SPMV_SELL) { /* lanes argument = first slice of the launch */
+    lsb_k_spmv(LSB_SPMV_SELL, s->n, (const int *)s->d_sptr, s->d_scols, s->d_svals, NULL, NULL,
+               s->nslice, 0, s->sp_flags, s->sp_grid, xfull, y, xdot, partials, np, st, NULL,
+               g_stream);
+    return;
+  }
   lsb_k_spmv(s->variant, s->n, s->d_offs, s->d_cols, s->d_vals, s->d_rowblk, s->d_blklanes,
              s->nblk, s->lanes, s->sp_flags, s->sp_grid, xfull, y, xdot, partials, np, st,
              NULL, g_stream);
@@ -956,9 +1007,11 @@ static void spmv_shard(struct shard *s, const double *xfull, double *y,
 static int can_overlap(const lsb_hip_solver *sv) {
   if (!sv->multi || !sv->o.overlap)
     return 0;
-  for (int i = 0; i < sv->nshard; i++)
-    if (!sv->sh[i].ov_ok || sv->sh[i].variant != LSB_SPMV_ADAPTIVE)
+  for (int i = 0; i < sv->nshard; i++) {
+    const struct shard *s = &sv->sh[i];
+    if (!(s->variant == LSB_SPMV_ADAPTIVE && s->ov_ok) && !(s->variant == LSB_SPMV_SELL && s->ov_sok))
       return 0;
+  }
   /* auto: the split SpMV costs 2 launches (direct path) or 2 launches and two
    * cross-stream events (RCCL), 6-20 us; a halo of >= 64 Ki doubles takes
    * longer than that on one xGMI link.  agree_halo is the largest halo of ANY
@@ -968,9 +1021,21 @@ static int can_overlap(const lsb_hip_solver *sv) {
   return 1;
 }
 
-static void spmv_range(struct shard *s, unsigned b0, unsigned b1, double *y, double *partials,
-                       unsigned *np, const struct lsb_pcg_state *st) {
+/* part 0: the rows that need no halo; 1 / 2: the ones before / after them */
+static void spmv_range(struct shard *s, int part, double *y, double *partials, unsigned *np,
+                       const struct lsb_pcg_state *st) {
   *np = 0;
+  if (s->variant == LSB_SPMV_SELL) {
+    const unsigned b0 = part == 0 ? s->ov_s1 : part == 1 ? 0 : s->ov_s2;
+    const unsigned b1 = part == 0 ? s->ov_s2 : part == 1 ? s->ov_s1 : s->nslice;
+    if (b1 > b0)
+      lsb_k_spmv(LSB_SPMV_SELL, s->n, (const int *)s->d_sptr, s->d_scols, s->d_svals, NULL, NULL,
+                 b1 - b0, b0, s->sp_flags, s->sp_grid, s->d_pfull, y, s->d_pfull + s->row_begin,
+                 partials, np, st, NULL, g_stream);
+    return;
+  }
+  const unsigned b0 = part == 0 ? s->ov_b1 : part == 1 ? 0 : s->ov_b2;
+  const unsigned b1 = part == 0 ? s->ov_b2 : part == 1 ? s->ov_b1 : s->nblk;
   if (b1 > b0)
     lsb_k_spmv(LSB_SPMV_ADAPTIVE, s->n, s->d_offs, s->d_cols, s->d_vals, s->d_rowblk + b0,
                s->d_blklanes + b0, b1 - b0, s->lanes, s->sp_flags, s->sp_grid, s->d_pfull, y,
@@ -1007,7 +1072,7 @@ static void exchange_and_spmv(lsb_hip_solver *sv, int sample) {
   unsigned na, nb, nc;
   for (int i = 0; i < sv->nshard; i++) {                         /* interior: no halo     */
     struct shard *s = &sv->sh[i];
-    spmv_range(s, s->ov_b1, s->ov_b2, s->d_q, s->d_parts_pq, &na, s->d_st);
+    spmv_range(s, 0, s->d_q, s->d_parts_pq, &na, s->d_st);
     s->npq = na;
   }
   if (sv->p2p_halo) {
@@ -1017,8 +1082,8 @@ static void exchange_and_spmv(lsb_hip_solver *sv, int sample) {
     LSB_CHK_HIP(hipStreamWaitEvent(g_stream, sv->ev_halo, 0));
   for (int i = 0; i < sv->nshard; i++) {                         /* boundary rows         */
     struct shard *s = &sv->sh[i];
-    spmv_range(s, 0, s->ov_b1, s->d_q, s->d_parts_pq + s->npq, &nb, s->d_st);
-    spmv_range(s, s->ov_b2, s->nblk, s->d_q, s->d_parts_pq + s->npq + nb, &nc, s->d_st);
+    spmv_range(s, 1, s->d_q, s->d_parts_pq + s->npq, &nb, s->d_st);
+    spmv_range(s, 2, s->d_q, s->d_parts_pq + s->npq + nb, &nc, s->d_st);
     s->npq += nb + nc;
   }
   if (sample >= 0) {
@@ -1045,18 +1110,39 @@ static void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
     s->sp_flags = (unsigned)o->spmv_tune & 3u;
     return;
   }
-  if ((s->variant != LSB_SPMV_ADAPTIVE && s->variant != LSB_SPMV_PANEL) ||
+  if (s->variant == LSB_SPMV_SELL && !s->d_sptr)
+    s->variant = LSB_SPMV_ADAPTIVE; /* the operator did not qualify for the copy */
+  if ((s->variant != LSB_SPMV_ADAPTIVE && s->variant != LSB_SPMV_PANEL &&
+       s->variant != LSB_SPMV_SELL) ||
       s->nnz < 4000000ull)
     return; /* small operators are launch-latency bound: nothing to tune */
   float best = 1e30f;
   unsigned bf = s->sp_flags, np;
   int bv = s->variant;
-  const int nvar = (s->pn && o->spmv_variant == LSB_SPMV_AUTO) ? 2 : 1;
-  for (int vi = 0; vi < nvar; vi++) {
-    if (nvar == 2)
-      s->variant = vi ? LSB_SPMV_PANEL : LSB_SPMV_ADAPTIVE;
+  /* candidates: the variant asked for, or (auto) every form this shard has */
+  int cand[3], ncand = 0;
+  if (o->spmv_variant == LSB_SPMV_AUTO) {
+    cand[ncand++] = LSB_SPMV_ADAPTIVE;
+    if (s->pn)
+      cand[ncand++] = LSB_SPMV_PANEL;
+    if (s->d_sptr)
+      cand[ncand++] = LSB_SPMV_SELL;
+  } else
+    cand[ncand++] = s->variant;
+  const unsigned grid0 = s->sp_grid;
+  unsigned bg = grid0;
+  for (int vi = 0; vi < ncand; vi++) {
+    s->variant = cand[vi];
     for (unsigned f = 0; f < 4; f++) {
-      s->sp_flags = f;
+      /* the sliced-ELL kernel has no prefetch flavour; its second pair of
+       * runs tries 6 instead of 8 resident workgroups per CU */
+      s->sp_grid = grid0;
+      if (s->variant == LSB_SPMV_SELL && (f & LSB_SP_PREFETCH)) {
+        if (o->spmv_grid > 0)
+          continue;
+        s->sp_grid = 1536;
+      }
+      s->sp_flags = s->variant == LSB_SPMV_SELL ? (f & LSB_SP_NT) : f;
       spmv_shard(s, s->d_pfull, s->d_q, s->d_pfull + s->row_begin, s->d_parts_pq, &np, NULL);
       LSB_CHK_HIP(hipEventRecord(sv->ev_t0, g_stream));
       for (int r = 0; r < 3; r++)
@@ -1069,9 +1155,10 @@ static void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
         fprintf(stderr, "hip_cdna4: spmv tune variant=%d flags=%u: %.1f us\n", s->variant, f,
                 ms * 1e3f / 3);
       if (ms < best)
-        best = ms, bf = f, bv = s->variant;
+        best = ms, bf = s->sp_flags, bv = s->variant, bg = s->sp_grid;
     }
   }
+  s->sp_grid = bg;
   s->variant = bv;
   s->sp_flags = bf;
 }
@@ -1687,12 +1774,16 @@ int lsb_hip_spmv_csr_f64(int variant, unsigned n, const int *d_offs,
     variant = d_rowblk ? LSB_SPMV_ADAPTIVE : LSB_SPMV_SUBWAVE;
   if (variant == LSB_SPMV_ADAPTIVE && (!d_rowblk || nblk == 0))
     return 2;
-  if (variant < LSB_SPMV_ADAPTIVE || variant > LSB_SPMV_SCALAR || n == 0)
+  if ((variant < LSB_SPMV_ADAPTIVE || variant > LSB_SPMV_SCALAR) && variant != LSB_SPMV_SELL)
+    return 2;
+  if (n == 0 || (variant == LSB_SPMV_SELL && nblk != (n + LSB_SELL_ROWS - 1) / LSB_SELL_ROWS))
     return 2;
   if (d_dot && (!d_work || !d_xdot))
     return 2;
   unsigned L = pow2_ceil(mean_row_len ? mean_row_len : 1);
   L = L < 2 ? 2 : (L > 64 ? 64 : L);
+  if (variant == LSB_SPMV_SELL)
+    L = 0; /* that launcher reads this argument as "first slice" */
   unsigned np = 0;
   lsb_k_spmv(variant, n, d_offs, d_cols, d_vals, d_rowblk, d_blklanes, nblk, L, flags, 0,
              d_x, d_y, d_dot ? d_xdot : NULL, d_dot ? d_work : NULL, &np, NULL, NULL, stream);

@@ -806,6 +806,90 @@ static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 static int g_blas1_nt = 1;
 
+// --------------------------------------------------------------------------
+// a2-1, sliced-ELL form (LSB_SPMV_SELL, host side lsb_csr_sellize): slices of
+// 128 rows stored column-major; lane l of the slice's wavefront owns rows 2l
+// and 2l+1 and reads their j-th entries as ONE int2 + ONE double2, so every
+// stream instruction of a wave moves a contiguous 512 B / 1 KiB, and for a
+// stencil the gathers of a wave are contiguous runs of x as well.  No LDS, no
+// barrier, no row offsets; a row's products are added in column order by one
+// lane (the order of a sequential CSR loop).  10 M-row 5-point: 140 us against
+// 152 us for the row-blocked kernel; 64 M-row 7-point: 1.23 ms against 1.55 ms
+// (tools/spmv_lab.hip).  Groups of four slices are dealt to the XCDs like the
+// row blocks of k_spmv_adaptive.  [s0, s0+ns) = the slices of this launch.
+// --------------------------------------------------------------------------
+typedef int i2v __attribute__((ext_vector_type(2)));
+typedef double sell_d2v __attribute__((ext_vector_type(2)));
+#define SELL_U 5
+template <int FLAGS>
+__global__ __launch_bounds__(WG, 6) void k_spmv_sell(
+    const unsigned *__restrict__ sptr, unsigned s0, unsigned ns, unsigned n,
+    const int *__restrict__ cols, const double *__restrict__ vals,
+    const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ xdot,
+    double *__restrict__ partials, const lsb_pcg_state *__restrict__ st) {
+  __shared__ double sred[4];
+  const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const unsigned gx = gridDim.x / NXCD, xcd = blockIdx.x % NXCD, slot = blockIdx.x / NXCD;
+  const unsigned ngrp = (ns + 3) / 4, chunk = (ngrp + NXCD - 1) / NXCD;
+  const unsigned g0 = xcd * chunk, g1 = min(g0 + chunk, ngrp);
+  const int stopped = st ? st->status : 0; // tested behind the first loads
+  double dot = 0.0;
+  for (unsigned g = g0 + slot; g < g1; g += gx) {
+    const unsigned si = __builtin_amdgcn_readfirstlane(g * 4 + wave);
+    if (si < ns) {
+      const unsigned s = s0 + si;
+      const unsigned base = sptr[s], len = (sptr[s + 1] - base) / LSB_SELL_ROWS;
+      const i2v *cp = (const i2v *)(cols + base) + lane;
+      const sell_d2v *vp = (const sell_d2v *)(vals + base) + lane;
+      double a0 = 0.0, a1 = 0.0;
+      for (unsigned j0 = 0; j0 < len; j0 += SELL_U) {
+        i2v c[SELL_U];
+        sell_d2v v[SELL_U];
+#pragma unroll
+        for (int u = 0; u < SELL_U; u++)
+          if (j0 + u < len) {
+            if (FLAGS & SP_NT) {
+              c[u] = __builtin_nontemporal_load(cp + (size_t)(j0 + u) * 64);
+              v[u] = __builtin_nontemporal_load(vp + (size_t)(j0 + u) * 64);
+            } else {
+              c[u] = cp[(size_t)(j0 + u) * 64];
+              v[u] = vp[(size_t)(j0 + u) * 64];
+            }
+          }
+        if (stopped)
+          return;
+#pragma unroll
+        for (int u = 0; u < SELL_U; u++)
+          if (j0 + u < len) {
+            a0 += v[u].x * x[c[u].x];
+            a1 += v[u].y * x[c[u].y];
+          }
+      }
+      const unsigned row = s * LSB_SELL_ROWS + 2 * lane;
+      if (row + 1 < n) {
+        const sell_d2v o = {a0, a1};
+        *(sell_d2v *)(y + row) = o;
+        if (xdot) {
+          dot += a0 * xdot[row];
+          dot += a1 * xdot[row + 1];
+        }
+      } else if (row < n) {
+        y[row] = a0;
+        if (xdot)
+          dot += a0 * xdot[row];
+      }
+    }
+  }
+  if (stopped)
+    return;
+  if (partials) {
+    double d[1] = {dot};
+    wg_sum<1>(d, sred);
+    if (tid == 0)
+      partials[blockIdx.x] = d[0];
+  }
+}
+
 extern "C" {
 
 void lsb_k_set_blas1_nt(int on) { g_blas1_nt = on ? 1 : 0; }
@@ -822,7 +906,11 @@ unsigned lsb_k_blas1_grid(unsigned n) {
 unsigned lsb_k_spmv_grid(int variant, unsigned n, unsigned nblk,
                          unsigned lanes_per_row, unsigned grid_cap) {
   unsigned items;
-  if (variant == LSB_SPMV_ADAPTIVE)
+  if (variant == LSB_SPMV_SELL) { /* four slices per workgroup step */
+    items = div_up(nblk, 4);
+    if (grid_cap == 0)
+      grid_cap = 1536;
+  } else if (variant == LSB_SPMV_ADAPTIVE)
     items = nblk;
   else if (variant == LSB_SPMV_SUBWAVE)
     items = div_up(n, WG / (lanes_per_row ? lanes_per_row : 1));
@@ -850,7 +938,17 @@ void lsb_k_spmv(int variant, unsigned n, const int *offs, const int *cols,
   const unsigned g = lsb_k_spmv_grid(variant, n, nblk, lanes_per_row, grid_cap);
   if (npartials)
     *npartials = g;
-  if (variant == LSB_SPMV_ADAPTIVE) {
+  if (variant == LSB_SPMV_SELL) {
+    /* offs = slice offsets, nblk = slices of this launch, rowblk (if given) =
+     * pointer whose VALUE is irrelevant; lanes_per_row = first slice */
+    const unsigned *sp = (const unsigned *)offs;
+    if (flags & SP_NT)
+      k_spmv_sell<SP_NT><<<g, WG, 0, s>>>(sp, lanes_per_row, nblk, n, cols, vals, x, y, xdot,
+                                          partials, st);
+    else
+      k_spmv_sell<0><<<g, WG, 0, s>>>(sp, lanes_per_row, nblk, n, cols, vals, x, y, xdot,
+                                      partials, st);
+  } else if (variant == LSB_SPMV_ADAPTIVE) {
 #define LSB_ADAPTIVE(FL)                                                       \
   case FL:                                                                     \
     k_spmv_adaptive<LSB_BLOCK_NNZ, FL><<<g, WG, 0, s>>>(                       \

@@ -495,3 +495,66 @@ double lsb_csr_mean_scatter(const struct csr *A, unsigned row_begin) {
     }
   return cnt ? sum / (double)cnt : 0.0;
 }
+
+/* ------------------------------------------------------------------------ */
+/* Sliced-ELL copy (LSB_SPMV_SELL).  No reference counterpart: a device      */
+/* layout of the same operator.                        */
+/* ------------------------------------------------------------------------ */
+unsigned long long lsb_csr_sell_stored(const struct csr *A) {
+  unsigned long long tot = 0;
+  for (unsigned r0 = 0; r0 < A->nrows; r0 += LSB_SELL_ROWS) {
+    unsigned len = 0;
+    const unsigned r1 = r0 + LSB_SELL_ROWS < A->nrows ? r0 + LSB_SELL_ROWS : A->nrows;
+    for (unsigned r = r0; r < r1; r++)
+      if (A->offs[r + 1] - A->offs[r] > len)
+        len = A->offs[r + 1] - A->offs[r];
+    tot += (unsigned long long)len * LSB_SELL_ROWS;
+  }
+  return tot;
+}
+
+struct lsb_sell *lsb_csr_sellize(const struct csr *A) {
+  if (!A)
+    return NULL;
+  const unsigned long long stored = lsb_csr_sell_stored(A);
+  if (stored > 0xFFFFFF00ull)
+    return NULL;
+  struct lsb_sell *S = lsb_calloc(struct lsb_sell, 1);
+  const unsigned n = A->nrows, ns = (n + LSB_SELL_ROWS - 1) / LSB_SELL_ROWS;
+  S->nrows = n, S->nslice = ns, S->stored = stored;
+  S->sptr = lsb_calloc(unsigned, (size_t)ns + 1);
+  S->cols = (int *)calloc((size_t)stored + LSB_SELL_ROWS, sizeof(int));
+  S->vals = (double *)calloc((size_t)stored + LSB_SELL_ROWS, sizeof(double));
+  if (!S->cols || !S->vals)
+    errx(EXIT_FAILURE, "lsb_csr_sellize: out of memory");
+  for (unsigned sl = 0; sl < ns; sl++) {
+    unsigned len = 0;
+    for (unsigned r = sl * LSB_SELL_ROWS; r < n && r < (sl + 1) * LSB_SELL_ROWS; r++)
+      if (A->offs[r + 1] - A->offs[r] > len)
+        len = A->offs[r + 1] - A->offs[r];
+    S->sptr[sl + 1] = S->sptr[sl] + len * LSB_SELL_ROWS;
+  }
+#pragma omp parallel for schedule(static)
+  for (unsigned sl = 0; sl < ns; sl++) {
+    const unsigned len = (S->sptr[sl + 1] - S->sptr[sl]) / LSB_SELL_ROWS;
+    for (unsigned l = 0; l < LSB_SELL_ROWS; l++) {
+      const unsigned r = sl * LSB_SELL_ROWS + l;
+      const unsigned a = r < n ? A->offs[r] : 0, b = r < n ? A->offs[r + 1] : 0;
+      const int padc = b > a ? (int)(A->cols[b - 1] - A->base) : 0;
+      for (unsigned j = 0; j < len; j++) {
+        const size_t at = (size_t)S->sptr[sl] + (size_t)j * LSB_SELL_ROWS + l;
+        if (a + j < b)
+          S->cols[at] = (int)(A->cols[a + j] - A->base), S->vals[at] = A->vals[a + j];
+        else
+          S->cols[at] = padc, S->vals[at] = 0.0;
+      }
+    }
+  }
+  return S;
+}
+
+void lsb_sell_free(struct lsb_sell *S) {
+  if (!S)
+    return;
+  free(S->sptr), free(S->cols), free(S->vals), free(S);
+}

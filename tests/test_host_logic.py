@@ -268,3 +268,53 @@ def test_cli_hip_without_gpu_is_quiet_noop():
     m = os.path.join(GOLD, "matrices", "I1_05x05.txt")
     r = _run("--matrix", m, "--solver", "hip", "--trials=2")
     assert r.returncode == 0 and "no usable GPU" in r.stderr and "===matrix" not in r.stdout
+
+
+def _sell_spmv(sptr, cols, vals, x, n):
+    """numpy evaluation of the sliced-ELL layout lsb_csr_sellize documents:
+    entry j of row 128 s + i sits at sptr[s] + 128 j + i."""
+    R = la.SELL_ROWS
+    y = np.zeros(len(sptr) * R - R)
+    for s in range(len(sptr) - 1):
+        ln = (int(sptr[s + 1]) - int(sptr[s])) // R
+        blkc = cols[sptr[s]:sptr[s + 1]].reshape(ln, R)
+        blkv = vals[sptr[s]:sptr[s + 1]].reshape(ln, R)
+        acc = np.zeros(R)
+        for j in range(ln):                       # column order, like a CSR row loop
+            acc += blkv[j] * x[blkc[j]]
+        y[s * R:(s + 1) * R] = acc
+    return y[:n]
+
+
+@pytest.mark.parametrize("spec", ["lap2d:nx=37,ny=23", "lap3d:nx=9,ny=8,nz=7",
+                                  "powerlaw:n=1500,avg=6,max=40,seed=4", "lap2d:nx=128,ny=1"])
+def test_sliced_ell_copy(spec):
+    A = la.lsbench_matrix_synth(spec)
+    sptr, cols, vals = la.lsb_csr_sellize(A)
+    n, R = A.nrows, la.SELL_ROWS
+    assert len(sptr) == (n + R - 1) // R + 1 and sptr[0] == 0
+    lens = np.diff(A.offs.astype(np.int64))
+    for s in range(len(sptr) - 1):                # every slice padded to its longest row
+        assert (int(sptr[s + 1]) - int(sptr[s])) == R * int(lens[s * R:(s + 1) * R].max())
+    assert np.count_nonzero(vals) == np.count_nonzero(A.vals)
+    assert cols.min() >= 0 and cols.max() < max(n, int(A.cols.max()) + 1)
+    x = np.random.default_rng(5).standard_normal(max(n, int(A.cols.max()) + 1))
+    y = _sell_spmv(sptr, cols, vals, x, n)
+    yo = O.spmv(A.offs, A.cols, A.vals, x)
+    assert np.allclose(y, yo, rtol=1e-13, atol=1e-13)
+    # padding entries point at a column the row already references
+    for r in (0, n // 2, n - 1):
+        s, i = divmod(r, R)
+        ln = (int(sptr[s + 1]) - int(sptr[s])) // R
+        rowc = cols[sptr[s]:sptr[s + 1]].reshape(ln, R)[:, i]
+        assert set(rowc.tolist()) == set(A.cols[A.offs[r]:A.offs[r + 1]].tolist())
+
+
+def test_sliced_ell_copy_base1(matrix_path):
+    A = la.lsbench_matrix_read(matrix_path("xn3b_A_10"))          # base-1 file
+    S = la.lsb_csr_symmetrize_upper(A)
+    sptr, cols, vals = la.lsb_csr_sellize(A)
+    x = np.random.default_rng(6).standard_normal(A.nrows)
+    yo = O.spmv(A.offs, A.cols - A.base, A.vals, x)
+    assert np.allclose(_sell_spmv(sptr, cols, vals, x, A.nrows), yo, rtol=1e-12, atol=1e-12)
+    assert S.nrows == A.nrows

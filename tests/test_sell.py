@@ -1,0 +1,105 @@
+"""LSB_SPMV_SELL: the sliced-ELL kernel (k_spmv_sell) against the oracle's CSR
+SpMV, on the shapes the row-blocked kernel is tested on, and inside solves."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from test_gpu_parity import GAMMA, _check_spmv, _dev, _edge_matrix
+
+pytestmark = pytest.mark.gpu
+
+
+def _sell_kernel(hip, A, x, flags, with_dot=True):
+    import torch
+    lib = hip._lib.load()
+    sptr, cols, vals = hip.lsb_csr_sellize(A)
+    pad = hip.SELL_ROWS                       # the kernel may read one slice row past the end
+    d = dict(sptr=_dev(sptr.astype(np.int32)), cols=_dev(np.concatenate([cols, np.zeros(pad, np.int32)])),
+             vals=_dev(np.concatenate([vals, np.zeros(pad)])), x=_dev(x))
+    y = torch.full((A.nrows,), float("nan"), dtype=torch.float64, device="cuda:0")
+    w = torch.zeros(lib.lsb_hip_partials_capacity(), dtype=torch.float64, device="cuda:0")
+    dot = torch.zeros(1, dtype=torch.float64, device="cuda:0")
+    rc = lib.lsb_hip_spmv_csr_f64(hip.SPMV_SELL, A.nrows, d["sptr"].data_ptr(), d["cols"].data_ptr(),
+                                  d["vals"].data_ptr(), None, None, len(sptr) - 1, 0, flags,
+                                  d["x"].data_ptr(), y.data_ptr(),
+                                  d["x"].data_ptr() if with_dot else None,
+                                  dot.data_ptr() if with_dot else None, w.data_ptr(),
+                                  lib.lsb_hip_stream())
+    assert rc == 0
+    lib.lsb_hip_sync()
+    return y.cpu().numpy(), dot.item()
+
+
+@pytest.mark.parametrize("flags", [0, 2])
+def test_sell_kernel_vs_oracle(hip, flags, matrix_path):
+    rng = np.random.default_rng(40 + flags)
+    mats = [hip.lsb_csr_symmetrize_upper(hip.lsbench_matrix_read(matrix_path("xn3b_A_18"))),
+            hip.lsbench_matrix_synth("lap2d:nx=301,ny=97"),          # n odd, not a slice multiple
+            hip.lsbench_matrix_synth("lap3d:nx=31,ny=17,nz=23"),
+            hip.lsbench_matrix_synth("lap2d:nx=700,ny=300"),
+            hip.lsbench_matrix_synth("powerlaw:n=20000,gamma=%r,max=512,seed=3" % GAMMA),
+            hip.lsbench_matrix_synth("lap2d:nx=1,ny=1"), hip.lsbench_matrix_synth("lap2d:nx=128,ny=1"),
+            hip.lsbench_matrix_synth("lap2d:nx=129,ny=1")]
+    for A in mats:
+        x = rng.standard_normal(A.nrows)
+        y, dot = _sell_kernel(hip, A, x, flags)
+        yo = _check_spmv(A, x, y)
+        assert abs(dot - float(x @ yo)) <= 1e-12 * max(np.abs(x * yo).sum(), 1e-300)
+    E, ncol = _edge_matrix(hip)               # empty rows, a 5000-entry row, rectangular gather
+    x = rng.standard_normal(ncol)
+    y, _ = _sell_kernel(hip, E, x, flags, with_dot=False)
+    _check_spmv(E, x, y)
+    assert y[0] == 0 and y[1] == 0 and y[-1] == 0
+    # wrong slice count for n is refused, not launched
+    lib = hip._lib.load()
+    assert lib.lsb_hip_spmv_csr_f64(hip.SPMV_SELL, 300, None, None, None, None, None, 1, 0, 0, None,
+                                    None, None, None, None, lib.lsb_hip_stream()) == 2
+
+
+@pytest.mark.parametrize("name", ["xn3b_A_18", "tj7a_A_12"])
+def test_solves_through_sell_match_golden(hip, name, matrix_path, golden_x):
+    A = hip.lsbench_matrix_read(matrix_path(name))
+    s = hip.Solver(A, hip.default_opts(spmv_variant=hip.SPMV_SELL, use_graph=0))
+    assert s.spmv_variant == hip.SPMV_SELL
+    x, r = s.solve(O.rhs(A.nrows))
+    s.destroy()
+    xg = golden_x(name)
+    assert r.status == 1 and np.linalg.norm(x - xg) / np.linalg.norm(xg) <= 1e-10
+
+
+@pytest.mark.parametrize("comm", ["COMM_RCCL", "COMM_P2P"])
+def test_sharded_solve_with_sell_and_overlap(hip, comm):
+    """virtual shards, each with its own sliced-ELL copy (global column ids),
+    interior / boundary SLICE ranges for the overlapped exchange"""
+    L = hip.lsbench_matrix_synth("lap2d:nx=300,ny=200")
+    offs, cols, vals = O.lap2d(300, 200)
+    b = O.rhs(L.nrows)
+    xo, ito, _, _ = O.pcg_jacobi(offs, cols, vals, b, tol=1e-10)
+    for ov in (0, 1):
+        s = hip.Solver(L, hip.default_opts(op_mode=hip.OP_RAW, nvirt=3, overlap=ov, tol=1e-10,
+                                           comm=getattr(hip, comm), spmv_variant=hip.SPMV_SELL,
+                                           krylov=hip.KRYLOV_AUTO))
+        assert s.spmv_variant == hip.SPMV_SELL and s.overlaps == bool(ov)
+        x, r = s.solve(b)
+        s.destroy()
+        assert r.status == 1 and abs(int(r.iters) - ito) <= 4
+        assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-8
+
+
+def test_tuning_pass_picks_among_forms(hip):
+    """A 6 M-nnz stencil has all forms; the pass keeps one of them and the
+    SpMV through the solver agrees with the oracle whichever it is."""
+    import torch
+    A = hip.lsbench_matrix_synth("lap2d:nx=1200,ny=1000")
+    s = hip.Solver(A, hip.default_opts(op_mode=hip.OP_RAW))
+    assert s.spmv_variant in (hip.SPMV_ADAPTIVE, hip.SPMV_SELL)
+    x = np.random.default_rng(8).standard_normal(A.nrows)
+    d_y = torch.empty(A.nrows, dtype=torch.float64, device="cuda:0")
+    s.spmv_dev(_dev(x), d_y)
+    _check_spmv(A, x, d_y.cpu().numpy())
+    s.destroy()
+    # a ragged operator gets no sliced-ELL copy at all (padding > 1/8)
+    P = hip.lsbench_matrix_synth("powerlaw:n=300000,gamma=%r,max=4096,seed=5" % GAMMA)
+    s = hip.Solver(P, hip.default_opts(op_mode=hip.OP_RAW, precond=hip.PRECOND_NONE))
+    assert s.spmv_variant != hip.SPMV_SELL
+    s.destroy()

@@ -578,6 +578,133 @@ __global__ __launch_bounds__(WG, MINW) void k_adaptive_cyc(const int *__restrict
   }
 }
 
+// ---- SELL-64: rows in slices of 64 (one wavefront), a slice stored column-
+// major and padded to its longest row: lane i owns row 64s+i, every stream load
+// of a wave is one contiguous 256 B / 512 B run, the gathers of a stencil row
+// group are contiguous too, no LDS, no barrier, no row offsets.  cols/vals point
+// at the SELL arrays, g_sell_ptr at the slice offsets; `per` carries n.
+__device__ const unsigned *g_sell_ptr;
+template <int FLAGS, int U>
+__global__ __launch_bounds__(WG, 8) void k_sell(const int *, unsigned nslice, unsigned n, const int *,
+                                                const int *__restrict__ cols,
+                                                const double *__restrict__ vals,
+                                                const double *__restrict__ x,
+                                                double *__restrict__ y,
+                                                double *__restrict__ partials) {
+  __shared__ double sred[4];
+  const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const unsigned gx = gridDim.x / NXCD, xcd = blockIdx.x % NXCD, slot = blockIdx.x / NXCD;
+  const unsigned ngrp = (nslice + 3) / 4, chunk = (ngrp + NXCD - 1) / NXCD;
+  const unsigned g0 = xcd * chunk, g1 = g0 + chunk < ngrp ? g0 + chunk : ngrp;
+  const unsigned *sp = g_sell_ptr;
+  double dot = 0.0;
+  for (unsigned g = g0 + slot; g < g1; g += gx) {
+    const unsigned s = __builtin_amdgcn_readfirstlane(g * 4 + wave);
+    if (s < nslice) {
+      const unsigned base = sp[s], len = (sp[s + 1] - base) >> 6;
+      const int *cp = cols + base + lane;
+      const double *vp = vals + base + lane;
+      double acc = 0.0;
+      int c[U];
+      double v[U];
+#pragma unroll
+      for (int u = 0; u < U; u++)
+        if ((unsigned)u < len) {
+          c[u] = ldg<FLAGS>(cp + u * 64);
+          v[u] = ldg<FLAGS>(vp + u * 64);
+        }
+#pragma unroll
+      for (int u = 0; u < U; u++)
+        if ((unsigned)u < len)
+          acc += v[u] * x[c[u]];
+      for (unsigned j = U; j < len; j++)
+        acc += ldg<FLAGS>(vp + j * 64) * x[ldg<FLAGS>(cp + j * 64)];
+      const unsigned row = s * 64 + lane;
+      if (row < n) {
+        y[row] = acc;
+        if (!(FLAGS & F_NODOT))
+          dot += acc * x[row];
+      }
+    }
+  }
+  if (!(FLAGS & F_NODOT)) {
+    double d[1] = {dot};
+    wg_sum<1>(d, sred);
+    if (tid == 0)
+      partials[xcd * gx + slot] = d[0];
+  }
+}
+
+// ---- SELL-128x2: slices of 128 rows, lane l owns rows 2l and 2l+1, whose j-th
+// entries sit side by side: 8 B column / 16 B value loads per lane.
+typedef int lab_i2v __attribute__((ext_vector_type(2)));
+typedef double lab_d2vb __attribute__((ext_vector_type(2)));
+__device__ const unsigned *g_sell2_ptr;
+template <int FLAGS, int U, int MINW>
+__global__ __launch_bounds__(WG, MINW) void k_sell2(const int *, unsigned nslice, unsigned n, const int *,
+                                                 const int *__restrict__ cols,
+                                                 const double *__restrict__ vals,
+                                                 const double *__restrict__ x,
+                                                 double *__restrict__ y,
+                                                 double *__restrict__ partials) {
+  __shared__ double sred[4];
+  const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const unsigned gx = gridDim.x / NXCD, xcd = blockIdx.x % NXCD, slot = blockIdx.x / NXCD;
+  const unsigned ngrp = (nslice + 3) / 4, chunk = (ngrp + NXCD - 1) / NXCD;
+  const unsigned g0 = xcd * chunk, g1 = g0 + chunk < ngrp ? g0 + chunk : ngrp;
+  const unsigned *sp = g_sell2_ptr;
+  double dot = 0.0;
+  for (unsigned g = g0 + slot; g < g1; g += gx) {
+    const unsigned s = __builtin_amdgcn_readfirstlane(g * 4 + wave);
+    if (s < nslice) {
+      const unsigned base = sp[s], len = (sp[s + 1] - base) >> 7;
+      const lab_i2v *cp = (const lab_i2v *)(cols + base) + lane;
+      const lab_d2vb *vp = (const lab_d2vb *)(vals + base) + lane;
+      double a0 = 0.0, a1 = 0.0;
+      lab_i2v c[U];
+      lab_d2vb v[U];
+#pragma unroll
+      for (int u = 0; u < U; u++)
+        if ((unsigned)u < len) {
+          c[u] = ldg<FLAGS>(cp + u * 64);
+          v[u] = ldg<FLAGS>(vp + u * 64);
+        }
+#pragma unroll
+      for (int u = 0; u < U; u++)
+        if ((unsigned)u < len) {
+          a0 += v[u].x * x[c[u].x];
+          a1 += v[u].y * x[c[u].y];
+        }
+      for (unsigned j = U; j < len; j++) {
+        const lab_i2v cc = ldg<FLAGS>(cp + j * 64);
+        const lab_d2vb vv = ldg<FLAGS>(vp + j * 64);
+        a0 += vv.x * x[cc.x];
+        a1 += vv.y * x[cc.y];
+      }
+      const unsigned row = s * 128 + 2 * lane;
+      if (row + 1 < n) {
+        lab_d2vb o = {a0, a1};
+        *(lab_d2vb *)(y + row) = o;
+        if (!(FLAGS & F_NODOT)) {
+          const lab_d2vb xx = *(const lab_d2vb *)(x + row);
+          dot += a0 * xx.x;
+          dot += a1 * xx.y;
+        }
+      } else if (row < n) {
+        y[row] = a0;
+        if (!(FLAGS & F_NODOT))
+          dot += a0 * x[row];
+      }
+    }
+  }
+  if (!(FLAGS & F_NODOT)) {
+    double d[1] = {dot};
+    wg_sum<1>(d, sred);
+    if (tid == 0)
+      partials[xcd * gx + slot] = d[0];
+  }
+}
+
 // ---- V5: V3 with 16 B/lane stream loads.  A block's nnz range [j0,j1) is
 // widened to 4-aligned [j0&~3, ...); each lane owns QPT quads of 4 consecutive
 // non-zeros (cols as int4, vals as 2 x double2).  Row blocks are built with
@@ -989,6 +1116,14 @@ LAUNCHER(l_wave512_pf7, (k_wave<512, F_PREFETCH, 7>))
 LAUNCHER(l_wave512_pf6, (k_wave<512, F_PREFETCH, 6>))
 LAUNCHER(l_cyc_pf_nt, (k_adaptive_cyc<2048, F_CYCLIC | F_PREFETCH | F_NT>))
 LAUNCHER(l_cyc_nt, (k_adaptive_cyc<2048, F_CYCLIC | F_NT>))
+LAUNCHER(l_sell_nt8, (k_sell<F_NT, 8>))
+LAUNCHER(l_sell2_nt8, (k_sell2<F_NT, 8, 4>))
+LAUNCHER(l_sell2_nt5, (k_sell2<F_NT, 5, 6>))
+LAUNCHER(l_sell2_nt7, (k_sell2<F_NT, 7, 5>))
+LAUNCHER(l_sell2_nt4, (k_sell2<F_NT, 4, 8>))
+LAUNCHER(l_sell_8, (k_sell<0, 8>))
+LAUNCHER(l_sell_nt4, (k_sell<F_NT, 4>))
+LAUNCHER(l_sell_nt8_nodot, (k_sell<F_NT | F_NODOT, 8>))
 LAUNCHER(l_c16, (k_adaptive_cyc<2048, F_CYCLIC | F_NT | F_PREFETCH | F_C16>))
 LAUNCHER(l_c16_nopf, (k_adaptive_cyc<2048, F_CYCLIC | F_NT | F_C16>))
 LAUNCHER(l_c16w, (k_adaptive_cyc<2048, F_CYCLIC | F_NT | F_PREFETCH | F_C16W>))
@@ -1046,6 +1181,15 @@ int main(int argc, char **argv) {
       {"adaptive cap2048 g2048 (round-1a lib)", 2048, l_base2048, 2048},
       {"cyc+prefetch+nt cap2048 (library)", 2048, l_cyc_pf_nt, 2048},
       {"cyc+nt cap2048", 2048, l_cyc_nt, 2048},
+      {"SELL64 nt U8", 2048, l_sell_nt8, 2048},
+      {"SELL128x2 nt U8 occ4", 2048, l_sell2_nt8, 1024},
+      {"SELL128x2 nt U7 occ5", 2048, l_sell2_nt7, 1280},
+      {"SELL128x2 nt U5 occ6", 2048, l_sell2_nt5, 1536},
+      {"SELL128x2 nt U4 occ8", 2048, l_sell2_nt4, 2048},
+      {"SELL128x2 nt U8 occ4 g2048", 2048, l_sell2_nt8, 2048},
+      {"SELL64 nt U4", 2048, l_sell_nt4, 2048},
+
+      {"probe: SELL64 nt U8 no dot", 2048, l_sell_nt8_nodot, 2048},
       {"C16 cyc+pf+nt (int16 row-relative cols)", 2048, l_c16, 2048},
       {"C16 cyc+nt", 2048, l_c16_nopf, 2048},
       {"C16W cyc+pf+nt (4 windows x 14 bit)", 2048, l_c16w, 2048},
@@ -1072,6 +1216,74 @@ int main(int argc, char **argv) {
       rbs.push_back({v.cap, {d, (unsigned)rb.size() - 1}});
       v.d_rb = d, v.nblk = (unsigned)rb.size() - 1;
     }
+  }
+  // SELL-64
+  int *d_scols = nullptr;
+  double *d_svals = nullptr;
+  unsigned nslice = (unsigned)((A.n + 63) / 64);
+  {
+    std::vector<unsigned> sptr(nslice + 1, 0);
+    for (unsigned sl = 0; sl < nslice; sl++) {
+      int len = 0;
+      for (int r = sl * 64; r < std::min<long>(A.n, (long)sl * 64 + 64); r++)
+        len = std::max(len, A.offs[r + 1] - A.offs[r]);
+      sptr[sl + 1] = sptr[sl] + 64u * (unsigned)len;
+    }
+    const size_t tot = sptr[nslice];
+    std::vector<int> sc(tot + 64, 0);
+    std::vector<double> sv(tot + 64, 0.0);
+#pragma omp parallel for
+    for (unsigned sl = 0; sl < nslice; sl++) {
+      const unsigned len = (sptr[sl + 1] - sptr[sl]) / 64;
+      for (unsigned l = 0; l < 64; l++) {
+        const long r = (long)sl * 64 + l;
+        const int a = r < A.n ? A.offs[r] : 0, b = r < A.n ? A.offs[r + 1] : 0;
+        const int padc = b > a ? A.cols[b - 1] : 0;
+        for (unsigned j = 0; j < len; j++) {
+          const size_t at = (size_t)sptr[sl] + (size_t)j * 64 + l;
+          if (a + (int)j < b) sc[at] = A.cols[a + j], sv[at] = A.vals[a + j];
+          else sc[at] = padc, sv[at] = 0.0;
+        }
+      }
+    }
+    printf("SELL-64: %u slices, %zu stored entries for %zu non-zeros (padding %.3f%%)\n", nslice, tot, nnz,
+           100.0 * ((double)tot - (double)nnz) / (double)nnz);
+    d_scols = upload(sc), d_svals = upload(sv);
+    unsigned *d_sp = upload(sptr);
+    CHK(hipMemcpyToSymbol(HIP_SYMBOL(g_sell_ptr), &d_sp, sizeof(d_sp)));
+  }
+  // SELL-128x2
+  int *d_s2cols = nullptr;
+  double *d_s2vals = nullptr;
+  unsigned nslice2 = (unsigned)((A.n + 127) / 128);
+  {
+    std::vector<unsigned> sptr(nslice2 + 1, 0);
+    for (unsigned sl = 0; sl < nslice2; sl++) {
+      int len = 0;
+      for (long r = (long)sl * 128; r < std::min<long>(A.n, (long)sl * 128 + 128); r++)
+        len = std::max(len, A.offs[r + 1] - A.offs[r]);
+      sptr[sl + 1] = sptr[sl] + 128u * (unsigned)len;
+    }
+    const size_t tot = sptr[nslice2];
+    std::vector<int> sc(tot + 128, 0);
+    std::vector<double> sv(tot + 128, 0.0);
+#pragma omp parallel for
+    for (unsigned sl = 0; sl < nslice2; sl++) {
+      const unsigned len = (sptr[sl + 1] - sptr[sl]) / 128;
+      for (unsigned l = 0; l < 128; l++) {
+        const long r = (long)sl * 128 + l;
+        const int a = r < A.n ? A.offs[r] : 0, b = r < A.n ? A.offs[r + 1] : 0;
+        const int padc = b > a ? A.cols[b - 1] : 0;
+        for (unsigned j = 0; j < len; j++) {
+          const size_t at = (size_t)sptr[sl] + (size_t)j * 128 + l; // rows 2l,2l+1 adjacent
+          if (a + (int)j < b) sc[at] = A.cols[a + j], sv[at] = A.vals[a + j];
+          else sc[at] = padc, sv[at] = 0.0;
+        }
+      }
+    }
+    d_s2cols = upload(sc), d_s2vals = upload(sv);
+    unsigned *d_sp = upload(sptr);
+    CHK(hipMemcpyToSymbol(HIP_SYMBOL(g_sell2_ptr), &d_sp, sizeof(d_sp)));
   }
   // 16-bit column encodings over the cap-2048 row blocks
   short *d_c16 = nullptr;
@@ -1127,6 +1339,16 @@ int main(int argc, char **argv) {
       per = (unsigned)std::max(8.0, std::round(bw / rows_per_blk));
     }
     const int *cp = d_cols;
+    if (v.name.find("SELL128x2") != std::string::npos) {
+      unsigned gs = std::min(v.maxgrid, ((((nslice2 + 3) / 4) + 7) / 8) * 8);
+      v.launch(v, gs, (unsigned)A.n, nslice2, v.d_rb, d_offs, d_s2cols, d_s2vals, d_x, d_y, d_parts, (int)nnz);
+      return;
+    }
+    if (v.name.find("SELL64") != std::string::npos) {
+      unsigned gs = std::min(v.maxgrid, ((((nslice + 3) / 4) + 7) / 8) * 8);
+      v.launch(v, gs, (unsigned)A.n, nslice, v.d_rb, d_offs, d_scols, d_svals, d_x, d_y, d_parts, (int)nnz);
+      return;
+    }
     if (v.name.rfind("C16W", 0) == 0) cp = (const int *)d_c16w;
     else if (v.name.rfind("C16", 0) == 0) cp = (const int *)d_c16;
     if (v.name.rfind("C16", 0) == 0 && !cp) return;
