@@ -215,13 +215,25 @@ struct lsb_sell {
   unsigned nrows, nslice;
   unsigned long long stored; /* entries incl. padding = sptr[nslice]        */
   unsigned *sptr;            /* nslice+1                                    */
-  int *cols;                 /* stored (+ LSB_SELL_ROWS slack)              */
+  int *cols;                 /* stored (+ LSB_SELL_ROWS slack); NULL in the
+                                16-bit form                                 */
   double *vals;
+  /* 16-bit form (lsb_csr_sellize16): column of the entry in slot j of row r =
+   * r + row_begin + sbase[sptr[s]/128 + j] + codes[.]; a slot of a slice holds
+   * entries of ONE diagonal band (+-32767 around its base), so a row's entries
+   * may be interleaved with padding (value 0: the kernel does not gather for
+   * those).  Entries of a row keep their column order. */
+  short *codes;              /* stored, or NULL in the 32-bit form          */
+  int *sbase;                /* stored / LSB_SELL_ROWS                      */
 };
 /* entries a sliced-ELL copy of A would store (to decide before building it) */
 unsigned long long lsb_csr_sell_stored(const struct csr *A);
 /* NULL when the copy would not fit 32-bit offsets */
 struct lsb_sell *lsb_csr_sellize(const struct csr *A);
+/* The 16-bit form, 10 instead of 12 bytes per entry; row_begin = global index
+ * of A's first row (column ids are global).  NULL when some slice would need
+ * more than 255 slots or the copy does not fit 32-bit offsets. */
+struct lsb_sell *lsb_csr_sellize16(const struct csr *A, unsigned row_begin);
 void lsb_sell_free(struct lsb_sell *S);
 /* mean |col - (row + row_begin)| over a sample of the rows */
 double lsb_csr_mean_scatter(const struct csr *A, unsigned row_begin);
@@ -337,7 +349,12 @@ int lsb_hip_comm_barrier(void);
  * (two-stage, fixed order; d_work must then hold
  * lsb_hip_partials_capacity() doubles). */
 /* LSB_SPMV_SELL: pass the device copies of lsb_sell's sptr as d_offs, cols as
- * d_cols, vals as d_vals and nslice as nblk (d_rowblk, d_blklanes unused). */
+ * d_cols, vals as d_vals and nslice as nblk (d_rowblk, d_blklanes unused).
+ * With flags & LSB_SPMV_FLAG_C16 (the 16-bit form, row_begin = 0): codes as
+ * d_cols and sbase as d_rowblk. */
+#define LSB_SPMV_FLAG_PREFETCH 1u
+#define LSB_SPMV_FLAG_NT 2u
+#define LSB_SPMV_FLAG_C16 4u
 int lsb_hip_spmv_csr_f64(int variant, unsigned n, const int *d_offs,
                          const int *d_cols, const double *d_vals,
                          const int *d_rowblk, const unsigned char *d_blklanes,

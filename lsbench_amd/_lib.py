@@ -21,6 +21,7 @@ PRECOND_JACOBI, PRECOND_NONE = 0, 1
 KRYLOV_PCG, KRYLOV_GMRES, KRYLOV_PCG1, KRYLOV_AUTO = 0, 1, 2, 3
 SPMV_AUTO, SPMV_ADAPTIVE, SPMV_SUBWAVE, SPMV_SCALAR, SPMV_PANEL, SPMV_SELL = 0, 1, 2, 3, 4, 5
 SELL_ROWS = 128
+SPMV_FLAG_PREFETCH, SPMV_FLAG_NT, SPMV_FLAG_C16 = 1, 2, 4
 STATUS_RUNNING, STATUS_CONVERGED, STATUS_BREAKDOWN, STATUS_MAXIT = 0, 1, 2, 3
 STATUS_COMM = 4
 COMM_AUTO, COMM_RCCL, COMM_P2P = 0, 1, 2
@@ -73,7 +74,8 @@ class Sell(C.Structure):
     """struct lsb_sell."""
     _fields_ = [("nrows", C.c_uint), ("nslice", C.c_uint), ("stored", C.c_ulonglong),
                 ("sptr", C.POINTER(C.c_uint)), ("cols", C.POINTER(C.c_int)),
-                ("vals", C.POINTER(C.c_double))]
+                ("vals", C.POINTER(C.c_double)), ("codes", C.POINTER(C.c_short)),
+                ("sbase", C.POINTER(C.c_int))]
 
 
 class Xfer(C.Structure):
@@ -119,6 +121,7 @@ SIGNATURES = {
     "lsb_panel_csr_free": (None, [C.POINTER(PanelCsr)]),
     "lsb_csr_sell_stored": (C.c_ulonglong, [_csrp]),
     "lsb_csr_sellize": (C.POINTER(Sell), [_csrp]),
+    "lsb_csr_sellize16": (C.POINTER(Sell), [_csrp, _u]),
     "lsb_sell_free": (None, [C.POINTER(Sell)]),
     "lsb_csr_mean_scatter": (_d, [_csrp, _u]),
     "lsb_csr_col_hull": (None, [_csrp, C.POINTER(_u), C.POINTER(_u)]),

@@ -148,6 +148,22 @@ def lsb_csr_sellize(A):
     return sptr, cols, vals
 
 
+def lsb_csr_sellize16(A, row_begin=0):
+    """(sptr, codes, sbase, vals) of the 16-bit sliced-ELL copy, or None when
+    the operator cannot be encoded."""
+    lib = L.load()
+    p = lib.lsb_csr_sellize16(A.ptr, row_begin)
+    if not p:
+        return None
+    S = p.contents
+    sptr = np.ctypeslib.as_array(S.sptr, (S.nslice + 1,)).copy()
+    codes = np.ctypeslib.as_array(S.codes, (max(S.stored, 1),)).copy()[:S.stored]
+    vals = np.ctypeslib.as_array(S.vals, (max(S.stored, 1),)).copy()[:S.stored]
+    sbase = np.ctypeslib.as_array(S.sbase, (S.stored // L.SELL_ROWS + 1,)).copy()[:S.stored // L.SELL_ROWS]
+    lib.lsb_sell_free(p)
+    return sptr, codes, sbase, vals
+
+
 def lsb_csr_rcm(A):
     perm = np.zeros(A.nrows, np.uint32)
     L.check(L.load().lsb_csr_rcm(A.ptr, perm.ctypes.data_as(C.POINTER(C.c_uint))), "rcm")

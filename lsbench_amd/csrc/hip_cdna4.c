@@ -232,6 +232,11 @@ struct shard {
   double *d_svals;
   unsigned nslice, ov_s1, ov_s2;
   int ov_sok;
+  /* ... and its 16-bit-code form (LSB_SP_C16 in sp_flags), own slice offsets */
+  unsigned *d_sptr16;
+  short *d_scodes;
+  int *d_sbase;
+  double *d_svals16;
   double *d_parts_pq, *d_parts2;
   double *d_scal; /* [0] p.q   [1] r.z'  [2] r.r   (multi-shard path) */
   struct lsb_pcg_state *d_st;
@@ -466,6 +471,21 @@ static void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
       s->ov_sok = ok && s2 > s1, s->ov_s1 = s1, s->ov_s2 = s2;
       LSB_CHK_HIP(hipStreamSynchronize(g_stream));
       lsb_sell_free(E);
+      /* 10 instead of 12 bytes per entry where every slot of every slice is
+       * one diagonal band (stencils, banded meshes) */
+      struct lsb_sell *H = getenv("LSBENCH_HIP_NO_C16") ? NULL : lsb_csr_sellize16(&gview, row_begin);
+      if (H && H->stored > s->nnz + s->nnz / 8) {
+        lsb_sell_free(H);
+        H = NULL;
+      }
+      if (H) {
+        s->d_sptr16 = (unsigned *)dev_upload(H->sptr, ((size_t)H->nslice + 1) * sizeof(unsigned));
+        s->d_scodes = (short *)dev_upload(H->codes, ((size_t)H->stored + LSB_SELL_ROWS) * sizeof(short));
+        s->d_sbase = (int *)dev_upload(H->sbase, ((size_t)H->stored / LSB_SELL_ROWS + 1) * sizeof(int));
+        s->d_svals16 = (double *)dev_upload(H->vals, ((size_t)H->stored + LSB_SELL_ROWS) * sizeof(double));
+        LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+        lsb_sell_free(H);
+      }
     }
   }
   LSB_CHK_HIP(hipStreamSynchronize(g_stream)); /* host staging is freed next */
@@ -516,6 +536,8 @@ static void shard_free(struct shard *s) {
   lsb_hip_free(s->pd_offs), lsb_hip_free(s->pd_cols), lsb_hip_free(s->pd_vals);
   lsb_hip_free(s->pd_rowmap), lsb_hip_free(s->pd_rowblk), lsb_hip_free(s->pd_blklanes);
   lsb_hip_free(s->d_sptr), lsb_hip_free(s->d_scols), lsb_hip_free(s->d_svals);
+  lsb_hip_free(s->d_sptr16), lsb_hip_free(s->d_scodes), lsb_hip_free(s->d_sbase);
+  lsb_hip_free(s->d_svals16);
   free(s->h_pblk);
   free(s->recv), free(s->send);
 }
@@ -967,6 +989,17 @@ static void allreduce_pq(lsb_hip_solver *sv, unsigned cnt, int with2) {
   allreduce_scal(sv, 0, cnt);
 }
 
+static void sell_launch(struct shard *s, unsigned s0, unsigned ns, const double *xfull, double *y,
+                        const double *xdot, double *partials, unsigned *np,
+                        const struct lsb_pcg_state *st) {
+  if ((s->sp_flags & LSB_SP_C16) && s->d_scodes)
+    lsb_k_spmv_sell(s->sp_flags, s->sp_grid, s->d_sptr16, s0, ns, s->n, s->row_begin, s->d_scodes,
+                    s->d_sbase, s->d_svals16, xfull, y, xdot, partials, np, st, g_stream);
+  else
+    lsb_k_spmv_sell(s->sp_flags & ~LSB_SP_C16, s->sp_grid, s->d_sptr, s0, ns, s->n, s->row_begin,
+                    s->d_scols, NULL, s->d_svals, xfull, y, xdot, partials, np, st, g_stream);
+}
+
 static void spmv_shard(struct shard *s, const double *xfull, double *y,
                        const double *xdot, double *partials, unsigned *np,
                        const struct lsb_pcg_state *st) {
@@ -985,10 +1018,8 @@ static void spmv_shard(struct shard *s, const double *xfull, double *y,
       lsb_k_dot(s->n, y, xdot, partials, np, g_stream);
     return;
   }
-  if (s->variant == LSB_SPMV_SELL) { /* lanes argument = first slice of the launch */
-    lsb_k_spmv(LSB_SPMV_SELL, s->n, (const int *)s->d_sptr, s->d_scols, s->d_svals, NULL, NULL,
-               s->nslice, 0, s->sp_flags, s->sp_grid, xfull, y, xdot, partials, np, st, NULL,
-               g_stream);
+  if (s->variant == LSB_SPMV_SELL) {
+    sell_launch(s, 0, s->nslice, xfull, y, xdot, partials, np, st);
     return;
   }
   lsb_k_spmv(s->variant, s->n, s->d_offs, s->d_cols, s->d_vals, s->d_rowblk, s->d_blklanes,
@@ -1029,9 +1060,7 @@ static void spmv_range(struct shard *s, int part, double *y, double *partials, u
     const unsigned b0 = part == 0 ? s->ov_s1 : part == 1 ? 0 : s->ov_s2;
     const unsigned b1 = part == 0 ? s->ov_s2 : part == 1 ? s->ov_s1 : s->nslice;
     if (b1 > b0)
-      lsb_k_spmv(LSB_SPMV_SELL, s->n, (const int *)s->d_sptr, s->d_scols, s->d_svals, NULL, NULL,
-                 b1 - b0, b0, s->sp_flags, s->sp_grid, s->d_pfull, y, s->d_pfull + s->row_begin,
-                 partials, np, st, NULL, g_stream);
+      sell_launch(s, b0, b1 - b0, s->d_pfull, y, s->d_pfull + s->row_begin, partials, np, st);
     return;
   }
   const unsigned b0 = part == 0 ? s->ov_b1 : part == 1 ? 0 : s->ov_b2;
@@ -1107,7 +1136,7 @@ static void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
   s->sp_flags = LSB_SP_PREFETCH | LSB_SP_NT;
   s->sp_grid = o->spmv_grid > 0 ? (unsigned)o->spmv_grid : LSB_MAX_PARTIALS;
   if (o->spmv_tune >= 0) {
-    s->sp_flags = (unsigned)o->spmv_tune & 3u;
+    s->sp_flags = (unsigned)o->spmv_tune & 7u; /* bit 2: 16-bit codes, where that copy exists */
     return;
   }
   if (s->variant == LSB_SPMV_SELL && !s->d_sptr)
@@ -1119,48 +1148,61 @@ static void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
   float best = 1e30f;
   unsigned bf = s->sp_flags, np;
   int bv = s->variant;
-  /* candidates: the variant asked for, or (auto) every form this shard has */
-  int cand[3], ncand = 0;
-  if (o->spmv_variant == LSB_SPMV_AUTO) {
-    cand[ncand++] = LSB_SPMV_ADAPTIVE;
-    if (s->pn)
-      cand[ncand++] = LSB_SPMV_PANEL;
-    if (s->d_sptr)
-      cand[ncand++] = LSB_SPMV_SELL;
-  } else
-    cand[ncand++] = s->variant;
   const unsigned grid0 = s->sp_grid;
   unsigned bg = grid0;
-  for (int vi = 0; vi < ncand; vi++) {
-    s->variant = cand[vi];
-    for (unsigned f = 0; f < 4; f++) {
-      /* the sliced-ELL kernel has no prefetch flavour; its second pair of
-       * runs tries 6 instead of 8 resident workgroups per CU */
-      s->sp_grid = grid0;
-      if (s->variant == LSB_SPMV_SELL && (f & LSB_SP_PREFETCH)) {
-        if (o->spmv_grid > 0)
-          continue;
-        s->sp_grid = 1536;
-      }
-      s->sp_flags = s->variant == LSB_SPMV_SELL ? (f & LSB_SP_NT) : f;
-      spmv_shard(s, s->d_pfull, s->d_q, s->d_pfull + s->row_begin, s->d_parts_pq, &np, NULL);
-      LSB_CHK_HIP(hipEventRecord(sv->ev_t0, g_stream));
-      for (int r = 0; r < 3; r++)
-        spmv_shard(s, s->d_pfull, s->d_q, s->d_pfull + s->row_begin, s->d_parts_pq, &np, NULL);
-      LSB_CHK_HIP(hipEventRecord(sv->ev_t1, g_stream));
-      LSB_CHK_HIP(hipEventSynchronize(sv->ev_t1));
-      float ms = 0.f;
-      LSB_CHK_HIP(hipEventElapsedTime(&ms, sv->ev_t0, sv->ev_t1));
-      if (o->verbose > 1)
-        fprintf(stderr, "hip_cdna4: spmv tune variant=%d flags=%u: %.1f us\n", s->variant, f,
-                ms * 1e3f / 3);
-      if (ms < best)
-        best = ms, bf = s->sp_flags, bv = s->variant, bg = s->sp_grid;
+  /* candidates {form, flags, grid}: the form asked for, or (auto) every form
+   * this shard has; the sliced-ELL kernels have no prefetch flavour, they try
+   * 6 instead of 8 resident workgroups per CU instead */
+  struct {
+    int v;
+    unsigned f, g;
+  } cand[16];
+  int ncand = 0;
+  const int any = o->spmv_variant == LSB_SPMV_AUTO;
+  if (any || s->variant == LSB_SPMV_ADAPTIVE)
+    for (unsigned f = 0; f < 4; f++)
+      cand[ncand].v = LSB_SPMV_ADAPTIVE, cand[ncand].f = f, cand[ncand++].g = grid0;
+  if (s->pn && (any || s->variant == LSB_SPMV_PANEL))
+    for (unsigned f = 0; f < 4; f++)
+      cand[ncand].v = LSB_SPMV_PANEL, cand[ncand].f = f, cand[ncand++].g = grid0;
+  if (s->d_sptr && (any || s->variant == LSB_SPMV_SELL))
+    for (unsigned c16 = 0; c16 <= (s->d_scodes ? LSB_SP_C16 : 0u); c16 += LSB_SP_C16) {
+      cand[ncand].v = LSB_SPMV_SELL, cand[ncand].f = c16 | LSB_SP_NT, cand[ncand++].g = grid0;
+      cand[ncand].v = LSB_SPMV_SELL, cand[ncand].f = c16, cand[ncand++].g = grid0;
+      if (o->spmv_grid <= 0)
+        cand[ncand].v = LSB_SPMV_SELL, cand[ncand].f = c16 | LSB_SP_NT, cand[ncand++].g = 1536;
     }
+  for (int ci = 0; ci < ncand; ci++) {
+    s->variant = cand[ci].v, s->sp_flags = cand[ci].f, s->sp_grid = cand[ci].g;
+    spmv_shard(s, s->d_pfull, s->d_q, s->d_pfull + s->row_begin, s->d_parts_pq, &np, NULL);
+    LSB_CHK_HIP(hipEventRecord(sv->ev_t0, g_stream));
+    for (int r = 0; r < 3; r++)
+      spmv_shard(s, s->d_pfull, s->d_q, s->d_pfull + s->row_begin, s->d_parts_pq, &np, NULL);
+    LSB_CHK_HIP(hipEventRecord(sv->ev_t1, g_stream));
+    LSB_CHK_HIP(hipEventSynchronize(sv->ev_t1));
+    float ms = 0.f;
+    LSB_CHK_HIP(hipEventElapsedTime(&ms, sv->ev_t0, sv->ev_t1));
+    if (o->verbose > 1)
+      fprintf(stderr, "hip_cdna4: spmv tune form=%d flags=%u grid=%u: %.1f us\n", s->variant,
+              s->sp_flags, s->sp_grid, ms * 1e3f / 3);
+    if (ms < best)
+      best = ms, bf = s->sp_flags, bv = s->variant, bg = s->sp_grid;
   }
   s->sp_grid = bg;
   s->variant = bv;
   s->sp_flags = bf;
+  /* the copies that lost are not kept */
+  if (!(bv == LSB_SPMV_SELL && (bf & LSB_SP_C16))) {
+    lsb_hip_free(s->d_sptr16), lsb_hip_free(s->d_scodes), lsb_hip_free(s->d_sbase);
+    lsb_hip_free(s->d_svals16);
+    s->d_sptr16 = NULL, s->d_scodes = NULL, s->d_sbase = NULL, s->d_svals16 = NULL;
+  }
+  if (any && !(bv == LSB_SPMV_SELL && !(bf & LSB_SP_C16))) {
+    lsb_hip_free(s->d_scols), lsb_hip_free(s->d_svals);
+    s->d_scols = NULL, s->d_svals = NULL;
+    if (bv != LSB_SPMV_SELL)
+      lsb_hip_free(s->d_sptr), s->d_sptr = NULL;
+  }
 }
 
 /* ------------------------------------------------------------------------ */
@@ -1782,9 +1824,14 @@ int lsb_hip_spmv_csr_f64(int variant, unsigned n, const int *d_offs,
     return 2;
   unsigned L = pow2_ceil(mean_row_len ? mean_row_len : 1);
   L = L < 2 ? 2 : (L > 64 ? 64 : L);
-  if (variant == LSB_SPMV_SELL)
-    L = 0; /* that launcher reads this argument as "first slice" */
+
   unsigned np = 0;
+  if (variant == LSB_SPMV_SELL) {
+    if ((flags & LSB_SP_C16) && !d_rowblk)
+      return 2; /* the 16-bit form needs its slot bases */
+    lsb_k_spmv_sell(flags, 0, (const unsigned *)d_offs, 0, nblk, n, 0, d_cols, d_rowblk, d_vals,
+                    d_x, d_y, d_dot ? d_xdot : NULL, d_dot ? d_work : NULL, &np, NULL, stream);
+  } else
   lsb_k_spmv(variant, n, d_offs, d_cols, d_vals, d_rowblk, d_blklanes, nblk, L, flags, 0,
              d_x, d_y, d_dot ? d_xdot : NULL, d_dot ? d_work : NULL, &np, NULL, NULL, stream);
   if (d_dot)

@@ -890,6 +890,90 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_sell(
   }
 }
 
+// The same with 16-bit column codes (lsb_csr_sellize16): the column of the entry
+// in slot j of global row g is g + sbase[slice, j] + code, the base one scalar
+// load per slice and slot.  10 instead of 12 bytes per entry: 10 M-row 5-point
+// 146 -> 122 us on the same box (tools/spmv_lab.hip).  A slot holds entries of
+// one diagonal band, so rows can have padding BETWEEN their entries; padding
+// has value 0 and is recognised by that (no gather, contributes an exact 0).
+typedef short s2v __attribute__((ext_vector_type(2)));
+template <int FLAGS>
+__global__ __launch_bounds__(WG, 6) void k_spmv_sell16(
+    const unsigned *__restrict__ sptr, unsigned s0, unsigned ns, unsigned n, unsigned row_begin,
+    const short *__restrict__ codes, const int *__restrict__ sbase,
+    const double *__restrict__ vals, const double *__restrict__ x, double *__restrict__ y,
+    const double *__restrict__ xdot, double *__restrict__ partials,
+    const lsb_pcg_state *__restrict__ st) {
+  __shared__ double sred[4];
+  const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const unsigned gx = gridDim.x / NXCD, xcd = blockIdx.x % NXCD, slot = blockIdx.x / NXCD;
+  const unsigned ngrp = (ns + 3) / 4, chunk = (ngrp + NXCD - 1) / NXCD;
+  const unsigned g0 = xcd * chunk, g1 = min(g0 + chunk, ngrp);
+  const int stopped = st ? st->status : 0; // tested behind the first loads
+  double dot = 0.0;
+  for (unsigned g = g0 + slot; g < g1; g += gx) {
+    const unsigned si = __builtin_amdgcn_readfirstlane(g * 4 + wave);
+    if (si < ns) {
+      const unsigned s = s0 + si;
+      const unsigned base = sptr[s], len = (sptr[s + 1] - base) / LSB_SELL_ROWS;
+      const s2v *cp = (const s2v *)(codes + base) + lane;
+      const sell_d2v *vp = (const sell_d2v *)(vals + base) + lane;
+      const int *bp = sbase + base / LSB_SELL_ROWS;
+      const unsigned row = s * LSB_SELL_ROWS + 2 * lane;
+      const int grow = (int)(row + row_begin);
+      double a0 = 0.0, a1 = 0.0;
+      for (unsigned j0 = 0; j0 < len; j0 += SELL_U) {
+        s2v c[SELL_U];
+        sell_d2v v[SELL_U];
+        int b[SELL_U];
+#pragma unroll
+        for (int u = 0; u < SELL_U; u++)
+          if (j0 + u < len) {
+            if (FLAGS & SP_NT) {
+              c[u] = __builtin_nontemporal_load(cp + (size_t)(j0 + u) * 64);
+              v[u] = __builtin_nontemporal_load(vp + (size_t)(j0 + u) * 64);
+            } else {
+              c[u] = cp[(size_t)(j0 + u) * 64];
+              v[u] = vp[(size_t)(j0 + u) * 64];
+            }
+            b[u] = bp[j0 + u];
+          }
+        if (stopped)
+          return;
+#pragma unroll
+        for (int u = 0; u < SELL_U; u++)
+          if (j0 + u < len) {
+            const bool p0 = v[u].x != 0.0, p1 = v[u].y != 0.0;
+            const double t0 = x[p0 ? grow + b[u] + (int)c[u].x : 0];
+            const double t1 = x[p1 ? grow + 1 + b[u] + (int)c[u].y : 0];
+            a0 += v[u].x * (p0 ? t0 : 0.0);
+            a1 += v[u].y * (p1 ? t1 : 0.0);
+          }
+      }
+      if (row + 1 < n) {
+        const sell_d2v o = {a0, a1};
+        *(sell_d2v *)(y + row) = o;
+        if (xdot) {
+          dot += a0 * xdot[row];
+          dot += a1 * xdot[row + 1];
+        }
+      } else if (row < n) {
+        y[row] = a0;
+        if (xdot)
+          dot += a0 * xdot[row];
+      }
+    }
+  }
+  if (stopped)
+    return;
+  if (partials) {
+    double d[1] = {dot};
+    wg_sum<1>(d, sred);
+    if (tid == 0)
+      partials[blockIdx.x] = d[0];
+  }
+}
+
 extern "C" {
 
 void lsb_k_set_blas1_nt(int on) { g_blas1_nt = on ? 1 : 0; }
@@ -906,11 +990,9 @@ unsigned lsb_k_blas1_grid(unsigned n) {
 unsigned lsb_k_spmv_grid(int variant, unsigned n, unsigned nblk,
                          unsigned lanes_per_row, unsigned grid_cap) {
   unsigned items;
-  if (variant == LSB_SPMV_SELL) { /* four slices per workgroup step */
+  if (variant == LSB_SPMV_SELL) /* four slices per workgroup step */
     items = div_up(nblk, 4);
-    if (grid_cap == 0)
-      grid_cap = 1536;
-  } else if (variant == LSB_SPMV_ADAPTIVE)
+  else if (variant == LSB_SPMV_ADAPTIVE)
     items = nblk;
   else if (variant == LSB_SPMV_SUBWAVE)
     items = div_up(n, WG / (lanes_per_row ? lanes_per_row : 1));
@@ -938,17 +1020,7 @@ void lsb_k_spmv(int variant, unsigned n, const int *offs, const int *cols,
   const unsigned g = lsb_k_spmv_grid(variant, n, nblk, lanes_per_row, grid_cap);
   if (npartials)
     *npartials = g;
-  if (variant == LSB_SPMV_SELL) {
-    /* offs = slice offsets, nblk = slices of this launch, rowblk (if given) =
-     * pointer whose VALUE is irrelevant; lanes_per_row = first slice */
-    const unsigned *sp = (const unsigned *)offs;
-    if (flags & SP_NT)
-      k_spmv_sell<SP_NT><<<g, WG, 0, s>>>(sp, lanes_per_row, nblk, n, cols, vals, x, y, xdot,
-                                          partials, st);
-    else
-      k_spmv_sell<0><<<g, WG, 0, s>>>(sp, lanes_per_row, nblk, n, cols, vals, x, y, xdot,
-                                      partials, st);
-  } else if (variant == LSB_SPMV_ADAPTIVE) {
+  if (variant == LSB_SPMV_ADAPTIVE) {
 #define LSB_ADAPTIVE(FL)                                                       \
   case FL:                                                                     \
     k_spmv_adaptive<LSB_BLOCK_NNZ, FL><<<g, WG, 0, s>>>(                       \
@@ -986,6 +1058,34 @@ void lsb_k_spmv(int variant, unsigned n, const int *offs, const int *cols,
     const unsigned rpw = div_up(n, g);
     k_spmv_scalar<<<g, WG, 0, s>>>(n, rpw, offs, cols, vals, x, y, xdot, partials, st);
   }
+}
+
+/* Sliced-ELL launch over the slices [s0, s0+ns).  flags & LSB_SP_C16: `cols` is
+ * the 16-bit code array and `sbase` the slot bases (row_begin = global index
+ * of local row 0); else `cols` holds 32-bit column ids and sbase is unused. */
+void lsb_k_spmv_sell(unsigned flags, unsigned grid_cap, const unsigned *sptr, unsigned s0,
+                     unsigned ns, unsigned n, unsigned row_begin, const void *cols,
+                     const int *sbase, const double *vals, const double *x, double *y,
+                     const double *xdot, double *partials, unsigned *npartials,
+                     const struct lsb_pcg_state *st, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned g = lsb_k_spmv_grid(LSB_SPMV_SELL, n, ns, 0, grid_cap ? grid_cap : 1536);
+  if (npartials)
+    *npartials = g;
+  const int nt = (flags & SP_NT) != 0;
+  if (flags & LSB_SP_C16) {
+    if (nt)
+      k_spmv_sell16<SP_NT><<<g, WG, 0, s>>>(sptr, s0, ns, n, row_begin, (const short *)cols,
+                                            sbase, vals, x, y, xdot, partials, st);
+    else
+      k_spmv_sell16<0><<<g, WG, 0, s>>>(sptr, s0, ns, n, row_begin, (const short *)cols, sbase,
+                                        vals, x, y, xdot, partials, st);
+  } else if (nt)
+    k_spmv_sell<SP_NT><<<g, WG, 0, s>>>(sptr, s0, ns, n, (const int *)cols, vals, x, y, xdot,
+                                        partials, st);
+  else
+    k_spmv_sell<0><<<g, WG, 0, s>>>(sptr, s0, ns, n, (const int *)cols, vals, x, y, xdot,
+                                    partials, st);
 }
 
 void lsb_k_reduce_final(const double *partials, unsigned nparts, unsigned width,

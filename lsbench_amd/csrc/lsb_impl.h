@@ -65,6 +65,12 @@ unsigned lsb_k_spmv_grid(int variant, unsigned n, unsigned nblk,
 /* flags of the adaptive SpMV (picked by the timing pass at solver creation) */
 #define LSB_SP_PREFETCH 1u
 #define LSB_SP_NT 2u
+#define LSB_SP_C16 4u /* sliced-ELL only: 16-bit column codes */
+void lsb_k_spmv_sell(unsigned flags, unsigned grid_cap, const unsigned *sptr, unsigned s0,
+                     unsigned ns, unsigned n, unsigned row_begin, const void *cols,
+                     const int *sbase, const double *vals, const double *x, double *y,
+                     const double *xdot, double *partials, unsigned *npartials,
+                     const struct lsb_pcg_state *st, void *stream);
 void lsb_k_reduce_final(const double *partials, unsigned nparts, unsigned width,
                         double *out, int take_sqrt,
                         const struct lsb_pcg_state *st, void *stream);

@@ -553,8 +553,103 @@ struct lsb_sell *lsb_csr_sellize(const struct csr *A) {
   return S;
 }
 
+/* Slot bases of one slice: every entry (as delta = column - global row) must
+ * find, in column order, a slot whose base is within +-32767 of it; a new base
+ * is inserted where none is.  Returns the number of slots, 0 on overflow. */
+#define SELL16_MAX_SLOTS 255
+#define SELL16_REACH 32767L
+static unsigned sell16_slots(const struct csr *A, unsigned row_begin, unsigned r0, unsigned r1,
+                             long *B) {
+  unsigned nb = 0;
+  for (unsigned r = r0; r < r1; r++) {
+    unsigned j = 0;
+    for (unsigned k = A->offs[r]; k < A->offs[r + 1]; k++) {
+      const long e = (long)(A->cols[k] - A->base) - ((long)r + (long)row_begin);
+      while (j < nb && B[j] < e - SELL16_REACH)
+        j++;
+      if (!(j < nb && B[j] <= e + SELL16_REACH)) {
+        if (nb == SELL16_MAX_SLOTS)
+          return 0;
+        memmove(B + j + 1, B + j, (size_t)(nb - j) * sizeof(long));
+        B[j] = e, nb++;
+      }
+      j++;
+    }
+  }
+  return nb;
+}
+
+struct lsb_sell *lsb_csr_sellize16(const struct csr *A, unsigned row_begin) {
+  if (!A)
+    return NULL;
+  const unsigned n = A->nrows, ns = (n + LSB_SELL_ROWS - 1) / LSB_SELL_ROWS;
+  unsigned *sptr = lsb_calloc(unsigned, (size_t)ns + 1);
+  unsigned char *nslot = (unsigned char *)calloc(ns ? ns : 1, 1);
+  int ok = 1;
+#pragma omp parallel for schedule(static) reduction(& : ok)
+  for (unsigned sl = 0; sl < ns; sl++) {
+    long B[SELL16_MAX_SLOTS + 1];
+    const unsigned r0 = sl * LSB_SELL_ROWS, r1 = r0 + LSB_SELL_ROWS < n ? r0 + LSB_SELL_ROWS : n;
+    const unsigned nb = sell16_slots(A, row_begin, r0, r1, B);
+    unsigned has = 0;
+    for (unsigned r = r0; r < r1 && !has; r++)
+      has = A->offs[r + 1] > A->offs[r];
+    if (nb == 0 && has)
+      ok = 0;
+    nslot[sl] = (unsigned char)nb;
+  }
+  unsigned long long stored = 0;
+  for (unsigned sl = 0; sl < ns && ok; sl++) {
+    stored += (unsigned long long)nslot[sl] * LSB_SELL_ROWS;
+    if (stored > 0xFFFFFF00ull)
+      ok = 0;
+    sptr[sl + 1] = (unsigned)stored;
+  }
+  if (!ok) {
+    free(sptr), free(nslot);
+    return NULL;
+  }
+  struct lsb_sell *S = lsb_calloc(struct lsb_sell, 1);
+  S->nrows = n, S->nslice = ns, S->stored = stored, S->sptr = sptr;
+  S->codes = (short *)calloc((size_t)stored + LSB_SELL_ROWS, sizeof(short));
+  S->vals = (double *)calloc((size_t)stored + LSB_SELL_ROWS, sizeof(double));
+  S->sbase = (int *)calloc((size_t)stored / LSB_SELL_ROWS + 1, sizeof(int));
+  if (!S->codes || !S->vals || !S->sbase)
+    errx(EXIT_FAILURE, "lsb_csr_sellize16: out of memory");
+#pragma omp parallel for schedule(static) reduction(& : ok)
+  for (unsigned sl = 0; sl < ns; sl++) {
+    long B[SELL16_MAX_SLOTS + 1];
+    const unsigned r0 = sl * LSB_SELL_ROWS, r1 = r0 + LSB_SELL_ROWS < n ? r0 + LSB_SELL_ROWS : n;
+    const unsigned nb = sell16_slots(A, row_begin, r0, r1, B);
+    const size_t at0 = sptr[sl];
+    for (unsigned j = 0; j < nb; j++)
+      S->sbase[at0 / LSB_SELL_ROWS + j] = (int)B[j];
+    for (unsigned r = r0; r < r1; r++) {
+      unsigned j = 0;
+      for (unsigned k = A->offs[r]; k < A->offs[r + 1]; k++) {
+        const long e = (long)(A->cols[k] - A->base) - ((long)r + (long)row_begin);
+        while (j < nb && B[j] < e - SELL16_REACH)
+          j++;
+        if (!(j < nb && B[j] <= e + SELL16_REACH)) {
+          ok = 0; /* cannot happen: the bases were built from these very rows */
+          break;
+        }
+        const size_t at = at0 + (size_t)j * LSB_SELL_ROWS + (r - r0);
+        S->codes[at] = (short)(e - B[j]), S->vals[at] = A->vals[k];
+        j++;
+      }
+    }
+  }
+  free(nslot);
+  if (!ok) {
+    lsb_sell_free(S);
+    return NULL;
+  }
+  return S;
+}
+
 void lsb_sell_free(struct lsb_sell *S) {
   if (!S)
     return;
-  free(S->sptr), free(S->cols), free(S->vals), free(S);
+  free(S->sptr), free(S->cols), free(S->vals), free(S->codes), free(S->sbase), free(S);
 }

@@ -44,5 +44,10 @@ def test_hot_kernels_have_no_spills_and_full_occupancy(tmp_path):
         assert v["Occupancy"] == 8, (k, v)
         if "k_spmv_adaptive" in k:
             assert v["LDS Size"] <= 16 * 1024 + 64, (k, v)
+    sell = {k: v for k, v in info.items() if "k_spmv_sell" in k}
+    assert len(sell) == 4                                         # {32-bit, 16-bit columns} x {plain, nontemporal}
+    for k, v in sell.items():                                     # no LDS staging, >= 6 workgroups per CU
+        assert v["ScratchSize"] == 0 and v["VGPRs"] <= 80 and v["Occupancy"] >= 6, (k, v)
+        assert v["LDS Size"] <= 64, (k, v)
     for k, v in info.items():
         assert v.get("ScratchSize", 0) == 0, (k, v)

@@ -318,3 +318,67 @@ def test_sliced_ell_copy_base1(matrix_path):
     yo = O.spmv(A.offs, A.cols - A.base, A.vals, x)
     assert np.allclose(_sell_spmv(sptr, cols, vals, x, A.nrows), yo, rtol=1e-12, atol=1e-12)
     assert S.nrows == A.nrows
+
+
+def _sell16_spmv(sptr, codes, sbase, vals, x, n, row_begin=0):
+    """numpy evaluation of the 16-bit sliced-ELL layout: the entry in slot j of
+    row r has column r + row_begin + sbase[sptr[s]/128 + j] + code; value 0 =
+    padding (no gather)."""
+    R = la.SELL_ROWS
+    y = np.zeros((len(sptr) - 1) * R)
+    rows = np.arange(R)
+    for s in range(len(sptr) - 1):
+        ln = (int(sptr[s + 1]) - int(sptr[s])) // R
+        c = codes[sptr[s]:sptr[s + 1]].reshape(ln, R).astype(np.int64)
+        v = vals[sptr[s]:sptr[s + 1]].reshape(ln, R)
+        b = sbase[int(sptr[s]) // R:int(sptr[s]) // R + ln].astype(np.int64)
+        acc = np.zeros(R)
+        for j in range(ln):
+            col = s * R + rows + row_begin + b[j] + c[j]
+            live = v[j] != 0.0
+            assert np.all((col[live] >= 0) & (col[live] < len(x)))
+            acc += np.where(live, v[j] * x[np.where(live, col, 0)], 0.0)
+        y[s * R:(s + 1) * R] = acc
+    return y[:n]
+
+
+@pytest.mark.parametrize("spec", ["lap2d:nx=37,ny=23", "lap3d:nx=9,ny=8,nz=7", "lap2d:nx=129,ny=1",
+                                  "lap3d:nx=200,ny=190,nz=3",         # plane 38000 > 32767: aligned slots
+                                  "powerlaw:n=1500,avg=6,max=40,seed=4"])
+def test_sliced_ell_copy_16bit(spec):
+    A = la.lsbench_matrix_synth(spec)
+    out = la.lsb_csr_sellize16(A)
+    assert out is not None
+    sptr, codes, sbase, vals = out
+    n, R = A.nrows, la.SELL_ROWS
+    assert len(sptr) == (n + R - 1) // R + 1 and len(sbase) == sptr[-1] // R
+    assert np.count_nonzero(vals) == np.count_nonzero(A.vals)
+    x = np.random.default_rng(7).standard_normal(n)
+    yo = O.spmv(A.offs, A.cols, A.vals, x)
+    assert np.allclose(_sell16_spmv(sptr, codes, sbase, vals, x, n), yo, rtol=1e-13, atol=1e-13)
+    if spec.startswith("lap3d:nx=200"):
+        # +-38000 neighbours cannot share a slot with the +-200 ones: a slice in the
+        # middle plane has 7 slots (6 in the outer planes) and boundary rows keep gaps
+        # instead of shifting their entries left
+        assert set(np.diff(sptr.astype(np.int64)) // R) <= {5, 6, 7}
+        assert sptr[-1] > A.nnz
+    if spec.startswith("lap2d:nx=37"):
+        assert sptr[-1] == la.lsb_csr_sellize(A)[0][-1]          # no extra padding when all deltas fit
+
+
+def test_sliced_ell_copy_16bit_row_slice_and_refusal():
+    spec = "lap3d:nx=40,ny=30,nz=20"
+    n = la.lsbench_matrix_synth(spec, 0, 1).n_global
+    r0, r1 = 7000, 19000
+    A = la.lsbench_matrix_synth(spec, r0, r1)                     # global column ids
+    full = la.lsbench_matrix_synth(spec)
+    sptr, codes, sbase, vals = la.lsb_csr_sellize16(A, r0)
+    x = np.random.default_rng(8).standard_normal(n)
+    yo = O.spmv(full.offs, full.cols, full.vals, x)[r0:r1]
+    assert np.allclose(_sell16_spmv(sptr, codes, sbase, vals, x, r1 - r0, r0), yo, rtol=1e-13, atol=1e-13)
+    # > 255 diagonal bands in one slice: refused (the caller keeps 32-bit columns)
+    cols = (np.arange(300, dtype=np.uint32) * 70001)             # 300 bands, 70001 apart
+    B = la.Matrix.from_arrays(np.array([0, len(cols)]), cols, np.ones(len(cols)))
+    assert la.lsb_csr_sellize16(B) is None
+    ok = la.lsb_csr_sellize16(la.Matrix.from_arrays(np.array([0, 255]), cols[:255], np.ones(255)))
+    assert ok is not None and ok[0][-1] == 255 * la.SELL_ROWS

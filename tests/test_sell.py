@@ -30,6 +30,65 @@ def _sell_kernel(hip, A, x, flags, with_dot=True):
     return y.cpu().numpy(), dot.item()
 
 
+def _sell16_kernel(hip, A, x, flags, with_dot=True):
+    import torch
+    lib = hip._lib.load()
+    out = hip.lsb_csr_sellize16(A)
+    if out is None:
+        return None
+    sptr, codes, sbase, vals = out
+    pad = hip.SELL_ROWS
+    d = dict(sptr=_dev(sptr.astype(np.int32)), codes=_dev(np.concatenate([codes, np.zeros(pad, np.int16)])),
+             sbase=_dev(np.concatenate([sbase, np.zeros(1, np.int32)])),
+             vals=_dev(np.concatenate([vals, np.zeros(pad)])), x=_dev(x))
+    y = torch.full((A.nrows,), float("nan"), dtype=torch.float64, device="cuda:0")
+    w = torch.zeros(lib.lsb_hip_partials_capacity(), dtype=torch.float64, device="cuda:0")
+    dot = torch.zeros(1, dtype=torch.float64, device="cuda:0")
+    rc = lib.lsb_hip_spmv_csr_f64(hip.SPMV_SELL, A.nrows, d["sptr"].data_ptr(), d["codes"].data_ptr(),
+                                  d["vals"].data_ptr(), d["sbase"].data_ptr(), None, len(sptr) - 1, 0,
+                                  flags | hip.SPMV_FLAG_C16, d["x"].data_ptr(), y.data_ptr(),
+                                  d["x"].data_ptr() if with_dot else None,
+                                  dot.data_ptr() if with_dot else None, w.data_ptr(),
+                                  lib.lsb_hip_stream())
+    assert rc == 0
+    lib.lsb_hip_sync()
+    return y.cpu().numpy(), dot.item()
+
+
+@pytest.mark.parametrize("flags", [0, 2])
+def test_sell16_kernel_vs_oracle(hip, flags, matrix_path):
+    rng = np.random.default_rng(60 + flags)
+    mats = [hip.lsb_csr_symmetrize_upper(hip.lsbench_matrix_read(matrix_path("xn3b_A_18"))),
+            hip.lsbench_matrix_synth("lap2d:nx=301,ny=97"),
+            hip.lsbench_matrix_synth("lap3d:nx=31,ny=17,nz=23"),
+            hip.lsbench_matrix_synth("lap3d:nx=200,ny=190,nz=4"),    # +-38000: aligned slots, padding inside rows
+            hip.lsbench_matrix_synth("lap2d:nx=40000,ny=3"),         # +-40000
+            hip.lsbench_matrix_synth("powerlaw:n=20000,gamma=%r,max=200,seed=3" % GAMMA),
+            hip.lsbench_matrix_synth("lap2d:nx=1,ny=1"), hip.lsbench_matrix_synth("lap2d:nx=129,ny=1")]
+    done = 0
+    for A in mats:
+        x = rng.standard_normal(A.nrows)
+        out = _sell16_kernel(hip, A, x, flags)
+        if out is None:
+            continue
+        done += 1
+        yo = _check_spmv(A, x, out[0])
+        assert abs(out[1] - float(x @ yo)) <= 1e-12 * max(np.abs(x * yo).sum(), 1e-300)
+    assert done >= 6
+    # padding never gathers: a NaN in x only reaches the rows that reference it
+    A = hip.lsbench_matrix_synth("lap3d:nx=200,ny=190,nz=4")
+    x = rng.standard_normal(A.nrows)
+    x[0] = np.nan
+    y, _ = _sell16_kernel(hip, A, x, flags, with_dot=False)
+    hit = set(np.flatnonzero(np.isnan(y)).tolist())
+    ref = set(np.flatnonzero(np.isnan(O.spmv(A.offs, A.cols, A.vals, x))).tolist())
+    assert hit == ref == {0, 1, 200, 38000}
+    lib = hip._lib.load()                      # the 16-bit form without slot bases is refused
+    assert lib.lsb_hip_spmv_csr_f64(hip.SPMV_SELL, 128, None, None, None, None, None, 1, 0,
+                                    hip.SPMV_FLAG_C16, None, None, None, None, None,
+                                    lib.lsb_hip_stream()) == 2
+
+
 @pytest.mark.parametrize("flags", [0, 2])
 def test_sell_kernel_vs_oracle(hip, flags, matrix_path):
     rng = np.random.default_rng(40 + flags)
@@ -59,16 +118,18 @@ def test_sell_kernel_vs_oracle(hip, flags, matrix_path):
 @pytest.mark.parametrize("name", ["xn3b_A_18", "tj7a_A_12"])
 def test_solves_through_sell_match_golden(hip, name, matrix_path, golden_x):
     A = hip.lsbench_matrix_read(matrix_path(name))
-    s = hip.Solver(A, hip.default_opts(spmv_variant=hip.SPMV_SELL, use_graph=0))
-    assert s.spmv_variant == hip.SPMV_SELL
-    x, r = s.solve(O.rhs(A.nrows))
-    s.destroy()
     xg = golden_x(name)
-    assert r.status == 1 and np.linalg.norm(x - xg) / np.linalg.norm(xg) <= 1e-10
+    for tune in (2, 6):
+        s = hip.Solver(A, hip.default_opts(spmv_variant=hip.SPMV_SELL, use_graph=0, spmv_tune=tune))
+        assert s.spmv_variant == hip.SPMV_SELL
+        x, r = s.solve(O.rhs(A.nrows))
+        s.destroy()
+        assert r.status == 1 and np.linalg.norm(x - xg) / np.linalg.norm(xg) <= 1e-10
 
 
 @pytest.mark.parametrize("comm", ["COMM_RCCL", "COMM_P2P"])
-def test_sharded_solve_with_sell_and_overlap(hip, comm):
+@pytest.mark.parametrize("tune", [2, 6])       # 32-bit columns / 16-bit codes, nontemporal
+def test_sharded_solve_with_sell_and_overlap(hip, comm, tune):
     """virtual shards, each with its own sliced-ELL copy (global column ids),
     interior / boundary SLICE ranges for the overlapped exchange"""
     L = hip.lsbench_matrix_synth("lap2d:nx=300,ny=200")
@@ -78,8 +139,8 @@ def test_sharded_solve_with_sell_and_overlap(hip, comm):
     for ov in (0, 1):
         s = hip.Solver(L, hip.default_opts(op_mode=hip.OP_RAW, nvirt=3, overlap=ov, tol=1e-10,
                                            comm=getattr(hip, comm), spmv_variant=hip.SPMV_SELL,
-                                           krylov=hip.KRYLOV_AUTO))
-        assert s.spmv_variant == hip.SPMV_SELL and s.overlaps == bool(ov)
+                                           krylov=hip.KRYLOV_AUTO, spmv_tune=tune))
+        assert s.spmv_variant == hip.SPMV_SELL and s.overlaps == bool(ov) and s.spmv_flags == tune
         x, r = s.solve(b)
         s.destroy()
         assert r.status == 1 and abs(int(r.iters) - ito) <= 4

@@ -705,6 +705,65 @@ __global__ __launch_bounds__(WG, MINW) void k_sell2(const int *, unsigned nslice
   }
 }
 
+// ---- SELL-128x2 with 16-bit row-relative column codes (probe: how much of the
+// 4 B/nnz of column traffic converts into time).  cols = short deltas col - row.
+typedef short lab_s2v __attribute__((ext_vector_type(2)));
+template <int FLAGS, int U, int MINW>
+__global__ __launch_bounds__(WG, MINW) void k_sell2c16(const int *, unsigned nslice, unsigned n, const int *,
+                                                    const int *__restrict__ cols,
+                                                    const double *__restrict__ vals,
+                                                    const double *__restrict__ x,
+                                                    double *__restrict__ y,
+                                                    double *__restrict__ partials) {
+  __shared__ double sred[4];
+  const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const unsigned gx = gridDim.x / NXCD, xcd = blockIdx.x % NXCD, slot = blockIdx.x / NXCD;
+  const unsigned ngrp = (nslice + 3) / 4, chunk = (ngrp + NXCD - 1) / NXCD;
+  const unsigned g0 = xcd * chunk, g1 = g0 + chunk < ngrp ? g0 + chunk : ngrp;
+  const unsigned *sp = g_sell2_ptr;
+  double dot = 0.0;
+  for (unsigned g = g0 + slot; g < g1; g += gx) {
+    const unsigned s = __builtin_amdgcn_readfirstlane(g * 4 + wave);
+    if (s < nslice) {
+      const unsigned base = sp[s], len = (sp[s + 1] - base) >> 7;
+      const lab_s2v *cp = (const lab_s2v *)((const short *)cols + base) + lane;
+      const lab_d2vb *vp = (const lab_d2vb *)(vals + base) + lane;
+      const int row = (int)(s * 128 + 2 * lane);
+      double a0 = 0.0, a1 = 0.0;
+      for (unsigned j0 = 0; j0 < len; j0 += U) {
+        lab_s2v c[U];
+        lab_d2vb v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+          if (j0 + u < len) {
+            c[u] = ldg<FLAGS>(cp + (j0 + u) * 64);
+            v[u] = ldg<FLAGS>(vp + (j0 + u) * 64);
+          }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+          if (j0 + u < len) {
+            a0 += v[u].x * x[row + (int)c[u].x];
+            a1 += v[u].y * x[row + 1 + (int)c[u].y];
+          }
+      }
+      if ((unsigned)row + 1 < n) {
+        lab_d2vb o = {a0, a1};
+        *(lab_d2vb *)(y + row) = o;
+        const lab_d2vb xx = *(const lab_d2vb *)(x + row);
+        dot += a0 * xx.x;
+        dot += a1 * xx.y;
+      } else if ((unsigned)row < n) {
+        y[row] = a0;
+        dot += a0 * x[row];
+      }
+    }
+  }
+  double d[1] = {dot};
+  wg_sum<1>(d, sred);
+  if (tid == 0)
+    partials[xcd * gx + slot] = d[0];
+}
+
 // ---- V5: V3 with 16 B/lane stream loads.  A block's nnz range [j0,j1) is
 // widened to 4-aligned [j0&~3, ...); each lane owns QPT quads of 4 consecutive
 // non-zeros (cols as int4, vals as 2 x double2).  Row blocks are built with
@@ -1118,6 +1177,8 @@ LAUNCHER(l_cyc_pf_nt, (k_adaptive_cyc<2048, F_CYCLIC | F_PREFETCH | F_NT>))
 LAUNCHER(l_cyc_nt, (k_adaptive_cyc<2048, F_CYCLIC | F_NT>))
 LAUNCHER(l_sell_nt8, (k_sell<F_NT, 8>))
 LAUNCHER(l_sell2_nt8, (k_sell2<F_NT, 8, 4>))
+LAUNCHER(l_s2c16_u5, (k_sell2c16<F_NT, 5, 8>))
+LAUNCHER(l_s2c16_u8, (k_sell2c16<F_NT, 8, 6>))
 LAUNCHER(l_sell2_nt5, (k_sell2<F_NT, 5, 6>))
 LAUNCHER(l_sell2_nt7, (k_sell2<F_NT, 7, 5>))
 LAUNCHER(l_sell2_nt4, (k_sell2<F_NT, 4, 8>))
@@ -1182,6 +1243,9 @@ int main(int argc, char **argv) {
       {"cyc+prefetch+nt cap2048 (library)", 2048, l_cyc_pf_nt, 2048},
       {"cyc+nt cap2048", 2048, l_cyc_nt, 2048},
       {"SELL64 nt U8", 2048, l_sell_nt8, 2048},
+      {"S2C16 nt U5 g2048", 2048, l_s2c16_u5, 2048},
+      {"S2C16 nt U5 g1536", 2048, l_s2c16_u5, 1536},
+      {"S2C16 nt U8 g1536", 2048, l_s2c16_u8, 1536},
       {"SELL128x2 nt U8 occ4", 2048, l_sell2_nt8, 1024},
       {"SELL128x2 nt U7 occ5", 2048, l_sell2_nt7, 1280},
       {"SELL128x2 nt U5 occ6", 2048, l_sell2_nt5, 1536},
@@ -1254,6 +1318,7 @@ int main(int argc, char **argv) {
   }
   // SELL-128x2
   int *d_s2cols = nullptr;
+  short *d_s2c16 = nullptr;
   double *d_s2vals = nullptr;
   unsigned nslice2 = (unsigned)((A.n + 127) / 128);
   {
@@ -1280,6 +1345,24 @@ int main(int argc, char **argv) {
           else sc[at] = padc, sv[at] = 0.0;
         }
       }
+    }
+    {
+      std::vector<short> s16(tot + 128, 0);
+      bool fits = true;
+      for (unsigned sl = 0; sl < nslice2; sl++) {
+        const unsigned len = (sptr[sl + 1] - sptr[sl]) / 128;
+        for (unsigned j = 0; j < len; j++)
+          for (unsigned l = 0; l < 128; l++) {
+            const size_t at = (size_t)sptr[sl] + (size_t)j * 128 + l;
+            const long r_ = (long)sl * 128 + l;
+            long d = (long)sc[at] - r_;
+            if (sv[at] == 0.0 && (d < -32768 || d > 32767)) d = (r_ < A.n ? 0 : (long)A.n - 1 - r_);
+            if (d < -32768 || d > 32767) fits = false;
+            s16[at] = (short)d;
+          }
+      }
+      printf("SELL row-relative int16 column codes: %s\n", fits ? "fit" : "DO NOT FIT");
+      if (fits) d_s2c16 = upload(s16);
     }
     d_s2cols = upload(sc), d_s2vals = upload(sv);
     unsigned *d_sp = upload(sptr);
@@ -1339,6 +1422,12 @@ int main(int argc, char **argv) {
       per = (unsigned)std::max(8.0, std::round(bw / rows_per_blk));
     }
     const int *cp = d_cols;
+    if (v.name.find("S2C16") != std::string::npos) {
+      if (!d_s2c16) return;
+      unsigned gs = std::min(v.maxgrid, ((((nslice2 + 3) / 4) + 7) / 8) * 8);
+      v.launch(v, gs, (unsigned)A.n, nslice2, v.d_rb, d_offs, (const int *)d_s2c16, d_s2vals, d_x, d_y, d_parts, (int)nnz);
+      return;
+    }
     if (v.name.find("SELL128x2") != std::string::npos) {
       unsigned gs = std::min(v.maxgrid, ((((nslice2 + 3) / 4) + 7) / 8) * 8);
       v.launch(v, gs, (unsigned)A.n, nslice2, v.d_rb, d_offs, d_s2cols, d_s2vals, d_x, d_y, d_parts, (int)nnz);
@@ -1361,6 +1450,7 @@ int main(int argc, char **argv) {
     CHK(hipDeviceSynchronize());
     if (!v.check) continue;
     if (v.name.rfind("C16W", 0) == 0 ? !d_c16w : (v.name.rfind("C16", 0) == 0 && !d_c16)) { v.check = false; continue; }
+    if (v.name.find("S2C16") != std::string::npos && !d_s2c16) { v.check = false; continue; }
     CHK(hipMemcpy(hy.data(), d_y, (size_t)A.n * 8, hipMemcpyDeviceToHost));
     double worst = 0;
     for (int i = 0; i < A.n; i++) {
