@@ -308,10 +308,16 @@ def main():
         spmv_avg_ms = solver.time_spmv(20, 200)  # graph replay: events do not fit inside
         how = "hipEvents around 200 back-to-back launches after the timed solves"
     gbps = bytes_spmv / spmv_avg_ms / 1e6
-    traffic = None
+    kernel = {la.SPMV_ADAPTIVE: "k_spmv_adaptive", la.SPMV_SUBWAVE: "k_spmv_subwave",
+              la.SPMV_SCALAR: "k_spmv_scalar", la.SPMV_PANEL: "k_spmv_adaptive",
+              la.SPMV_SELL: "k_spmv_sell16" if solver.spmv_flags & la.SPMV_FLAG_C16 else "k_spmv_sell"
+              }.get(solver.spmv_variant, "?")
+    traffic = None  # PMC bytes of THIS kernel on this workload, from the committed profile
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            traffic = json.load(f).get(a.workload if world == 1 else None)
+            t = json.load(f).get(a.workload if world == 1 else None)
+        if isinstance(t, dict) and t.get("kernel") == kernel:
+            traffic = t["bytes"]
     except OSError:
         pass
     n_tot_nnz = nnz_loc
@@ -339,9 +345,7 @@ def main():
                      modes="0 one shard, 1 RCCL, 2 direct xGMI all-reduce, 3 direct xGMI halos too"),
         "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": gbps / HBM_PEAK_GBPS, "traffic": traffic,
-                     "kernel": {la.SPMV_ADAPTIVE: "k_spmv_adaptive", la.SPMV_SUBWAVE: "k_spmv_subwave",
-                                la.SPMV_SCALAR: "k_spmv_scalar", la.SPMV_PANEL: "k_spmv_adaptive (panels)",
-                                la.SPMV_SELL: "k_spmv_sell"}.get(solver.spmv_variant, "?") + " (fused p.q)",
+                     "kernel": kernel + (" (panels)" if solver.spmv_variant == la.SPMV_PANEL else "") + " (fused p.q)",
                      "launch_ms": spmv_avg_ms,
                      "spmv_flags": solver.spmv_flags,
                      "algorithmic_bytes": bytes_spmv, "measured": how},

@@ -44,8 +44,12 @@ for k, d in sorted(pmc.items()):
     wb = d["WRITE_SIZE_KB_median"] * 1024
     lines.append("%s,%d,%.1f,%.0f,%.1f,%.0f,%.0f" % (k, d["launches_FETCH_SIZE"], d["FETCH_SIZE_KB_median"], fb,
                                                      d["WRITE_SIZE_KB_median"], wb, fb + wb))
-    if "k_spmv_adaptive" in k and d["launches_FETCH_SIZE"] > 20:
-        traffic["lap2d"] = fb + wb
+    if "k_spmv_" in k and d["launches_FETCH_SIZE"] > 20:
+        # the SpMV kernel the solve ran (the timing pass at setup launches the
+        # other forms a few times each)
+        name = k.split("<")[0].split()[-1]
+        if d["launches_FETCH_SIZE"] > traffic.get("lap2d", {}).get("launches", 0):
+            traffic["lap2d"] = {"bytes": fb + wb, "kernel": name, "launches": d["launches_FETCH_SIZE"]}
 open(os.path.join(out, "%s_pmc_traffic_lap2d.csv" % rnd), "w").write("\n".join(lines) + "\n")
 if traffic:
     json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
