@@ -35,7 +35,8 @@ def main():
     r0 = (n * rank // world) & ~1
     r1 = (n * (rank + 1) // world) & ~1 if rank + 1 < world else n
     A = la.lsbench_matrix_synth(spec, r0, r1)
-    kry = {"cg": la.KRYLOV_PCG, "cg1": la.KRYLOV_PCG1, "auto": la.KRYLOV_AUTO}[krylov]
+    kry = {"cg": la.KRYLOV_PCG, "cg1": la.KRYLOV_PCG1, "auto": la.KRYLOV_AUTO,
+           "gmres": la.KRYLOV_GMRES}[krylov]
     s = la.Solver(A, la.default_opts(op_mode=la.OP_RAW, tol=tol, krylov=kry, maxit=50000, comm=comm,
                                      overlap=overlap, spmv_variant=la.SPMV_ADAPTIVE if overlap else 0),
                   row_begin=r0, n_global=n)

@@ -69,6 +69,22 @@ def test_multi_process_solve_matches_oracle(world, spec, krylov, comm, overlap, 
     assert np.allclose(y, O.spmv(A.offs, A.cols, A.vals, v), rtol=1e-12, atol=1e-12)
 
 
+def test_multi_process_gmres(tmp_path):
+    """GMRES(m) across three processes: wide all-reduces (the j+1 Gram-Schmidt
+    coefficients of a step in one call) through the communicator."""
+    import lsbench_amd as la
+    spec = "lap2d:nx=90,ny=70"
+    _run(3, [os.path.join(ROOT, "tests", "dist_gpu_worker.py"), spec, str(tmp_path), "gmres", "1e-10",
+             "rccl", "0"], 29611)
+    A = la.lsbench_matrix_synth(spec)
+    xo, _, _, _ = O.pcg_jacobi(A.offs, A.cols, A.vals, O.rhs(A.nrows), 1e-12)
+    metas = [np.load(tmp_path / ("m%d.npy" % r)) for r in range(3)]
+    x = np.concatenate([np.load(tmp_path / ("x%d.npy" % r)) for r in range(3)])
+    assert all(m[1] == 1 and m[3] == 1 for m in metas)
+    assert len({int(m[0]) for m in metas}) == 1 and int(metas[0][2]) == int(metas[0][0])
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-8
+
+
 def test_bench_two_ranks_on_one_gpu():
     """bench.py's N > 1 branch end to end (gloo for torch.distributed, the test
     double for the library's collectives): same iteration count as N = 1."""

@@ -93,6 +93,30 @@ def test_hip_gmres_matches_oracle(hip, name, restart):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name,nvirt", [("convdiff", 2), ("convdiff", 5), ("powerlaw", 3)])
+def test_hip_gmres_over_row_range_shards(hip, name, nvirt):
+    """GMRES(m) with the operator split into row-range shards: halo exchange in
+    front of every SpMV, ONE all-reduce per Gram-Schmidt pass (all j+1
+    coefficients together) and one per norm; every shard keeps its own copy of
+    the small state and must take the same decisions."""
+    A = operators()[name]
+    b = O.rhs(A.shape[0])
+    M = _matrix(hip, A)
+    kw = dict(op_mode=hip.OP_RAW, krylov=hip.KRYLOV_GMRES, restart=20, tol=1e-10, maxit=5000)
+    s1 = hip.Solver(M, hip.default_opts(**kw))
+    x1, r1 = s1.solve(b)
+    s1.destroy()
+    sp_ = hip.Solver(M, hip.default_opts(nvirt=nvirt, **kw))
+    xp, rp = sp_.solve(b)
+    xq, rq = sp_.solve(b)
+    sp_.destroy()
+    assert rp.status == hip.STATUS_CONVERGED and abs(int(rp.iters) - int(r1.iters)) <= 2
+    assert rq.iters == rp.iters and np.array_equal(xp, xq)
+    assert np.linalg.norm(xp - x1) / np.linalg.norm(x1) <= 1e-8
+    assert np.linalg.norm(b - A @ xp) / np.linalg.norm(b) <= 2e-10
+
+
+@pytest.mark.gpu
 def test_hip_gmres_on_the_raw_reference_matrix(hip, matrix_path, golden_x, golden_meta):
     """The file matrix as-is (unsymmetric by 3.6e-7): GMRES solves A x = b, which
     is NOT CHOLMOD's operator -- the answer differs from the golden vector by
