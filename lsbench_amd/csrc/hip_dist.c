@@ -1,0 +1,323 @@
+/*
+ * What a sharded solve adds to an iteration (DESIGN.md
+ * section 6): the exchange of the gather vector's halos, the all-reduce of the
+ * dot products, the overlap of the two with the SpMV's interior rows -- over
+ * RCCL (hip_comm.c), over direct xGMI stores (hip_p2p.hip), or by device copies
+ * between the virtual shards of one process.
+ */
+#define _GNU_SOURCE
+#include "hip_solver.h"
+
+/* ------------------------------------------------------------------------ */
+/* communication steps: RCCL between processes, device copies between the     */
+/* virtual shards of one process                                              */
+/* ------------------------------------------------------------------------ */
+void exchange_on(lsb_hip_solver *sv, hipStream_t stream) {
+  if (sv->dist) {
+    struct shard *s = &sv->sh[0];
+    lsb_hip_comm_exchange(s->d_pfull, s->send, s->nsend, s->recv, s->nrecv, stream);
+    return;
+  }
+  for (int i = 0; i < sv->nshard; i++) {
+    struct shard *s = &sv->sh[i];
+    for (int k = 0; k < s->nrecv; k++) {
+      const struct lsb_xfer *x = &s->recv[k];
+      LSB_CHK_HIP(hipMemcpyAsync(s->d_pfull + x->offset,
+                                 sv->sh[x->peer].d_pfull + x->offset,
+                                 x->count * sizeof(double), hipMemcpyDeviceToDevice,
+                                 stream));
+    }
+  }
+}
+
+void exchange_p(lsb_hip_solver *sv) {
+  if (sv->p2p_halo && sv->dist) { /* peers are other GPUs: both roles in one launch */
+    lsb_p2p_sendrecv(sv->p2p[0], sv->sh[0].d_pfull, g_ar_nostate ? NULL : sv->sh[0].d_st,
+                     g_stream);
+    return;
+  }
+  if (sv->p2p_halo) { /* all sends before any wait: virtual shards share a stream */
+    for (int i = 0; i < sv->nshard; i++)
+      lsb_p2p_send(sv->p2p[i], sv->sh[i].d_pfull, g_ar_nostate ? NULL : sv->sh[i].d_st, g_stream);
+    for (int i = 0; i < sv->nshard; i++)
+      lsb_p2p_recv(sv->p2p[i], sv->sh[i].d_pfull, g_ar_nostate ? NULL : sv->sh[i].d_st, g_stream);
+    return;
+  }
+  exchange_on(sv, g_stream);
+}
+
+/* d_scal[off .. off+cnt) <- sum over shards.  With the direct path the
+ * shard's own partial sums are folded into the same launch: the first `width`
+ * values come from the SpMV's dot partials, the next s->ar2_width from the
+ * array the sweep kernel left in s->ar2_parts, and only the rest must already
+ * sit, reduced, in d_scal. */
+static void allreduce_parts(lsb_hip_solver *sv, unsigned off, unsigned cnt, unsigned width,
+                            int with2) {
+  for (int ph = 1; ph <= 2; ph++)
+    for (int i = 0; i < sv->nshard; i++) {
+      struct shard *s = &sv->sh[i];
+      const double *parts = width ? s->d_parts_pq : NULL;
+      const unsigned w2 = with2 ? s->ar2_width : 0;
+      struct lsb_pcg_state *st = g_ar_nostate ? NULL : s->d_st;
+      const int phases = sv->nshard == 1 ? 3 : ph;
+      if (sv->nshard == 1 && ph == 2)
+        continue;
+      lsb_p2p_allreduce(sv->p2p[i], parts, s->npq, width, s->ar2_parts, s->ar2_n, w2,
+                        s->d_scal + off + width + w2, cnt - width - w2, s->d_scal + off, st,
+                        phases, g_stream);
+    }
+}
+
+void allreduce_scal(lsb_hip_solver *sv, unsigned off, unsigned cnt) {
+  if (sv->p2p_on) {
+    allreduce_parts(sv, off, cnt, 0, 0);
+    return;
+  }
+  if (sv->dist)
+    lsb_hip_comm_allreduce_stream(sv->sh[0].d_scal + off, (int)cnt, g_stream);
+  else if (sv->nshard > 1)
+    lsb_k_vreduce(sv->d_scal_all, SCAL_STRIDE, (unsigned)sv->nshard, off, cnt, g_stream);
+}
+
+/* d_scal[0] <- all-reduced sum of the SpMV's dot partials; d_scal[1..cnt) are
+ * all-reduced along with it */
+void allreduce_pq(lsb_hip_solver *sv, unsigned cnt, int with2) {
+  if (sv->p2p_on) {
+    allreduce_parts(sv, 0, cnt, 1, with2);
+    return;
+  }
+  for (int i = 0; i < sv->nshard; i++) {
+    struct shard *s = &sv->sh[i];
+    lsb_k_reduce_final(s->d_parts_pq, s->npq, 1, s->d_scal + 0, 0, s->d_st, g_stream);
+  }
+  allreduce_scal(sv, 0, cnt);
+}
+
+/*
+ * Exchange + SpMV of one iteration with the halo transfer hidden behind the
+ * rows that do not need it: the exchange runs on its
+ * own stream as soon as the vector is final, the interior row blocks start at
+ * once on the compute stream, the boundary blocks wait for the halo.  Three
+ * launches of the same kernel on sub-ranges of the row blocks; their partial
+ * sums land in consecutive regions of the shard's partial buffer.
+ */
+int can_overlap(const lsb_hip_solver *sv) {
+  if (!sv->multi || !sv->o.overlap)
+    return 0;
+  for (int i = 0; i < sv->nshard; i++) {
+    const struct shard *s = &sv->sh[i];
+    if (!(s->variant == LSB_SPMV_ADAPTIVE && s->ov_ok) && !(s->variant == LSB_SPMV_SELL && s->ov_sok))
+      return 0;
+  }
+  /* auto: the split SpMV costs 2 launches (direct path) or 2 launches and two
+   * cross-stream events (RCCL), 6-20 us; a halo of >= 64 Ki doubles takes
+   * longer than that on one xGMI link.  agree_halo is the largest halo of ANY
+   * rank, so every rank takes the same branch. */
+  if (sv->o.overlap < 0)
+    return sv->agree_halo >= 65536u;
+  return 1;
+}
+
+/* part 0: the rows that need no halo; 1 / 2: the ones before / after them */
+void spmv_range(struct shard *s, int part, double *y, double *partials, unsigned *np,
+                       const struct lsb_pcg_state *st) {
+  *np = 0;
+  if (s->variant == LSB_SPMV_SELL) {
+    const unsigned b0 = part == 0 ? s->ov_s1 : part == 1 ? 0 : s->ov_s2;
+    const unsigned b1 = part == 0 ? s->ov_s2 : part == 1 ? s->ov_s1 : s->nslice;
+    if (b1 > b0)
+      sell_launch(s, b0, b1 - b0, s->d_pfull, y, s->d_pfull + s->row_begin, partials, np, st);
+    return;
+  }
+  const unsigned b0 = part == 0 ? s->ov_b1 : part == 1 ? 0 : s->ov_b2;
+  const unsigned b1 = part == 0 ? s->ov_b2 : part == 1 ? s->ov_b1 : s->nblk;
+  if (b1 > b0)
+    lsb_k_spmv(LSB_SPMV_ADAPTIVE, s->n, s->d_offs, s->d_cols, s->d_vals, s->d_rowblk + b0,
+               s->d_blklanes + b0, b1 - b0, s->lanes, s->sp_flags, s->sp_grid, s->d_pfull, y,
+               s->d_pfull + s->row_begin, partials, np, st, NULL, g_stream);
+}
+
+void exchange_and_spmv(lsb_hip_solver *sv, int sample) {
+  if (!can_overlap(sv)) {
+    exchange_p(sv);
+    for (int i = 0; i < sv->nshard; i++) {
+      struct shard *s = &sv->sh[i];
+      if (i == 0 && sample >= 0)
+        LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample], g_stream));
+      spmv_shard(s, s->d_pfull, s->d_q, s->d_pfull + s->row_begin, s->d_parts_pq, &s->npq, s->d_st);
+      if (i == 0 && sample >= 0) {
+        LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 1], g_stream));
+        LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 2], g_stream));
+        LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 3], g_stream));
+      }
+    }
+    return;
+  }
+  if (sv->p2p_halo) { /* direct stores to the peers: no second stream needed */
+    for (int i = 0; i < sv->nshard; i++)
+      lsb_p2p_send(sv->p2p[i], sv->sh[i].d_pfull, sv->sh[i].d_st, g_stream);
+  } else {
+    LSB_CHK_HIP(hipEventRecord(sv->ev_vec, g_stream));          /* the vector is final   */
+    LSB_CHK_HIP(hipStreamWaitEvent(g_comm_stream, sv->ev_vec, 0));
+    exchange_on(sv, g_comm_stream);
+    LSB_CHK_HIP(hipEventRecord(sv->ev_halo, g_comm_stream));    /* the halo has landed   */
+  }
+  if (sample >= 0)
+    LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample], g_stream));
+  unsigned na, nb, nc;
+  for (int i = 0; i < sv->nshard; i++) {                         /* interior: no halo     */
+    struct shard *s = &sv->sh[i];
+    spmv_range(s, 0, s->d_q, s->d_parts_pq, &na, s->d_st);
+    s->npq = na;
+  }
+  if (sv->p2p_halo) {
+    for (int i = 0; i < sv->nshard; i++)
+      lsb_p2p_recv(sv->p2p[i], sv->sh[i].d_pfull, sv->sh[i].d_st, g_stream);
+  } else
+    LSB_CHK_HIP(hipStreamWaitEvent(g_stream, sv->ev_halo, 0));
+  for (int i = 0; i < sv->nshard; i++) {                         /* boundary rows         */
+    struct shard *s = &sv->sh[i];
+    spmv_range(s, 1, s->d_q, s->d_parts_pq + s->npq, &nb, s->d_st);
+    spmv_range(s, 2, s->d_q, s->d_parts_pq + s->npq + nb, &nc, s->d_st);
+    s->npq += nb + nc;
+  }
+  if (sample >= 0) {
+    LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 1], g_stream));
+    LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 2], g_stream));
+    LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 3], g_stream));
+  }
+}
+
+/*
+ * Direct xGMI path: build it, prove it, time it, and only then use it.
+ *   dist:    collective.  Every rank runs P2P_ROUNDS rounds of {pattern ->
+ *            exchange -> check the halos bit by bit -> all-reduce of three
+ *            known values -> check the sums}, then times 100 x {exchange +
+ *            all-reduce} on this path and on RCCL.  The path is kept when
+ *            EVERY rank saw zero mismatches, no time-out, and (comm = auto) a
+ *            faster loop; the decision is taken on all-gathered numbers, so
+ *            all ranks take the same one.
+ *   virtual: only on request (comm = p2p), for the one-GPU tests of the
+ *            kernels; device copies remain the default there.
+ */
+#define P2P_ROUNDS 24
+#define P2P_TIMED 100
+static void p2p_rounds(lsb_hip_solver *sv, int rounds, int check, unsigned *d_bad) {
+  for (int t = 0; t < rounds; t++) {
+    for (int i = 0; i < sv->nshard && check; i++)
+      lsb_p2p_test_pattern(sv->sh[i].d_pfull, sv->sh[i].row_begin, sv->sh[i].n, (unsigned)t,
+                           g_stream);
+    exchange_p(sv);
+    for (int i = 0; i < sv->nshard && check; i++) {
+      struct shard *s = &sv->sh[i];
+      for (int k = 0; k < s->nrecv && sv->p2p_halo; k++)
+        lsb_p2p_test_check_range(s->d_pfull, s->recv[k].offset, s->recv[k].count, (unsigned)t,
+                                 d_bad, g_stream);
+      lsb_p2p_test_setvals(s->d_scal, sv->dist ? lsb_hip_comm_rank() : i, (unsigned)t, g_stream);
+    }
+    allreduce_scal(sv, 0, 3);
+    for (int i = 0; i < sv->nshard && check; i++)
+      lsb_p2p_test_checkvals(sv->sh[i].d_scal, sv->dist ? lsb_hip_comm_size() : sv->nshard,
+                             (unsigned)t, d_bad, g_stream);
+  }
+}
+
+static float timed_rounds(lsb_hip_solver *sv) {
+  float ms = 0;
+  if (sv->dist)
+    lsb_hip_comm_barrier();
+  p2p_rounds(sv, 8, 0, NULL);
+  LSB_CHK_HIP(hipEventRecord(sv->ev_t0, g_stream));
+  p2p_rounds(sv, P2P_TIMED, 0, NULL);
+  LSB_CHK_HIP(hipEventRecord(sv->ev_t1, g_stream));
+  LSB_CHK_HIP(hipEventSynchronize(sv->ev_t1));
+  LSB_CHK_HIP(hipEventElapsedTime(&ms, sv->ev_t0, sv->ev_t1));
+  return ms * 1e3f / P2P_TIMED;
+}
+
+void p2p_setup(lsb_hip_solver *sv) {
+  if (!sv->multi || sv->o.comm == LSB_COMM_RCCL || (!sv->dist && sv->o.comm != LSB_COMM_P2P))
+    return;
+  const int P = sv->dist ? lsb_hip_comm_size() : 1;
+  sv->p2p = lsb_calloc(struct lsb_p2p *, sv->nshard);
+  int ok;
+  if (sv->dist) {
+    struct shard *s = &sv->sh[0];
+    sv->p2p[0] = lsb_p2p_create_dist(s->recv, s->nrecv, s->send, s->nsend);
+    ok = sv->p2p[0] != NULL;
+  } else {
+    struct lsb_xfer **rv = lsb_calloc(struct lsb_xfer *, sv->nshard),
+                    **sd = lsb_calloc(struct lsb_xfer *, sv->nshard);
+    int *nr = lsb_calloc(int, sv->nshard), *ns = lsb_calloc(int, sv->nshard);
+    for (int i = 0; i < sv->nshard; i++)
+      rv[i] = sv->sh[i].recv, sd[i] = sv->sh[i].send, nr[i] = sv->sh[i].nrecv,
+      ns[i] = sv->sh[i].nsend;
+    ok = lsb_p2p_create_virtual(sv->p2p, sv->nshard, rv, nr, sd, ns) == 0;
+    free(rv), free(sd), free(nr), free(ns);
+  }
+  unsigned mine[3] = {(unsigned)ok, 0, 0}, *all = lsb_calloc(unsigned, 3 * (size_t)P);
+#define AGREE() (sv->dist ? (void)lsb_hip_comm_allgather_u32(mine, 3, all) : (void)memcpy(all, mine, sizeof mine))
+  AGREE();
+  for (int q = 0; q < P; q++)
+    ok &= all[3 * q] != 0;
+  if (ok) {
+    unsigned *d_bad = (unsigned *)lsb_hip_malloc(sizeof(unsigned)), bad = 0;
+    LSB_CHK_HIP(hipMemsetAsync(d_bad, 0, sizeof(unsigned), g_stream));
+    for (int i = 0; i < sv->nshard; i++)
+      LSB_CHK_HIP(hipMemsetAsync(sv->sh[i].d_st, 0, sizeof(struct lsb_pcg_state), g_stream));
+    sv->p2p_on = 1, sv->p2p_halo = lsb_p2p_has_halo(sv->p2p[0]);
+    if (sv->dist)
+      lsb_hip_comm_barrier();
+    p2p_rounds(sv, P2P_ROUNDS, 1, d_bad);
+    LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+    lsb_hip_memcpy_d2h(&bad, d_bad, sizeof(unsigned));
+    for (int i = 0; i < sv->nshard; i++) {
+      struct lsb_pcg_state hst;
+      lsb_hip_memcpy_d2h(&hst, sv->sh[i].d_st, sizeof hst);
+      bad += hst.status != 0;
+    }
+    lsb_hip_free(d_bad);
+    mine[0] = bad == 0;
+    AGREE(); /* nobody times a path somebody saw fail */
+    for (int q = 0; q < P; q++)
+      ok &= all[3 * q] != 0;
+    for (int i = 0; i < sv->nshard; i++)
+      LSB_CHK_HIP(hipMemsetAsync(sv->sh[i].d_st, 0, sizeof(struct lsb_pcg_state), g_stream));
+    if (ok) {
+      sv->p2p_us = timed_rounds(sv);
+      const int halo = sv->p2p_halo;
+      sv->p2p_on = sv->p2p_halo = 0;
+      sv->rccl_us = timed_rounds(sv);
+      sv->p2p_on = 1, sv->p2p_halo = halo;
+    }
+    mine[0] = (unsigned)ok, mine[1] = (unsigned)(sv->p2p_us * 1e3),
+    mine[2] = (unsigned)(sv->rccl_us * 1e3);
+    AGREE();
+    unsigned tp = 0, tr = 0;
+    for (int q = 0; q < P; q++) {
+      tp = all[3 * q + 1] > tp ? all[3 * q + 1] : tp;
+      tr = all[3 * q + 2] > tr ? all[3 * q + 2] : tr;
+    }
+    if (sv->o.comm == LSB_COMM_AUTO && tp >= tr)
+      ok = 0;
+    if (sv->o.verbose)
+      fprintf(stderr, "hip_cdna4: direct xGMI path %s: %u mismatches here, exchange+all-reduce "
+                      "%.1f us vs %.1f us over RCCL -> %s\n",
+              lsb_p2p_has_halo(sv->p2p[0]) ? "(halos + all-reduce)" : "(all-reduce only)", bad,
+              tp * 1e-3, tr * 1e-3, ok ? "used" : "not used");
+  }
+#undef AGREE
+  free(all);
+  if (!ok) {
+    if (sv->o.comm == LSB_COMM_P2P)
+      errx(EXIT_FAILURE, "hip_cdna4: comm = p2p requested, but the direct xGMI path is not "
+                         "available or failed its self-test");
+    sv->p2p_on = sv->p2p_halo = 0;
+    for (int i = 0; i < sv->nshard; i++)
+      lsb_p2p_destroy(sv->p2p[i]);
+    free(sv->p2p), sv->p2p = NULL;
+  }
+  for (int i = 0; i < sv->nshard; i++)
+    LSB_CHK_HIP(hipMemsetAsync(sv->sh[i].d_st, 0, sizeof(struct lsb_pcg_state), g_stream));
+  LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+}

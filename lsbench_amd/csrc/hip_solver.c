@@ -1,0 +1,670 @@
+/*
+ * Shards of the solver object: upload of a row range in the layouts the
+ * kernels want, choice and timing of the SpMV form,
+ * creation / destruction of solvers, SpMV entry points.
+ */
+#define _GNU_SOURCE
+#include "hip_solver.h"
+
+unsigned pow2_ceil(unsigned v) {
+  unsigned p = 1;
+  while (p < v)
+    p <<= 1;
+  return p;
+}
+
+/* SpMV kernel choice: rows of a few dozen non-zeros at most stream through
+ * LDS (adaptive); long-row matrices go wavefront-per-row. */
+void choose_spmv(struct shard *s, const struct lsb_hip_opts *o) {
+  const unsigned mean = s->n ? (unsigned)((s->nnz + s->n - 1) / s->n) : 1;
+  int v = o->spmv_variant;
+  /* A matrix of a few hundred thousand non-zeros is launch-latency bound: the
+   * sub-wavefront kernel has a shorter dependent-load chain (offs -> cols ->
+   * x) than the row-blocked one (rowblk -> offs -> cols -> x -> LDS -> offs)
+   * and wins 3.2 vs 5.7 us per launch on tests/xn3b_A_18.txt. */
+  if (v == LSB_SPMV_AUTO)
+    v = s->nnz <= 500000ull ? LSB_SPMV_SUBWAVE : LSB_SPMV_ADAPTIVE;
+  if (v == LSB_SPMV_PANEL && !s->pn)
+    v = LSB_SPMV_ADAPTIVE; /* the operator did not qualify for panels */
+  if (v == LSB_SPMV_SELL && !s->d_sptr)
+    v = LSB_SPMV_ADAPTIVE; /* no sliced-ELL copy (32-bit offsets exceeded) */
+  s->variant = v;
+  unsigned L = pow2_ceil(mean ? mean : 1);
+  if (L < 2)
+    L = 2;
+  if (L > 64)
+    L = 64;
+  s->lanes = L;
+}
+
+
+/* Column-panel form of the shard (lsb_csr_panelize) + its row blocks, one run
+ * of blocks per panel so that a launch never crosses a panel. */
+static void shard_build_panels(struct shard *s, const struct csr *view, unsigned width) {
+  struct lsb_panel_csr *P = lsb_csr_panelize(view, width);
+  const unsigned np = P->npanels;
+  s->h_pblk = lsb_calloc(unsigned, (size_t)np + 1);
+  size_t cap = (size_t)P->offs[P->npairs] / LSB_BLOCK_NNZ * 2 + 4 * (size_t)np + 16, nb = 0;
+  unsigned *rball = (unsigned *)malloc((cap + 1) * sizeof(unsigned));
+  unsigned char *lanes = (unsigned char *)malloc(cap + 1);
+  for (unsigned p = 0; p < np; p++) {
+    const unsigned b0 = P->pair_begin[p], cnt = P->pair_begin[p + 1] - b0;
+    s->h_pblk[p] = (unsigned)nb;
+    if (cnt == 0)
+      continue;
+    struct csr sub = {cnt, 0, P->offs + b0, NULL, NULL};
+    unsigned *rb = NULL;
+    const unsigned k = lsb_csr_row_blocks(&sub, LSB_BLOCK_NNZ, &rb);
+    if (nb + k + 1 > cap)
+      errx(EXIT_FAILURE, "hip_cdna4: panel row-block estimate too small");
+    lsb_csr_block_lanes(&sub, rb, k, lanes + nb);
+    for (unsigned i = 0; i <= k; i++)
+      rball[nb + i] = rb[i] + b0; /* the last entry is the next panel's first */
+    nb += k;
+    free(rb);
+  }
+  s->h_pblk[np] = (unsigned)nb;
+  rball[nb] = P->npairs;
+  s->pn = np;
+  s->pd_offs = (int *)dev_upload(P->offs, ((size_t)P->npairs + 1) * sizeof(int));
+  s->pd_cols = (int *)dev_upload(P->cols, (size_t)P->offs[P->npairs] * sizeof(int));
+  s->pd_vals = (double *)dev_upload(P->vals, (size_t)P->offs[P->npairs] * sizeof(double));
+  s->pd_rowmap = (int *)dev_upload(P->pair_row, (size_t)P->npairs * sizeof(int));
+  s->pd_rowblk = (int *)dev_upload(rball, (nb + 1) * sizeof(int));
+  s->pd_blklanes = (unsigned char *)dev_upload(lanes, nb ? nb : 1);
+  LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+  free(rball), free(lanes);
+  lsb_panel_csr_free(P);
+}
+
+/* Upload rows [r0,r1) of the 0-based operator `S` (global column ids) as one
+ * shard.  When `S` holds only the shard's rows, pass local=1. */
+void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
+                         unsigned r1, int local, unsigned row_begin,
+                         unsigned n_glob, const struct lsb_hip_opts *o) {
+  const unsigned a = local ? 0 : r0, b = local ? S->nrows : r1;
+  const unsigned n = b - a, j0 = S->offs[a], j1 = S->offs[b];
+  const unsigned base = S->base;
+  s->row_begin = row_begin, s->n = n, s->nnz = j1 - j0;
+  int *offs = (int *)malloc(((size_t)n + 1) * sizeof(int));
+  int *cols = (int *)malloc(((size_t)s->nnz + 1) * sizeof(int));
+  unsigned lo = 0xFFFFFFFFu, hi = 0;
+  for (unsigned i = 0; i <= n; i++)
+    offs[i] = (int)(S->offs[a + i] - j0);
+  for (unsigned j = j0; j < j1; j++) {
+    const unsigned c = S->cols[j] - base;
+    if (c >= n_glob)
+      errx(EXIT_FAILURE, "column %u outside the %u-column operator", c, n_glob);
+    cols[j - j0] = (int)c;
+    if (c < lo)
+      lo = c;
+    if (c + 1 > hi)
+      hi = c + 1;
+  }
+  if (s->nnz == 0)
+    lo = hi = row_begin;
+  s->col_lo = lo, s->col_hi = hi;
+  if ((unsigned long long)s->nnz > 0x7FFFFFFFull || n_glob > 0x7FFFFFFFu)
+    errx(EXIT_FAILURE, "shard too large for int32 device indices");
+  s->d_offs = (int *)dev_upload(offs, ((size_t)n + 1) * sizeof(int));
+  s->d_cols = (int *)dev_upload(cols, (size_t)s->nnz * sizeof(int));
+  s->d_vals = (double *)dev_upload(S->vals + j0, (size_t)s->nnz * sizeof(double));
+  /* row blocks of the adaptive kernel, on the local offsets */
+  struct csr view = {n, 0, (unsigned *)offs, NULL, NULL};
+  unsigned *rb = NULL;
+  s->nblk = lsb_csr_row_blocks(&view, LSB_BLOCK_NNZ, &rb);
+  s->d_rowblk = (int *)dev_upload(rb, ((size_t)s->nblk + 1) * sizeof(int));
+  unsigned char *lanes = (unsigned char *)malloc((size_t)s->nblk + 1);
+  lsb_csr_block_lanes(&view, rb, s->nblk, lanes);
+  s->d_blklanes = (unsigned char *)dev_upload(lanes, (size_t)s->nblk);
+  /* Which row blocks touch columns owned by other shards?  Under row-range
+   * partitioning of a banded operator they are a prefix and a suffix; the
+   * blocks in between can start before the halo has arrived. */
+  {
+    const int row_end = (int)(row_begin + n);
+    unsigned b1 = 0, b2 = s->nblk;
+    int ok = 1;
+    unsigned char *ext = (unsigned char *)calloc(s->nblk ? s->nblk : 1, 1);
+    for (unsigned k = 0; k < s->nblk; k++)
+      for (unsigned r = rb[k]; r < rb[k + 1] && !ext[k]; r++)
+        if (offs[r + 1] > offs[r] &&
+            (cols[offs[r]] < (int)row_begin || cols[offs[r + 1] - 1] >= row_end))
+          ext[k] = 1;
+    while (b1 < s->nblk && ext[b1])
+      b1++;
+    while (b2 > b1 && ext[b2 - 1])
+      b2--;
+    for (unsigned k = b1; k < b2; k++)
+      ok &= !ext[k];
+    free(ext);
+    s->ov_ok = ok && b2 > b1, s->ov_b1 = b1, s->ov_b2 = b2;
+  }
+  /* Scattered rows (mean |col-row| in the millions, x far beyond L2): also
+   * build the column-panel form; tune_spmv() keeps whichever is faster. */
+  {
+    struct csr gview = {n, 0, (unsigned *)offs, (unsigned *)cols, (double *)(S->vals + j0)};
+    const char *e = getenv("LSBENCH_HIP_PANEL_COLS");
+    const unsigned width = e ? (unsigned)strtoul(e, NULL, 10) : 262144u; /* 2 MiB of x */
+    const int forced = o->spmv_variant == LSB_SPMV_PANEL;
+    const int scattered = s->nnz > 4000000ull && (double)(hi - lo) * 8.0 > 16.0e6 &&
+                          lsb_csr_mean_scatter(&gview, row_begin) > 1.0e6;
+    if (width && (forced || (o->spmv_variant == LSB_SPMV_AUTO && scattered)))
+      shard_build_panels(s, &gview, width);
+  }
+  /* Near-uniform row lengths (stencils, meshes): also keep a sliced-ELL copy;
+   * tune_spmv() keeps whichever kernel is faster on this shard. */
+  {
+    struct csr gview = {n, 0, (unsigned *)offs, (unsigned *)cols, (double *)(S->vals + j0)};
+    const int forced = o->spmv_variant == LSB_SPMV_SELL;
+    const unsigned long long stored = (forced || s->nnz >= 4000000ull) ? lsb_csr_sell_stored(&gview) : 0;
+    struct lsb_sell *E = NULL;
+    if (stored && (forced || (o->spmv_variant == LSB_SPMV_AUTO && stored <= s->nnz + s->nnz / 8)))
+      E = lsb_csr_sellize(&gview);
+    if (E) {
+      s->nslice = E->nslice;
+      s->d_sptr = (unsigned *)dev_upload(E->sptr, ((size_t)E->nslice + 1) * sizeof(unsigned));
+      s->d_scols = (int *)dev_upload(E->cols, ((size_t)E->stored + LSB_SELL_ROWS) * sizeof(int));
+      s->d_svals = (double *)dev_upload(E->vals, ((size_t)E->stored + LSB_SELL_ROWS) * sizeof(double));
+      const int row_end = (int)(row_begin + n);
+      unsigned s1 = 0, s2 = E->nslice;
+      int ok = 1;
+      unsigned char *ext = (unsigned char *)calloc(E->nslice ? E->nslice : 1, 1);
+      for (unsigned k = 0; k < E->nslice; k++)
+        for (unsigned r = k * LSB_SELL_ROWS; r < n && r < (k + 1) * LSB_SELL_ROWS && !ext[k]; r++)
+          if (offs[r + 1] > offs[r] &&
+              (cols[offs[r]] < (int)row_begin || cols[offs[r + 1] - 1] >= row_end))
+            ext[k] = 1;
+      while (s1 < E->nslice && ext[s1])
+        s1++;
+      while (s2 > s1 && ext[s2 - 1])
+        s2--;
+      for (unsigned k = s1; k < s2; k++)
+        ok &= !ext[k];
+      free(ext);
+      s->ov_sok = ok && s2 > s1, s->ov_s1 = s1, s->ov_s2 = s2;
+      LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+      lsb_sell_free(E);
+      /* 10 instead of 12 bytes per entry where every slot of every slice is
+       * one diagonal band (stencils, banded meshes) */
+      struct lsb_sell *H = getenv("LSBENCH_HIP_NO_C16") ? NULL : lsb_csr_sellize16(&gview, row_begin);
+      if (H && H->stored > s->nnz + s->nnz / 8) {
+        lsb_sell_free(H);
+        H = NULL;
+      }
+      if (H) {
+        s->d_sptr16 = (unsigned *)dev_upload(H->sptr, ((size_t)H->nslice + 1) * sizeof(unsigned));
+        s->d_scodes = (short *)dev_upload(H->codes, ((size_t)H->stored + LSB_SELL_ROWS) * sizeof(short));
+        s->d_sbase = (int *)dev_upload(H->sbase, ((size_t)H->stored / LSB_SELL_ROWS + 1) * sizeof(int));
+        s->d_svals16 = (double *)dev_upload(H->vals, ((size_t)H->stored + LSB_SELL_ROWS) * sizeof(double));
+        LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+        lsb_sell_free(H);
+      }
+    }
+  }
+  LSB_CHK_HIP(hipStreamSynchronize(g_stream)); /* host staging is freed next */
+  free(rb), free(offs), free(cols), free(lanes);
+
+  s->d_dinv = (double *)lsb_hip_malloc((size_t)n * sizeof(double));
+  s->d_r = (double *)lsb_hip_malloc((size_t)n * sizeof(double));
+  s->d_q = (double *)lsb_hip_malloc((size_t)n * sizeof(double));
+  s->d_pfull = (double *)lsb_hip_malloc((size_t)n_glob * sizeof(double));
+  LSB_CHK_HIP(hipMemsetAsync(s->d_pfull, 0, (size_t)n_glob * sizeof(double), g_stream));
+  s->d_parts_pq = (double *)lsb_hip_malloc(3 * LSB_MAX_PARTIALS * sizeof(double));
+  /* two buffers: k_cg1_update reads the previous launch's partials while
+   * writing its own */
+  s->d_parts2 = (double *)lsb_hip_malloc(4 * LSB_MAX_PARTIALS * sizeof(double));
+  s->d_st = (struct lsb_pcg_state *)lsb_hip_malloc(sizeof(struct lsb_pcg_state));
+  LSB_CHK_HIP(hipMemsetAsync(s->d_st, 0, sizeof(struct lsb_pcg_state), g_stream));
+  choose_spmv(s, o);
+
+  if (o->precond == LSB_PRECOND_JACOBI) {
+    int *d_nz = (int *)lsb_hip_malloc(sizeof(int)), nz = 0;
+    LSB_CHK_HIP(hipMemsetAsync(d_nz, 0, sizeof(int), g_stream));
+    lsb_k_jacobi_setup(n, row_begin, s->d_offs, s->d_cols, s->d_vals, s->d_dinv,
+                       d_nz, g_stream);
+    LSB_CHK_HIP(hipMemcpyAsync(&nz, d_nz, sizeof(int), hipMemcpyDeviceToHost, g_stream));
+    LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+    lsb_hip_free(d_nz);
+    if (nz)
+      errx(EXIT_FAILURE, "hip_cdna4: %d rows have no non-zero diagonal entry; "
+                         "Jacobi preconditioning needs one (cf. the stored-diagonal "
+                         "assumption of src/cholmod-impl.h:13)", nz);
+  } else {
+    /* dinv = 1: unpreconditioned CG through the same kernels */
+    double *ones = (double *)malloc((size_t)(n ? n : 1) * sizeof(double));
+    for (unsigned i = 0; i < n; i++)
+      ones[i] = 1.0;
+    LSB_CHK_HIP(hipMemcpy(s->d_dinv, ones, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    free(ones);
+  }
+}
+
+void shard_free(struct shard *s) {
+  lsb_hip_free(s->d_offs), lsb_hip_free(s->d_cols), lsb_hip_free(s->d_vals);
+  lsb_hip_free(s->d_rowblk), lsb_hip_free(s->d_blklanes);
+  lsb_hip_free(s->d_dinv), lsb_hip_free(s->d_r);
+  lsb_hip_free(s->d_q), lsb_hip_free(s->d_pfull), lsb_hip_free(s->d_parts_pq);
+  lsb_hip_free(s->d_p1), lsb_hip_free(s->d_s1);
+  lsb_hip_free(s->d_parts2), lsb_hip_free(s->d_st);
+  lsb_hip_free(s->pd_offs), lsb_hip_free(s->pd_cols), lsb_hip_free(s->pd_vals);
+  lsb_hip_free(s->pd_rowmap), lsb_hip_free(s->pd_rowblk), lsb_hip_free(s->pd_blklanes);
+  lsb_hip_free(s->d_sptr), lsb_hip_free(s->d_scols), lsb_hip_free(s->d_svals);
+  lsb_hip_free(s->d_sptr16), lsb_hip_free(s->d_scodes), lsb_hip_free(s->d_sbase);
+  lsb_hip_free(s->d_svals16);
+  free(s->h_pblk);
+  free(s->recv), free(s->send);
+}
+
+void plan_exchange(struct shard *s, int me, int nall, const unsigned *hull) {
+  s->recv = lsb_calloc(struct lsb_xfer, nall);
+  s->send = lsb_calloc(struct lsb_xfer, nall);
+  lsb_plan_exchange(me, nall, hull, s->recv, &s->nrecv, s->send, &s->nsend);
+}
+
+lsb_hip_solver *solver_alloc(int nshard, const struct lsb_hip_opts *o) {
+  lsb_hip_solver *sv = lsb_calloc(lsb_hip_solver, 1);
+  sv->nshard = nshard;
+  sv->sh = lsb_calloc(struct shard, nshard);
+  sv->o = *o;
+  LSB_CHK_HIP(hipHostMalloc((void **)&sv->h_st, 2 * sizeof(struct lsb_pcg_state), 0));
+  return sv;
+}
+
+void solver_finish_setup(lsb_hip_solver *sv) {
+  sv->d_scal_all = (double *)lsb_hip_malloc((size_t)sv->nshard * SCAL_STRIDE * sizeof(double));
+  LSB_CHK_HIP(hipMemsetAsync(sv->d_scal_all, 0,
+                             (size_t)sv->nshard * SCAL_STRIDE * sizeof(double), g_stream));
+  for (int i = 0; i < sv->nshard; i++)
+    sv->sh[i].d_scal = sv->d_scal_all + (size_t)i * SCAL_STRIDE;
+  sv->d_tmp = (double *)lsb_hip_malloc((size_t)sv->n_here * sizeof(double));
+  for (int i = 0; i < 4 * MAX_SAMPLES; i++)
+    LSB_CHK_HIP(hipEventCreate(&sv->ev[i]));
+  LSB_CHK_HIP(hipEventCreate(&sv->ev_t0));
+  LSB_CHK_HIP(hipEventCreate(&sv->ev_t1));
+  LSB_CHK_HIP(hipEventCreateWithFlags(&sv->ev_poll[0], hipEventDisableTiming));
+  LSB_CHK_HIP(hipEventCreateWithFlags(&sv->ev_poll[1], hipEventDisableTiming));
+  LSB_CHK_HIP(hipEventCreateWithFlags(&sv->ev_vec, hipEventDisableTiming));
+  LSB_CHK_HIP(hipEventCreateWithFlags(&sv->ev_halo, hipEventDisableTiming));
+  sv->have_events = 1;
+  LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+  for (int i = 0; i < sv->nshard; i++)
+    tune_spmv(sv, &sv->sh[i]);
+  LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+  p2p_setup(sv);
+}
+
+lsb_hip_solver *lsb_hip_solver_create(const struct csr *A,
+                                      const struct lsb_hip_opts *o_in) {
+  if (!lsb_initialized || !A || A->nrows == 0)
+    return NULL;
+  struct lsb_hip_opts o;
+  if (o_in)
+    o = *o_in;
+  else
+    lsb_hip_get_opts(&o);
+  /* the operator, 0-based, both triangles */
+  struct csr *S = o.op_mode == LSB_OP_CHOLMOD_UPPER ? lsb_csr_symmetrize_upper(A)
+                                                    : lsb_csr_copy_base0(A);
+  int P = o.nvirt > 1 ? o.nvirt : 1;
+  if ((unsigned)P > S->nrows / 2)
+    P = 1;
+  lsb_hip_solver *sv = solver_alloc(P, &o);
+  if (o.reorder) {
+    /* Q = RCM(S); S <- Q S Q^T (src/cusparse.c:67-97) */
+    unsigned *perm = (unsigned *)malloc((size_t)S->nrows * sizeof(unsigned));
+    if (!perm || lsb_csr_rcm(S, perm))
+      errx(EXIT_FAILURE, "hip_cdna4: out of memory computing the RCM ordering");
+    struct csr *Sp = lsb_csr_permute_sym(S, perm);
+    if (o.verbose)
+      fprintf(stderr, "hip_cdna4: RCM bandwidth %u -> %u\n", lsb_csr_bandwidth(S),
+              lsb_csr_bandwidth(Sp));
+    lsbench_matrix_free(S);
+    S = Sp;
+    sv->d_perm = (int *)dev_upload(perm, (size_t)S->nrows * sizeof(int));
+    LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+    free(perm);
+    sv->d_bp = (double *)lsb_hip_malloc((size_t)S->nrows * sizeof(double));
+    sv->d_xp = (double *)lsb_hip_malloc((size_t)S->nrows * sizeof(double));
+  }
+  sv->n_glob = sv->n_here = S->nrows, sv->row_first = 0;
+  sv->dist = 0, sv->multi = P > 1;
+  unsigned *bounds = lsb_calloc(unsigned, (size_t)P + 1);
+  lsb_csr_partition_rows(S, (unsigned)P, bounds);
+  unsigned *hull = lsb_calloc(unsigned, 4 * (size_t)P);
+  for (int q = 0; q < P; q++) {
+    shard_upload(&sv->sh[q], S, bounds[q], bounds[q + 1], 0, bounds[q], S->nrows, &o);
+    hull[4 * q] = bounds[q], hull[4 * q + 1] = bounds[q + 1] - bounds[q];
+    hull[4 * q + 2] = sv->sh[q].col_lo, hull[4 * q + 3] = sv->sh[q].col_hi;
+  }
+  for (int q = 0; q < P; q++) {
+    plan_exchange(&sv->sh[q], q, P, hull);
+    for (int k = 0; k < sv->sh[q].nrecv; k++)
+      if (sv->sh[q].recv[k].count > sv->agree_halo)
+        sv->agree_halo = (unsigned)sv->sh[q].recv[k].count;
+  }
+  free(hull), free(bounds);
+  lsbench_matrix_free(S);
+  solver_finish_setup(sv);
+  return sv;
+}
+
+lsb_hip_solver *lsb_hip_solver_create_dist(const struct csr *A_rows,
+                                           unsigned row_begin,
+                                           unsigned n_global,
+                                           const struct lsb_hip_opts *o_in) {
+  if (!lsb_initialized || !A_rows)
+    return NULL;
+  struct lsb_hip_opts o;
+  if (o_in)
+    o = *o_in;
+  else
+    lsb_hip_get_opts(&o);
+  const int P = lsb_hip_comm_size(), me = lsb_hip_comm_rank();
+  lsb_hip_solver *sv = solver_alloc(1, &o);
+  sv->n_glob = n_global, sv->n_here = A_rows->nrows, sv->row_first = row_begin;
+  sv->dist = P > 1, sv->multi = P > 1;
+  shard_upload(&sv->sh[0], A_rows, 0, 0, 1, row_begin, n_global, &o);
+  unsigned mine[4] = {row_begin, A_rows->nrows, sv->sh[0].col_lo, sv->sh[0].col_hi};
+  unsigned *hull = lsb_calloc(unsigned, 4 * (size_t)P);
+  lsb_hip_comm_allgather_u32(mine, 4, hull);
+  /* every rank must enqueue the SAME number of iterations between polls (the
+   * collectives inside have to pair up), so the chunk size is derived from
+   * numbers all ranks agree on: the largest shard */
+  {
+    unsigned nz = (unsigned)sv->sh[0].nnz, *allnz = lsb_calloc(unsigned, (size_t)P);
+    lsb_hip_comm_allgather_u32(&nz, 1, allnz);
+    for (int q = 0; q < P; q++) {
+      if (allnz[q] > sv->agree_nnz)
+        sv->agree_nnz = allnz[q];
+      if (hull[4 * q + 1] > sv->agree_n)
+        sv->agree_n = hull[4 * q + 1];
+    }
+    free(allnz);
+  }
+  /* sanity: the shards must tile [0, n_global) in rank order */
+  unsigned expect = 0;
+  int full = 1, equal = 1;
+  for (int q = 0; q < P; q++) {
+    if (hull[4 * q] != expect)
+      errx(EXIT_FAILURE, "hip_cdna4: rank %d owns rows from %u, expected %u "
+                         "(row ranges must tile the operator in rank order)",
+           q, hull[4 * q], expect);
+    expect += hull[4 * q + 1];
+    full &= hull[4 * q + 2] == 0 && hull[4 * q + 3] == n_global;
+    equal &= hull[4 * q + 1] == hull[1];
+  }
+  if (expect != n_global)
+    errx(EXIT_FAILURE, "hip_cdna4: shards cover %u rows, operator has %u", expect, n_global);
+  plan_exchange(&sv->sh[0], me, P, hull);
+  if (P > 1 && full && equal) {
+    /* every shard references every row: the north-star all-gather of x */
+    sv->sh[0].nsend = 1, sv->sh[0].send[0].peer = -1;
+    sv->sh[0].send[0].offset = row_begin, sv->sh[0].send[0].count = A_rows->nrows;
+    sv->sh[0].nrecv = 0;
+  }
+  free(hull);
+  {
+    unsigned h = 0, *allh = lsb_calloc(unsigned, (size_t)P);
+    for (int k = 0; k < sv->sh[0].nrecv; k++)
+      if (sv->sh[0].recv[k].count > h)
+        h = (unsigned)sv->sh[0].recv[k].count;
+    lsb_hip_comm_allgather_u32(&h, 1, allh);
+    for (int q = 0; q < P; q++)
+      if (allh[q] > sv->agree_halo)
+        sv->agree_halo = allh[q];
+    free(allh);
+  }
+  solver_finish_setup(sv);
+  return sv;
+}
+
+void lsb_hip_solver_destroy(lsb_hip_solver *sv) {
+  if (!sv)
+    return;
+  LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+  drop_graphs(sv);
+  if (sv->p2p) {
+    if (sv->dist) /* no peer may still be storing into a mailbox that goes away */
+      lsb_hip_comm_barrier();
+    for (int i = 0; i < sv->nshard; i++)
+      lsb_p2p_destroy(sv->p2p[i]);
+    free(sv->p2p);
+  }
+  for (int i = 0; i < sv->nshard; i++)
+    shard_free(&sv->sh[i]);
+  if (sv->have_events) {
+    for (int i = 0; i < 4 * MAX_SAMPLES; i++)
+      LSB_CHK_HIP(hipEventDestroy(sv->ev[i]));
+    LSB_CHK_HIP(hipEventDestroy(sv->ev_t0));
+    LSB_CHK_HIP(hipEventDestroy(sv->ev_t1));
+    LSB_CHK_HIP(hipEventDestroy(sv->ev_poll[0]));
+    LSB_CHK_HIP(hipEventDestroy(sv->ev_poll[1]));
+    LSB_CHK_HIP(hipEventDestroy(sv->ev_vec));
+    LSB_CHK_HIP(hipEventDestroy(sv->ev_halo));
+  }
+  lsb_hip_free(sv->d_scal_all), lsb_hip_free(sv->d_tmp);
+  lsb_hip_free(sv->d_perm), lsb_hip_free(sv->d_bp), lsb_hip_free(sv->d_xp);
+  for (int i = 0; sv->gm && i < sv->nshard; i++) {
+    lsb_hip_free(sv->gm[i].V), lsb_hip_free(sv->gm[i].parts);
+    lsb_hip_free(sv->gm[i].ax), lsb_hip_free(sv->gm[i].st);
+  }
+  free(sv->gm);
+  lsb_hip_free(sv->gm_red);
+  if (sv->gm_hst)
+    LSB_CHK_HIP(hipHostFree(sv->gm_hst));
+  LSB_CHK_HIP(hipHostFree(sv->h_st));
+  free(sv->sh), free(sv);
+}
+
+unsigned lsb_hip_solver_nrows_local(const lsb_hip_solver *s) { return s->n_here; }
+unsigned lsb_hip_solver_nrows_global(const lsb_hip_solver *s) { return s->n_glob; }
+unsigned long long lsb_hip_solver_nnz_local(const lsb_hip_solver *s) {
+  unsigned long long z = 0;
+  for (int i = 0; i < s->nshard; i++)
+    z += s->sh[i].nnz;
+  return z;
+}
+unsigned lsb_hip_solver_nblocks(const lsb_hip_solver *s) { return s->sh[0].nblk; }
+int lsb_hip_solver_spmv_variant(const lsb_hip_solver *s) { return s->sh[0].variant; }
+unsigned lsb_hip_solver_spmv_flags(const lsb_hip_solver *s) { return s->sh[0].sp_flags; }
+unsigned lsb_hip_solver_spmv_grid(const lsb_hip_solver *s) { return s->sh[0].sp_grid; }
+int can_overlap(const lsb_hip_solver *sv);
+int lsb_hip_solver_overlaps(const lsb_hip_solver *s) { return can_overlap(s); }
+int lsb_hip_solver_comm(const lsb_hip_solver *s, double *p2p_us, double *rccl_us) {
+  if (p2p_us)
+    *p2p_us = s->p2p_us;
+  if (rccl_us)
+    *rccl_us = s->rccl_us;
+  return !s->multi ? 0 : !s->p2p_on ? 1 : s->p2p_halo ? 3 : 2;
+}
+
+
+void sell_launch(struct shard *s, unsigned s0, unsigned ns, const double *xfull, double *y,
+                        const double *xdot, double *partials, unsigned *np,
+                        const struct lsb_pcg_state *st) {
+  if ((s->sp_flags & LSB_SP_C16) && s->d_scodes)
+    lsb_k_spmv_sell(s->sp_flags, s->sp_grid, s->d_sptr16, s0, ns, s->n, s->row_begin, s->d_scodes,
+                    s->d_sbase, s->d_svals16, xfull, y, xdot, partials, np, st, g_stream);
+  else
+    lsb_k_spmv_sell(s->sp_flags & ~LSB_SP_C16, s->sp_grid, s->d_sptr, s0, ns, s->n, s->row_begin,
+                    s->d_scols, NULL, s->d_svals, xfull, y, xdot, partials, np, st, g_stream);
+}
+
+void spmv_shard(struct shard *s, const double *xfull, double *y,
+                       const double *xdot, double *partials, unsigned *np,
+                       const struct lsb_pcg_state *st) {
+  if (s->variant == LSB_SPMV_PANEL) {
+    /* y = 0, then one launch per column panel accumulates into it: inside a
+     * launch every XCD gathers from the same 2 MiB slice of x, out of its L2 */
+    LSB_CHK_HIP(hipMemsetAsync(y, 0, (size_t)s->n * sizeof(double), g_stream));
+    for (unsigned p = 0; p < s->pn; p++) {
+      const unsigned b0 = s->h_pblk[p], nb = s->h_pblk[p + 1] - b0;
+      if (nb)
+        lsb_k_spmv(LSB_SPMV_ADAPTIVE, s->n, s->pd_offs, s->pd_cols, s->pd_vals,
+                   s->pd_rowblk + b0, s->pd_blklanes + b0, nb, s->lanes, s->sp_flags,
+                   s->sp_grid, xfull, y, NULL, NULL, NULL, st, s->pd_rowmap, g_stream);
+    }
+    if (partials)
+      lsb_k_dot(s->n, y, xdot, partials, np, g_stream);
+    return;
+  }
+  if (s->variant == LSB_SPMV_SELL) {
+    sell_launch(s, 0, s->nslice, xfull, y, xdot, partials, np, st);
+    return;
+  }
+  lsb_k_spmv(s->variant, s->n, s->d_offs, s->d_cols, s->d_vals, s->d_rowblk, s->d_blklanes,
+             s->nblk, s->lanes, s->sp_flags, s->sp_grid, xfull, y, xdot, partials, np, st,
+             NULL, g_stream);
+}
+
+/*
+ * Pick the adaptive SpMV's flavour for this operator by timing it (setup is
+ * untimed, like the reference's csr_init): {plain, prefetch, nontemporal,
+ * both}, 3 launches each after one warm-up, on the
+ * shard's own matrix with the dot product fused as in the solve.  Which one
+ * wins depends on how much of x's gather window survives in L2 next to the
+ * matrix stream: on the 10M-row 5-point operator nontemporal stream loads win
+ * by 15%, on the 7-point 256^3 one prefetch without nontemporal does.
+ */
+void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
+  const struct lsb_hip_opts *o = &sv->o;
+  s->sp_flags = LSB_SP_PREFETCH | LSB_SP_NT;
+  s->sp_grid = o->spmv_grid > 0 ? (unsigned)o->spmv_grid : LSB_MAX_PARTIALS;
+  if (o->spmv_tune >= 0) {
+    s->sp_flags = (unsigned)o->spmv_tune & 7u; /* bit 2: 16-bit codes, where that copy exists */
+    return;
+  }
+  if (s->variant == LSB_SPMV_SELL && !s->d_sptr)
+    s->variant = LSB_SPMV_ADAPTIVE; /* the operator did not qualify for the copy */
+  if ((s->variant != LSB_SPMV_ADAPTIVE && s->variant != LSB_SPMV_PANEL &&
+       s->variant != LSB_SPMV_SELL) ||
+      s->nnz < 4000000ull)
+    return; /* small operators are launch-latency bound: nothing to tune */
+  float best = 1e30f;
+  unsigned bf = s->sp_flags, np;
+  int bv = s->variant;
+  const unsigned grid0 = s->sp_grid;
+  unsigned bg = grid0;
+  /* candidates {form, flags, grid}: the form asked for, or (auto) every form
+   * this shard has; the sliced-ELL kernels have no prefetch flavour, they try
+   * 6 instead of 8 resident workgroups per CU instead */
+  struct {
+    int v;
+    unsigned f, g;
+  } cand[16];
+  int ncand = 0;
+  const int any = o->spmv_variant == LSB_SPMV_AUTO;
+  if (any || s->variant == LSB_SPMV_ADAPTIVE)
+    for (unsigned f = 0; f < 4; f++)
+      cand[ncand].v = LSB_SPMV_ADAPTIVE, cand[ncand].f = f, cand[ncand++].g = grid0;
+  if (s->pn && (any || s->variant == LSB_SPMV_PANEL))
+    for (unsigned f = 0; f < 4; f++)
+      cand[ncand].v = LSB_SPMV_PANEL, cand[ncand].f = f, cand[ncand++].g = grid0;
+  if (s->d_sptr && (any || s->variant == LSB_SPMV_SELL))
+    for (unsigned c16 = 0; c16 <= (s->d_scodes ? LSB_SP_C16 : 0u); c16 += LSB_SP_C16) {
+      cand[ncand].v = LSB_SPMV_SELL, cand[ncand].f = c16 | LSB_SP_NT, cand[ncand++].g = grid0;
+      cand[ncand].v = LSB_SPMV_SELL, cand[ncand].f = c16, cand[ncand++].g = grid0;
+      if (o->spmv_grid <= 0)
+        cand[ncand].v = LSB_SPMV_SELL, cand[ncand].f = c16 | LSB_SP_NT, cand[ncand++].g = 1536;
+    }
+  for (int ci = 0; ci < ncand; ci++) {
+    s->variant = cand[ci].v, s->sp_flags = cand[ci].f, s->sp_grid = cand[ci].g;
+    spmv_shard(s, s->d_pfull, s->d_q, s->d_pfull + s->row_begin, s->d_parts_pq, &np, NULL);
+    LSB_CHK_HIP(hipEventRecord(sv->ev_t0, g_stream));
+    for (int r = 0; r < 3; r++)
+      spmv_shard(s, s->d_pfull, s->d_q, s->d_pfull + s->row_begin, s->d_parts_pq, &np, NULL);
+    LSB_CHK_HIP(hipEventRecord(sv->ev_t1, g_stream));
+    LSB_CHK_HIP(hipEventSynchronize(sv->ev_t1));
+    float ms = 0.f;
+    LSB_CHK_HIP(hipEventElapsedTime(&ms, sv->ev_t0, sv->ev_t1));
+    if (o->verbose > 1)
+      fprintf(stderr, "hip_cdna4: spmv tune form=%d flags=%u grid=%u: %.1f us\n", s->variant,
+              s->sp_flags, s->sp_grid, ms * 1e3f / 3);
+    if (ms < best)
+      best = ms, bf = s->sp_flags, bv = s->variant, bg = s->sp_grid;
+  }
+  s->sp_grid = bg;
+  s->variant = bv;
+  s->sp_flags = bf;
+  /* the copies that lost are not kept */
+  if (!(bv == LSB_SPMV_SELL && (bf & LSB_SP_C16))) {
+    lsb_hip_free(s->d_sptr16), lsb_hip_free(s->d_scodes), lsb_hip_free(s->d_sbase);
+    lsb_hip_free(s->d_svals16);
+    s->d_sptr16 = NULL, s->d_scodes = NULL, s->d_sbase = NULL, s->d_svals16 = NULL;
+  }
+  if (any && !(bv == LSB_SPMV_SELL && !(bf & LSB_SP_C16))) {
+    lsb_hip_free(s->d_scols), lsb_hip_free(s->d_svals);
+    s->d_scols = NULL, s->d_svals = NULL;
+    if (bv != LSB_SPMV_SELL)
+      lsb_hip_free(s->d_sptr), s->d_sptr = NULL;
+  }
+}
+
+/* y = Op x for the rows of this process */
+int lsb_hip_solver_spmv_dev(lsb_hip_solver *sv, const double *d_x, double *d_y) {
+  if (!lsb_initialized)
+    return 1;
+  if (!sv || !d_x || !d_y)
+    return 2;
+  double *d_yout = NULL;
+  if (sv->d_perm) { /* y = Q^T (Q S Q^T) Q x */
+    lsb_k_perm_gather(sv->n_here, sv->d_perm, d_x, sv->d_bp, g_stream);
+    d_x = sv->d_bp, d_yout = d_y, d_y = sv->d_xp;
+  }
+  for (int i = 0; i < sv->nshard; i++) {
+    struct shard *s = &sv->sh[i];
+    LSB_CHK_HIP(hipMemcpyAsync(s->d_pfull + s->row_begin, d_x + (s->row_begin - sv->row_first),
+                               (size_t)s->n * sizeof(double), hipMemcpyDeviceToDevice,
+                               g_stream));
+  }
+  g_ar_nostate = 1;
+  if (sv->multi)
+    exchange_p(sv);
+  g_ar_nostate = 0;
+  for (int i = 0; i < sv->nshard; i++) {
+    struct shard *s = &sv->sh[i];
+    spmv_shard(s, s->d_pfull, d_y + (s->row_begin - sv->row_first), NULL, NULL, NULL, NULL);
+  }
+  if (d_yout)
+    lsb_k_perm_scatter(sv->n_here, sv->d_perm, d_y, d_yout, g_stream);
+  LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+  return 0;
+}
+
+int lsb_hip_solver_time_spmv(lsb_hip_solver *sv, int warm, int reps, double *ms_avg) {
+  if (!lsb_initialized)
+    return 1;
+  if (!sv || reps < 1 || !ms_avg)
+    return 2;
+  struct shard *s = &sv->sh[0];
+  unsigned np;
+  for (int i = 0; i < warm; i++)
+    spmv_shard(s, s->d_pfull, s->d_q, s->d_pfull + s->row_begin, s->d_parts_pq, &np, NULL);
+  LSB_CHK_HIP(hipEventRecord(sv->ev_t0, g_stream));
+  for (int i = 0; i < reps; i++)
+    spmv_shard(s, s->d_pfull, s->d_q, s->d_pfull + s->row_begin, s->d_parts_pq, &np, NULL);
+  LSB_CHK_HIP(hipEventRecord(sv->ev_t1, g_stream));
+  LSB_CHK_HIP(hipEventSynchronize(sv->ev_t1));
+  float ms = 0.f;
+  LSB_CHK_HIP(hipEventElapsedTime(&ms, sv->ev_t0, sv->ev_t1));
+  *ms_avg = (double)ms / reps;
+  return 0;
+}
+
+int lsb_hip_solver_jacobi_sweep_dev(lsb_hip_solver *sv, double w, const double *d_b,
+                                    double *d_x) {
+  if (!lsb_initialized)
+    return 1;
+  if (!sv || !d_b || !d_x)
+    return 2;
+  int rc = lsb_hip_solver_spmv_dev(sv, d_x, sv->d_tmp);
+  if (rc)
+    return rc;
+  for (int i = 0; i < sv->nshard; i++) {
+    struct shard *s = &sv->sh[i];
+    const size_t o = s->row_begin - sv->row_first;
+    lsb_k_jacobi_sweep(s->n, w, s->d_dinv, d_b + o, sv->d_tmp + o, d_x + o, g_stream);
+  }
+  LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+  return 0;
+}

@@ -1,0 +1,155 @@
+/*
+ * Internals of the solver object shared by the host-side C files of the HIP
+ * backend:
+ *   hip_cdna4.c      backend entry points (init / finalize / bench), options,
+ *                    device memory helpers, kernel-level C-ABI
+ *   hip_solver.c     shards: upload, kernel forms, timing pass, create / destroy
+ *   hip_dist.c       what sharded solves add: exchange, all-reduce, overlap,
+ *                    the direct xGMI path's set-up
+ *   hip_pcg.c        PCG / single-reduction PCG iteration and the host loop
+ *   hip_gmres_drv.c  GMRES(m) driver
+ * Nothing here is part of the C-ABI (include/lsbench_hip.h).
+ */
+#ifndef HIP_SOLVER_H
+#define HIP_SOLVER_H
+
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+#include <math.h>
+#include <string.h>
+#include <strings.h>
+#include <time.h>
+
+#include "lsb_impl.h"
+
+#define LSB_INTERNAL __attribute__((visibility("hidden")))
+
+/* backend globals (defined in hip_cdna4.c; reference style, src/cusparse.c:33-36) */
+extern LSB_INTERNAL int lsb_initialized;
+extern LSB_INTERNAL hipStream_t g_stream, g_comm_stream; /* compute / halo exchange */
+extern LSB_INTERNAL struct lsb_hip_result g_last;
+/* 1: communicate although no solve is running (the device state's status is
+ * whatever the last solve left there) */
+extern LSB_INTERNAL int g_ar_nostate;
+
+/* ------------------------------------------------------------------------ */
+/* solver object                                                             */
+/* ------------------------------------------------------------------------ */
+#define SCAL_STRIDE 8 /* doubles per shard in the scalar slab */
+#define MAX_SAMPLES 64
+
+struct shard {
+  unsigned row_begin, n;
+  unsigned long long nnz;
+  int *d_offs, *d_cols, *d_rowblk;
+  unsigned char *d_blklanes;
+  unsigned sp_flags, sp_grid; /* adaptive-SpMV flavour, picked by tune_spmv() */
+  double *d_vals, *d_dinv, *d_r, *d_q, *d_pfull;
+  double *d_p1, *d_s1; /* single-reduction CG: p and s = S p (pfull then holds u) */
+  unsigned npq, np2;   /* partial counts of the SpMV / sweep launches */
+  const double *ar2_parts; /* sweep partials the next all-reduce folds in */
+  unsigned ar2_n, ar2_width;
+  /* rows that reference other shards' columns sit in row blocks [0,ov_b1) and
+   * [ov_b2,nblk); the blocks in between need no halo (0,0 = not separable) */
+  unsigned ov_b1, ov_b2;
+  int ov_ok;
+  /* sliced-ELL copy (LSB_SPMV_SELL), built when padding stays under 1/8; the
+   * same prefix/interior/suffix split in slices */
+  unsigned *d_sptr;
+  int *d_scols;
+  double *d_svals;
+  unsigned nslice, ov_s1, ov_s2;
+  int ov_sok;
+  /* ... and its 16-bit-code form (LSB_SP_C16 in sp_flags), own slice offsets */
+  unsigned *d_sptr16;
+  short *d_scodes;
+  int *d_sbase;
+  double *d_svals16;
+  double *d_parts_pq, *d_parts2;
+  double *d_scal; /* [0] p.q   [1] r.z'  [2] r.r   (multi-shard path) */
+  struct lsb_pcg_state *d_st;
+  unsigned nblk, lanes;
+  int variant;
+  unsigned col_lo, col_hi; /* column hull referenced by the shard's rows */
+  /* column-panel form (LSB_SPMV_PANEL), built for scattered operators only */
+  unsigned pn;       /* panels, 0 = not built */
+  unsigned *h_pblk;  /* pn+1: first row block of each panel */
+  int *pd_offs, *pd_cols, *pd_rowmap, *pd_rowblk;
+  unsigned char *pd_blklanes;
+  double *pd_vals;
+  struct lsb_xfer *recv, *send;
+  int nrecv, nsend;
+};
+
+struct lsb_hip_solver {
+  unsigned n_glob;   /* rows of the whole operator                         */
+  unsigned n_here;   /* rows held by this process (sum over its shards)     */
+  unsigned row_first; /* first row held by this process                     */
+  int nshard;        /* shards in this process (1, or nvirt)                */
+  int dist;          /* 1: shards of other processes exist (RCCL)           */
+  int multi;         /* nshard > 1 || dist: scalars go through all-reduce   */
+  struct shard *sh;
+  double *d_scal_all; /* nshard * SCAL_STRIDE doubles                        */
+  struct lsb_hip_opts o;
+  struct lsb_pcg_state *h_st; /* pinned, 2 slots */
+  struct {
+    hipGraphExec_t exec;
+    int iters;
+    double *x;
+  } gcache[2];
+  int gnext;
+  unsigned hint_iters; /* iterations of the previous solve, 0 = none yet */
+  unsigned agree_nnz, agree_n; /* distributed: largest shard, identical on all ranks */
+  unsigned agree_halo;         /* largest halo (doubles) any shard receives from one peer */
+  /* reordering: d_perm[new] = old; b and x are permuted through d_bp / d_xp */
+  int *d_perm;
+  double *d_bp, *d_xp;
+  /* GMRES workspace (allocated on first use) */
+  struct gm_work { /* per shard */
+    double *V, *parts, *ax;
+    struct lsb_gmres_state *st;
+    size_t ld;
+  } *gm;
+  double *gm_red; /* nshard x GM_RED doubles: [0] a norm, [8..) h, [48..) h2 -- all-reduced */
+  struct lsb_gmres_state *gm_hst;
+  int gm_m;
+  hipEvent_t ev_poll[2], ev_vec, ev_halo;
+  hipEvent_t ev[4 * MAX_SAMPLES], ev_t0, ev_t1; /* per sample: e0 SpMV e1 e2 e3 */
+  int have_events;
+  double *d_tmp; /* n_here doubles: scratch for spmv_dev / jacobi sweep */
+  /* direct xGMI path (hip_p2p.hip), one context per shard; p2p_on: used for
+   * the all-reduces, p2p_halo: also for the halo exchange */
+  struct lsb_p2p **p2p;
+  int p2p_on, p2p_halo;
+  double p2p_us, rccl_us; /* self-test: one exchange + all-reduce, each way */
+};
+
+/* hip_cdna4.c */
+LSB_INTERNAL double wall_seconds(void);
+LSB_INTERNAL void *dev_upload(const void *h, size_t bytes);
+/* hip_solver.c */
+LSB_INTERNAL unsigned pow2_ceil(unsigned v);
+LSB_INTERNAL void sell_launch(struct shard *s, unsigned s0, unsigned ns, const double *xfull, double *y,
+                              const double *xdot, double *partials, unsigned *np,
+                              const struct lsb_pcg_state *st);
+LSB_INTERNAL void spmv_shard(struct shard *s, const double *xfull, double *y, const double *xdot,
+                             double *partials, unsigned *np, const struct lsb_pcg_state *st);
+LSB_INTERNAL void tune_spmv(lsb_hip_solver *sv, struct shard *s);
+/* hip_dist.c */
+LSB_INTERNAL void p2p_setup(lsb_hip_solver *sv);
+LSB_INTERNAL void exchange_on(lsb_hip_solver *sv, hipStream_t stream);
+LSB_INTERNAL void exchange_p(lsb_hip_solver *sv);
+LSB_INTERNAL void allreduce_scal(lsb_hip_solver *sv, unsigned off, unsigned cnt);
+LSB_INTERNAL void allreduce_pq(lsb_hip_solver *sv, unsigned cnt, int with2);
+LSB_INTERNAL int can_overlap(const lsb_hip_solver *sv);
+LSB_INTERNAL void exchange_and_spmv(lsb_hip_solver *sv, int sample);
+LSB_INTERNAL double true_relres(lsb_hip_solver *sv, const double *d_b, const double *d_x);
+/* hip_pcg.c */
+LSB_INTERNAL void drop_graphs(lsb_hip_solver *sv);
+LSB_INTERNAL int solve_core(lsb_hip_solver *sv, const double *d_b, double *d_x,
+                            struct lsb_hip_result *res);
+/* hip_gmres_drv.c */
+LSB_INTERNAL int gmres_solve_dev(lsb_hip_solver *sv, const double *d_b, double *d_x,
+                                 struct lsb_hip_result *res);
+
+#endif

@@ -1,5 +1,5 @@
 """The N>1 host logic on the CPU: world_size-2 (and 3) gloo ranks run the
-row-partitioned PCG exactly as hip_cdna4.c sequences it (exchange -> SpMV on
+row-partitioned PCG exactly as hip_pcg.c / hip_dist.c sequence it (exchange -> SpMV on
 the global-index vector -> all-reduce(p.q) -> x/r update -> all-reduce(r.z,r.r)
 -> p update), with the PRODUCT's partitioner, shard generator and exchange plan
 (C, through the C-ABI) and the oracle's CPU kernels standing in for the HIP
