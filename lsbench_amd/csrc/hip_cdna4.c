@@ -39,7 +39,6 @@
 int lsb_initialized = 0;
 hipStream_t g_stream = 0, g_comm_stream = 0;
 struct lsb_hip_result g_last;
-int g_ar_nostate = 0;
 static struct lsb_hip_opts g_opts;
 static int g_opts_set = 0;
 

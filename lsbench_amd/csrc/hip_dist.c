@@ -30,17 +30,19 @@ void exchange_on(lsb_hip_solver *sv, hipStream_t stream) {
   }
 }
 
-void exchange_p(lsb_hip_solver *sv) {
+/* gated = 1: part of a running solve (a launch no-ops once the device state has
+ * left RUNNING); 0: communicate whatever the last solve left in that state */
+void exchange_p(lsb_hip_solver *sv, int gated) {
   if (sv->p2p_halo && sv->dist) { /* peers are other GPUs: both roles in one launch */
-    lsb_p2p_sendrecv(sv->p2p[0], sv->sh[0].d_pfull, g_ar_nostate ? NULL : sv->sh[0].d_st,
+    lsb_p2p_sendrecv(sv->p2p[0], sv->sh[0].d_pfull, gated ? sv->sh[0].d_st : NULL,
                      g_stream);
     return;
   }
   if (sv->p2p_halo) { /* all sends before any wait: virtual shards share a stream */
     for (int i = 0; i < sv->nshard; i++)
-      lsb_p2p_send(sv->p2p[i], sv->sh[i].d_pfull, g_ar_nostate ? NULL : sv->sh[i].d_st, g_stream);
+      lsb_p2p_send(sv->p2p[i], sv->sh[i].d_pfull, gated ? sv->sh[i].d_st : NULL, g_stream);
     for (int i = 0; i < sv->nshard; i++)
-      lsb_p2p_recv(sv->p2p[i], sv->sh[i].d_pfull, g_ar_nostate ? NULL : sv->sh[i].d_st, g_stream);
+      lsb_p2p_recv(sv->p2p[i], sv->sh[i].d_pfull, gated ? sv->sh[i].d_st : NULL, g_stream);
     return;
   }
   exchange_on(sv, g_stream);
@@ -52,13 +54,13 @@ void exchange_p(lsb_hip_solver *sv) {
  * array the sweep kernel left in s->ar2_parts, and only the rest must already
  * sit, reduced, in d_scal. */
 static void allreduce_parts(lsb_hip_solver *sv, unsigned off, unsigned cnt, unsigned width,
-                            int with2) {
+                            int with2, int gated) {
   for (int ph = 1; ph <= 2; ph++)
     for (int i = 0; i < sv->nshard; i++) {
       struct shard *s = &sv->sh[i];
       const double *parts = width ? s->d_parts_pq : NULL;
       const unsigned w2 = with2 ? s->ar2_width : 0;
-      struct lsb_pcg_state *st = g_ar_nostate ? NULL : s->d_st;
+      struct lsb_pcg_state *st = gated ? s->d_st : NULL;
       const int phases = sv->nshard == 1 ? 3 : ph;
       if (sv->nshard == 1 && ph == 2)
         continue;
@@ -68,9 +70,9 @@ static void allreduce_parts(lsb_hip_solver *sv, unsigned off, unsigned cnt, unsi
     }
 }
 
-void allreduce_scal(lsb_hip_solver *sv, unsigned off, unsigned cnt) {
+void allreduce_scal(lsb_hip_solver *sv, unsigned off, unsigned cnt, int gated) {
   if (sv->p2p_on) {
-    allreduce_parts(sv, off, cnt, 0, 0);
+    allreduce_parts(sv, off, cnt, 0, 0, gated);
     return;
   }
   if (sv->dist)
@@ -83,14 +85,14 @@ void allreduce_scal(lsb_hip_solver *sv, unsigned off, unsigned cnt) {
  * all-reduced along with it */
 void allreduce_pq(lsb_hip_solver *sv, unsigned cnt, int with2) {
   if (sv->p2p_on) {
-    allreduce_parts(sv, 0, cnt, 1, with2);
+    allreduce_parts(sv, 0, cnt, 1, with2, 1);
     return;
   }
   for (int i = 0; i < sv->nshard; i++) {
     struct shard *s = &sv->sh[i];
     lsb_k_reduce_final(s->d_parts_pq, s->npq, 1, s->d_scal + 0, 0, s->d_st, g_stream);
   }
-  allreduce_scal(sv, 0, cnt);
+  allreduce_scal(sv, 0, cnt, 1);
 }
 
 /*
@@ -139,7 +141,7 @@ void spmv_range(struct shard *s, int part, double *y, double *partials, unsigned
 
 void exchange_and_spmv(lsb_hip_solver *sv, int sample) {
   if (!can_overlap(sv)) {
-    exchange_p(sv);
+    exchange_p(sv, 1);
     for (int i = 0; i < sv->nshard; i++) {
       struct shard *s = &sv->sh[i];
       if (i == 0 && sample >= 0)
@@ -207,7 +209,7 @@ static void p2p_rounds(lsb_hip_solver *sv, int rounds, int check, unsigned *d_ba
     for (int i = 0; i < sv->nshard && check; i++)
       lsb_p2p_test_pattern(sv->sh[i].d_pfull, sv->sh[i].row_begin, sv->sh[i].n, (unsigned)t,
                            g_stream);
-    exchange_p(sv);
+    exchange_p(sv, 1);
     for (int i = 0; i < sv->nshard && check; i++) {
       struct shard *s = &sv->sh[i];
       for (int k = 0; k < s->nrecv && sv->p2p_halo; k++)
@@ -215,7 +217,7 @@ static void p2p_rounds(lsb_hip_solver *sv, int rounds, int check, unsigned *d_ba
                                  d_bad, g_stream);
       lsb_p2p_test_setvals(s->d_scal, sv->dist ? lsb_hip_comm_rank() : i, (unsigned)t, g_stream);
     }
-    allreduce_scal(sv, 0, 3);
+    allreduce_scal(sv, 0, 3, 1);
     for (int i = 0; i < sv->nshard && check; i++)
       lsb_p2p_test_checkvals(sv->sh[i].d_scal, sv->dist ? lsb_hip_comm_size() : sv->nshard,
                              (unsigned)t, d_bad, g_stream);

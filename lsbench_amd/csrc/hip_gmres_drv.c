@@ -65,7 +65,6 @@ int gmres_solve_dev(lsb_hip_solver *sv, const double *d_b, double *d_x,
     LSB_CHK_HIP(hipMemsetAsync(d_x + o, 0, (size_t)s->n * sizeof(double), g_stream));
     LSB_CHK_HIP(hipMemsetAsync(w->ax, 0, (size_t)s->n * sizeof(double), g_stream));
   }
-  g_ar_nostate = 1; /* exchanges here are not tied to a PCG state */
   for (int cycle = 0;; cycle++) {
     if (cycle > 0) { /* ax = Op x for the restart residual */
       EACH(i, s, w) {
@@ -75,7 +74,7 @@ int gmres_solve_dev(lsb_hip_solver *sv, const double *d_b, double *d_x,
                                    g_stream));
       }
       if (sv->multi)
-        exchange_p(sv);
+        exchange_p(sv, 0); /* not tied to a PCG state */
       EACH(i, s, w) spmv_shard(s, s->d_pfull, w->ax, NULL, NULL, NULL, NULL);
     }
     EACH(i, s, w) {
@@ -98,7 +97,7 @@ int gmres_solve_dev(lsb_hip_solver *sv, const double *d_b, double *d_x,
         lsb_k_gm_scale_prec(s->n, vj, vj, s->d_dinv, s->d_pfull + s->row_begin, w->st, g_stream);
       }
       if (sv->multi)
-        exchange_p(sv);
+        exchange_p(sv, 0); /* not tied to a PCG state */
       EACH(i, s, w) spmv_shard(s, s->d_pfull, w->V + (size_t)(j + 1) * w->ld, NULL, NULL, NULL, NULL);
       /* classical Gram-Schmidt, twice (CGS2): h = V^T w ; w -= V h ; h2 likewise */
       for (int pass = 0; pass < 2; pass++) {
@@ -134,7 +133,6 @@ int gmres_solve_dev(lsb_hip_solver *sv, const double *d_b, double *d_x,
       errx(EXIT_FAILURE, "hip_cdna4: GMRES ran past maxit without a status");
   }
 #undef EACH
-  g_ar_nostate = 0;
   struct lsb_hip_result r;
   memset(&r, 0, sizeof r);
   r.iters = (unsigned)sv->gm_hst->iters;

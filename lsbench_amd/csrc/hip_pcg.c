@@ -28,9 +28,7 @@ static void pcg_enqueue_init(lsb_hip_solver *sv, const double *d_b, double *d_x)
       lsb_k_reduce_final(s->d_parts2, np2, 2, s->d_scal + 1, 0, NULL, g_stream);
   }
   if (sv->multi) {
-    g_ar_nostate = 1; /* the device state still holds the previous solve's status */
-    allreduce_scal(sv, 1, 2);
-    g_ar_nostate = 0;
+    allreduce_scal(sv, 1, 2, 0); /* the device state still holds the previous solve's status */
   }
   for (int i = 0; i < sv->nshard; i++) {
     struct shard *s = &sv->sh[i];
@@ -79,7 +77,7 @@ static void pcg_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int sa
       lsb_k_reduce_final(s->d_parts2, np2, 2, s->d_scal + 1, 0, s->d_st, g_stream);
   }
   if (sv->multi)
-    allreduce_scal(sv, 1, 2);
+    allreduce_scal(sv, 1, 2, 1);
   for (int i = 0; i < sv->nshard; i++) {
     struct shard *s = &sv->sh[i];
     lsb_k_pcg_update_p(s->n, s->d_r, s->d_dinv, s->d_pfull + s->row_begin, s->d_st, parity,
@@ -117,9 +115,7 @@ static void cg1_enqueue_init(lsb_hip_solver *sv, const double *d_b, double *d_x)
       lsb_k_reduce_final(s->d_parts2, s->np2, 2, s->d_scal + 1, 0, NULL, g_stream);
   }
   if (sv->multi) {
-    g_ar_nostate = 1; /* the device state still holds the previous solve's status */
-    allreduce_scal(sv, 1, 2);
-    g_ar_nostate = 0;
+    allreduce_scal(sv, 1, 2, 0); /* the device state still holds the previous solve's status */
   }
   for (int i = 0; i < sv->nshard; i++) {
     struct shard *s = &sv->sh[i];
@@ -251,7 +247,7 @@ double true_relres(lsb_hip_solver *sv, const double *d_b, const double *d_x) {
     LSB_CHK_HIP(hipMemcpyAsync(s->d_scal + 5, &minus_one, sizeof(double), hipMemcpyHostToDevice,
                                g_stream));
   }
-  exchange_p(sv);
+  exchange_p(sv, 0);
   for (int i = 0; i < sv->nshard; i++) {
     struct shard *s = &sv->sh[i];
     const size_t o = s->row_begin - sv->row_first;
@@ -261,7 +257,7 @@ double true_relres(lsb_hip_solver *sv, const double *d_b, const double *d_x) {
     lsb_k_dot(s->n, s->d_q, s->d_q, s->d_parts_pq, &np, g_stream);
     lsb_k_reduce_final(s->d_parts_pq, np, 1, s->d_scal + 4, 0, NULL, g_stream);
   }
-  allreduce_scal(sv, 4, 1);
+  allreduce_scal(sv, 4, 1, 0);
   LSB_CHK_HIP(hipMemcpyAsync(&rr, sv->sh[0].d_scal + 4, sizeof rr, hipMemcpyDeviceToHost,
                              g_stream));
   LSB_CHK_HIP(hipStreamSynchronize(g_stream));
@@ -376,10 +372,8 @@ int solve_core(lsb_hip_solver *sv, const double *d_b, double *d_x,
       double *last = s->d_parts2 + (size_t)(hst[0].iters & 1) * 2 * LSB_MAX_PARTIALS;
       lsb_k_reduce_final(last, s->np2, 2, s->d_scal + 1, 0, NULL, g_stream);
     }
-    g_ar_nostate = 1;
     if (sv->multi)
-      allreduce_scal(sv, 1, 2);
-    g_ar_nostate = 0;
+      allreduce_scal(sv, 1, 2, 0);
     LSB_CHK_HIP(hipMemcpyAsync(&rr, sv->sh[0].d_scal + 2, sizeof rr, hipMemcpyDeviceToHost,
                                g_stream));
     LSB_CHK_HIP(hipStreamSynchronize(g_stream));

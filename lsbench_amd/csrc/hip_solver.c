@@ -617,10 +617,8 @@ int lsb_hip_solver_spmv_dev(lsb_hip_solver *sv, const double *d_x, double *d_y) 
                                (size_t)s->n * sizeof(double), hipMemcpyDeviceToDevice,
                                g_stream));
   }
-  g_ar_nostate = 1;
   if (sv->multi)
-    exchange_p(sv);
-  g_ar_nostate = 0;
+    exchange_p(sv, 0);
   for (int i = 0; i < sv->nshard; i++) {
     struct shard *s = &sv->sh[i];
     spmv_shard(s, s->d_pfull, d_y + (s->row_begin - sv->row_first), NULL, NULL, NULL, NULL);

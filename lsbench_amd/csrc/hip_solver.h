@@ -28,9 +28,6 @@
 extern LSB_INTERNAL int lsb_initialized;
 extern LSB_INTERNAL hipStream_t g_stream, g_comm_stream; /* compute / halo exchange */
 extern LSB_INTERNAL struct lsb_hip_result g_last;
-/* 1: communicate although no solve is running (the device state's status is
- * whatever the last solve left there) */
-extern LSB_INTERNAL int g_ar_nostate;
 
 /* ------------------------------------------------------------------------ */
 /* solver object                                                             */
@@ -138,8 +135,8 @@ LSB_INTERNAL void tune_spmv(lsb_hip_solver *sv, struct shard *s);
 /* hip_dist.c */
 LSB_INTERNAL void p2p_setup(lsb_hip_solver *sv);
 LSB_INTERNAL void exchange_on(lsb_hip_solver *sv, hipStream_t stream);
-LSB_INTERNAL void exchange_p(lsb_hip_solver *sv);
-LSB_INTERNAL void allreduce_scal(lsb_hip_solver *sv, unsigned off, unsigned cnt);
+LSB_INTERNAL void exchange_p(lsb_hip_solver *sv, int gated);
+LSB_INTERNAL void allreduce_scal(lsb_hip_solver *sv, unsigned off, unsigned cnt, int gated);
 LSB_INTERNAL void allreduce_pq(lsb_hip_solver *sv, unsigned cnt, int with2);
 LSB_INTERNAL int can_overlap(const lsb_hip_solver *sv);
 LSB_INTERNAL void exchange_and_spmv(lsb_hip_solver *sv, int sample);
