@@ -82,7 +82,10 @@ int hip_cdna4_bench(double *x, struct csr *A, const double *r,
 
 enum { LSB_OP_CHOLMOD_UPPER = 0, /* S = triu(A)+triu(A,1)^T (default)      */
        LSB_OP_RAW = 1 };         /* the CSR exactly as handed in            */
-enum { LSB_PRECOND_JACOBI = 0, LSB_PRECOND_NONE = 1 };
+enum { LSB_PRECOND_JACOBI = 0, LSB_PRECOND_NONE = 1,
+       LSB_PRECOND_L1JACOBI = 2 }; /* M = diag(sum_j |S_ij|): SPD for every
+                                      symmetric S with non-empty rows, no
+                                      stored diagonal needed */
 enum { LSB_KRYLOV_PCG = 0,    /* preconditioned CG (symmetric operators)    */
        LSB_KRYLOV_GMRES = 1,  /* restarted GMRES(m), right-preconditioned,
                                  for LSB_OP_RAW / unsymmetric operators;

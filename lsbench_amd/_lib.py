@@ -17,7 +17,7 @@ UNIQUE_ID_BYTES = 128
 # enums of include/lsbench.h / include/lsbench_hip.h
 SOLVER_HIP = 6
 OP_CHOLMOD_UPPER, OP_RAW = 0, 1
-PRECOND_JACOBI, PRECOND_NONE = 0, 1
+PRECOND_JACOBI, PRECOND_NONE, PRECOND_L1JACOBI = 0, 1, 2
 KRYLOV_PCG, KRYLOV_GMRES, KRYLOV_PCG1, KRYLOV_AUTO = 0, 1, 2, 3
 SPMV_AUTO, SPMV_ADAPTIVE, SPMV_SUBWAVE, SPMV_SCALAR, SPMV_PANEL, SPMV_SELL = 0, 1, 2, 3, 4, 5
 SELL_ROWS = 128

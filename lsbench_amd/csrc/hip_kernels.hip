@@ -386,6 +386,26 @@ __global__ __launch_bounds__(WG) void k_jacobi_setup(
   }
 }
 
+// l1-Jacobi: dinv[i] = 1 / sum_j |S_ij| (the whole row, also its entries in
+// other shards' columns: independent of the partition)
+__global__ __launch_bounds__(WG) void k_l1_setup(unsigned n, const int *__restrict__ offs,
+                                                 const double *__restrict__ vals,
+                                                 double *__restrict__ dinv,
+                                                 int *__restrict__ nzero) {
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * WG) {
+    double d = 0.0;
+    for (int j = offs[i]; j < offs[i + 1]; j++)
+      d += fabs(vals[j]);
+    if (d != 0.0) {
+      dinv[i] = 1.0 / d;
+    } else {
+      dinv[i] = 0.0;
+      atomicAdd(nzero, 1);
+    }
+  }
+}
+
 __global__ __launch_bounds__(WG) void k_jacobi_apply(
     unsigned n, const double *__restrict__ dinv, const double *__restrict__ r,
     double *__restrict__ z) {
@@ -1124,6 +1144,11 @@ void lsb_k_jacobi_setup(unsigned n, unsigned row_begin, const int *offs,
                         int *nzero, void *stream) {
   k_jacobi_setup<<<ew_grid(n), WG, 0, (hipStream_t)stream>>>(n, row_begin, offs, cols,
                                                              vals, dinv, nzero);
+}
+
+void lsb_k_l1_setup(unsigned n, const int *offs, const double *vals, double *dinv, int *nzero,
+                    void *stream) {
+  k_l1_setup<<<ew_grid(n), WG, 0, (hipStream_t)stream>>>(n, offs, vals, dinv, nzero);
 }
 
 void lsb_k_jacobi_apply(unsigned n, const double *dinv, const double *r,

@@ -217,18 +217,22 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
   LSB_CHK_HIP(hipMemsetAsync(s->d_st, 0, sizeof(struct lsb_pcg_state), g_stream));
   choose_spmv(s, o);
 
-  if (o->precond == LSB_PRECOND_JACOBI) {
+  if (o->precond == LSB_PRECOND_JACOBI || o->precond == LSB_PRECOND_L1JACOBI) {
     int *d_nz = (int *)lsb_hip_malloc(sizeof(int)), nz = 0;
     LSB_CHK_HIP(hipMemsetAsync(d_nz, 0, sizeof(int), g_stream));
-    lsb_k_jacobi_setup(n, row_begin, s->d_offs, s->d_cols, s->d_vals, s->d_dinv,
-                       d_nz, g_stream);
+    if (o->precond == LSB_PRECOND_L1JACOBI)
+      lsb_k_l1_setup(n, s->d_offs, s->d_vals, s->d_dinv, d_nz, g_stream);
+    else
+      lsb_k_jacobi_setup(n, row_begin, s->d_offs, s->d_cols, s->d_vals, s->d_dinv, d_nz,
+                         g_stream);
     LSB_CHK_HIP(hipMemcpyAsync(&nz, d_nz, sizeof(int), hipMemcpyDeviceToHost, g_stream));
     LSB_CHK_HIP(hipStreamSynchronize(g_stream));
     lsb_hip_free(d_nz);
     if (nz)
-      errx(EXIT_FAILURE, "hip_cdna4: %d rows have no non-zero diagonal entry; "
+      errx(EXIT_FAILURE, "hip_cdna4: %d rows have no non-zero %s; "
                          "Jacobi preconditioning needs one (cf. the stored-diagonal "
-                         "assumption of src/cholmod-impl.h:13)", nz);
+                         "assumption of src/cholmod-impl.h:13)", nz,
+           o->precond == LSB_PRECOND_L1JACOBI ? "entry" : "diagonal entry");
   } else {
     /* dinv = 1: unpreconditioned CG through the same kernels */
     double *ones = (double *)malloc((size_t)(n ? n : 1) * sizeof(double));

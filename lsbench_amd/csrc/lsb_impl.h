@@ -83,6 +83,8 @@ void lsb_k_xpay(unsigned n, const double *beta, const double *x, double *y,
 void lsb_k_jacobi_setup(unsigned n, unsigned row_begin, const int *offs,
                         const int *cols, const double *vals, double *dinv,
                         int *nzero, void *stream);
+void lsb_k_l1_setup(unsigned n, const int *offs, const double *vals, double *dinv, int *nzero,
+                    void *stream);
 void lsb_k_jacobi_apply(unsigned n, const double *dinv, const double *r,
                         double *z, void *stream);
 void lsb_k_jacobi_sweep(unsigned n, double w, const double *dinv,

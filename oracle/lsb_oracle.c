@@ -283,7 +283,9 @@ int orc_pcg_jacobi(uint64_t n, const uint64_t *offs, const uint32_t *cols,
   for (int64_t i = 0; i < (int64_t)n; i++) {
     double d = 0.0;
     for (uint64_t j = offs[i]; j < offs[i + 1]; j++)
-      if (cols[j] == (uint64_t)i)
+      if (use_jacobi == 2) /* l1-Jacobi: the row's absolute sum, in column order */
+        d += fabs(vals[j]);
+      else if (cols[j] == (uint64_t)i)
         d = vals[j];
     dinv[i] = (use_jacobi && d != 0.0) ? 1.0 / d : (use_jacobi ? 0.0 : 1.0);
   }

@@ -151,7 +151,8 @@ def spmv(offs, cols, vals, x, threads=1):
 
 
 def pcg_jacobi(offs, cols, vals, b, tol=1e-12, maxit=20000, jacobi=True, threads=1):
-    """Returns (x, iters, relres, status); status 1 converged, 2 breakdown, 3 maxit."""
+    """Returns (x, iters, relres, status); status 1 converged, 2 breakdown, 3 maxit.
+    jacobi: False/0 no preconditioner, True/1 M = diag(S), 2 M = diag(sum_j |S_ij|)."""
     L = lib()
     L.orc_set_threads(threads)
     n = len(offs) - 1
@@ -160,7 +161,7 @@ def pcg_jacobi(offs, cols, vals, b, tol=1e-12, maxit=20000, jacobi=True, threads
     st = L.orc_pcg_jacobi(n, _as64(offs), np.ascontiguousarray(cols, np.uint32),
                           np.ascontiguousarray(vals, np.float64),
                           np.ascontiguousarray(b, np.float64), x, tol, maxit,
-                          1 if jacobi else 0, C.byref(it), C.byref(rel))
+                          int(jacobi), C.byref(it), C.byref(rel))
     return x, it.value, rel.value, st
 
 

@@ -476,3 +476,28 @@ def test_column_panel_spmv(hip, width, monkeypatch):
     x, res = s.solve(bb)
     s.destroy()
     assert res.status == 1 and np.linalg.norm(bb - M @ x) / np.linalg.norm(bb) <= 2e-10
+
+
+@pytest.mark.parametrize("nvirt", [1, 3])
+def test_l1_jacobi_preconditioner(hip, nvirt, matrix_path, golden_x):
+    """LSB_PRECOND_L1JACOBI through the same fused kernels:
+    iteration counts of the oracle's l1-Jacobi PCG, the direct solution."""
+    A = hip.lsbench_matrix_read(matrix_path("xn3b_A_18"))
+    S = O.operator_upper(O.matrix_read(matrix_path("xn3b_A_18")))
+    b = O.rhs(A.nrows)
+    xo, ito, _, sto = O.pcg_jacobi(S.offs, S.cols, S.vals, b, 1e-12, jacobi=2)
+    s = hip.Solver(A, hip.default_opts(precond=hip.PRECOND_L1JACOBI, nvirt=nvirt))
+    x, r = s.solve(b)
+    s.destroy()
+    xg = golden_x("xn3b_A_18")
+    assert sto == 1 and r.status == 1 and abs(int(r.iters) - ito) <= 3
+    assert np.linalg.norm(x - xg) / np.linalg.norm(xg) <= 1e-10
+    # an operator WITHOUT stored diagonal entries: Jacobi is refused, l1-Jacobi works
+    n = 400
+    offs = np.arange(0, 2 * n + 1, 2)
+    cols = np.stack([(np.arange(n) - 1) % n, (np.arange(n) + 1) % n], 1)
+    cols.sort(axis=1)
+    Z = hip.Matrix.from_arrays(offs, cols.ravel(), np.ones(2 * n))       # ring graph adjacency
+    s = hip.Solver(Z, hip.default_opts(op_mode=hip.OP_RAW, precond=hip.PRECOND_L1JACOBI, maxit=5))
+    assert s.n_local == n
+    s.destroy()

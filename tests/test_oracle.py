@@ -185,3 +185,41 @@ def test_powerlaw_definition():
     # any row range reproduces the same rows
     o2, c2, v2 = O.powerlaw(n, thr, 20240607, 1000, 1500)
     assert np.array_equal(c2, c[o[1000]:o[1500]]) and np.array_equal(v2, v[o[1000]:o[1500]])
+
+
+def test_l1_jacobi_pcg_oracle(matrix_path, golden_x):
+    """M = diag(sum_j |S_ij|).  Same solution as the
+    direct solve; on a 5-point Laplacian interior rows have l1 norm 8 = 2 x the
+    diagonal, so the iteration count equals plain Jacobi's (M is a multiple of
+    it up to the boundary rows) within a few."""
+    A = O.matrix_read(matrix_path("xn3b_A_18"))
+    S = O.operator_upper(A)
+    b = O.rhs(S.nrows)
+    x, it, rel, st = O.pcg_jacobi(S.offs, S.cols, S.vals, b, 1e-12, jacobi=2)
+    xg = golden_x("xn3b_A_18")
+    assert st == 1 and np.linalg.norm(x - xg) / np.linalg.norm(xg) <= 1e-10
+    # against a numpy statement of the same recurrences
+    M = S.to_scipy()
+    dinv = 1.0 / np.asarray(abs(M).sum(axis=1)).ravel()
+    xr = np.zeros(S.nrows)
+    r = b.copy()
+    z = dinv * r
+    p = z.copy()
+    rz = r @ z
+    k = 0
+    while True:
+        q = M @ p
+        a = rz / (p @ q)
+        xr += a * p
+        r -= a * q
+        k += 1
+        if r @ r <= 1e-24 * (b @ b):
+            break
+        z = dinv * r
+        rz, rz0 = r @ z, rz
+        p = z + (rz / rz0) * p
+    assert abs(k - it) <= 2 and np.linalg.norm(xr - x) / np.linalg.norm(x) <= 1e-9
+    o, c, v = O.lap2d(60, 50)
+    _, it1, _, _ = O.pcg_jacobi(o, c, v, O.rhs(3000), 1e-10, jacobi=1)
+    _, it2, _, _ = O.pcg_jacobi(o, c, v, O.rhs(3000), 1e-10, jacobi=2)
+    assert abs(it1 - it2) <= max(4, it1 // 10)
