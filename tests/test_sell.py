@@ -115,7 +115,10 @@ def test_sell_kernel_vs_oracle(hip, flags, matrix_path):
                                     None, None, None, None, lib.lsb_hip_stream()) == 2
 
 
-@pytest.mark.parametrize("name", ["xn3b_A_18", "tj7a_A_12"])
+from conftest import SPD  # noqa: E402
+
+
+@pytest.mark.parametrize("name", SPD)
 def test_solves_through_sell_match_golden(hip, name, matrix_path, golden_x):
     A = hip.lsbench_matrix_read(matrix_path(name))
     xg = golden_x(name)
@@ -125,6 +128,12 @@ def test_solves_through_sell_match_golden(hip, name, matrix_path, golden_x):
         x, r = s.solve(O.rhs(A.nrows))
         s.destroy()
         assert r.status == 1 and np.linalg.norm(x - xg) / np.linalg.norm(xg) <= 1e-10
+    # with the rows renumbered by reverse Cuthill-McKee first (narrow band: every
+    # slice of the permuted operator fits the 16-bit codes with few slots)
+    s = hip.Solver(A, hip.default_opts(spmv_variant=hip.SPMV_SELL, use_graph=0, spmv_tune=6, reorder=1))
+    x, r = s.solve(O.rhs(A.nrows))
+    s.destroy()
+    assert r.status == 1 and np.linalg.norm(x - xg) / np.linalg.norm(xg) <= 1e-10
 
 
 @pytest.mark.parametrize("comm", ["COMM_RCCL", "COMM_P2P"])
