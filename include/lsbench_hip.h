@@ -222,12 +222,16 @@ struct lsb_sell {
                                 16-bit form                                 */
   double *vals;
   /* 16-bit form (lsb_csr_sellize16): column of the entry in slot j of row r =
-   * r + row_begin + sbase[sptr[s]/128 + j] + codes[.]; a slot of a slice holds
+   * r + row_begin + base + code with {base, k} = sbase[2q], sbase[2q+1],
+   * q = sptr[s]/128 + j; k >= 0: the slot's 128 codes are codes[128k ..);
+   * k = -1: all its live entries share one code, which has been folded into
+   * the base (every slot of a structured-grid operator).  A slot of a slice holds
    * entries of ONE diagonal band (+-32767 around its base), so a row's entries
    * may be interleaved with padding (value 0: the kernel does not gather for
    * those).  Entries of a row keep their column order. */
-  short *codes;              /* stored, or NULL in the 32-bit form          */
-  int *sbase;                /* stored / LSB_SELL_ROWS                      */
+  short *codes;              /* 128 * ncode_slots, or NULL in the 32-bit form */
+  int *sbase;                /* 2 * stored / LSB_SELL_ROWS                  */
+  unsigned ncode_slots;
 };
 /* entries a sliced-ELL copy of A would store (to decide before building it) */
 unsigned long long lsb_csr_sell_stored(const struct csr *A);

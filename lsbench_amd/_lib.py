@@ -75,7 +75,7 @@ class Sell(C.Structure):
     _fields_ = [("nrows", C.c_uint), ("nslice", C.c_uint), ("stored", C.c_ulonglong),
                 ("sptr", C.POINTER(C.c_uint)), ("cols", C.POINTER(C.c_int)),
                 ("vals", C.POINTER(C.c_double)), ("codes", C.POINTER(C.c_short)),
-                ("sbase", C.POINTER(C.c_int))]
+                ("sbase", C.POINTER(C.c_int)), ("ncode_slots", C.c_uint)]
 
 
 class Xfer(C.Structure):

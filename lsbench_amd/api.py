@@ -157,9 +157,11 @@ def lsb_csr_sellize16(A, row_begin=0):
         return None
     S = p.contents
     sptr = np.ctypeslib.as_array(S.sptr, (S.nslice + 1,)).copy()
-    codes = np.ctypeslib.as_array(S.codes, (max(S.stored, 1),)).copy()[:S.stored]
+    nq = S.stored // L.SELL_ROWS
+    codes = np.ctypeslib.as_array(S.codes, (max(S.ncode_slots, 1) * L.SELL_ROWS,)).copy()[
+        :S.ncode_slots * L.SELL_ROWS]
     vals = np.ctypeslib.as_array(S.vals, (max(S.stored, 1),)).copy()[:S.stored]
-    sbase = np.ctypeslib.as_array(S.sbase, (S.stored // L.SELL_ROWS + 1,)).copy()[:S.stored // L.SELL_ROWS]
+    sbase = np.ctypeslib.as_array(S.sbase, (2 * nq + 2,)).copy()[:2 * nq].reshape(nq, 2)
     lib.lsb_sell_free(p)
     return sptr, codes, sbase, vals
 

@@ -911,8 +911,10 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_sell(
 }
 
 // The same with 16-bit column codes (lsb_csr_sellize16): the column of the entry
-// in slot j of global row g is g + sbase[slice, j] + code, the base one scalar
-// load per slice and slot.  10 instead of 12 bytes per entry: 10 M-row 5-point
+// in slot j of global row g is g + base + code, {base, k} = sbase[slice, j] one
+// 8-byte scalar load per slice and slot; k >= 0 says where the slot's 128 codes
+// are, k = -1 that the slot has none (all its entries lie on ONE diagonal,
+// folded into the base -- every slot of a structured-grid operator).  10 instead of 12 bytes per entry: 10 M-row 5-point
 // 146 -> 122 us on the same box (tools/spmv_lab.hip).  A slot holds entries of
 // one diagonal band, so rows can have padding BETWEEN their entries; padding
 // has value 0 and is recognised by that (no gather, contributes an exact 0).
@@ -936,9 +938,8 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_sell16(
     if (si < ns) {
       const unsigned s = s0 + si;
       const unsigned base = sptr[s], len = (sptr[s + 1] - base) / LSB_SELL_ROWS;
-      const s2v *cp = (const s2v *)(codes + base) + lane;
       const sell_d2v *vp = (const sell_d2v *)(vals + base) + lane;
-      const int *bp = sbase + base / LSB_SELL_ROWS;
+      const i2v *bp = (const i2v *)sbase + base / LSB_SELL_ROWS; // {base, code slot or -1}
       const unsigned row = s * LSB_SELL_ROWS + 2 * lane;
       const int grow = (int)(row + row_begin);
       double a0 = 0.0, a1 = 0.0;
@@ -949,14 +950,17 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_sell16(
 #pragma unroll
         for (int u = 0; u < SELL_U; u++)
           if (j0 + u < len) {
-            if (FLAGS & SP_NT) {
-              c[u] = __builtin_nontemporal_load(cp + (size_t)(j0 + u) * 64);
-              v[u] = __builtin_nontemporal_load(vp + (size_t)(j0 + u) * 64);
-            } else {
-              c[u] = cp[(size_t)(j0 + u) * 64];
-              v[u] = vp[(size_t)(j0 + u) * 64];
+            const i2v bk = bp[j0 + u]; // wave-uniform: scalar load
+            b[u] = bk.x;
+            c[u] = (s2v){0, 0};
+            if (bk.y >= 0) { // slots with one common code carry none
+              const s2v *cp = (const s2v *)codes + (size_t)bk.y * 64 + lane;
+              c[u] = (FLAGS & SP_NT) ? __builtin_nontemporal_load(cp) : *cp;
             }
-            b[u] = bp[j0 + u];
+            if (FLAGS & SP_NT)
+              v[u] = __builtin_nontemporal_load(vp + (size_t)(j0 + u) * 64);
+            else
+              v[u] = vp[(size_t)(j0 + u) * 64];
           }
         if (stopped)
           return;

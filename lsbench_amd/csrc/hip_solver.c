@@ -193,8 +193,8 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
       }
       if (H) {
         s->d_sptr16 = (unsigned *)dev_upload(H->sptr, ((size_t)H->nslice + 1) * sizeof(unsigned));
-        s->d_scodes = (short *)dev_upload(H->codes, ((size_t)H->stored + LSB_SELL_ROWS) * sizeof(short));
-        s->d_sbase = (int *)dev_upload(H->sbase, ((size_t)H->stored / LSB_SELL_ROWS + 1) * sizeof(int));
+        s->d_scodes = (short *)dev_upload(H->codes, ((size_t)H->ncode_slots + 1) * LSB_SELL_ROWS * sizeof(short));
+        s->d_sbase = (int *)dev_upload(H->sbase, 2 * ((size_t)H->stored / LSB_SELL_ROWS + 1) * sizeof(int));
         s->d_svals16 = (double *)dev_upload(H->vals, ((size_t)H->stored + LSB_SELL_ROWS) * sizeof(double));
         LSB_CHK_HIP(hipStreamSynchronize(g_stream));
         lsb_sell_free(H);

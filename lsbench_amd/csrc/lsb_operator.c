@@ -558,23 +558,45 @@ struct lsb_sell *lsb_csr_sellize(const struct csr *A) {
  * is inserted where none is.  Returns the number of slots, 0 on overflow. */
 #define SELL16_MAX_SLOTS 255
 #define SELL16_REACH 32767L
-static unsigned sell16_slots(const struct csr *A, unsigned row_begin, unsigned r0, unsigned r1,
-                             long *B) {
+static unsigned sell16_sweep(const struct csr *A, unsigned row_begin, unsigned r0, unsigned r1,
+                             long *B, long reach, unsigned limit) {
   unsigned nb = 0;
   for (unsigned r = r0; r < r1; r++) {
     unsigned j = 0;
     for (unsigned k = A->offs[r]; k < A->offs[r + 1]; k++) {
       const long e = (long)(A->cols[k] - A->base) - ((long)r + (long)row_begin);
-      while (j < nb && B[j] < e - SELL16_REACH)
+      while (j < nb && B[j] < e - reach)
         j++;
-      if (!(j < nb && B[j] <= e + SELL16_REACH)) {
-        if (nb == SELL16_MAX_SLOTS)
+      if (!(j < nb && B[j] <= e + reach)) {
+        if (nb == limit)
           return 0;
         memmove(B + j + 1, B + j, (size_t)(nb - j) * sizeof(long));
         B[j] = e, nb++;
       }
       j++;
     }
+  }
+  return nb;
+}
+
+/* First choice: one slot per DIAGONAL of the slice (reach 0), as long as that
+ * pads the slice by no more than a quarter -- on a structured grid it costs
+ * nothing and no slot needs a code array.  Otherwise bands of +-32767.
+ * *reach receives the rule the slots were built with (the fill uses it too). */
+static unsigned sell16_slots(const struct csr *A, unsigned row_begin, unsigned r0, unsigned r1,
+                             long *B, long *reach) {
+  unsigned longest = 0;
+  for (unsigned r = r0; r < r1; r++)
+    if (A->offs[r + 1] - A->offs[r] > longest)
+      longest = A->offs[r + 1] - A->offs[r];
+  unsigned limit = longest + longest / 4 + 1;
+  if (limit > SELL16_MAX_SLOTS)
+    limit = SELL16_MAX_SLOTS;
+  *reach = 0;
+  unsigned nb = sell16_sweep(A, row_begin, r0, r1, B, 0, limit);
+  if (nb == 0 && longest) {
+    *reach = SELL16_REACH;
+    nb = sell16_sweep(A, row_begin, r0, r1, B, SELL16_REACH, SELL16_MAX_SLOTS);
   }
   return nb;
 }
@@ -588,9 +610,9 @@ struct lsb_sell *lsb_csr_sellize16(const struct csr *A, unsigned row_begin) {
   int ok = 1;
 #pragma omp parallel for schedule(static) reduction(& : ok)
   for (unsigned sl = 0; sl < ns; sl++) {
-    long B[SELL16_MAX_SLOTS + 1];
+    long B[SELL16_MAX_SLOTS + 1], reach;
     const unsigned r0 = sl * LSB_SELL_ROWS, r1 = r0 + LSB_SELL_ROWS < n ? r0 + LSB_SELL_ROWS : n;
-    const unsigned nb = sell16_slots(A, row_begin, r0, r1, B);
+    const unsigned nb = sell16_slots(A, row_begin, r0, r1, B, &reach);
     unsigned has = 0;
     for (unsigned r = r0; r < r1 && !has; r++)
       has = A->offs[r + 1] > A->offs[r];
@@ -613,24 +635,24 @@ struct lsb_sell *lsb_csr_sellize16(const struct csr *A, unsigned row_begin) {
   S->nrows = n, S->nslice = ns, S->stored = stored, S->sptr = sptr;
   S->codes = (short *)calloc((size_t)stored + LSB_SELL_ROWS, sizeof(short));
   S->vals = (double *)calloc((size_t)stored + LSB_SELL_ROWS, sizeof(double));
-  S->sbase = (int *)calloc((size_t)stored / LSB_SELL_ROWS + 1, sizeof(int));
+  S->sbase = (int *)calloc(2 * ((size_t)stored / LSB_SELL_ROWS + 1), sizeof(int));
   if (!S->codes || !S->vals || !S->sbase)
     errx(EXIT_FAILURE, "lsb_csr_sellize16: out of memory");
 #pragma omp parallel for schedule(static) reduction(& : ok)
   for (unsigned sl = 0; sl < ns; sl++) {
-    long B[SELL16_MAX_SLOTS + 1];
+    long B[SELL16_MAX_SLOTS + 1], reach;
     const unsigned r0 = sl * LSB_SELL_ROWS, r1 = r0 + LSB_SELL_ROWS < n ? r0 + LSB_SELL_ROWS : n;
-    const unsigned nb = sell16_slots(A, row_begin, r0, r1, B);
+    const unsigned nb = sell16_slots(A, row_begin, r0, r1, B, &reach);
     const size_t at0 = sptr[sl];
     for (unsigned j = 0; j < nb; j++)
-      S->sbase[at0 / LSB_SELL_ROWS + j] = (int)B[j];
+      S->sbase[2 * (at0 / LSB_SELL_ROWS + j)] = (int)B[j];
     for (unsigned r = r0; r < r1; r++) {
       unsigned j = 0;
       for (unsigned k = A->offs[r]; k < A->offs[r + 1]; k++) {
         const long e = (long)(A->cols[k] - A->base) - ((long)r + (long)row_begin);
-        while (j < nb && B[j] < e - SELL16_REACH)
+        while (j < nb && B[j] < e - reach)
           j++;
-        if (!(j < nb && B[j] <= e + SELL16_REACH)) {
+        if (!(j < nb && B[j] <= e + reach)) {
           ok = 0; /* cannot happen: the bases were built from these very rows */
           break;
         }
@@ -645,6 +667,33 @@ struct lsb_sell *lsb_csr_sellize16(const struct csr *A, unsigned row_begin) {
     lsb_sell_free(S);
     return NULL;
   }
+  /* A slot whose live entries (value != 0) all carry the same code needs no
+   * code array: the code moves into the base.  On a structured grid that is
+   * every slot.  The others keep their 128 codes, packed in slot order. */
+  const size_t nslots = (size_t)stored / LSB_SELL_ROWS;
+  size_t nc = 0;
+  for (size_t q = 0; q < nslots; q++) {
+    const short *c = S->codes + q * LSB_SELL_ROWS;
+    const double *v = S->vals + q * LSB_SELL_ROWS;
+    int have = 0, uniform = 1;
+    short c0 = 0;
+    for (unsigned l = 0; l < LSB_SELL_ROWS && uniform; l++)
+      if (v[l] != 0.0) {
+        if (!have)
+          c0 = c[l], have = 1;
+        else
+          uniform = c[l] == c0;
+      }
+    if (uniform) {
+      S->sbase[2 * q] += c0, S->sbase[2 * q + 1] = -1;
+    } else {
+      S->sbase[2 * q + 1] = (int)nc;
+      if (nc != q)
+        memmove(S->codes + nc * LSB_SELL_ROWS, c, LSB_SELL_ROWS * sizeof(short));
+      nc++;
+    }
+  }
+  S->ncode_slots = (unsigned)nc;
   return S;
 }
 

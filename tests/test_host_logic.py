@@ -322,19 +322,21 @@ def test_sliced_ell_copy_base1(matrix_path):
 
 def _sell16_spmv(sptr, codes, sbase, vals, x, n, row_begin=0):
     """numpy evaluation of the 16-bit sliced-ELL layout: the entry in slot j of
-    row r has column r + row_begin + sbase[sptr[s]/128 + j] + code; value 0 =
-    padding (no gather)."""
+    row r has column r + row_begin + base + code, {base, k} = sbase[sptr[s]/128 + j];
+    k >= 0: the slot's codes are codes[128 k ..), k = -1: code 0 for the whole
+    slot; value 0 = padding (no gather)."""
     R = la.SELL_ROWS
     y = np.zeros((len(sptr) - 1) * R)
     rows = np.arange(R)
     for s in range(len(sptr) - 1):
         ln = (int(sptr[s + 1]) - int(sptr[s])) // R
-        c = codes[sptr[s]:sptr[s + 1]].reshape(ln, R).astype(np.int64)
         v = vals[sptr[s]:sptr[s + 1]].reshape(ln, R)
-        b = sbase[int(sptr[s]) // R:int(sptr[s]) // R + ln].astype(np.int64)
+        bk = sbase[int(sptr[s]) // R:int(sptr[s]) // R + ln].astype(np.int64)
         acc = np.zeros(R)
         for j in range(ln):
-            col = s * R + rows + row_begin + b[j] + c[j]
+            k = int(bk[j, 1])
+            cj = codes[k * R:(k + 1) * R].astype(np.int64) if k >= 0 else np.zeros(R, np.int64)
+            col = s * R + rows + row_begin + bk[j, 0] + cj
             live = v[j] != 0.0
             assert np.all((col[live] >= 0) & (col[live] < len(x)))
             acc += np.where(live, v[j] * x[np.where(live, col, 0)], 0.0)
@@ -351,7 +353,11 @@ def test_sliced_ell_copy_16bit(spec):
     assert out is not None
     sptr, codes, sbase, vals = out
     n, R = A.nrows, la.SELL_ROWS
-    assert len(sptr) == (n + R - 1) // R + 1 and len(sbase) == sptr[-1] // R
+    assert len(sptr) == (n + R - 1) // R + 1 and sbase.shape == (sptr[-1] // R, 2)
+    kept = sbase[:, 1][sbase[:, 1] >= 0]
+    assert np.array_equal(kept, np.arange(len(kept))) and len(codes) == len(kept) * R
+    if spec.startswith("lap"):                 # structured grid: no slot needs a code array
+        assert len(kept) == 0
     assert np.count_nonzero(vals) == np.count_nonzero(A.vals)
     x = np.random.default_rng(7).standard_normal(n)
     yo = O.spmv(A.offs, A.cols, A.vals, x)

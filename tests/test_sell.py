@@ -39,7 +39,7 @@ def _sell16_kernel(hip, A, x, flags, with_dot=True):
     sptr, codes, sbase, vals = out
     pad = hip.SELL_ROWS
     d = dict(sptr=_dev(sptr.astype(np.int32)), codes=_dev(np.concatenate([codes, np.zeros(pad, np.int16)])),
-             sbase=_dev(np.concatenate([sbase, np.zeros(1, np.int32)])),
+             sbase=_dev(np.concatenate([sbase.ravel(), np.zeros(2, np.int32)])),
              vals=_dev(np.concatenate([vals, np.zeros(pad)])), x=_dev(x))
     y = torch.full((A.nrows,), float("nan"), dtype=torch.float64, device="cuda:0")
     w = torch.zeros(lib.lsb_hip_partials_capacity(), dtype=torch.float64, device="cuda:0")
