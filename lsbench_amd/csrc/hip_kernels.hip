@@ -455,7 +455,7 @@ __global__ __launch_bounds__(WG) void k_fill_index(unsigned n, unsigned first,
 // x = 0, r = b, p = dinv.*b ; partials (r.z, b.b)
 template <bool V2>
 __global__ __launch_bounds__(WG) void k_pcg_init(
-    unsigned n, const double *__restrict__ b, const double *__restrict__ dinv,
+    unsigned n, const double *__restrict__ b, const double *__restrict__ dinv, double dc,
     double *__restrict__ x, double *__restrict__ r, double *__restrict__ p,
     double *__restrict__ partials2) {
   __shared__ double sred[8];
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(WG) void k_pcg_init(
     const double2 *b2 = (const double2 *)b, *d2 = (const double2 *)dinv;
     double2 *x2 = (double2 *)x, *r2 = (double2 *)r, *p2 = (double2 *)p;
     for (size_t i = gtid; i < n2; i += gsz) {
-      const double2 bv = b2[i], dv = d2[i];
+      const double2 bv = b2[i], dv = dinv ? d2[i] : double2{dc, dc};
       double2 pv;
       pv.x = dv.x * bv.x, pv.y = dv.y * bv.y;
       x2[i] = make_double2(0.0, 0.0);
@@ -480,13 +480,13 @@ __global__ __launch_bounds__(WG) void k_pcg_init(
     }
     if ((n & 1) && gtid == gsz - 1) {
       const size_t i = n - 1;
-      const double bv = b[i], pv = dinv[i] * bv;
+      const double bv = b[i], pv = (dinv ? dinv[i] : dc) * bv;
       x[i] = 0.0, r[i] = bv, p[i] = pv;
       acc[0] += bv * pv, acc[1] += bv * bv;
     }
   } else {
     for (size_t i = gtid; i < n; i += gsz) {
-      const double bv = b[i], pv = dinv[i] * bv;
+      const double bv = b[i], pv = (dinv ? dinv[i] : dc) * bv;
       x[i] = 0.0, r[i] = bv, p[i] = pv;
       acc[0] += bv * pv, acc[1] += bv * bv;
     }
@@ -534,6 +534,15 @@ __device__ __forceinline__ d2v ld2(const d2v *p) {
 // Stores of vectors nobody reads before the NEXT sweep (x; in the single-
 // reduction form also p, s, r): nontemporal, so that they do not sit as dirty
 // lines in L2 / Infinity Cache while the SpMV that follows streams the matrix.
+// Jacobi diagonal: a vector, or -- d2 == nullptr -- ONE value for every row (an
+// operator with a constant diagonal: the preconditioner is a scaling and its
+// vector need not be read; same arithmetic, the factor comes from a register).
+template <bool NT>
+__device__ __forceinline__ d2v ldd(const d2v *d2, size_t i, double dc) {
+  if (!d2)
+    return d2v{dc, dc};
+  return ld2<NT>(d2 + i);
+}
 template <bool NT>
 __device__ __forceinline__ void st2(d2v *p, d2v v) {
   if (NT)
@@ -546,7 +555,7 @@ __device__ __forceinline__ void st2(d2v *p, d2v v) {
 template <bool V2, bool NT>
 __global__ __launch_bounds__(WG) void k_pcg_update_xr(
     unsigned n, const double *__restrict__ p, const double *__restrict__ q,
-    const double *__restrict__ dinv, double *__restrict__ x,
+    const double *__restrict__ dinv, double dc, double *__restrict__ x,
     double *__restrict__ r, lsb_pcg_state *__restrict__ st, int parity,
     const double *__restrict__ pq_parts, unsigned npq,
     double *__restrict__ partials2) {
@@ -565,7 +574,7 @@ __global__ __launch_bounds__(WG) void k_pcg_update_xr(
   d2v pv = {0.0, 0.0}, qv = pv, dv = pv, xv = pv, rv = pv;
   const bool first = V2 && gtid < n2;
   if (first) {
-    pv = ld2<NT>(p2 + gtid), qv = ld2<NT>(q2 + gtid), dv = ld2<NT>(d2 + gtid);
+    pv = ld2<NT>(p2 + gtid), qv = ld2<NT>(q2 + gtid), dv = ldd<NT>(d2, gtid, dc);
     xv = ld2<NT>(x2 + gtid), rv = ld2<NT>(r2 + gtid);
   }
   double pqv[1];
@@ -596,7 +605,7 @@ __global__ __launch_bounds__(WG) void k_pcg_update_xr(
         i += gsz;
         if (i >= n2)
           break;
-        pv = ld2<NT>(p2 + i), qv = ld2<NT>(q2 + i), dv = ld2<NT>(d2 + i);
+        pv = ld2<NT>(p2 + i), qv = ld2<NT>(q2 + i), dv = ldd<NT>(d2, i, dc);
         xv = ld2<NT>(x2 + i), rv = ld2<NT>(r2 + i);
       }
     }
@@ -605,14 +614,14 @@ __global__ __launch_bounds__(WG) void k_pcg_update_xr(
       x[i] += alpha * p[i];
       const double rs = r[i] - alpha * q[i];
       r[i] = rs;
-      acc[0] += rs * (dinv[i] * rs), acc[1] += rs * rs;
+      acc[0] += rs * ((dinv ? dinv[i] : dc) * rs), acc[1] += rs * rs;
     }
   } else {
     for (size_t i = gtid; i < n; i += gsz) {
       x[i] += alpha * p[i];
       const double rs = r[i] - alpha * q[i];
       r[i] = rs;
-      acc[0] += rs * (dinv[i] * rs), acc[1] += rs * rs;
+      acc[0] += rs * ((dinv ? dinv[i] : dc) * rs), acc[1] += rs * rs;
     }
   }
   wg_sum<2>(acc, sred);
@@ -625,7 +634,7 @@ __global__ __launch_bounds__(WG) void k_pcg_update_xr(
 // (rz', rr) = sum partials ; stop test ; beta = rz'/rz ; p = dinv.*r + beta p
 template <bool V2, bool NT>
 __global__ __launch_bounds__(WG) void k_pcg_update_p(
-    unsigned n, const double *__restrict__ r, const double *__restrict__ dinv,
+    unsigned n, const double *__restrict__ r, const double *__restrict__ dinv, double dc,
     double *__restrict__ p, lsb_pcg_state *__restrict__ st, int parity,
     const double *__restrict__ parts2, unsigned nparts2) {
   __shared__ double sred[8];
@@ -640,7 +649,7 @@ __global__ __launch_bounds__(WG) void k_pcg_update_p(
   d2v rv = {0.0, 0.0}, dv = rv, pv = rv;
   const bool first = V2 && gtid < n2;
   if (first)
-    rv = ld2<NT>(r2 + gtid), dv = ld2<NT>(d2 + gtid), pv = ld2<NT>(p2 + gtid);
+    rv = ld2<NT>(r2 + gtid), dv = ldd<NT>(d2, gtid, dc), pv = ld2<NT>(p2 + gtid);
   double v[2];
   wg_sum_partials<2>(parts2, nparts2, v, sred);
   if (stopped)
@@ -671,14 +680,14 @@ __global__ __launch_bounds__(WG) void k_pcg_update_p(
         i += gsz;
         if (i >= n2)
           break;
-        rv = ld2<NT>(r2 + i), dv = ld2<NT>(d2 + i), pv = ld2<NT>(p2 + i);
+        rv = ld2<NT>(r2 + i), dv = ldd<NT>(d2, i, dc), pv = ld2<NT>(p2 + i);
       }
     }
     if ((n & 1) && gtid == gsz - 1)
-      p[n - 1] = dinv[n - 1] * r[n - 1] + beta * p[n - 1];
+      p[n - 1] = (dinv ? dinv[n - 1] : dc) * r[n - 1] + beta * p[n - 1];
   } else {
     for (size_t i = gtid; i < n; i += gsz)
-      p[i] = dinv[i] * r[i] + beta * p[i];
+      p[i] = (dinv ? dinv[i] : dc) * r[i] + beta * p[i];
   }
 }
 
@@ -699,7 +708,7 @@ __global__ __launch_bounds__(WG) void k_pcg_update_p(
 template <bool V2, bool NT>
 __global__ __launch_bounds__(WG) void k_cg1_update(
     unsigned n, double *__restrict__ u, const double *__restrict__ w,
-    const double *__restrict__ dinv, double *__restrict__ p, double *__restrict__ sv,
+    const double *__restrict__ dinv, double dc, double *__restrict__ p, double *__restrict__ sv,
     double *__restrict__ x, double *__restrict__ r, lsb_pcg_state *__restrict__ st,
     int parity, const double *__restrict__ parts_gr, unsigned ngr,
     const double *__restrict__ parts_d, unsigned nd, double *__restrict__ partials2) {
@@ -714,7 +723,7 @@ __global__ __launch_bounds__(WG) void k_cg1_update(
   d2v uv = {0.0, 0.0}, wv = uv, dv = uv, pv = uv, sw = uv, xv = uv, rv = uv;
   const bool first = V2 && gtid < n2;
   if (first) {
-    uv = ld2<NT>(u2 + gtid), wv = ld2<NT>(w2 + gtid), dv = ld2<NT>(d2 + gtid);
+    uv = ld2<NT>(u2 + gtid), wv = ld2<NT>(w2 + gtid), dv = ldd<NT>(d2, gtid, dc);
     pv = ld2<NT>(p2 + gtid), sw = ld2<NT>(s2 + gtid), xv = ld2<NT>(x2 + gtid);
     rv = ld2<NT>(r2 + gtid);
   }
@@ -771,7 +780,7 @@ __global__ __launch_bounds__(WG) void k_cg1_update(
         i += gsz;
         if (i >= n2)
           break;
-        uv = ld2<NT>(u2 + i), wv = ld2<NT>(w2 + i), dv = ld2<NT>(d2 + i);
+        uv = ld2<NT>(u2 + i), wv = ld2<NT>(w2 + i), dv = ldd<NT>(d2, i, dc);
         pv = ld2<NT>(p2 + i), sw = ld2<NT>(s2 + i), xv = ld2<NT>(x2 + i);
         rv = ld2<NT>(r2 + i);
       }
@@ -781,7 +790,7 @@ __global__ __launch_bounds__(WG) void k_cg1_update(
       const double pi = u[i] + beta * p[i], si = w[i] + beta * sv[i];
       p[i] = pi, sv[i] = si;
       x[i] += alpha * pi;
-      const double ri = r[i] - alpha * si, ui = dinv[i] * ri;
+      const double ri = r[i] - alpha * si, ui = (dinv ? dinv[i] : dc) * ri;
       r[i] = ri, u[i] = ui;
       acc[0] += ri * ui, acc[1] += ri * ri;
     }
@@ -790,7 +799,7 @@ __global__ __launch_bounds__(WG) void k_cg1_update(
       const double pi = u[i] + beta * p[i], si = w[i] + beta * sv[i];
       p[i] = pi, sv[i] = si;
       x[i] += alpha * pi;
-      const double ri = r[i] - alpha * si, ui = dinv[i] * ri;
+      const double ri = r[i] - alpha * si, ui = (dinv ? dinv[i] : dc) * ri;
       r[i] = ri, u[i] = ui;
       acc[0] += ri * ui, acc[1] += ri * ri;
     }
@@ -1185,15 +1194,15 @@ void lsb_k_fill_index(unsigned n, unsigned first, double *v, void *stream) {
   k_fill_index<<<ew_grid(n), WG, 0, (hipStream_t)stream>>>(n, first, v);
 }
 
-void lsb_k_pcg_init(unsigned n, const double *b, const double *dinv, double *x,
+void lsb_k_pcg_init(unsigned n, const double *b, const double *dinv, double dc, double *x,
                     double *r, double *p, double *partials2,
                     unsigned *npartials, void *stream) {
   const unsigned g = lsb_k_blas1_grid(n);
   *npartials = g;
   if (aligned16(b) && aligned16(dinv) && aligned16(x) && aligned16(r) && aligned16(p))
-    k_pcg_init<true><<<g, WG, 0, (hipStream_t)stream>>>(n, b, dinv, x, r, p, partials2);
+    k_pcg_init<true><<<g, WG, 0, (hipStream_t)stream>>>(n, b, dinv, dc, x, r, p, partials2);
   else
-    k_pcg_init<false><<<g, WG, 0, (hipStream_t)stream>>>(n, b, dinv, x, r, p, partials2);
+    k_pcg_init<false><<<g, WG, 0, (hipStream_t)stream>>>(n, b, dinv, dc, x, r, p, partials2);
 }
 
 void lsb_k_pcg_init_state(struct lsb_pcg_state *st, const double *partials2,
@@ -1203,7 +1212,7 @@ void lsb_k_pcg_init_state(struct lsb_pcg_state *st, const double *partials2,
 }
 
 void lsb_k_pcg_update_xr(unsigned n, const double *p, const double *q,
-                         const double *dinv, double *x, double *r,
+                         const double *dinv, double dc, double *x, double *r,
                          struct lsb_pcg_state *st, int parity,
                          const double *pq_parts, unsigned npq,
                          double *partials2, unsigned *npartials, void *stream) {
@@ -1212,17 +1221,18 @@ void lsb_k_pcg_update_xr(unsigned n, const double *p, const double *q,
   if (aligned16(p) && aligned16(q) && aligned16(dinv) && aligned16(x) && aligned16(r)) {
     if (g_blas1_nt)
       k_pcg_update_xr<true, true><<<g, WG, 0, (hipStream_t)stream>>>(
-          n, p, q, dinv, x, r, st, parity, pq_parts, npq, partials2);
+          n, p, q, dinv, dc, x, r, st, parity, pq_parts, npq, partials2);
     else
       k_pcg_update_xr<true, false><<<g, WG, 0, (hipStream_t)stream>>>(
-          n, p, q, dinv, x, r, st, parity, pq_parts, npq, partials2);
+          n, p, q, dinv, dc, x, r, st, parity, pq_parts, npq, partials2);
   } else {
     k_pcg_update_xr<false, false><<<g, WG, 0, (hipStream_t)stream>>>(
-        n, p, q, dinv, x, r, st, parity, pq_parts, npq, partials2);
+        n, p, q, dinv, dc, x, r, st, parity, pq_parts, npq, partials2);
   }
 }
 
-void lsb_k_cg1_update(unsigned n, double *u, const double *w, const double *dinv, double *p,
+void lsb_k_cg1_update(unsigned n, double *u, const double *w, const double *dinv, double dc,
+                      double *p,
                       double *s, double *x, double *r, struct lsb_pcg_state *st, int parity,
                       const double *parts_gr, unsigned ngr, const double *parts_d, unsigned nd,
                       double *partials2, unsigned *npartials, void *stream) {
@@ -1232,30 +1242,30 @@ void lsb_k_cg1_update(unsigned n, double *u, const double *w, const double *dinv
   if (aligned16(u) && aligned16(w) && aligned16(dinv) && aligned16(p) && aligned16(s) &&
       aligned16(x) && aligned16(r)) {
     if (g_blas1_nt)
-      k_cg1_update<true, true><<<g, WG, 0, hs>>>(n, u, w, dinv, p, s, x, r, st, parity, parts_gr,
+      k_cg1_update<true, true><<<g, WG, 0, hs>>>(n, u, w, dinv, dc, p, s, x, r, st, parity, parts_gr,
                                                  ngr, parts_d, nd, partials2);
     else
-      k_cg1_update<true, false><<<g, WG, 0, hs>>>(n, u, w, dinv, p, s, x, r, st, parity,
+      k_cg1_update<true, false><<<g, WG, 0, hs>>>(n, u, w, dinv, dc, p, s, x, r, st, parity,
                                                   parts_gr, ngr, parts_d, nd, partials2);
   } else {
-    k_cg1_update<false, false><<<g, WG, 0, hs>>>(n, u, w, dinv, p, s, x, r, st, parity, parts_gr,
+    k_cg1_update<false, false><<<g, WG, 0, hs>>>(n, u, w, dinv, dc, p, s, x, r, st, parity, parts_gr,
                                                  ngr, parts_d, nd, partials2);
   }
 }
 
-void lsb_k_pcg_update_p(unsigned n, const double *r, const double *dinv,
+void lsb_k_pcg_update_p(unsigned n, const double *r, const double *dinv, double dc,
                         double *p, struct lsb_pcg_state *st, int parity,
                         const double *parts2, unsigned nparts2, void *stream) {
   const unsigned g = lsb_k_blas1_grid(n);
   if (aligned16(r) && aligned16(dinv) && aligned16(p)) {
     if (g_blas1_nt)
-      k_pcg_update_p<true, true><<<g, WG, 0, (hipStream_t)stream>>>(n, r, dinv, p, st, parity,
+      k_pcg_update_p<true, true><<<g, WG, 0, (hipStream_t)stream>>>(n, r, dinv, dc, p, st, parity,
                                                                     parts2, nparts2);
     else
-      k_pcg_update_p<true, false><<<g, WG, 0, (hipStream_t)stream>>>(n, r, dinv, p, st, parity,
+      k_pcg_update_p<true, false><<<g, WG, 0, (hipStream_t)stream>>>(n, r, dinv, dc, p, st, parity,
                                                                      parts2, nparts2);
   } else {
-    k_pcg_update_p<false, false><<<g, WG, 0, (hipStream_t)stream>>>(n, r, dinv, p, st, parity,
+    k_pcg_update_p<false, false><<<g, WG, 0, (hipStream_t)stream>>>(n, r, dinv, dc, p, st, parity,
                                                                     parts2, nparts2);
   }
 }

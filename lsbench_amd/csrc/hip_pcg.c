@@ -6,6 +6,10 @@
 #define _GNU_SOURCE
 #include "hip_solver.h"
 
+/* the Jacobi diagonal as the fused sweeps take it: the vector, or (NULL, c) when
+ * every entry is the same c -- then nobody reads 8 n bytes to learn it */
+#define DINV(s) ((s)->dinv_uniform ? NULL : (s)->d_dinv), (s)->dinv_const
+
 /* ------------------------------------------------------------------------ */
 /* PCG                                                                       */
 /* ------------------------------------------------------------------------ */
@@ -22,7 +26,7 @@ static void pcg_enqueue_init(lsb_hip_solver *sv, const double *d_b, double *d_x)
   for (int i = 0; i < sv->nshard; i++) {
     struct shard *s = &sv->sh[i];
     const size_t o = s->row_begin - sv->row_first;
-    lsb_k_pcg_init(s->n, d_b + o, s->d_dinv, d_x + o, s->d_r, s->d_pfull + s->row_begin,
+    lsb_k_pcg_init(s->n, d_b + o, DINV(s), d_x + o, s->d_r, s->d_pfull + s->row_begin,
                    s->d_parts2, &np2, g_stream);
     if (sv->multi)
       lsb_k_reduce_final(s->d_parts2, np2, 2, s->d_scal + 1, 0, NULL, g_stream);
@@ -70,7 +74,7 @@ static void pcg_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int sa
   for (int i = 0; i < sv->nshard; i++) {
     struct shard *s = &sv->sh[i];
     const size_t o = s->row_begin - sv->row_first;
-    lsb_k_pcg_update_xr(s->n, s->d_pfull + s->row_begin, s->d_q, s->d_dinv, d_x + o, s->d_r,
+    lsb_k_pcg_update_xr(s->n, s->d_pfull + s->row_begin, s->d_q, DINV(s), d_x + o, s->d_r,
                         s->d_st, parity, sv->multi ? s->d_scal : s->d_parts_pq,
                         sv->multi ? 1u : npq, s->d_parts2, &np2, g_stream);
     if (sv->multi)
@@ -80,7 +84,7 @@ static void pcg_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int sa
     allreduce_scal(sv, 1, 2, 1);
   for (int i = 0; i < sv->nshard; i++) {
     struct shard *s = &sv->sh[i];
-    lsb_k_pcg_update_p(s->n, s->d_r, s->d_dinv, s->d_pfull + s->row_begin, s->d_st, parity,
+    lsb_k_pcg_update_p(s->n, s->d_r, DINV(s), s->d_pfull + s->row_begin, s->d_st, parity,
                        sv->multi ? s->d_scal + 1 : s->d_parts2, sv->multi ? 1u : np2,
                        g_stream);
   }
@@ -107,7 +111,7 @@ static void cg1_enqueue_init(lsb_hip_solver *sv, const double *d_b, double *d_x)
       s->d_s1 = (double *)lsb_hip_malloc(bytes);
     }
     /* x = 0, r = b, u = D^-1 b (into the gather vector), partials (r.u, b.b) */
-    lsb_k_pcg_init(s->n, d_b + o, s->d_dinv, d_x + o, s->d_r, s->d_pfull + s->row_begin,
+    lsb_k_pcg_init(s->n, d_b + o, DINV(s), d_x + o, s->d_r, s->d_pfull + s->row_begin,
                    s->d_parts2, &s->np2, g_stream);
     LSB_CHK_HIP(hipMemsetAsync(s->d_p1, 0, bytes, g_stream));
     LSB_CHK_HIP(hipMemsetAsync(s->d_s1, 0, bytes, g_stream));
@@ -142,7 +146,7 @@ static void cg1_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int sa
     double *gr_in = s->d_parts2 + (size_t)parity * 2 * LSB_MAX_PARTIALS;
     double *gr_out = s->d_parts2 + (size_t)(parity ^ 1) * 2 * LSB_MAX_PARTIALS;
     unsigned np2 = 0;
-    lsb_k_cg1_update(s->n, s->d_pfull + s->row_begin, s->d_q, s->d_dinv, s->d_p1, s->d_s1,
+    lsb_k_cg1_update(s->n, s->d_pfull + s->row_begin, s->d_q, DINV(s), s->d_p1, s->d_s1,
                      d_x + o, s->d_r, s->d_st, parity, sv->multi ? s->d_scal + 1 : gr_in,
                      sv->multi ? 1u : s->np2, sv->multi ? s->d_scal : s->d_parts_pq,
                      sv->multi ? 1u : s->npq, gr_out, &np2, g_stream);

@@ -241,6 +241,17 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
     LSB_CHK_HIP(hipMemcpy(s->d_dinv, ones, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
     free(ones);
   }
+  /* One value for every row (no preconditioner; the Laplacians' constant
+   * diagonal)?  Then the fused sweeps take it as a kernel argument. */
+  if (n && !getenv("LSBENCH_HIP_NO_UNIFORM_DINV")) {
+    double *h = (double *)malloc((size_t)n * sizeof(double));
+    LSB_CHK_HIP(hipMemcpy(h, s->d_dinv, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    int same = 1;
+    for (unsigned i = 1; i < n && same; i++)
+      same = h[i] == h[0];
+    s->dinv_uniform = same, s->dinv_const = h[0];
+    free(h);
+  }
 }
 
 void shard_free(struct shard *s) {

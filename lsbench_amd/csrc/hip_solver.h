@@ -58,6 +58,8 @@ struct shard {
   unsigned nslice, ov_s1, ov_s2;
   int ov_sok;
   /* ... and its 16-bit-code form (LSB_SP_C16 in sp_flags), own slice offsets */
+  int dinv_uniform;   /* all entries of dinv equal dinv_const */
+  double dinv_const;
   unsigned *d_sptr16;
   short *d_scodes;
   int *d_sbase;

@@ -91,21 +91,23 @@ void lsb_k_jacobi_sweep(unsigned n, double w, const double *dinv,
                         const double *b, const double *ax, double *x,
                         void *stream);
 /* PCG fused sweeps */
-void lsb_k_pcg_init(unsigned n, const double *b, const double *dinv, double *x,
+/* dinv == NULL: the Jacobi diagonal is the constant dc (not read from memory) */
+void lsb_k_pcg_init(unsigned n, const double *b, const double *dinv, double dc, double *x,
                     double *r, double *p, double *partials2,
                     unsigned *npartials, void *stream);
 void lsb_k_pcg_init_state(struct lsb_pcg_state *st, const double *partials2,
                           unsigned nparts, double tol, int maxit,
                           void *stream);
 void lsb_k_pcg_update_xr(unsigned n, const double *p, const double *q,
-                         const double *dinv, double *x, double *r,
+                         const double *dinv, double dc, double *x, double *r,
                          struct lsb_pcg_state *st, int parity,
                          const double *pq_parts, unsigned npq,
                          double *partials2, unsigned *npartials, void *stream);
-void lsb_k_pcg_update_p(unsigned n, const double *r, const double *dinv,
+void lsb_k_pcg_update_p(unsigned n, const double *r, const double *dinv, double dc,
                         double *p, struct lsb_pcg_state *st, int parity,
                         const double *parts2, unsigned nparts2, void *stream);
-void lsb_k_cg1_update(unsigned n, double *u, const double *w, const double *dinv, double *p,
+void lsb_k_cg1_update(unsigned n, double *u, const double *w, const double *dinv, double dc,
+                      double *p,
                       double *s, double *x, double *r, struct lsb_pcg_state *st, int parity,
                       const double *parts_gr, unsigned ngr, const double *parts_d, unsigned nd,
                       double *partials2, unsigned *npartials, void *stream);

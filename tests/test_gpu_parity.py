@@ -501,3 +501,24 @@ def test_l1_jacobi_preconditioner(hip, nvirt, matrix_path, golden_x):
     s = hip.Solver(Z, hip.default_opts(op_mode=hip.OP_RAW, precond=hip.PRECOND_L1JACOBI, maxit=5))
     assert s.n_local == n
     s.destroy()
+
+
+@pytest.mark.parametrize("krylov", ["PCG", "PCG1"])
+def test_constant_diagonal_is_passed_by_value(hip, krylov, monkeypatch):
+    """An operator whose Jacobi diagonal is one number for all rows: the fused
+    sweeps take it as an argument instead of reading the vector.  Same
+    arithmetic, so the iterates are the same bits as with the vector."""
+    A = hip.lsbench_matrix_synth("lap3d:nx=50,ny=40,nz=30")
+    b = O.rhs(A.nrows)
+    kw = dict(op_mode=hip.OP_RAW, tol=1e-10, krylov=getattr(hip, "KRYLOV_" + krylov), use_graph=0)
+    s = hip.Solver(A, hip.default_opts(**kw))
+    x1, r1 = s.solve(b)
+    s.destroy()
+    monkeypatch.setenv("LSBENCH_HIP_NO_UNIFORM_DINV", "1")
+    s = hip.Solver(A, hip.default_opts(**kw))
+    x2, r2 = s.solve(b)
+    s.destroy()
+    assert r1.status == 1 and r1.iters == r2.iters and np.array_equal(x1, x2)
+    offs, cols, vals = O.lap3d(50, 40, 30)
+    xo, ito, _, _ = O.pcg_jacobi(offs, cols, vals, b, 1e-10)
+    assert abs(int(r1.iters) - ito) <= 3 and np.linalg.norm(x1 - xo) / np.linalg.norm(xo) <= 1e-8
