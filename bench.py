@@ -348,6 +348,10 @@ def main():
                      modes="0 one shard, 1 RCCL, 2 direct xGMI all-reduce, 3 direct xGMI halos too"),
         "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": gbps / HBM_PEAK_GBPS, "traffic": traffic,
+                     # what the HBM actually moved per second (PMC bytes of the committed
+                     # profile / this run's launch time): the layout stores fewer bytes than
+                     # the CSR accounting `achieved` is quoted on
+                     "traffic_GBps": (traffic / spmv_avg_ms / 1e6) if traffic else None,
                      "kernel": kernel + (" (panels)" if solver.spmv_variant == la.SPMV_PANEL else "") + " (fused p.q)",
                      "launch_ms": spmv_avg_ms, "back_to_back_launch_ms": b2b_ms,
                      "spmv_flags": solver.spmv_flags,
