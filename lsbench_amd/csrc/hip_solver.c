@@ -533,13 +533,18 @@ void spmv_shard(struct shard *s, const double *xfull, double *y,
 }
 
 /*
- * Pick the adaptive SpMV's flavour for this operator by timing it (setup is
- * untimed, like the reference's csr_init): {plain, prefetch, nontemporal,
- * both}, 3 launches each after one warm-up, on the
- * shard's own matrix with the dot product fused as in the solve.  Which one
- * wins depends on how much of x's gather window survives in L2 next to the
- * matrix stream: on the 10M-row 5-point operator nontemporal stream loads win
- * by 15%, on the 7-point 256^3 one prefetch without nontemporal does.
+ * Pick the SpMV form and flavour for this shard by timing them (setup is
+ * untimed, like the reference's csr_init): every form the shard has -- the
+ * row-blocked CSR kernel {plain, prefetch, nontemporal, both}, the column-panel
+ * form of scattered shards, the sliced-ELL copies {32-bit columns, 16-bit codes}
+ * x {plain, nontemporal} x {8, 6 resident workgroups per CU} -- 3 launches each
+ * after one warm-up, on the shard's own matrix with the dot product fused as
+ * in the solve.  Which one wins depends on the operator: stencils and banded
+ * meshes take the 16-bit sliced-ELL form (10 M-row 5-point: 104 us against
+ * 152 us row-blocked), ragged rows have no sliced-ELL copy at all, and whether
+ * nontemporal stream loads pay depends on how much of x's gather window
+ * survives next to the matrix stream (64 M-row 7-point: plain loads).  The
+ * copies that lose are freed.
  */
 void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
   const struct lsb_hip_opts *o = &sv->o;
