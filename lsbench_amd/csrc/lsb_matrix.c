@@ -26,6 +26,8 @@
 #include <ctype.h>
 #include <errno.h>
 #include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 struct rec {
   unsigned r, c;
@@ -223,7 +225,94 @@ static struct csr *csr_from_file(const char *fname) {
   return A;
 }
 
+/*
+ * Binary cache of a parsed file, opt-in:
+ * LSBENCH_MATRIX_CACHE=1 keeps "<file>.lsbcsr" next to the text file,
+ * LSBENCH_MATRIX_CACHE=<dir> keeps it in <dir>.  Layout: 8-byte magic, the
+ * text file's size and mtime (a stale cache is ignored and rewritten), nrows,
+ * base, nnz, then offs / cols / vals exactly as in struct csr.  What it holds
+ * is the OUTPUT of the parser above, so every loader rule (sorting, summed
+ * duplicates, dense row renumbering, kept base) is applied once, by that code.
+ */
+struct cache_hdr {
+  char magic[8];
+  long long src_size, src_mtime_ns;
+  unsigned nrows, base;
+  unsigned long long nnz;
+};
+static const char CACHE_MAGIC[8] = {'L', 'S', 'B', 'C', 'S', 'R', '1', 0};
+
+static int cache_path(const char *fname, char *out, size_t cap) {
+  const char *e = getenv("LSBENCH_MATRIX_CACHE");
+  if (!e || !*e || !strcmp(e, "0"))
+    return 0;
+  if (!strcmp(e, "1"))
+    return snprintf(out, cap, "%s.lsbcsr", fname) < (int)cap;
+  const char *b = strrchr(fname, '/');
+  return snprintf(out, cap, "%s/%s.lsbcsr", e, b ? b + 1 : fname) < (int)cap;
+}
+
+static struct csr *cache_load(const char *cpath, const struct stat *src) {
+  FILE *f = fopen(cpath, "rb");
+  if (!f)
+    return NULL;
+  struct cache_hdr h;
+  struct csr *A = NULL;
+  if (fread(&h, sizeof h, 1, f) == 1 && !memcmp(h.magic, CACHE_MAGIC, 8) &&
+      h.src_size == (long long)src->st_size &&
+      h.src_mtime_ns == (long long)src->st_mtim.tv_sec * 1000000000ll + src->st_mtim.tv_nsec) {
+    A = lsb_calloc(struct csr, 1);
+    A->nrows = h.nrows, A->base = h.base;
+    A->offs = (unsigned *)malloc(((size_t)h.nrows + 1) * sizeof(unsigned));
+    A->cols = (unsigned *)malloc((size_t)(h.nnz ? h.nnz : 1) * sizeof(unsigned));
+    A->vals = (double *)malloc((size_t)(h.nnz ? h.nnz : 1) * sizeof(double));
+    if (!A->offs || !A->cols || !A->vals ||
+        fread(A->offs, sizeof(unsigned), (size_t)h.nrows + 1, f) != (size_t)h.nrows + 1 ||
+        fread(A->cols, sizeof(unsigned), (size_t)h.nnz, f) != (size_t)h.nnz ||
+        fread(A->vals, sizeof(double), (size_t)h.nnz, f) != (size_t)h.nnz ||
+        A->offs[h.nrows] != h.nnz) {
+      lsbench_matrix_free(A); /* truncated or foreign file: parse the text instead */
+      A = NULL;
+    }
+  }
+  fclose(f);
+  return A;
+}
+
+static void cache_store(const char *cpath, const struct stat *src, const struct csr *A) {
+  char tmp[4200];
+  if (snprintf(tmp, sizeof tmp, "%s.tmp%d", cpath, (int)getpid()) >= (int)sizeof tmp)
+    return;
+  FILE *f = fopen(tmp, "wb");
+  if (!f)
+    return; /* a cache that cannot be written is not an error */
+  struct cache_hdr h;
+  memset(&h, 0, sizeof h);
+  memcpy(h.magic, CACHE_MAGIC, 8);
+  h.src_size = (long long)src->st_size;
+  h.src_mtime_ns = (long long)src->st_mtim.tv_sec * 1000000000ll + src->st_mtim.tv_nsec;
+  h.nrows = A->nrows, h.base = A->base, h.nnz = A->offs[A->nrows];
+  const int ok = fwrite(&h, sizeof h, 1, f) == 1 &&
+                 fwrite(A->offs, sizeof(unsigned), (size_t)A->nrows + 1, f) == (size_t)A->nrows + 1 &&
+                 fwrite(A->cols, sizeof(unsigned), (size_t)h.nnz, f) == (size_t)h.nnz &&
+                 fwrite(A->vals, sizeof(double), (size_t)h.nnz, f) == (size_t)h.nnz;
+  if (fclose(f) != 0 || !ok || rename(tmp, cpath) != 0)
+    remove(tmp);
+}
+
 struct csr *lsbench_matrix_read(const char *fname) {
+  char cpath[4096];
+  struct stat sb;
+  if (strncmp(fname, "synth:", 6) != 0 && cache_path(fname, cpath, sizeof cpath) &&
+      stat(fname, &sb) == 0) {
+    struct csr *C = cache_load(cpath, &sb);
+    if (C)
+      return C;
+    C = csr_from_file(fname);
+    if (C)
+      cache_store(cpath, &sb, C);
+    return C;
+  }
   if (strncmp(fname, "synth:", 6) == 0) {
     unsigned n;
     struct csr *A = lsbench_matrix_synth(fname + 6, 0, 0, &n);

@@ -388,3 +388,46 @@ def test_sliced_ell_copy_16bit_row_slice_and_refusal():
     assert la.lsb_csr_sellize16(B) is None
     ok = la.lsb_csr_sellize16(la.Matrix.from_arrays(np.array([0, 255]), cols[:255], np.ones(255)))
     assert ok is not None and ok[0][-1] == 255 * la.SELL_ROWS
+
+
+def test_binary_matrix_cache(tmp_path, matrix_path, monkeypatch):
+    """LSBENCH_MATRIX_CACHE: the parsed CSR is kept
+    next to the text; a second read comes from it, a changed text file
+    invalidates it, a damaged cache is ignored."""
+    import shutil
+    src = tmp_path / "m.txt"
+    shutil.copy(matrix_path("xn3b_A_10"), src)
+    plain = la.lsbench_matrix_read(str(src))
+    monkeypatch.setenv("LSBENCH_MATRIX_CACHE", "1")
+    first = la.lsbench_matrix_read(str(src))
+    cache = tmp_path / "m.txt.lsbcsr"
+    assert cache.exists() and cache.stat().st_size > plain.nnz * 12
+    second = la.lsbench_matrix_read(str(src))
+    for M in (first, second):
+        assert (M.nrows, M.base) == (plain.nrows, plain.base)
+        assert np.array_equal(M.offs, plain.offs) and np.array_equal(M.cols, plain.cols)
+        assert np.array_equal(M.vals, plain.vals)
+    # proof that the second read did not parse the text: same size and mtime, other content
+    st = src.stat()
+    txt = src.read_bytes()
+    src.write_bytes(txt)
+    os.utime(src, ns=(st.st_atime_ns, st.st_mtime_ns))
+    raw = bytearray(cache.read_bytes())
+    raw[-8:] = np.float64(12345.0).tobytes()                     # last value of the cache
+    cache.write_bytes(bytes(raw))
+    assert la.lsbench_matrix_read(str(src)).vals[-1] == 12345.0
+    # a newer text file: the cache is stale, the text is parsed again and the cache rewritten
+    os.utime(src, ns=(st.st_atime_ns, st.st_mtime_ns + 5_000_000_000))
+    fresh = la.lsbench_matrix_read(str(src))
+    assert fresh.vals[-1] == plain.vals[-1]
+    assert np.frombuffer(cache.read_bytes()[-8:], np.float64)[0] == plain.vals[-1]
+    # truncated cache: ignored
+    cache.write_bytes(cache.read_bytes()[:200])
+    again = la.lsbench_matrix_read(str(src))
+    assert np.array_equal(again.vals, plain.vals)
+    # a cache directory
+    d = tmp_path / "cache"
+    d.mkdir()
+    monkeypatch.setenv("LSBENCH_MATRIX_CACHE", str(d))
+    la.lsbench_matrix_read(str(src))
+    assert (d / "m.txt.lsbcsr").exists()

@@ -764,6 +764,76 @@ __global__ __launch_bounds__(WG, MINW) void k_sell2c16(const int *, unsigned nsl
     partials[xcd * gx + slot] = d[0];
 }
 
+// ---- probe: the p update folded into the sliced-ELL SpMV.  Every gathered
+// column computes p_new = c r + beta p_old on the fly (two gathers instead of
+// one), the row owner also stores p_new; q = S p_new.  Compare with
+// "S2C16" + a separate 240 MB sweep (p = c r + beta p).
+__device__ const double *g_fuse_r;
+__device__ double *g_fuse_pnew;
+template <int FLAGS, int U, int MINW>
+__global__ __launch_bounds__(WG, MINW) void k_sell2c16p(const int *, unsigned nslice, unsigned n, const int *,
+                                                     const int *__restrict__ cols,
+                                                     const double *__restrict__ vals,
+                                                     const double *__restrict__ x,
+                                                     double *__restrict__ y,
+                                                     double *__restrict__ partials) {
+  __shared__ double sred[4];
+  const double cc = 0.25, beta = 0.37;
+  const double *__restrict__ rr = g_fuse_r;
+  double *__restrict__ pn = g_fuse_pnew;
+  const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const unsigned gx = gridDim.x / NXCD, xcd = blockIdx.x % NXCD, slot = blockIdx.x / NXCD;
+  const unsigned ngrp = (nslice + 3) / 4, chunk = (ngrp + NXCD - 1) / NXCD;
+  const unsigned g0 = xcd * chunk, g1 = g0 + chunk < ngrp ? g0 + chunk : ngrp;
+  const unsigned *sp = g_sell2_ptr;
+  double dot = 0.0;
+  for (unsigned g = g0 + slot; g < g1; g += gx) {
+    const unsigned s = __builtin_amdgcn_readfirstlane(g * 4 + wave);
+    if (s < nslice) {
+      const unsigned base = sp[s], len = (sp[s + 1] - base) >> 7;
+      const lab_s2v *cp = (const lab_s2v *)((const short *)cols + base) + lane;
+      const lab_d2vb *vp = (const lab_d2vb *)(vals + base) + lane;
+      const int row = (int)(s * 128 + 2 * lane);
+      double a0 = 0.0, a1 = 0.0;
+      for (unsigned j0 = 0; j0 < len; j0 += U) {
+        lab_s2v c[U];
+        lab_d2vb v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+          if (j0 + u < len) {
+            c[u] = ldg<FLAGS>(cp + (j0 + u) * 64);
+            v[u] = ldg<FLAGS>(vp + (j0 + u) * 64);
+          }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+          if (j0 + u < len) {
+            const int i0 = row + (int)c[u].x, i1 = row + 1 + (int)c[u].y;
+            a0 += v[u].x * __fma_rn(beta, x[i0], cc * rr[i0]);
+            a1 += v[u].y * __fma_rn(beta, x[i1], cc * rr[i1]);
+          }
+      }
+      if ((unsigned)row + 1 < n) {
+        lab_d2vb o = {a0, a1};
+        *(lab_d2vb *)(y + row) = o;
+        const lab_d2vb xx = *(const lab_d2vb *)(x + row), r2 = *(const lab_d2vb *)(rr + row);
+        lab_d2vb pv = {__fma_rn(beta, xx.x, cc * r2.x), __fma_rn(beta, xx.y, cc * r2.y)};
+        *(lab_d2vb *)(pn + row) = pv;
+        dot += a0 * pv.x;
+        dot += a1 * pv.y;
+      } else if ((unsigned)row < n) {
+        y[row] = a0;
+        const double pv = __fma_rn(beta, x[row], cc * rr[row]);
+        pn[row] = pv;
+        dot += a0 * pv;
+      }
+    }
+  }
+  double d[1] = {dot};
+  wg_sum<1>(d, sred);
+  if (tid == 0)
+    partials[xcd * gx + slot] = d[0];
+}
+
 // ---- V5: V3 with 16 B/lane stream loads.  A block's nnz range [j0,j1) is
 // widened to 4-aligned [j0&~3, ...); each lane owns QPT quads of 4 consecutive
 // non-zeros (cols as int4, vals as 2 x double2).  Row blocks are built with
@@ -1178,6 +1248,8 @@ LAUNCHER(l_cyc_nt, (k_adaptive_cyc<2048, F_CYCLIC | F_NT>))
 LAUNCHER(l_sell_nt8, (k_sell<F_NT, 8>))
 LAUNCHER(l_sell2_nt8, (k_sell2<F_NT, 8, 4>))
 LAUNCHER(l_s2c16_u5, (k_sell2c16<F_NT, 5, 8>))
+LAUNCHER(l_s2c16p_u5, (k_sell2c16p<F_NT, 5, 8>))
+LAUNCHER(l_s2c16p_u5o6, (k_sell2c16p<F_NT, 5, 6>))
 LAUNCHER(l_s2c16_u8, (k_sell2c16<F_NT, 8, 6>))
 LAUNCHER(l_sell2_nt5, (k_sell2<F_NT, 5, 6>))
 LAUNCHER(l_sell2_nt7, (k_sell2<F_NT, 7, 5>))
@@ -1237,6 +1309,12 @@ int main(int argc, char **argv) {
   double *d_vals = upload(A.vals), *d_x = upload(hx), *d_y, *d_parts;
   CHK(hipMalloc(&d_y, (size_t)A.n * 8));
   CHK(hipMalloc(&d_parts, 4096 * 8));
+  {
+    double *d_r = upload(hx), *d_pn;
+    CHK(hipMalloc(&d_pn, (size_t)A.n * 8 + 64));
+    CHK(hipMemcpyToSymbol(HIP_SYMBOL(g_fuse_r), &d_r, sizeof(d_r)));
+    CHK(hipMemcpyToSymbol(HIP_SYMBOL(g_fuse_pnew), &d_pn, sizeof(d_pn)));
+  }
 
   std::vector<Variant> vs = {
       {"adaptive cap2048 g2048 (round-1a lib)", 2048, l_base2048, 2048},
@@ -1245,6 +1323,9 @@ int main(int argc, char **argv) {
       {"SELL64 nt U8", 2048, l_sell_nt8, 2048},
       {"S2C16 nt U5 g2048", 2048, l_s2c16_u5, 2048},
       {"S2C16 nt U5 g1536", 2048, l_s2c16_u5, 1536},
+      {"probe: S2C16 + fused p update g1536", 2048, l_s2c16p_u5, 1536},
+      {"probe: S2C16 + fused p update g2048", 2048, l_s2c16p_u5, 2048},
+      {"probe: S2C16 + fused p update occ6", 2048, l_s2c16p_u5o6, 1536},
       {"S2C16 nt U8 g1536", 2048, l_s2c16_u8, 1536},
       {"SELL128x2 nt U8 occ4", 2048, l_sell2_nt8, 1024},
       {"SELL128x2 nt U7 occ5", 2048, l_sell2_nt7, 1280},
