@@ -3,7 +3,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=gpurun_out/${1:-pmc}; mkdir -p $OUT; export TMPDIR=/tmp
 pass() { local name=$1; shift
-  timeout -k 10 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$OUT/$name" -- tools/spmv_lab lap2d 3162 1 > $OUT/$name.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$OUT/$name" -- tools/spmv_lab.bin lap2d 3162 1 > $OUT/$name.log 2>&1
   local rc=$?; echo "$name rc=$rc"; if [ $rc -ge 124 ]; then exit $rc; fi; }
 pass sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU
 pass sq2 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
