@@ -705,7 +705,11 @@ __global__ __launch_bounds__(WG) void k_pcg_update_p(
 // iteration instead of two.  Costs one more vector (s) and 96 n instead of 88 n
 // bytes per iteration, so the large single-GPU case keeps the classic form.
 // --------------------------------------------------------------------------
-template <bool V2, bool NT>
+// UI ("implicit u"): the Jacobi diagonal is the constant dc, so u = dc r is not
+// kept at all -- r itself lives in the gather vector, the SpMV in between
+// delivers t = S r and r.t, and w = dc t, w.u = dc^2 r.t are formed here:
+// 9 vector passes per sweep instead of 11 (u neither read nor written).
+template <bool V2, bool NT, bool UI>
 __global__ __launch_bounds__(WG) void k_cg1_update(
     unsigned n, double *__restrict__ u, const double *__restrict__ w,
     const double *__restrict__ dinv, double dc, double *__restrict__ p, double *__restrict__ sv,
@@ -723,16 +727,20 @@ __global__ __launch_bounds__(WG) void k_cg1_update(
   d2v uv = {0.0, 0.0}, wv = uv, dv = uv, pv = uv, sw = uv, xv = uv, rv = uv;
   const bool first = V2 && gtid < n2;
   if (first) {
-    uv = ld2<NT>(u2 + gtid), wv = ld2<NT>(w2 + gtid), dv = ldd<NT>(d2, gtid, dc);
+    wv = ld2<NT>(w2 + gtid), dv = ldd<NT>(d2, gtid, dc);
     pv = ld2<NT>(p2 + gtid), sw = ld2<NT>(s2 + gtid), xv = ld2<NT>(x2 + gtid);
     rv = ld2<NT>(r2 + gtid);
+    if (UI)
+      uv = dc * rv, wv = dc * wv;
+    else
+      uv = ld2<NT>(u2 + gtid);
   }
   double gr[2], dd[1];
   wg_sum_partials<2>(parts_gr, ngr, gr, sred);
   wg_sum_partials<1>(parts_d, nd, dd, sred);
   if (stopped)
     return;
-  const double g_new = gr[0], rr = gr[1], delta = dd[0];
+  const double g_new = gr[0], rr = gr[1], delta = UI ? dc * dc * dd[0] : dd[0];
   const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
   if (rr <= thresh2) { // r of the previous update already meets the tolerance
     if (leader)
@@ -771,8 +779,13 @@ __global__ __launch_bounds__(WG) void k_cg1_update(
         xv.x += alpha * pv.x, xv.y += alpha * pv.y;
         rv.x -= alpha * sw.x, rv.y -= alpha * sw.y;
         uv.x = dv.x * rv.x, uv.y = dv.y * rv.y;
-        st2<NT>(p2 + i, pv), st2<NT>(s2 + i, sw), st2<NT>(x2 + i, xv), st2<NT>(r2 + i, rv);
-        u2[i] = uv;
+        st2<NT>(p2 + i, pv), st2<NT>(s2 + i, sw), st2<NT>(x2 + i, xv);
+        if (UI) {
+          r2[i] = rv; // the SpMV gathers it next: keep it cached
+        } else {
+          st2<NT>(r2 + i, rv);
+          u2[i] = uv;
+        }
         acc[0] += rv.x * uv.x;
         acc[0] += rv.y * uv.y;
         acc[1] += rv.x * rv.x;
@@ -780,27 +793,37 @@ __global__ __launch_bounds__(WG) void k_cg1_update(
         i += gsz;
         if (i >= n2)
           break;
-        uv = ld2<NT>(u2 + i), wv = ld2<NT>(w2 + i), dv = ldd<NT>(d2, i, dc);
+        wv = ld2<NT>(w2 + i), dv = ldd<NT>(d2, i, dc);
         pv = ld2<NT>(p2 + i), sw = ld2<NT>(s2 + i), xv = ld2<NT>(x2 + i);
         rv = ld2<NT>(r2 + i);
+        if (UI)
+          uv = dc * rv, wv = dc * wv;
+        else
+          uv = ld2<NT>(u2 + i);
       }
     }
     if ((n & 1) && gtid == gsz - 1) {
       const size_t i = n - 1;
-      const double pi = u[i] + beta * p[i], si = w[i] + beta * sv[i];
+      const double ui0 = UI ? dc * r[i] : u[i], wi = UI ? dc * w[i] : w[i];
+      const double pi = ui0 + beta * p[i], si = wi + beta * sv[i];
       p[i] = pi, sv[i] = si;
       x[i] += alpha * pi;
       const double ri = r[i] - alpha * si, ui = (dinv ? dinv[i] : dc) * ri;
-      r[i] = ri, u[i] = ui;
+      r[i] = ri;
+      if (!UI)
+        u[i] = ui;
       acc[0] += ri * ui, acc[1] += ri * ri;
     }
   } else {
     for (size_t i = gtid; i < n; i += gsz) {
-      const double pi = u[i] + beta * p[i], si = w[i] + beta * sv[i];
+      const double ui0 = UI ? dc * r[i] : u[i], wi = UI ? dc * w[i] : w[i];
+      const double pi = ui0 + beta * p[i], si = wi + beta * sv[i];
       p[i] = pi, sv[i] = si;
       x[i] += alpha * pi;
       const double ri = r[i] - alpha * si, ui = (dinv ? dinv[i] : dc) * ri;
-      r[i] = ri, u[i] = ui;
+      r[i] = ri;
+      if (!UI)
+        u[i] = ui;
       acc[0] += ri * ui, acc[1] += ri * ri;
     }
   }
@@ -1239,18 +1262,27 @@ void lsb_k_cg1_update(unsigned n, double *u, const double *w, const double *dinv
   const unsigned g = lsb_k_blas1_grid(n);
   *npartials = g;
   hipStream_t hs = (hipStream_t)stream;
-  if (aligned16(u) && aligned16(w) && aligned16(dinv) && aligned16(p) && aligned16(s) &&
-      aligned16(x) && aligned16(r)) {
-    if (g_blas1_nt)
-      k_cg1_update<true, true><<<g, WG, 0, hs>>>(n, u, w, dinv, dc, p, s, x, r, st, parity, parts_gr,
-                                                 ngr, parts_d, nd, partials2);
+  const bool v2 = aligned16(u) && aligned16(w) && aligned16(dinv) && aligned16(p) &&
+                  aligned16(s) && aligned16(x) && aligned16(r);
+#define LSB_CG1(V, N, U)                                                                  \
+  k_cg1_update<V, N, U><<<g, WG, 0, hs>>>(n, u, w, dinv, dc, p, s, x, r, st, parity, parts_gr, \
+                                          ngr, parts_d, nd, partials2)
+  if (!u) { /* implicit u = dc r: r is the gather vector (needs the constant diagonal) */
+    if (dinv)
+      errx(EXIT_FAILURE, "lsb_k_cg1_update: implicit u needs a constant diagonal");
+    if (v2 && g_blas1_nt)
+      LSB_CG1(true, true, true);
+    else if (v2)
+      LSB_CG1(true, false, true);
     else
-      k_cg1_update<true, false><<<g, WG, 0, hs>>>(n, u, w, dinv, dc, p, s, x, r, st, parity,
-                                                  parts_gr, ngr, parts_d, nd, partials2);
-  } else {
-    k_cg1_update<false, false><<<g, WG, 0, hs>>>(n, u, w, dinv, dc, p, s, x, r, st, parity, parts_gr,
-                                                 ngr, parts_d, nd, partials2);
-  }
+      LSB_CG1(false, false, true);
+  } else if (v2 && g_blas1_nt)
+    LSB_CG1(true, true, false);
+  else if (v2)
+    LSB_CG1(true, false, false);
+  else
+    LSB_CG1(false, false, false);
+#undef LSB_CG1
 }
 
 void lsb_k_pcg_update_p(unsigned n, const double *r, const double *dinv, double dc,

@@ -110,9 +110,15 @@ static void cg1_enqueue_init(lsb_hip_solver *sv, const double *d_b, double *d_x)
       s->d_p1 = (double *)lsb_hip_malloc(bytes);
       s->d_s1 = (double *)lsb_hip_malloc(bytes);
     }
-    /* x = 0, r = b, u = D^-1 b (into the gather vector), partials (r.u, b.b) */
-    lsb_k_pcg_init(s->n, d_b + o, DINV(s), d_x + o, s->d_r, s->d_pfull + s->row_begin,
-                   s->d_parts2, &s->np2, g_stream);
+    /* x = 0, r = b, u = D^-1 b (into the gather vector), partials (r.u, b.b);
+     * implicit u (constant diagonal): r itself goes into the gather vector and
+     * u = c b lands in a scratch nobody reads */
+    if (sv->cg1_implicit)
+      lsb_k_pcg_init(s->n, d_b + o, DINV(s), d_x + o, s->d_pfull + s->row_begin, s->d_r,
+                     s->d_parts2, &s->np2, g_stream);
+    else
+      lsb_k_pcg_init(s->n, d_b + o, DINV(s), d_x + o, s->d_r, s->d_pfull + s->row_begin,
+                     s->d_parts2, &s->np2, g_stream);
     LSB_CHK_HIP(hipMemsetAsync(s->d_p1, 0, bytes, g_stream));
     LSB_CHK_HIP(hipMemsetAsync(s->d_s1, 0, bytes, g_stream));
     if (sv->multi)
@@ -146,8 +152,10 @@ static void cg1_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int sa
     double *gr_in = s->d_parts2 + (size_t)parity * 2 * LSB_MAX_PARTIALS;
     double *gr_out = s->d_parts2 + (size_t)(parity ^ 1) * 2 * LSB_MAX_PARTIALS;
     unsigned np2 = 0;
-    lsb_k_cg1_update(s->n, s->d_pfull + s->row_begin, s->d_q, DINV(s), s->d_p1, s->d_s1,
-                     d_x + o, s->d_r, s->d_st, parity, sv->multi ? s->d_scal + 1 : gr_in,
+    lsb_k_cg1_update(s->n, sv->cg1_implicit ? NULL : s->d_pfull + s->row_begin, s->d_q, DINV(s),
+                     s->d_p1, s->d_s1, d_x + o,
+                     sv->cg1_implicit ? s->d_pfull + s->row_begin : s->d_r, s->d_st, parity,
+                     sv->multi ? s->d_scal + 1 : gr_in,
                      sv->multi ? 1u : s->np2, sv->multi ? s->d_scal : s->d_parts_pq,
                      sv->multi ? 1u : s->npq, gr_out, &np2, g_stream);
     s->ar2_parts = gr_out, s->ar2_n = np2, s->ar2_width = 2;

@@ -305,6 +305,24 @@ void solver_finish_setup(lsb_hip_solver *sv) {
   for (int i = 0; i < sv->nshard; i++)
     tune_spmv(sv, &sv->sh[i]);
   LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+  /* one constant Jacobi diagonal on every shard of every rank? */
+  {
+    const double c = sv->sh[0].dinv_const;
+    int same = 1;
+    for (int i = 0; i < sv->nshard; i++)
+      same &= sv->sh[i].dinv_uniform && sv->sh[i].dinv_const == c;
+    if (sv->dist) {
+      const int P = lsb_hip_comm_size();
+      unsigned mine[3], *all = lsb_calloc(unsigned, 3 * (size_t)P);
+      mine[0] = (unsigned)same;
+      memcpy(mine + 1, &c, sizeof c);
+      lsb_hip_comm_allgather_u32(mine, 3, all);
+      for (int q = 0; q < P; q++)
+        same &= all[3 * q] && all[3 * q + 1] == all[1] && all[3 * q + 2] == all[2];
+      free(all);
+    }
+    sv->cg1_implicit = same;
+  }
   p2p_setup(sv);
 }
 

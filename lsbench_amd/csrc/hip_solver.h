@@ -118,6 +118,9 @@ struct lsb_hip_solver {
   double *d_tmp; /* n_here doubles: scratch for spmv_dev / jacobi sweep */
   /* direct xGMI path (hip_p2p.hip), one context per shard; p2p_on: used for
    * the all-reduces, p2p_halo: also for the halo exchange */
+  /* single-reduction PCG without the vector u = D^-1 r: every shard of every
+   * rank has the same constant Jacobi diagonal (k_cg1_update<UI>) */
+  int cg1_implicit;
   struct lsb_p2p **p2p;
   int p2p_on, p2p_halo;
   double p2p_us, rccl_us; /* self-test: one exchange + all-reduce, each way */

@@ -507,7 +507,8 @@ def test_l1_jacobi_preconditioner(hip, nvirt, matrix_path, golden_x):
 def test_constant_diagonal_is_passed_by_value(hip, krylov, monkeypatch):
     """An operator whose Jacobi diagonal is one number for all rows: the fused
     sweeps take it as an argument instead of reading the vector.  Same
-    arithmetic, so the iterates are the same bits as with the vector."""
+    arithmetic in the classic form, so its iterates are the same bits as with
+    the vector."""
     A = hip.lsbench_matrix_synth("lap3d:nx=50,ny=40,nz=30")
     b = O.rhs(A.nrows)
     kw = dict(op_mode=hip.OP_RAW, tol=1e-10, krylov=getattr(hip, "KRYLOV_" + krylov), use_graph=0)
@@ -518,7 +519,14 @@ def test_constant_diagonal_is_passed_by_value(hip, krylov, monkeypatch):
     s = hip.Solver(A, hip.default_opts(**kw))
     x2, r2 = s.solve(b)
     s.destroy()
-    assert r1.status == 1 and r1.iters == r2.iters and np.array_equal(x1, x2)
+    assert r1.status == 1 and r2.status == 1
+    if krylov == "PCG":
+        assert r1.iters == r2.iters and np.array_equal(x1, x2)
+    else:
+        # the single-reduction form goes further: u = c r is not kept at all and the
+        # SpMV runs on r (w = c (S r) instead of S (c r): other roundings, same iterates)
+        assert abs(int(r1.iters) - int(r2.iters)) <= 2
+        assert np.linalg.norm(x1 - x2) / np.linalg.norm(x2) <= 1e-9
     offs, cols, vals = O.lap3d(50, 40, 30)
     xo, ito, _, _ = O.pcg_jacobi(offs, cols, vals, b, 1e-10)
     assert abs(int(r1.iters) - ito) <= 3 and np.linalg.norm(x1 - xo) / np.linalg.norm(xo) <= 1e-8
