@@ -352,6 +352,9 @@ def main():
                      # profile / this run's launch time): the layout stores fewer bytes than
                      # the CSR accounting `achieved` is quoted on
                      "traffic_GBps": (traffic / spmv_avg_ms / 1e6) if traffic else None,
+                     "note": "achieved/frac are quoted on SURVEY 8(d)'s CSR byte count (12 B per "
+                             "non-zero + 20 B per row); the sliced-ELL layout the kernel reads stores "
+                             "8-10 B per entry, so frac can pass 1 while the HBM moves traffic_GBps",
                      "kernel": kernel + (" (panels)" if solver.spmv_variant == la.SPMV_PANEL else "") + " (fused p.q)",
                      "launch_ms": spmv_avg_ms, "back_to_back_launch_ms": b2b_ms,
                      "spmv_flags": solver.spmv_flags,

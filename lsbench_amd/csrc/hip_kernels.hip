@@ -1035,8 +1035,18 @@ extern "C" {
 void lsb_k_set_blas1_nt(int on) { g_blas1_nt = on ? 1 : 0; }
 
 unsigned lsb_k_blas1_grid(unsigned n) {
-  // 16 B/lane => WG*2 elements per workgroup per trip; cap at MAX_PARTIALS
+  // 16 B/lane => WG*2 elements per workgroup per trip.  Up to 256 workgroups
+  // one trip each (small operators: all latency); beyond that four trips per
+  // lane before the grid grows -- every workgroup of the NEXT kernel re-reduces
+  // this kernel's partial sums, so a grid of 2048 on a 1 M-row shard costs more
+  // in its consumers than it gains (1.25 M rows: sweep 26.5 -> 20.8 us); cap at
+  // MAX_PARTIALS.
   unsigned g = div_up(n, WG * 2);
+  if (g > 256) {
+    g = div_up(n, WG * 2 * 4);
+    if (g < 256)
+      g = 256;
+  }
   if (g > LSB_MAX_PARTIALS)
     g = LSB_MAX_PARTIALS;
   return g ? g : 1;
@@ -1060,8 +1070,19 @@ unsigned lsb_k_spmv_grid(int variant, unsigned n, unsigned nblk,
   grid_cap = grid_cap / NXCD * NXCD;
   if (grid_cap < NXCD)
     grid_cap = NXCD;
-  if (g > grid_cap)
+  if (g > grid_cap) {
     g = grid_cap;
+    /* The persistent kernels cut the items into NXCD chunks and deal a chunk
+     * cyclically to the XCD's g/NXCD workgroups: size the grid so that every
+     * workgroup gets the same number of items (2440 items on 1536 workgroups
+     * is two rounds with the second 59 % full; on 1224 it is two full ones,
+     * and the consumers re-reduce 1224 partial sums instead of 1536). */
+    if (variant == LSB_SPMV_SELL || variant == LSB_SPMV_ADAPTIVE) {
+      const unsigned chunk = div_up(items, NXCD), cap = grid_cap / NXCD;
+      const unsigned per = div_up(chunk, cap);
+      g = div_up(chunk, per) * NXCD;
+    }
+  }
   return g;
 }
 
