@@ -106,3 +106,31 @@ def test_hip_pcg1_variants(hip, matrix_path, golden_x):
     x, res = s.solve(b)
     s.destroy()
     assert res.status == 1 and np.linalg.norm(x - xg) / np.linalg.norm(xg) <= 1e-10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("graph", [0, 1])
+def test_hip_pcg1_implicit_u_small_operator(hip, graph):
+    """constant diagonal + single-reduction form on a launch-bound operator
+    (sub-wavefront SpMV, iterations replayed from a hipGraph): the vector u is
+    never materialised, r is what the SpMV gathers"""
+    L = hip.lsbench_matrix_synth("lap2d:nx=120,ny=90")
+    offs, cols, vals = O.lap2d(120, 90)
+    b = O.rhs(L.nrows)
+    xo, ito, relo, sto = O.pcg1_jacobi(offs, cols, vals, b, tol=1e-11)
+    s = hip.Solver(L, hip.default_opts(op_mode=hip.OP_RAW, krylov=hip.KRYLOV_PCG1, tol=1e-11,
+                                       use_graph=graph))
+    x, r = s.solve(b)
+    x2, r2 = s.solve(b)
+    s.destroy()
+    assert sto == 1 and r.status == 1 and abs(int(r.iters) - ito) <= 3
+    assert r2.iters == r.iters and np.array_equal(x, x2)
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-9
+    # and MAXIT with the implicit form: the residual fix-up path
+    s = hip.Solver(L, hip.default_opts(op_mode=hip.OP_RAW, krylov=hip.KRYLOV_PCG1, maxit=17,
+                                       use_graph=graph))
+    x, r = s.solve(b)
+    s.destroy()
+    _, it17, rel17, st17 = O.pcg1_jacobi(offs, cols, vals, b, tol=1e-12, maxit=17)
+    assert r.status == hip.STATUS_MAXIT and r.iters == 17 and st17 == 3
+    assert abs(r.relres - rel17) <= 1e-9 * rel17
