@@ -90,7 +90,11 @@ void allreduce_pq(lsb_hip_solver *sv, unsigned cnt, int with2) {
   }
   for (int i = 0; i < sv->nshard; i++) {
     struct shard *s = &sv->sh[i];
-    lsb_k_reduce_final(s->d_parts_pq, s->npq, 1, s->d_scal + 0, 0, s->d_st, g_stream);
+    if (with2) /* the sweep's partial sums ride in the same launch */
+      lsb_k_reduce_final2(s->d_parts_pq, s->npq, 1, s->d_scal + 0, s->ar2_parts, s->ar2_n,
+                          s->ar2_width, s->d_scal + 1, s->d_st, g_stream);
+    else
+      lsb_k_reduce_final(s->d_parts_pq, s->npq, 1, s->d_scal + 0, 0, s->d_st, g_stream);
   }
   allreduce_scal(sv, 0, cnt, 1);
 }

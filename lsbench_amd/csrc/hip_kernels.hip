@@ -325,6 +325,28 @@ __global__ __launch_bounds__(WG) void k_reduce_final(
   }
 }
 
+// two of those in one launch (the RCCL path of the single-reduction iteration
+// needs the SpMV's and the sweep's partial sums reduced before ONE all-reduce)
+__global__ __launch_bounds__(WG) void k_reduce_final2(
+    const double *__restrict__ pa, unsigned na, unsigned wa, double *__restrict__ outa,
+    const double *__restrict__ pb, unsigned nb, unsigned wb, double *__restrict__ outb,
+    const lsb_pcg_state *__restrict__ st) {
+  if (st && st->status)
+    return;
+  __shared__ double sred[4];
+  for (unsigned k = 0; k < wa + wb; k++) {
+    const bool a = k < wa;
+    const double *p = a ? pa : pb;
+    const unsigned n = a ? na : nb, w = a ? wa : wb, c = a ? k : k - wa;
+    double v[1] = {0.0};
+    for (unsigned i = threadIdx.x; i < n; i += WG)
+      v[0] += p[(size_t)i * w + c];
+    wg_sum<1>(v, sred);
+    if (threadIdx.x == 0)
+      (a ? outa : outb)[c] = v[0];
+  }
+}
+
 // first stage of dot / nrm2 (b == a gives sum a_i^2)
 __global__ __launch_bounds__(WG) void k_dot(unsigned n,
                                             const double *__restrict__ a,
@@ -1170,6 +1192,12 @@ void lsb_k_reduce_final(const double *partials, unsigned nparts, unsigned width,
                         const struct lsb_pcg_state *st, void *stream) {
   k_reduce_final<<<1, WG, 0, (hipStream_t)stream>>>(partials, nparts, width, out,
                                                     take_sqrt, st);
+}
+
+void lsb_k_reduce_final2(const double *pa, unsigned na, unsigned wa, double *outa,
+                         const double *pb, unsigned nb, unsigned wb, double *outb,
+                         const struct lsb_pcg_state *st, void *stream) {
+  k_reduce_final2<<<1, WG, 0, (hipStream_t)stream>>>(pa, na, wa, outa, pb, nb, wb, outb, st);
 }
 
 void lsb_k_dot(unsigned n, const double *a, const double *b, double *partials,

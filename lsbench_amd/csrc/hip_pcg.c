@@ -158,9 +158,9 @@ static void cg1_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int sa
                      sv->multi ? s->d_scal + 1 : gr_in,
                      sv->multi ? 1u : s->np2, sv->multi ? s->d_scal : s->d_parts_pq,
                      sv->multi ? 1u : s->npq, gr_out, &np2, g_stream);
+    /* reduced together with the SpMV's partial sums, in the all-reduce's launch
+     * (direct path) or in the one reduction launch in front of it (RCCL) */
     s->ar2_parts = gr_out, s->ar2_n = np2, s->ar2_width = 2;
-    if (sv->multi && !sv->p2p_on) /* the direct all-reduce reduces these itself */
-      lsb_k_reduce_final(gr_out, np2, 2, s->d_scal + 1, 0, s->d_st, g_stream);
   }
   if (sv->multi)
     exchange_and_spmv(sv, sample);

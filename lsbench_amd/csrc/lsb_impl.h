@@ -74,6 +74,9 @@ void lsb_k_spmv_sell(unsigned flags, unsigned grid_cap, const unsigned *sptr, un
 void lsb_k_reduce_final(const double *partials, unsigned nparts, unsigned width,
                         double *out, int take_sqrt,
                         const struct lsb_pcg_state *st, void *stream);
+void lsb_k_reduce_final2(const double *pa, unsigned na, unsigned wa, double *outa,
+                         const double *pb, unsigned nb, unsigned wb, double *outb,
+                         const struct lsb_pcg_state *st, void *stream);
 void lsb_k_dot(unsigned n, const double *a, const double *b, double *partials,
                unsigned *npartials, void *stream);
 void lsb_k_axpy(unsigned n, const double *alpha, const double *x, double *y,
