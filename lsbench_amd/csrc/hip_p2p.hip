@@ -194,32 +194,36 @@ __global__ __launch_bounds__(P2P_WG) void k_p2p_allreduce(
     int phases, long long timeout) {
   if (st && st->status)
     return;
-  __shared__ double sred[P2P_WG / 64];
+  __shared__ double sred[3 * (P2P_WG / 64)];
   __shared__ double sval[3];
   const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const unsigned nvals = width + width2 + nextra, b = (unsigned)(epoch & 1);
   if (phases & 1) {
-    for (unsigned k = 0; k < width + width2; k++) { // my partial sums, fixed order
-      const bool first = k < width;
-      const double *pp = first ? parts : parts2;
-      const unsigned np = first ? nparts : nparts2, w = first ? width : width2,
-                     c = first ? k : k - width;
-      double v = 0.0;
-      for (unsigned i = tid; i < np; i += P2P_WG)
-        v += pp[(size_t)i * w + c];
+    // my partial sums, fixed order; all (up to three) columns in ONE pass and one
+    // workgroup reduction -- this kernel sits on the critical path of every
+    // sharded iteration
+    double v[3] = {0.0, 0.0, 0.0};
+    for (unsigned i = tid; i < nparts; i += P2P_WG)
+      for (unsigned c = 0; c < width; c++)
+        v[c] += parts[(size_t)i * width + c];
+    for (unsigned i = tid; i < nparts2; i += P2P_WG)
+      for (unsigned c = 0; c < width2; c++)
+        v[width + c] += parts2[(size_t)i * width2 + c];
+#pragma unroll
+    for (int k = 0; k < 3; k++)
       for (int off = 32; off > 0; off >>= 1)
-        v += __shfl_xor(v, off, 64);
-      if (lane == 0)
-        sred[wave] = v;
-      __syncthreads();
-      if (tid == 0) {
-        double s = 0.0;
-        for (unsigned q = 0; q < P2P_WG / 64; q++)
-          s += sred[q];
-        sval[k] = s;
-      }
-      __syncthreads();
+        v[k] += __shfl_xor(v[k], off, 64);
+    if (lane == 0)
+      for (int k = 0; k < 3; k++)
+        sred[wave * 3 + k] = v[k];
+    __syncthreads();
+    if (tid < 3) {
+      double t = 0.0;
+      for (unsigned w = 0; w < P2P_WG / 64; w++)
+        t += sred[w * 3 + tid];
+      sval[tid] = t;
     }
+    __syncthreads();
     if (tid < nextra)
       sval[width + width2 + tid] = extra[tid];
     __syncthreads();
