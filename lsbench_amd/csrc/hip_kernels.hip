@@ -275,6 +275,77 @@ __global__ __launch_bounds__(WG) void k_spmv_subwave(
   }
 }
 
+// The launch-bound operators' iteration with the direction update folded into
+// the SpMV: TWO launches per classic PCG iteration instead of three.  The
+// prologue is k_pcg_update_p's (partial sums of the previous sweep -> r.z, r.r,
+// stop test, beta); then q = S p_new with p_new = D^-1 r + beta p_old formed on
+// the fly for every gathered column (three gathers of vectors that sit in L2)
+// and stored, for the rows of this workgroup, into the OTHER direction buffer.
+// At a few thousand rows a launch costs more than all of that.
+__device__ __forceinline__ double pnew_of(double d, double r, double beta, double p) {
+  return __fma_rn(beta, p, d * r);
+}
+template <int L>
+__global__ __launch_bounds__(WG) void k_spmv_subwave_p(
+    unsigned n, unsigned rows_per_wg, const int *__restrict__ offs,
+    const int *__restrict__ cols, const double *__restrict__ vals,
+    const double *__restrict__ r, const double *__restrict__ dinv, double dc,
+    const double *__restrict__ pold, double *__restrict__ pnew, double *__restrict__ y,
+    double *__restrict__ partials, lsb_pcg_state *__restrict__ st, int parity,
+    const double *__restrict__ parts2, unsigned nparts2) {
+  __shared__ double sred[8];
+  const unsigned tid = threadIdx.x, slot = tid / L, l = tid % L;
+  constexpr unsigned SLOTS = WG / L;
+  const unsigned w = xcd_contiguous_wg();
+  const unsigned ra = min(w * rows_per_wg, n), rb = min(ra + rows_per_wg, n);
+  const int stopped = st->status;
+  const double rz_old = st->rz[parity], thresh2 = st->thresh2;
+  double v[2];
+  wg_sum_partials<2>(parts2, nparts2, v, sred);
+  if (stopped)
+    return;
+  const double rz_new = v[0], rr = v[1];
+  const bool conv = rr <= thresh2;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { // exactly k_pcg_update_p's bookkeeping
+    const int it = st->iters + 1;
+    st->iters = it;
+    st->rr = rr;
+    st->rz[parity ^ 1] = rz_new;
+    if (conv)
+      st->status = LSB_STATUS_CONVERGED;
+    else if (it >= st->maxit)
+      st->status = LSB_STATUS_MAXIT;
+  }
+  if (conv)
+    return;
+  const double beta = rz_new / rz_old;
+  double dot = 0.0;
+  for (unsigned base = ra; base < rb; base += SLOTS) {
+    const unsigned row = base + slot;
+    double s = 0.0, pi = 0.0;
+    if (row < rb) {
+      const int j0 = offs[row], j1 = offs[row + 1];
+      pi = pnew_of(dinv ? dinv[row] : dc, r[row], beta, pold[row]);
+      for (int j = j0 + (int)l; j < j1; j += L) {
+        const int c = cols[j];
+        s += vals[j] * pnew_of(dinv ? dinv[c] : dc, r[c], beta, pold[c]);
+      }
+    }
+#pragma unroll
+    for (int off = L >> 1; off > 0; off >>= 1)
+      s += __shfl_xor(s, off, 64);
+    if (row < rb && l == 0) {
+      pnew[row] = pi;
+      y[row] = s;
+      dot += s * pi;
+    }
+  }
+  double d[1] = {dot};
+  wg_sum<1>(d, sred);
+  if (tid == 0)
+    partials[w] = d[0];
+}
+
 // one lane per row: debug / test baseline only
 __global__ __launch_bounds__(WG) void k_spmv_scalar(
     unsigned n, unsigned rows_per_wg, const int *__restrict__ offs,
@@ -657,21 +728,24 @@ __global__ __launch_bounds__(WG) void k_pcg_update_xr(
 template <bool V2, bool NT>
 __global__ __launch_bounds__(WG) void k_pcg_update_p(
     unsigned n, const double *__restrict__ r, const double *__restrict__ dinv, double dc,
-    double *__restrict__ p, lsb_pcg_state *__restrict__ st, int parity,
+    const double *pin, double *p, lsb_pcg_state *__restrict__ st, int parity,
     const double *__restrict__ parts2, unsigned nparts2) {
+  // pin: where the previous direction is read from (== p, or the other buffer
+  // of the launch-bound path that folds this update into the SpMV)
   __shared__ double sred[8];
   const size_t gtid = (size_t)blockIdx.x * WG + threadIdx.x;
   const size_t gsz = (size_t)gridDim.x * WG;
   const size_t n2 = n / 2;
   const d2v *r2 = (const d2v *)r, *d2 = (const d2v *)dinv;
   d2v *p2 = (d2v *)p;
+  const d2v *pi2 = (const d2v *)pin;
   // as in k_pcg_update_xr: one round trip for status, scalars and operands
   const int stopped = st->status;
   const double rz_old = st->rz[parity], thresh2 = st->thresh2;
   d2v rv = {0.0, 0.0}, dv = rv, pv = rv;
   const bool first = V2 && gtid < n2;
   if (first)
-    rv = ld2<NT>(r2 + gtid), dv = ldd<NT>(d2, gtid, dc), pv = ld2<NT>(p2 + gtid);
+    rv = ld2<NT>(r2 + gtid), dv = ldd<NT>(d2, gtid, dc), pv = ld2<NT>(pi2 + gtid);
   double v[2];
   wg_sum_partials<2>(parts2, nparts2, v, sred);
   if (stopped)
@@ -702,14 +776,14 @@ __global__ __launch_bounds__(WG) void k_pcg_update_p(
         i += gsz;
         if (i >= n2)
           break;
-        rv = ld2<NT>(r2 + i), dv = ldd<NT>(d2, i, dc), pv = ld2<NT>(p2 + i);
+        rv = ld2<NT>(r2 + i), dv = ldd<NT>(d2, i, dc), pv = ld2<NT>(pi2 + i);
       }
     }
     if ((n & 1) && gtid == gsz - 1)
-      p[n - 1] = (dinv ? dinv[n - 1] : dc) * r[n - 1] + beta * p[n - 1];
+      p[n - 1] = (dinv ? dinv[n - 1] : dc) * r[n - 1] + beta * pin[n - 1];
   } else {
     for (size_t i = gtid; i < n; i += gsz)
-      p[i] = (dinv ? dinv[i] : dc) * r[i] + beta * p[i];
+      p[i] = (dinv ? dinv[i] : dc) * r[i] + beta * pin[i];
   }
 }
 
@@ -1159,6 +1233,36 @@ void lsb_k_spmv(int variant, unsigned n, const int *offs, const int *cols,
   }
 }
 
+/* sub-wavefront SpMV with the direction update of the previous iteration folded
+ * in (k_spmv_subwave_p); same grid as the plain sub-wavefront launch */
+void lsb_k_spmv_subwave_p(unsigned n, const int *offs, const int *cols, const double *vals,
+                          unsigned lanes_per_row, const double *r, const double *dinv, double dc,
+                          const double *pold, double *pnew, double *y, double *partials,
+                          unsigned *npartials, struct lsb_pcg_state *st, int parity,
+                          const double *parts2, unsigned nparts2, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned L = lanes_per_row;
+  const unsigned g = lsb_k_spmv_grid(LSB_SPMV_SUBWAVE, n, 0, L, 0);
+  *npartials = g;
+  const unsigned rpw = round_up(div_up(n, g), WG / L);
+#define LSB_SWP(LL)                                                                         \
+  case LL:                                                                                  \
+    k_spmv_subwave_p<LL><<<g, WG, 0, s>>>(n, rpw, offs, cols, vals, r, dinv, dc, pold, pnew, y, \
+                                          partials, st, parity, parts2, nparts2);           \
+    break;
+  switch (L) {
+    LSB_SWP(2)
+    LSB_SWP(4)
+    LSB_SWP(8)
+    LSB_SWP(16)
+    LSB_SWP(32)
+  default:
+    k_spmv_subwave_p<64><<<g, WG, 0, s>>>(n, round_up(div_up(n, g), 4), offs, cols, vals, r, dinv,
+                                          dc, pold, pnew, y, partials, st, parity, parts2, nparts2);
+  }
+#undef LSB_SWP
+}
+
 /* Sliced-ELL launch over the slices [s0, s0+ns).  flags & LSB_SP_C16: `cols` is
  * the 16-bit code array and `sbase` the slot bases (row_begin = global index
  * of local row 0); else `cols` holds 32-bit column ids and sbase is unused. */
@@ -1335,18 +1439,18 @@ void lsb_k_cg1_update(unsigned n, double *u, const double *w, const double *dinv
 }
 
 void lsb_k_pcg_update_p(unsigned n, const double *r, const double *dinv, double dc,
-                        double *p, struct lsb_pcg_state *st, int parity,
+                        const double *pin, double *p, struct lsb_pcg_state *st, int parity,
                         const double *parts2, unsigned nparts2, void *stream) {
   const unsigned g = lsb_k_blas1_grid(n);
-  if (aligned16(r) && aligned16(dinv) && aligned16(p)) {
+  if (aligned16(r) && aligned16(dinv) && aligned16(p) && aligned16(pin)) {
     if (g_blas1_nt)
-      k_pcg_update_p<true, true><<<g, WG, 0, (hipStream_t)stream>>>(n, r, dinv, dc, p, st, parity,
+      k_pcg_update_p<true, true><<<g, WG, 0, (hipStream_t)stream>>>(n, r, dinv, dc, pin, p, st, parity,
                                                                     parts2, nparts2);
     else
-      k_pcg_update_p<true, false><<<g, WG, 0, (hipStream_t)stream>>>(n, r, dinv, dc, p, st, parity,
+      k_pcg_update_p<true, false><<<g, WG, 0, (hipStream_t)stream>>>(n, r, dinv, dc, pin, p, st, parity,
                                                                      parts2, nparts2);
   } else {
-    k_pcg_update_p<false, false><<<g, WG, 0, (hipStream_t)stream>>>(n, r, dinv, dc, p, st, parity,
+    k_pcg_update_p<false, false><<<g, WG, 0, (hipStream_t)stream>>>(n, r, dinv, dc, pin, p, st, parity,
                                                                     parts2, nparts2);
   }
 }

@@ -14,6 +14,7 @@
 /* PCG                                                                       */
 /* ------------------------------------------------------------------------ */
 static int use_cg1(const lsb_hip_solver *sv);
+static int fuse_p(const lsb_hip_solver *sv);
 static void cg1_enqueue_init(lsb_hip_solver *sv, const double *d_b, double *d_x);
 static void cg1_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int sample);
 
@@ -28,6 +29,8 @@ static void pcg_enqueue_init(lsb_hip_solver *sv, const double *d_b, double *d_x)
     const size_t o = s->row_begin - sv->row_first;
     lsb_k_pcg_init(s->n, d_b + o, DINV(s), d_x + o, s->d_r, s->d_pfull + s->row_begin,
                    s->d_parts2, &np2, g_stream);
+    if (!s->d_p1 && fuse_p(sv)) /* second direction buffer of the two-launch iteration */
+      s->d_p1 = (double *)lsb_hip_malloc((size_t)s->n * sizeof(double));
     if (sv->multi)
       lsb_k_reduce_final(s->d_parts2, np2, 2, s->d_scal + 1, 0, NULL, g_stream);
   }
@@ -43,11 +46,46 @@ static void pcg_enqueue_init(lsb_hip_solver *sv, const double *d_b, double *d_x)
   }
 }
 
+/* Launch-bound operators (one shard, sub-wavefront SpMV, classic form): the
+ * direction update rides in the NEXT iteration's SpMV (k_spmv_subwave_p), two
+ * launches per iteration; the two direction buffers alternate.  Only the last
+ * iteration of an enqueued run closes with the stand-alone update, which also
+ * brings the direction back into the gather vector. */
+static int fuse_p(const lsb_hip_solver *sv) {
+  return !sv->multi && !use_cg1(sv) && sv->sh[0].variant == LSB_SPMV_SUBWAVE &&
+         !getenv("LSBENCH_HIP_NO_FUSE_P");
+}
+
+static void fused_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int pos) {
+  struct shard *s = &sv->sh[0];
+  double *buf[2] = {s->d_pfull, s->d_p1};
+  unsigned np2 = s->np2;
+  if (pos & 1) { /* first of the run: the direction is in the gather vector */
+    sv->pcur = 0;
+    spmv_shard(s, buf[0], s->d_q, buf[0], s->d_parts_pq, &s->npq, s->d_st);
+  } else { /* beta, stop test and p = D^-1 r + beta p of the previous iteration, then S p */
+    lsb_k_spmv_subwave_p(s->n, s->d_offs, s->d_cols, s->d_vals, s->lanes, s->d_r, DINV(s),
+                         buf[sv->pcur], buf[sv->pcur ^ 1], s->d_q, s->d_parts_pq, &s->npq, s->d_st,
+                         parity ^ 1, s->d_parts2, np2, g_stream);
+    sv->pcur ^= 1;
+  }
+  lsb_k_pcg_update_xr(s->n, buf[sv->pcur], s->d_q, DINV(s), d_x, s->d_r, s->d_st, parity,
+                      s->d_parts_pq, s->npq, s->d_parts2, &s->np2, g_stream);
+  if (pos & 2) /* last of the run */
+    lsb_k_pcg_update_p(s->n, s->d_r, DINV(s), buf[sv->pcur], buf[0], s->d_st, parity, s->d_parts2,
+                       s->np2, g_stream);
+}
+
 /* One PCG iteration, enqueued.  sample >= 0: bracket the SpMV of shard 0 with
- * events 4*sample .. 4*sample+3. */
-static void pcg_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int sample) {
+ * events 4*sample .. 4*sample+3.  pos: bit 0 = first, bit 1 = last iteration of
+ * the run being enqueued. */
+static void pcg_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int sample, int pos) {
   if (use_cg1(sv)) {
     cg1_enqueue_iter(sv, d_x, parity, sample);
+    return;
+  }
+  if (fuse_p(sv)) {
+    fused_enqueue_iter(sv, d_x, parity, pos);
     return;
   }
   unsigned npq = 0, np2 = 0;
@@ -84,7 +122,8 @@ static void pcg_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int sa
     allreduce_scal(sv, 1, 2, 1);
   for (int i = 0; i < sv->nshard; i++) {
     struct shard *s = &sv->sh[i];
-    lsb_k_pcg_update_p(s->n, s->d_r, DINV(s), s->d_pfull + s->row_begin, s->d_st, parity,
+    lsb_k_pcg_update_p(s->n, s->d_r, DINV(s), s->d_pfull + s->row_begin,
+                       s->d_pfull + s->row_begin, s->d_st, parity,
                        sv->multi ? s->d_scal + 1 : s->d_parts2, sv->multi ? 1u : np2,
                        g_stream);
   }
@@ -214,7 +253,7 @@ static hipGraphExec_t get_graph(lsb_hip_solver *sv, int iters, double *d_x) {
   hipGraph_t g;
   LSB_CHK_HIP(hipStreamBeginCapture(g_stream, hipStreamCaptureModeThreadLocal));
   for (int i = 0; i < iters; i++)
-    pcg_enqueue_iter(sv, d_x, i & 1, -1);
+    pcg_enqueue_iter(sv, d_x, i & 1, -1, (i == 0) | ((i == iters - 1) << 1));
   LSB_CHK_HIP(hipStreamEndCapture(g_stream, &g));
   LSB_CHK_HIP(hipGraphInstantiate(&sv->gcache[slot].exec, g, NULL, NULL, 0));
   LSB_CHK_HIP(hipGraphDestroy(g));
@@ -316,7 +355,7 @@ int solve_core(lsb_hip_solver *sv, const double *d_b, double *d_x,
         if (sampling && nsamp < MAX_SAMPLES &&                                 \
             ((done_iters + (unsigned)i_) % (unsigned)sv->o.sample_spmv) == 0)  \
           smp_ = nsamp++;                                                      \
-        pcg_enqueue_iter(sv, d_x, i_ & 1, smp_);                               \
+        pcg_enqueue_iter(sv, d_x, i_ & 1, smp_, (i_ == 0) | ((i_ == cnt_ - 1) << 1)); \
       }                                                                        \
     }                                                                          \
     done_iters += (unsigned)cnt_;                                              \

@@ -121,6 +121,7 @@ struct lsb_hip_solver {
   /* single-reduction PCG without the vector u = D^-1 r: every shard of every
    * rank has the same constant Jacobi diagonal (k_cg1_update<UI>) */
   int cg1_implicit;
+  int pcur; /* launch-bound fused path: which direction buffer is current */
   struct lsb_p2p **p2p;
   int p2p_on, p2p_halo;
   double p2p_us, rccl_us; /* self-test: one exchange + all-reduce, each way */

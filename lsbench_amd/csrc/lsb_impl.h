@@ -106,8 +106,13 @@ void lsb_k_pcg_update_xr(unsigned n, const double *p, const double *q,
                          struct lsb_pcg_state *st, int parity,
                          const double *pq_parts, unsigned npq,
                          double *partials2, unsigned *npartials, void *stream);
+void lsb_k_spmv_subwave_p(unsigned n, const int *offs, const int *cols, const double *vals,
+                          unsigned lanes_per_row, const double *r, const double *dinv, double dc,
+                          const double *pold, double *pnew, double *y, double *partials,
+                          unsigned *npartials, struct lsb_pcg_state *st, int parity,
+                          const double *parts2, unsigned nparts2, void *stream);
 void lsb_k_pcg_update_p(unsigned n, const double *r, const double *dinv, double dc,
-                        double *p, struct lsb_pcg_state *st, int parity,
+                        const double *pin, double *p, struct lsb_pcg_state *st, int parity,
                         const double *parts2, unsigned nparts2, void *stream);
 void lsb_k_cg1_update(unsigned n, double *u, const double *w, const double *dinv, double dc,
                       double *p,

@@ -530,3 +530,31 @@ def test_constant_diagonal_is_passed_by_value(hip, krylov, monkeypatch):
     offs, cols, vals = O.lap3d(50, 40, 30)
     xo, ito, _, _ = O.pcg_jacobi(offs, cols, vals, b, 1e-10)
     assert abs(int(r1.iters) - ito) <= 3 and np.linalg.norm(x1 - xo) / np.linalg.norm(xo) <= 1e-8
+
+
+@pytest.mark.parametrize("graph", [0, 1])
+def test_two_launch_iteration_of_small_operators(hip, graph, matrix_path, golden_x, monkeypatch):
+    """Launch-bound operators run classic PCG in TWO launches per iteration (the
+    direction update rides in the next SpMV, k_spmv_subwave_p): same iteration
+    counts and solution as the three-launch form, hint path, MAXIT, odd chunk."""
+    A = hip.lsbench_matrix_read(matrix_path("tj7a_A_12"))
+    b = O.rhs(A.nrows)
+    xg = golden_x("tj7a_A_12")
+    out = {}
+    for off in (0, 1):
+        if off:
+            monkeypatch.setenv("LSBENCH_HIP_NO_FUSE_P", "1")
+        s = hip.Solver(A, hip.default_opts(use_graph=graph, check_every=7))
+        x, r = s.solve(b)
+        x2, r2 = s.solve(b)                       # iteration-count hint: one run, one closing update
+        s5 = hip.Solver(A, hip.default_opts(use_graph=graph, maxit=5))
+        x5, r5 = s5.solve(b)
+        s.destroy(), s5.destroy()
+        assert r.status == 1 and r2.iters == r.iters and np.array_equal(x, x2)
+        assert np.linalg.norm(x - xg) / np.linalg.norm(xg) <= 1e-10
+        assert r5.status == hip.STATUS_MAXIT and r5.iters == 5
+        out[off] = (x, int(r.iters), x5, r5.relres)
+    assert abs(out[0][1] - out[1][1]) <= 1
+    assert np.linalg.norm(out[0][0] - out[1][0]) / np.linalg.norm(xg) <= 1e-11
+    assert np.linalg.norm(out[0][2] - out[1][2]) <= 1e-12 * np.linalg.norm(out[1][2])
+    assert abs(out[0][3] - out[1][3]) <= 1e-10 * out[1][3]
