@@ -12,7 +12,11 @@ C library, launched as
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Default workload = BASELINE.json configs[2], the roofline run: 5-point 2-D
-Laplacian, 3162^2 = 9,998,244 rows, 49,978,572 nnz.  Others:
+Laplacian, 3162^2 = 9,998,244 rows, 49,978,572 nnz.  Every line also carries a
+`cfg4` sub-record: configs[3] (7-point 400^3, 64 M rows, the configuration the
+">= 6x at 8 GPUs" target is stated on) solved on the same N GPUs right after the
+headline -- take the 1 -> 8 ratio of cfg4.value from the N = 1 and N = 8 lines.
+Others:
     --workload lap3d     configs[3]: 7-point 400^3, 64 M rows (the 8-GPU config)
     --workload powerlaw  configs[4]: SpMV-only (unsymmetric), reports GB/s
     --workload file:tests/golden/matrices/xn3b_A_18.txt.gz   configs[1]
@@ -77,15 +81,29 @@ def parse():
                         "(tol = 0); the line is marked and is NOT a solves/s figure")
     p.add_argument("--cpu-seconds", type=float, default=12.0,
                    help="budget of the CPU baseline leg (0 = skip)")
+    p.add_argument("--cfg4", type=int, default=1,
+                   help="1 = every line also carries a `cfg4` sub-record: BASELINE.json configs[3] "
+                        "(7-point 400^3, 64 M rows) solved --cfg4-steps times on the same N GPUs -- the "
+                        "workload the 8-vs-1 GPU target is stated on; 0 = skip it")
+    p.add_argument("--cfg4-steps", type=int, default=2)
+    p.add_argument("--verify", type=int, default=1,
+                   help="1 = a solve counts only once ||b - S x|| <= tol ||b|| holds for the residual "
+                        "recomputed from x (correction solves inside the timed region if needed)")
     return p.parse_args()
 
 
 def read_file_matrix(path):
     if path.endswith(".gz"):
-        tmp = os.path.join(tempfile.gettempdir(), os.path.basename(path)[:-3])
-        with gzip.open(path, "rb") as fi, open(tmp, "wb") as fo:
-            fo.write(fi.read())
-        path = tmp
+        # one private copy per process: the ranks of a torch.distributed.run job
+        # would otherwise write and parse the same /tmp path at the same time
+        fd, tmp = tempfile.mkstemp(prefix="lsb_r%s_" % os.environ.get("RANK", "0"),
+                                   suffix="_" + os.path.basename(path)[:-3])
+        try:
+            with gzip.open(path, "rb") as fi, os.fdopen(fd, "wb") as fo:
+                fo.write(fi.read())
+            return la.lsbench_matrix_read(tmp)
+        finally:
+            os.unlink(tmp)
     return la.lsbench_matrix_read(path)
 
 
@@ -161,79 +179,107 @@ def cpu_direct_baseline(A, trials=100):
                           float(np.linalg.norm(b - S @ x) / np.linalg.norm(b)))}
 
 
-def main():
-    a = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+class Ctx:
+    pass
+
+
+def setup_ranks(a):
+    c = Ctx()
+    c.rank = int(os.environ.get("RANK", "0"))
+    c.world = int(os.environ.get("WORLD_SIZE", "1"))
+    c.local = int(os.environ.get("LOCAL_RANK", "0"))
     # LSB_BENCH_FORCE_DIST=1 drives the multi-rank code path (process group, RCCL
     # communicator, distributed solver constructor) with a single rank -- the
     # only way to rehearse it on a one-GPU box
-    dist_on = world > 1 or os.environ.get("LSB_BENCH_FORCE_DIST") == "1"
-    if dist_on:
+    c.dist_on = c.world > 1 or os.environ.get("LSB_BENCH_FORCE_DIST") == "1"
+    if c.dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
+    if c.world != a.gpus:
+        if c.world == 1 and a.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
                      "--nproc-per-node %d" % (a.gpus, a.gpus))
-        a.gpus = world
+        a.gpus = c.world
     # rehearsal switches (tests/test_dist_gpu.py): several ranks on ONE device, gloo
     # for torch.distributed; the library's own collectives then run on a test
     # double of RCCL that is LD_PRELOADed by the test
-    torch.cuda.set_device(0 if os.environ.get("LSB_BENCH_ONE_GPU") == "1" else local)
-    backend = os.environ.get("LSB_BENCH_BACKEND", "nccl")
-    lib = la._lib.load()
+    torch.cuda.set_device(0 if os.environ.get("LSB_BENCH_ONE_GPU") == "1" else c.local)
+    c.backend = os.environ.get("LSB_BENCH_BACKEND", "nccl")
+    c.lib = la._lib.load()
     if la.hip_cdna4_init() != 0:
         sys.exit("hip_cdna4_init failed: no MI355X visible (there is no CPU path)")
-    if dist_on:
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local))
+    if c.dist_on:
+        if c.backend == "nccl":
+            dist.init_process_group("nccl", rank=c.rank, world_size=c.world,
+                                    device_id=torch.device("cuda", c.local))
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(c.backend, rank=c.rank, world_size=c.world)
         idb = ctypes.create_string_buffer(la._lib.UNIQUE_ID_BYTES)
-        if rank == 0:
-            lib.lsb_hip_comm_get_unique_id(idb)
+        if c.rank == 0:
+            c.lib.lsb_hip_comm_get_unique_id(idb)
         t = torch.frombuffer(bytearray(idb.raw), dtype=torch.uint8).clone()
-        t = t.cuda() if backend == "nccl" else t
+        t = t.cuda() if c.backend == "nccl" else t
         dist.broadcast(t, 0)
         idb = ctypes.create_string_buffer(bytes(t.cpu().tolist()), la._lib.UNIQUE_ID_BYTES)
-        la._lib.check(lib.lsb_hip_comm_init_rank(idb, world, rank), "comm_init_rank")
+        la._lib.check(c.lib.lsb_hip_comm_init_rank(idb, c.world, c.rank), "comm_init_rank")
+    c.cdev = "cuda" if c.backend == "nccl" else "cpu"
+    return c
 
-    # ---- operator: this rank's rows only --------------------------------
+
+def pmc_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` on `workload` from the committed PMC profile
+    (profiles/pmc_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3
+    passes of this same command, tools/gpu_profiles.sh).  The bench process
+    cannot read hardware counters itself; `traffic_source` says where it is from."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            t = json.load(f).get(workload)
+        if isinstance(t, dict) and t.get("kernel") == kernel:
+            return t["bytes"], t.get("source", "profiles/pmc_traffic.json")
+    except OSError:
+        pass
+    return None, None
+
+
+def run_workload(a, c, workload, steps, warmup, cpu_leg):
+    """Build the operator (this rank's rows), warm up, time EXACTLY `steps` solves
+    between barriers; returns the record (rank 0's view, times = max over ranks)."""
+    rank, world = c.rank, c.world
     t_setup = time.perf_counter()
     spmv_only = False
-    if a.workload.startswith("file:"):
-        Afile = read_file_matrix(a.workload[5:])
+    key = workload
+    if workload.startswith("file:"):
+        Afile = read_file_matrix(workload[5:])
         A = la.lsb_csr_symmetrize_upper(Afile)  # the operator CHOLMOD factorises
         n = A.nrows
-        name = os.path.basename(a.workload[5:])
-        if dist_on:
+        name = os.path.basename(workload[5:])
+        if c.dist_on:
             b = la.lsb_csr_partition_rows(A, world)
             r0, r1 = int(b[rank]), int(b[rank + 1])
             Aloc = la.lsb_csr_row_slice(A, r0, r1)
         else:
             r0, r1, Aloc = 0, n, A
     else:
-        spec = WORKLOADS.get(a.workload, a.workload)
-        spmv_only = spec.startswith("powerlaw")
+        spec = WORKLOADS.get(workload, workload)
+        spmv_only = spec.startswith("powerlaw") and "spd=1" not in spec
         probe = la.lsbench_matrix_synth(spec, 0, 1)
         n = probe.n_global
         r0, r1 = (n * rank // world) & ~1, ((n * (rank + 1) // world) & ~1 if rank + 1 < world else n)
         Aloc = la.lsbench_matrix_synth(spec, r0, r1)
         name = spec
     small = Aloc.nnz < 2000000
+    tol, maxit = a.tol, a.maxit
     if a.fixed_iters > 0:
-        a.tol, a.maxit = 0.0, a.fixed_iters
-    opts = la.default_opts(op_mode=la.OP_RAW, tol=a.tol, maxit=a.maxit, spmv_variant=a.spmv,
+        tol, maxit = 0.0, a.fixed_iters
+    opts = la.default_opts(op_mode=la.OP_RAW, tol=tol, maxit=maxit, spmv_variant=a.spmv,
                            use_graph=1 if small else 0, sample_spmv=0 if small else 16,
                            spmv_tune=a.spmv_tune, overlap=a.overlap,
                            comm={"auto": la.COMM_AUTO, "rccl": la.COMM_RCCL, "p2p": la.COMM_P2P}[a.comm],
                            krylov={"cg": la.KRYLOV_PCG, "cg1": la.KRYLOV_PCG1,
                                    "auto": la.KRYLOV_AUTO}[a.krylov],
-                           precond=la.PRECOND_NONE if spmv_only else la.PRECOND_JACOBI)
-    if dist_on:
+                           precond=la.PRECOND_NONE if spmv_only else la.PRECOND_JACOBI,
+                           verify=1 if (a.verify and a.fixed_iters == 0) else 0)
+    if c.dist_on:
         solver = la.Solver(Aloc, opts, row_begin=r0, n_global=n)
     else:
         solver = la.Solver(Aloc, opts)
@@ -244,61 +290,74 @@ def main():
     t_setup = time.perf_counter() - t_setup
 
     def barrier():
-        if dist_on:
+        if c.dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
     nnz_loc = Aloc.nnz
     bytes_spmv = 12 * nnz_loc + 20 * nl + 4
+    kernel = {la.SPMV_ADAPTIVE: "k_spmv_adaptive", la.SPMV_SUBWAVE: "k_spmv_subwave",
+              la.SPMV_SCALAR: "k_spmv_scalar", la.SPMV_PANEL: "k_spmv_adaptive",
+              la.SPMV_BINNED: "k_spmv_binned",
+              la.SPMV_SELL: "k_spmv_sell16" if solver.spmv_flags & la.SPMV_FLAG_C16 else "k_spmv_sell"
+              }.get(solver.spmv_variant, "?")
+    traffic, traffic_src = pmc_traffic(key if world == 1 else None, kernel)
 
     if spmv_only:
         # config 5: SpMV throughput only (the operator is unsymmetric)
-        ms = solver.time_spmv(a.warmup * 10, a.steps * 20)
+        ms = solver.time_spmv(warmup * 10, steps * 20)
         barrier()
         gbps = bytes_spmv / ms / 1e6
-        line = {"metric": "fp64_csr_spmv_GBps", "value": gbps * world, "unit": "GB/s",
-                "n_gpus": world, "steps": a.steps * 20, "warmup": a.warmup * 10,
-                "ms_per_step": ms, "higher_is_better": True, "scaling": "strong",
-                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                "config": {"workload": name, "rows": n, "nnz_per_gpu": nnz_loc},
-                "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS,
-                             "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS, "traffic": None,
-                             "kernel": "k_spmv_adaptive", "algorithmic_bytes": bytes_spmv}}
-        if rank == 0:
-            print(json.dumps(line), flush=True)
-        return
+        rec = {"metric": "fp64_csr_spmv_GBps", "value": gbps * world, "unit": "GB/s",
+               "n_gpus": world, "steps": steps * 20, "warmup": warmup * 10,
+               "ms_per_step": ms, "higher_is_better": True, "scaling": "strong",
+               "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": name, "rows": n, "nnz_per_gpu": nnz_loc},
+               "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS,
+                            "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS, "traffic": traffic,
+                            "frac_hbm": (traffic / ms / 1e6 / HBM_PEAK_GBPS) if traffic else None,
+                            "traffic_source": traffic_src,
+                            "kernel": kernel + (" (panels)" if solver.spmv_variant == la.SPMV_PANEL else ""),
+                            "launch_ms": ms, "algorithmic_bytes": bytes_spmv,
+                            "measured": "hipEvents around %d back-to-back SpMVs" % (steps * 20)}}
+        solver.destroy()
+        return rec
 
-    # ---- warm-up, then EXACTLY --steps timed solves ------------------------
-    for _ in range(a.warmup):
+    # ---- warm-up, then EXACTLY `steps` timed solves --------------------------
+    for _ in range(warmup):
         res = solver.solve_dev(d_b, d_x)
     barrier()
     t0 = time.perf_counter()
-    iters, spmv_ms, spmv_n = 0, 0.0, 0
-    for _ in range(a.steps):
+    iters, spmv_ms, spmv_n, corr = 0, 0.0, 0, 0
+    for _ in range(steps):
         res = solver.solve_dev(d_b, d_x)
         iters += res.iters
+        corr += res.corrections
         spmv_ms += res.spmv_ms * res.spmv_samples
         spmv_n += res.spmv_samples
     barrier()
     dt = time.perf_counter() - t0
-    if dist_on:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+    if c.dist_on:
+        tt = torch.tensor([dt], dtype=torch.float64, device=c.cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
     if res.status != la.STATUS_CONVERGED and not (a.fixed_iters > 0 and res.status == la.STATUS_MAXIT):
         sys.exit("solve did not converge (status %d after %d iterations): no valid number"
                  % (res.status, res.iters))
-    its = iters // max(a.steps, 1)
+    its = iters // max(steps, 1)
 
-    # ---- outside the timed region: ||b - S x|| / ||b|| recomputed from x ----
+    # ---- outside the timed region: ||b - S x|| / ||b|| recomputed from x, by torch ----
     d_y = torch.empty_like(d_x)
     solver.spmv_dev(d_x, d_y)
     sq = torch.stack([((d_b - d_y) ** 2).sum(), (d_b ** 2).sum()])
-    if dist_on:
-        sq = sq.to("cuda" if backend == "nccl" else "cpu")
+    if c.dist_on:
+        sq = sq.to(c.cdev)
         dist.all_reduce(sq)
     true_relres = float((sq[0] / sq[1]).sqrt())
     del d_y
+    if a.verify and a.fixed_iters == 0 and not true_relres <= tol * (1 + 1e-6):
+        sys.exit("true residual %.3e above tol %.1e after a verified solve: no valid number"
+                 % (true_relres, tol))
 
     # ---- dominant kernel: SpMV, HIP events on the library's stream ---------
     if spmv_n:
@@ -311,66 +370,76 @@ def main():
     # SURVEY.md section 8(d)'s protocol as well: >= 100 back-to-back launches after >= 10
     # warm-ups (warmer caches than inside the solve; reported, not used for `frac`)
     b2b_ms = solver.time_spmv(10, 100) if spmv_n else spmv_avg_ms
-    kernel = {la.SPMV_ADAPTIVE: "k_spmv_adaptive", la.SPMV_SUBWAVE: "k_spmv_subwave",
-              la.SPMV_SCALAR: "k_spmv_scalar", la.SPMV_PANEL: "k_spmv_adaptive",
-              la.SPMV_SELL: "k_spmv_sell16" if solver.spmv_flags & la.SPMV_FLAG_C16 else "k_spmv_sell"
-              }.get(solver.spmv_variant, "?")
-    traffic = None  # PMC bytes of THIS kernel on this workload, from the committed profile
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            t = json.load(f).get(a.workload if world == 1 else None)
-        if isinstance(t, dict) and t.get("kernel") == kernel:
-            traffic = t["bytes"]
-    except OSError:
-        pass
     n_tot_nnz = nnz_loc
-    if dist_on:
-        tt = torch.tensor([float(nnz_loc)], dtype=torch.float64,
-                          device="cuda" if backend == "nccl" else "cpu")
+    if c.dist_on:
+        tt = torch.tensor([float(nnz_loc)], dtype=torch.float64, device=c.cdev)
         dist.all_reduce(tt)
         n_tot_nnz = int(tt.item())
-    bytes_iter = 12 * n_tot_nnz + 20 * n + 136 * n  # unfused-PCG accounting, SURVEY 8(d)
-    line = {
-        "metric": "cg_solves_per_sec", "value": a.steps / dt, "unit": "solves/s",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not a.workload.startswith("file:") else "reference tests/ matrix",
+    rec = {
+        "metric": "cg_solves_per_sec", "value": steps / dt, "unit": "solves/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic" if not workload.startswith("file:") else "reference tests/ matrix",
         "config": {"workload": name, "rows": n, "nnz": n_tot_nnz,
                    "solver": "PCG+Jacobi" + (" (single-reduction form)" if (
                        a.krylov == "cg1" or (a.krylov == "auto" and world > 1)) else ""),
-                   "tol": a.tol, "rhs": "b_i=i", "partition": "row-range x%d" % world,
+                   "tol": tol, "rhs": "b_i=i", "partition": "row-range x%d" % world,
                    "iterations_per_solve": its, "relres": res.relres,
-                   "true_relres": true_relres},
+                   "true_relres": true_relres,
+                   "stop": ("||b - S x|| <= tol ||b|| verified on the residual recomputed from x, "
+                            "inside the timed region (%d correction solve(s) per solve; their "
+                            "iterations are counted)" % (corr // max(steps, 1)))
+                   if (a.verify and a.fixed_iters == 0) else "recurrence residual"},
         "iterations_per_sec": iters / dt,
-        "pcg_iteration_GBps": bytes_iter * iters / dt / 1e9,
         "setup_seconds": t_setup,
         "comm": dict(zip(("mode", "selftest_direct_us", "selftest_rccl_us"), solver.comm),
                      modes="0 one shard, 1 RCCL, 2 direct xGMI all-reduce, 3 direct xGMI halos too"),
         "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": gbps / HBM_PEAK_GBPS, "traffic": traffic,
-                     # what the HBM actually moved per second (PMC bytes of the committed
-                     # profile / this run's launch time): the layout stores fewer bytes than
-                     # the CSR accounting `achieved` is quoted on
-                     "traffic_GBps": (traffic / spmv_avg_ms / 1e6) if traffic else None,
+                     # what the HBM actually moved: PMC bytes of the committed profile of this
+                     # command / this run's launch time, as a fraction of peak
+                     "frac_hbm": (traffic / spmv_avg_ms / 1e6 / HBM_PEAK_GBPS) if traffic else None,
+                     "traffic_source": traffic_src,
                      "note": "achieved/frac are quoted on SURVEY 8(d)'s CSR byte count (12 B per "
                              "non-zero + 20 B per row); the sliced-ELL layout the kernel reads stores "
-                             "8-10 B per entry, so frac can pass 1 while the HBM moves traffic_GBps",
+                             "8-10 B per entry, so frac exceeds frac_hbm (PMC bytes / time / peak)",
                      "kernel": kernel + (" (panels)" if solver.spmv_variant == la.SPMV_PANEL else "") + " (fused p.q)",
                      "launch_ms": spmv_avg_ms, "back_to_back_launch_ms": b2b_ms,
                      "spmv_flags": solver.spmv_flags,
                      "algorithmic_bytes": bytes_spmv, "measured": how},
     }
     if a.fixed_iters > 0:
-        line["metric"] = "EXPERIMENT_fixed_%d_iterations_per_step" % a.fixed_iters
-    if rank == 0 and world == 1 and a.cpu_seconds > 0 and a.fixed_iters == 0:
-        line["cpu_baseline"] = cpu_baseline(Aloc, its, a.cpu_seconds, True)
-        if a.workload.startswith("file:"):
-            line["cpu_direct_baseline"] = cpu_direct_baseline(Aloc)
-    if rank == 0:
-        print(json.dumps(line), flush=True)
+        rec["metric"] = "EXPERIMENT_fixed_%d_iterations_per_step" % a.fixed_iters
+    if cpu_leg and rank == 0 and world == 1 and a.cpu_seconds > 0 and a.fixed_iters == 0:
+        rec["cpu_baseline"] = cpu_baseline(Aloc, its, a.cpu_seconds, True)
+        if workload.startswith("file:"):
+            rec["cpu_direct_baseline"] = cpu_direct_baseline(Aloc)
     solver.destroy()
-    if dist_on:
-        lib.lsb_hip_comm_destroy()
+    del d_b, d_x
+    torch.cuda.empty_cache()
+    return rec
+
+
+def main():
+    a = parse()
+    c = setup_ranks(a)
+    line = run_workload(a, c, a.workload, a.steps, a.warmup, cpu_leg=True)
+    spec = WORKLOADS.get(a.workload, a.workload)
+    if a.cfg4 and line["metric"] == "cg_solves_per_sec" and not spec.startswith("lap3d"):
+        r4 = run_workload(a, c, "lap3d", a.cfg4_steps, 1, cpu_leg=False)
+        line["cfg4"] = {k: r4[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup",
+                                           "ms_per_step", "scaling", "iterations_per_sec",
+                                           "setup_seconds", "comm")}
+        line["cfg4"]["config"] = r4["config"]
+        line["cfg4"]["spmv"] = {k: r4["roofline"][k] for k in ("kernel", "launch_ms", "achieved", "frac",
+                                                               "algorithmic_bytes")}
+        line["cfg4"]["note"] = ("BASELINE.json configs[3] on the same %d GPU(s): strong scaling of ONE 64 M-row "
+                                "operator; the >= 6x target is cfg4.value(N=8) / cfg4.value(N=1)" % c.world)
+    if c.rank == 0:
+        print(json.dumps(line), flush=True)
+    if c.dist_on:
+        c.lib.lsb_hip_comm_destroy()
         dist.destroy_process_group()
 
 

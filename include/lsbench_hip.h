@@ -83,9 +83,19 @@ int hip_cdna4_bench(double *x, struct csr *A, const double *r,
 enum { LSB_OP_CHOLMOD_UPPER = 0, /* S = triu(A)+triu(A,1)^T (default)      */
        LSB_OP_RAW = 1 };         /* the CSR exactly as handed in            */
 enum { LSB_PRECOND_JACOBI = 0, LSB_PRECOND_NONE = 1,
-       LSB_PRECOND_L1JACOBI = 2 }; /* M = diag(sum_j |S_ij|): SPD for every
-                                      symmetric S with non-empty rows, no
-                                      stored diagonal needed */
+       LSB_PRECOND_L1JACOBI = 2, /* M = diag(sum_j |S_ij|): SPD for every
+                                    symmetric S with non-empty rows, no
+                                    stored diagonal needed */
+       LSB_PRECOND_CHEBYSHEV = 3,   /* z = p_k(D^-1 S) D^-1 r: Chebyshev polynomial
+                                       of degree opts.cheb_degree on the interval
+                                       [lmax/30, 1.1 lmax] of D^-1 S, lmax from a
+                                       power iteration at setup (the smoother the
+                                       reference's AMG backends configure,
+                                       src/hypre.c:126-158, src/amgx.c:78-85) */
+       LSB_PRECOND_BLOCKJACOBI = 4 }; /* M = blockdiag(S) with opts.block_size rows
+                                       per block, blocks inverted at setup (the
+                                       block form of src/ginkgo.cpp:57-58's
+                                       Jacobi preconditioner)                 */
 enum { LSB_KRYLOV_PCG = 0,    /* preconditioned CG (symmetric operators)    */
        LSB_KRYLOV_GMRES = 1,  /* restarted GMRES(m), right-preconditioned,
                                  for LSB_OP_RAW / unsymmetric operators;
@@ -103,9 +113,15 @@ enum { LSB_SPMV_AUTO = 0,     /* pick by mean row length                    */
        LSB_SPMV_SCALAR = 3,   /* one lane per row (test/debug baseline)     */
        LSB_SPMV_PANEL = 4,    /* column panels with an L2-resident x window,
                                  for scattered rows (solver handle only)    */
-       LSB_SPMV_SELL = 5 };   /* sliced-ELL copy of the rows (lsb_csr_sellize):
+       LSB_SPMV_SELL = 5,     /* sliced-ELL copy of the rows (lsb_csr_sellize):
                                  128-row slices stored column-major, two rows
                                  per lane, no LDS; for near-uniform row lengths */
+       LSB_SPMV_BINNED = 6 }; /* scattered operators: entries binned by column
+                                 panel (an L2-sized window of x) and sorted by
+                                 row inside a bin, streamed as (row, col, value)
+                                 with a segmented reduction per row -- uniform
+                                 work per lane whatever the row lengths
+                                 (lsb_csr_binize; solver handle only)         */
 enum { LSB_STATUS_RUNNING = 0, LSB_STATUS_CONVERGED = 1,
        LSB_STATUS_BREAKDOWN = 2, LSB_STATUS_MAXIT = 3,
        LSB_STATUS_COMM = 4 /* a peer never arrived (direct xGMI path) */ };
@@ -138,7 +154,31 @@ struct lsb_hip_opts {
   int krylov;        /* LSB_KRYLOV_*                                  [PCG] */
   int restart;       /* GMRES restart length m, 1..32                  [30] */
   int verbose;
+  int ngpus;         /* hip_cdna4_bench only: row-partition the operator over
+                        this many GPUs of the node, all driven from the ONE
+                        caller process (one host thread per GPU); 0 = every
+                        visible device.  Also LSBENCH_HIP_NGPUS, --ngpus   [1] */
+  int verify;        /* 1: a solve the recurrence calls converged is reported
+                        only once ||b - S x||_2 <= tol ||b||_2 holds for the
+                        residual RECOMPUTED from x; if it does not, CG restarts
+                        on the true residual (correction solve) until it does;
+                        lsb_hip_result.true_relres carries the number      [0] */
+  int cheb_degree;   /* LSB_PRECOND_CHEBYSHEV: degree of the polynomial, 1..16 [4] */
+  int block_size;    /* LSB_PRECOND_BLOCKJACOBI: rows per diagonal block,
+                        2, 4, 8, 16 or 32                                  [8] */
+  int precision;     /* LSB_PREC_FP64, or LSB_PREC_MIXED: matrix values stored
+                        and streamed as fp32, vectors and every accumulation
+                        in fp64, fp64 iterative refinement around it -- the
+                        same tolerance on the fp64 operator's residual   [FP64] */
+  int persistent;    /* launch-bound operators (everything fits one XCD's L2):
+                        the whole solve as ONE launch confined to one XCD;
+                        -1 = where the creation-time timing says it is faster,
+                        0 off, 1 on                                       [-1] */
+  double comm_deadline_s; /* sharded solves: the host gives a poll of the device
+                        state at most this long before it reports a hung
+                        collective and exits non-zero                    [120] */
 };
+enum { LSB_PREC_FP64 = 0, LSB_PREC_MIXED = 1 };
 
 struct lsb_hip_result {
   unsigned iters;        /* PCG iterations performed                        */
@@ -147,6 +187,10 @@ struct lsb_hip_result {
   double seconds;        /* wall-clock of this solve (host, after sync)     */
   double spmv_ms;        /* mean duration of the sampled SpMV launches      */
   unsigned spmv_samples; /* how many launches were sampled                  */
+  unsigned corrections;  /* opts.verify / mixed precision: correction solves
+                            (restarts on the recomputed residual) it took   */
+  double true_relres;    /* ||b - S x|| / ||b|| recomputed from x (fp64
+                            operator); -1 when not computed                 */
 };
 
 void lsb_hip_opts_default(struct lsb_hip_opts *o);

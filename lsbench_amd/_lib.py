@@ -17,14 +17,15 @@ UNIQUE_ID_BYTES = 128
 # enums of include/lsbench.h / include/lsbench_hip.h
 SOLVER_HIP = 6
 OP_CHOLMOD_UPPER, OP_RAW = 0, 1
-PRECOND_JACOBI, PRECOND_NONE, PRECOND_L1JACOBI = 0, 1, 2
+PRECOND_JACOBI, PRECOND_NONE, PRECOND_L1JACOBI, PRECOND_CHEBYSHEV, PRECOND_BLOCKJACOBI = 0, 1, 2, 3, 4
 KRYLOV_PCG, KRYLOV_GMRES, KRYLOV_PCG1, KRYLOV_AUTO = 0, 1, 2, 3
-SPMV_AUTO, SPMV_ADAPTIVE, SPMV_SUBWAVE, SPMV_SCALAR, SPMV_PANEL, SPMV_SELL = 0, 1, 2, 3, 4, 5
+SPMV_AUTO, SPMV_ADAPTIVE, SPMV_SUBWAVE, SPMV_SCALAR, SPMV_PANEL, SPMV_SELL, SPMV_BINNED = 0, 1, 2, 3, 4, 5, 6
 SELL_ROWS = 128
 SPMV_FLAG_PREFETCH, SPMV_FLAG_NT, SPMV_FLAG_C16 = 1, 2, 4
 STATUS_RUNNING, STATUS_CONVERGED, STATUS_BREAKDOWN, STATUS_MAXIT = 0, 1, 2, 3
 STATUS_COMM = 4
 COMM_AUTO, COMM_RCCL, COMM_P2P = 0, 1, 2
+PREC_FP64, PREC_MIXED = 0, 1
 
 
 class LsbenchHipError(RuntimeError):
@@ -52,14 +53,18 @@ class Opts(C.Structure):
                 ("sample_spmv", C.c_int), ("nvirt", C.c_int), ("comm", C.c_int), ("overlap", C.c_int),
                 ("spmv_tune", C.c_int), ("spmv_grid", C.c_int), ("reorder", C.c_int),
                 ("krylov", C.c_int),
-                ("restart", C.c_int), ("verbose", C.c_int)]
+                ("restart", C.c_int), ("verbose", C.c_int),
+                ("ngpus", C.c_int), ("verify", C.c_int), ("cheb_degree", C.c_int),
+                ("block_size", C.c_int), ("precision", C.c_int), ("persistent", C.c_int),
+                ("comm_deadline_s", C.c_double)]
 
 
 class Result(C.Structure):
     """struct lsb_hip_result."""
     _fields_ = [("iters", C.c_uint), ("status", C.c_int), ("relres", C.c_double),
                 ("seconds", C.c_double), ("spmv_ms", C.c_double),
-                ("spmv_samples", C.c_uint)]
+                ("spmv_samples", C.c_uint), ("corrections", C.c_uint),
+                ("true_relres", C.c_double)]
 
 
 class PanelCsr(C.Structure):

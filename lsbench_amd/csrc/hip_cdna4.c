@@ -37,8 +37,9 @@
 /* backend globals (reference style: file statics, src/cusparse.c:33-36)     */
 /* ------------------------------------------------------------------------ */
 int lsb_initialized = 0;
-hipStream_t g_stream = 0, g_comm_stream = 0;
-struct lsb_hip_result g_last;
+__thread hipStream_t g_stream = 0;
+static __thread hipStream_t g_comm_stream = 0;
+__thread struct lsb_hip_result g_last;
 static struct lsb_hip_opts g_opts;
 static int g_opts_set = 0;
 
@@ -67,6 +68,13 @@ void lsb_hip_opts_default(struct lsb_hip_opts *o) {
   o->krylov = LSB_KRYLOV_PCG;
   o->restart = 30;
   o->verbose = 0;
+  o->ngpus = 1;
+  o->verify = 0;
+  o->cheb_degree = 4;
+  o->block_size = 8;
+  o->precision = LSB_PREC_FP64;
+  o->persistent = -1;
+  o->comm_deadline_s = 120.0;
 }
 
 static void opts_from_env(struct lsb_hip_opts *o) {
@@ -110,6 +118,20 @@ static void opts_from_env(struct lsb_hip_opts *o) {
     o->check_every = atoi(e);
   if ((e = getenv("LSBENCH_HIP_VERBOSE")))
     o->verbose = atoi(e);
+  if ((e = getenv("LSBENCH_HIP_NGPUS")))
+    o->ngpus = atoi(e);
+  if ((e = getenv("LSBENCH_HIP_VERIFY")))
+    o->verify = atoi(e);
+  if ((e = getenv("LSBENCH_HIP_CHEB_DEGREE")))
+    o->cheb_degree = atoi(e);
+  if ((e = getenv("LSBENCH_HIP_BLOCK_SIZE")))
+    o->block_size = atoi(e);
+  if ((e = getenv("LSBENCH_HIP_PRECISION")))
+    o->precision = (!strcasecmp(e, "fp32") || !strcasecmp(e, "mixed")) ? LSB_PREC_MIXED : LSB_PREC_FP64;
+  if ((e = getenv("LSBENCH_HIP_PERSISTENT")))
+    o->persistent = atoi(e);
+  if ((e = getenv("LSBENCH_HIP_COMM_DEADLINE_S")))
+    o->comm_deadline_s = atof(e);
 }
 
 void lsb_hip_set_opts(const struct lsb_hip_opts *o) {
@@ -149,11 +171,30 @@ int hip_cdna4_init(void) {
   if (e)
     LSB_CHK_HIP(hipSetDevice(atoi(e)));
   LSB_CHK_HIP(hipStreamCreate(&g_stream)); /* cf. src/cusparse.c:142 */
-  LSB_CHK_HIP(hipStreamCreate(&g_comm_stream));
   struct lsb_hip_opts o;
   lsb_hip_get_opts(&o);
   lsb_initialized = 1;
   return 0;
+}
+
+hipStream_t comm_stream(void) {
+  if (!g_comm_stream)
+    LSB_CHK_HIP(hipStreamCreate(&g_comm_stream));
+  return g_comm_stream;
+}
+
+/* a worker thread of hip_multi.c becomes a rank: its own device and stream */
+void rank_thread_attach(int device) {
+  LSB_CHK_HIP(hipSetDevice(device));
+  LSB_CHK_HIP(hipStreamCreate(&g_stream));
+}
+
+void rank_thread_detach(void) {
+  LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+  LSB_CHK_HIP(hipStreamDestroy(g_stream));
+  if (g_comm_stream)
+    LSB_CHK_HIP(hipStreamDestroy(g_comm_stream));
+  g_stream = 0, g_comm_stream = 0;
 }
 
 int hip_cdna4_finalize(void) {
@@ -161,7 +202,8 @@ int hip_cdna4_finalize(void) {
     return 1;
   LSB_CHK_HIP(hipStreamSynchronize(g_stream));
   LSB_CHK_HIP(hipStreamDestroy(g_stream));
-  LSB_CHK_HIP(hipStreamDestroy(g_comm_stream));
+  if (g_comm_stream)
+    LSB_CHK_HIP(hipStreamDestroy(g_comm_stream));
   g_stream = 0, g_comm_stream = 0;
   lsb_initialized = 0;
   return 0;
@@ -306,6 +348,10 @@ int hip_cdna4_bench(double *x, struct csr *A, const double *r,
   lsb_hip_get_opts(&o);
   const unsigned m = A->nrows, nnz = A->offs[m];
   const size_t bytes = (size_t)m * sizeof(double);
+  /* several GPUs of the node, driven from this one caller process */
+  const int ngpus = o.ngpus == 0 ? lsb_hip_device_count() : o.ngpus;
+  if (ngpus > 1)
+    return bench_multi(x, A, r, cb, &o, ngpus);
 
   /* untimed setup: operator build, upload, Jacobi, row blocks
    * (counterpart of csr_init, src/cusparse.c:47-125) */
@@ -314,6 +360,7 @@ int hip_cdna4_bench(double *x, struct csr *A, const double *r,
     errx(EXIT_FAILURE, "hip_cdna4: cannot set up the solver");
   double *d_r = (double *)lsb_hip_malloc(bytes), *d_x = (double *)lsb_hip_malloc(bytes);
   LSB_CHK_HIP(hipMemcpy(d_r, r, bytes, hipMemcpyHostToDevice));
+  LSB_CHK_HIP(hipMemset(d_x, 0, bytes)); /* --trials=0: x stays the initial guess */
 
   struct lsb_hip_result res;
   memset(&res, 0, sizeof res);

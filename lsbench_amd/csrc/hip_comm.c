@@ -27,8 +27,10 @@
            ncclGetErrorString(r_));                                            \
   } while (0)
 
-static ncclComm_t g_comm;
-static int g_have_comm = 0, g_nranks = 1, g_rank = 0;
+/* per host thread: a rank is a thread (the only one of a one-process-per-GPU
+ * job, or one of the workers hip_multi.c starts inside one caller process) */
+static __thread ncclComm_t g_comm;
+static __thread int g_have_comm = 0, g_nranks = 1, g_rank = 0;
 
 int lsb_hip_comm_get_unique_id(void *id128) {
   ncclUniqueId id;

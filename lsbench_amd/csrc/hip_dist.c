@@ -31,21 +31,44 @@ void exchange_on(lsb_hip_solver *sv, hipStream_t stream) {
 }
 
 /* gated = 1: part of a running solve (a launch no-ops once the device state has
- * left RUNNING); 0: communicate whatever the last solve left in that state */
+ * left RUNNING); 0: a communication step of its own -- gated on the shard's
+ * auxiliary state instead, which only ever leaves RUNNING through a time-out of
+ * the direct path (the host reports that: check_aux_status). */
 void exchange_p(lsb_hip_solver *sv, int gated) {
   if (sv->p2p_halo && sv->dist) { /* peers are other GPUs: both roles in one launch */
-    lsb_p2p_sendrecv(sv->p2p[0], sv->sh[0].d_pfull, gated ? sv->sh[0].d_st : NULL,
+    lsb_p2p_sendrecv(sv->p2p[0], sv->sh[0].d_pfull, gated ? sv->sh[0].d_st : sv->sh[0].d_st_aux,
                      g_stream);
+  } else if (sv->p2p_halo) { /* all sends before any wait: virtual shards share a stream */
+    for (int i = 0; i < sv->nshard; i++)
+      lsb_p2p_send(sv->p2p[i], sv->sh[i].d_pfull, gated ? sv->sh[i].d_st : sv->sh[i].d_st_aux,
+                   g_stream);
+    for (int i = 0; i < sv->nshard; i++)
+      lsb_p2p_recv(sv->p2p[i], sv->sh[i].d_pfull, gated ? sv->sh[i].d_st : sv->sh[i].d_st_aux,
+                   g_stream);
+  } else {
+    exchange_on(sv, g_stream);
     return;
   }
-  if (sv->p2p_halo) { /* all sends before any wait: virtual shards share a stream */
-    for (int i = 0; i < sv->nshard; i++)
-      lsb_p2p_send(sv->p2p[i], sv->sh[i].d_pfull, gated ? sv->sh[i].d_st : NULL, g_stream);
-    for (int i = 0; i < sv->nshard; i++)
-      lsb_p2p_recv(sv->p2p[i], sv->sh[i].d_pfull, gated ? sv->sh[i].d_st : NULL, g_stream);
+  /* Mailbox regions and flags are re-used by the next exchange; inside an
+   * iteration the all-reduce of the dot products lies in between.  An exchange
+   * outside one (SpMV entry point called in a row) gets a one-value all-reduce
+   * as its closing barrier: no rank rewrites a region a peer is still reading. */
+  if (!gated)
+    allreduce_scal(sv, 7, 1, 0);
+}
+
+/* A time-out recorded by an ungated communication step is fatal, like any
+ * failing HIP / RCCL call of this library. */
+void check_aux_status(lsb_hip_solver *sv, const char *where) {
+  if (!sv->p2p_on)
     return;
+  for (int i = 0; i < sv->nshard; i++) {
+    struct lsb_pcg_state h;
+    LSB_CHK_HIP(hipMemcpy(&h, sv->sh[i].d_st_aux, sizeof h, hipMemcpyDeviceToHost));
+    if (h.status == LSB_STATUS_COMM)
+      errx(EXIT_FAILURE, "hip_cdna4: %s: a peer did not arrive within the time-out of the direct "
+                         "xGMI path (LSBENCH_HIP_P2P_TIMEOUT_MS)", where);
   }
-  exchange_on(sv, g_stream);
 }
 
 /* d_scal[off .. off+cnt) <- sum over shards.  With the direct path the
@@ -60,7 +83,7 @@ static void allreduce_parts(lsb_hip_solver *sv, unsigned off, unsigned cnt, unsi
       struct shard *s = &sv->sh[i];
       const double *parts = width ? s->d_parts_pq : NULL;
       const unsigned w2 = with2 ? s->ar2_width : 0;
-      struct lsb_pcg_state *st = gated ? s->d_st : NULL;
+      struct lsb_pcg_state *st = gated ? s->d_st : s->d_st_aux;
       const int phases = sv->nshard == 1 ? 3 : ph;
       if (sv->nshard == 1 && ph == 2)
         continue;
@@ -164,9 +187,9 @@ void exchange_and_spmv(lsb_hip_solver *sv, int sample) {
       lsb_p2p_send(sv->p2p[i], sv->sh[i].d_pfull, sv->sh[i].d_st, g_stream);
   } else {
     LSB_CHK_HIP(hipEventRecord(sv->ev_vec, g_stream));          /* the vector is final   */
-    LSB_CHK_HIP(hipStreamWaitEvent(g_comm_stream, sv->ev_vec, 0));
-    exchange_on(sv, g_comm_stream);
-    LSB_CHK_HIP(hipEventRecord(sv->ev_halo, g_comm_stream));    /* the halo has landed   */
+    LSB_CHK_HIP(hipStreamWaitEvent(comm_stream(), sv->ev_vec, 0));
+    exchange_on(sv, comm_stream());
+    LSB_CHK_HIP(hipEventRecord(sv->ev_halo, comm_stream()));    /* the halo has landed   */
   }
   if (sample >= 0)
     LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample], g_stream));

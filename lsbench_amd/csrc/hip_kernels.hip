@@ -607,6 +607,7 @@ __global__ __launch_bounds__(WG) void k_pcg_init_state(
     st->pq = 0.0;
     st->iters = 0;
     st->maxit = maxit;
+    st->pad = 0; // "maxit-th update done, status pending" marker of k_cg1_update
     // b == 0 => x = 0 is the solution; maxit == 0 => nothing to do
     st->status = (v[1] == 0.0) ? LSB_STATUS_CONVERGED
                                : (maxit <= 0 ? LSB_STATUS_MAXIT : LSB_STATUS_RUNNING);
@@ -816,7 +817,14 @@ __global__ __launch_bounds__(WG) void k_cg1_update(
   const size_t gtid = (size_t)blockIdx.x * WG + threadIdx.x;
   const size_t gsz = (size_t)gridDim.x * WG;
   const size_t n2 = n / 2;
-  const int stopped = st->status;
+  // `pend`: the previous launch was the maxit-th update.  That launch does NOT
+  // publish LSB_STATUS_MAXIT itself: its workgroups read the status word on
+  // entry, and one that started after the leader's store would skip its slice
+  // of x/r/p/s (a mix of two iterates).  It raises st->pad instead, a word
+  // nobody tests in that launch; THIS launch promotes it to the final status --
+  // every workgroup sees pad = 1 (written one launch ago) and returns, whatever
+  // it reads in the status word.
+  const int stopped = st->status, pend = st->pad;
   const double g_old = st->rz[parity], a_old = st->alpha[parity], thresh2 = st->thresh2;
   d2v *u2 = (d2v *)u, *p2 = (d2v *)p, *s2 = (d2v *)sv, *x2 = (d2v *)x, *r2 = (d2v *)r;
   const d2v *w2 = (const d2v *)w, *d2 = (const d2v *)dinv;
@@ -838,9 +846,9 @@ __global__ __launch_bounds__(WG) void k_cg1_update(
     return;
   const double g_new = gr[0], rr = gr[1], delta = UI ? dc * dc * dd[0] : dd[0];
   const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
-  if (rr <= thresh2) { // r of the previous update already meets the tolerance
+  if (rr <= thresh2 || pend) { // r of the previous update meets the tolerance, or it was the last allowed
     if (leader)
-      st->status = LSB_STATUS_CONVERGED, st->rr = rr;
+      st->status = rr <= thresh2 ? LSB_STATUS_CONVERGED : LSB_STATUS_MAXIT, st->rr = rr;
     return;
   }
   double beta = 0.0, alpha;
@@ -863,7 +871,7 @@ __global__ __launch_bounds__(WG) void k_cg1_update(
     st->rz[parity ^ 1] = g_new;
     st->alpha[parity ^ 1] = alpha;
     if (it >= st->maxit)
-      st->status = LSB_STATUS_MAXIT; // this update still happens; later launches are no-ops
+      st->pad = 1; // promoted to LSB_STATUS_MAXIT / CONVERGED by the next launch (see `pend`)
   }
   double acc[2] = {0.0, 0.0};
   if (V2) {

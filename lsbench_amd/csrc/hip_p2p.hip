@@ -20,7 +20,11 @@
 //              the convergence test needs).
 // Flags are monotonically increasing epochs, so nothing is ever reset; slot
 // reuse is safe because an all-reduce separates two successive exchanges and
-// all-reduce k+2 cannot start anywhere before every rank has left k.
+// all-reduce k+2 cannot start anywhere before every rank has left k.  Inside a
+// Krylov iteration that all-reduce is the algorithm's own; an exchange issued
+// outside one (lsb_hip_solver_spmv_dev, the Jacobi sweep) is closed by a
+// one-value all-reduce for exactly this purpose (exchange_p, hip_dist.c) -- a
+// fast rank could otherwise overwrite a halo region its peer is still copying.
 // Every wait is bounded (wall_clock64): a peer that never arrives turns into
 // st->status = LSB_STATUS_COMM -- later kernels no-op, the host reports it --
 // never into a hung wave.
@@ -36,6 +40,7 @@
 // 2.2); the RCCL path in hip_comm.c stays the default wherever this one is not
 // available (no IPC, no peer access) or not faster.
 #include <hip/hip_runtime.h>
+#include <stdint.h>
 #include <string.h>
 
 #include "lsb_impl.h"
@@ -87,10 +92,12 @@ __device__ __forceinline__ double ld_sys(const double *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// true when *flag reached `epoch` before the deadline
+// true when *flag reached `epoch` before the deadline.  Epochs only grow, so
+// "reached" is >=: a waiter that arrives late for epoch k must not spin on a
+// flag its peer has meanwhile moved on to k+1.
 __device__ __forceinline__ bool wait_flag(const u64 *flag, u64 epoch, long long timeout) {
   const long long t0 = wall_clock64();
-  while (ld_sys(flag) != epoch) {
+  while (ld_sys(flag) < epoch) {
     __builtin_amdgcn_s_sleep(1);
     if (wall_clock64() - t0 > timeout)
       return false;
@@ -397,37 +404,76 @@ extern "C" void lsb_p2p_destroy(struct lsb_p2p *p) {
   free(p);
 }
 
-/* One process per GPU.  Collective over the RCCL communicator (the handles and
- * region tables travel by lsb_hip_comm_allgather_u32).  Returns NULL when the
- * path is unavailable HERE; the caller still has to agree with its peers. */
+/* One rank per GPU: a process each (bench.py under torch.distributed.run) or a
+ * host thread each inside one process (hip_multi.c).  Collective over the RCCL
+ * communicator: every rank's record -- IPC handle of its mailbox, process id,
+ * device, the mailbox's address, region table -- travels by
+ * lsb_hip_comm_allgather_u32.  A peer in ANOTHER process is reached through its
+ * IPC handle; a peer in THIS process through the address itself, after
+ * hipDeviceEnablePeerAccess (an IPC handle cannot be opened by the process that
+ * made it).  Returns NULL when the path is unavailable HERE; the caller still
+ * has to agree with its peers. */
+#include <unistd.h>
 extern "C" struct lsb_p2p *lsb_p2p_create_dist(const struct lsb_xfer *recv, int nrecv,
                                                const struct lsb_xfer *send, int nsend) {
   const int R = lsb_hip_comm_size(), me = lsb_hip_comm_rank();
   struct lsb_p2p *p = p2p_alloc(R, me, 0, recv, nrecv, send, nsend);
   /* every rank takes part in the all-gather, whatever happened locally */
-  const unsigned W = 16 + 2 + P2P_MAX_RANKS;
-  unsigned mine[16 + 2 + P2P_MAX_RANKS];
+  enum { R_OK_ = 16, R_HALO, R_IPC, R_PID, R_DEV, R_PTR_LO, R_PTR_HI, R_TAB };
+  const unsigned W = R_TAB + P2P_MAX_RANKS;
+  unsigned mine[R_TAB + P2P_MAX_RANKS];
   memset(mine, 0, sizeof mine);
   hipIpcMemHandle_t h;
-  int ok = p != NULL;
-  if (ok && hipIpcGetMemHandle(&h, p->mbox) != hipSuccess)
+  int ok = p != NULL, mydev = 0;
+  if (ok && hipGetDevice(&mydev) != hipSuccess)
     ok = 0, (void)hipGetLastError();
   if (ok) {
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle is 64 bytes");
-    memcpy(mine, &h, 64);
-    mine[16] = 1, mine[17] = (unsigned)p->halo;
+    if (hipIpcGetMemHandle(&h, p->mbox) == hipSuccess)
+      memcpy(mine, &h, 64), mine[R_IPC] = 1;
+    else
+      (void)hipGetLastError(); /* peers of this process do not need it */
+    const unsigned long long addr = (unsigned long long)(uintptr_t)p->mbox;
+    mine[R_OK_] = 1, mine[R_HALO] = (unsigned)p->halo;
+    mine[R_PID] = (unsigned)getpid(), mine[R_DEV] = (unsigned)mydev;
+    mine[R_PTR_LO] = (unsigned)(addr & 0xFFFFFFFFull), mine[R_PTR_HI] = (unsigned)(addr >> 32);
     for (int q = 0; q < R; q++)
-      mine[18 + q] = p->region_off[q];
+      mine[R_TAB + q] = p->region_off[q];
   }
   unsigned *all = (unsigned *)calloc((size_t)W * R, sizeof(unsigned));
   lsb_hip_comm_allgather_u32(mine, W, all);
   for (int q = 0; q < R; q++)
-    ok &= all[(size_t)q * W + 16] != 0;
+    ok &= all[(size_t)q * W + R_OK_] != 0;
   for (int q = 0; q < R && ok; q++) {
     if (q == me)
       continue;
+    const unsigned *rec = all + (size_t)q * W;
+    if (rec[R_PID] == (unsigned)getpid()) { /* a thread of this process */
+      const int qdev = (int)rec[R_DEV];
+      if (qdev != mydev) {
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, mydev, qdev) != hipSuccess || !can) {
+          (void)hipGetLastError();
+          ok = 0;
+          break;
+        }
+        const hipError_t pe = hipDeviceEnablePeerAccess(qdev, 0);
+        if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) {
+          (void)hipGetLastError();
+          ok = 0;
+          break;
+        }
+        (void)hipGetLastError();
+      }
+      p->peer[q] = (char *)(uintptr_t)(((unsigned long long)rec[R_PTR_HI] << 32) | rec[R_PTR_LO]);
+      continue;
+    }
+    if (!rec[R_IPC]) {
+      ok = 0;
+      break;
+    }
     hipIpcMemHandle_t hq;
-    memcpy(&hq, all + (size_t)q * W, 64);
+    memcpy(&hq, rec, 64);
     void *ptr = NULL;
     if (hipIpcOpenMemHandle(&ptr, hq, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
       (void)hipGetLastError();
@@ -439,9 +485,9 @@ extern "C" struct lsb_p2p *lsb_p2p_create_dist(const struct lsb_xfer *recv, int 
   if (ok) {
     unsigned tab[P2P_MAX_RANKS * P2P_MAX_RANKS], halo_ok[P2P_MAX_RANKS];
     for (int q = 0; q < R; q++) {
-      halo_ok[q] = all[(size_t)q * W + 17];
+      halo_ok[q] = all[(size_t)q * W + R_HALO];
       for (int s = 0; s < R; s++)
-        tab[(size_t)q * R + s] = all[(size_t)q * W + 18 + s];
+        tab[(size_t)q * R + s] = all[(size_t)q * W + R_TAB + s];
     }
     ok = p2p_connect(p, tab, halo_ok, recv, nrecv, send, nsend) == 0;
   }

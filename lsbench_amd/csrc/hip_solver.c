@@ -215,6 +215,8 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
   s->d_parts2 = (double *)lsb_hip_malloc(4 * LSB_MAX_PARTIALS * sizeof(double));
   s->d_st = (struct lsb_pcg_state *)lsb_hip_malloc(sizeof(struct lsb_pcg_state));
   LSB_CHK_HIP(hipMemsetAsync(s->d_st, 0, sizeof(struct lsb_pcg_state), g_stream));
+  s->d_st_aux = (struct lsb_pcg_state *)lsb_hip_malloc(sizeof(struct lsb_pcg_state));
+  LSB_CHK_HIP(hipMemsetAsync(s->d_st_aux, 0, sizeof(struct lsb_pcg_state), g_stream));
   choose_spmv(s, o);
 
   if (o->precond == LSB_PRECOND_JACOBI || o->precond == LSB_PRECOND_L1JACOBI) {
@@ -260,7 +262,7 @@ void shard_free(struct shard *s) {
   lsb_hip_free(s->d_dinv), lsb_hip_free(s->d_r);
   lsb_hip_free(s->d_q), lsb_hip_free(s->d_pfull), lsb_hip_free(s->d_parts_pq);
   lsb_hip_free(s->d_p1), lsb_hip_free(s->d_s1);
-  lsb_hip_free(s->d_parts2), lsb_hip_free(s->d_st);
+  lsb_hip_free(s->d_parts2), lsb_hip_free(s->d_st), lsb_hip_free(s->d_st_aux);
   lsb_hip_free(s->pd_offs), lsb_hip_free(s->pd_cols), lsb_hip_free(s->pd_vals);
   lsb_hip_free(s->pd_rowmap), lsb_hip_free(s->pd_rowblk), lsb_hip_free(s->pd_blklanes);
   lsb_hip_free(s->d_sptr), lsb_hip_free(s->d_scols), lsb_hip_free(s->d_svals);
@@ -476,6 +478,7 @@ void lsb_hip_solver_destroy(lsb_hip_solver *sv) {
     LSB_CHK_HIP(hipEventDestroy(sv->ev_halo));
   }
   lsb_hip_free(sv->d_scal_all), lsb_hip_free(sv->d_tmp);
+  lsb_hip_free(sv->d_vr), lsb_hip_free(sv->d_ve);
   lsb_hip_free(sv->d_perm), lsb_hip_free(sv->d_bp), lsb_hip_free(sv->d_xp);
   for (int i = 0; sv->gm && i < sv->nshard; i++) {
     lsb_hip_free(sv->gm[i].V), lsb_hip_free(sv->gm[i].parts);
@@ -664,6 +667,7 @@ int lsb_hip_solver_spmv_dev(lsb_hip_solver *sv, const double *d_x, double *d_y) 
   if (d_yout)
     lsb_k_perm_scatter(sv->n_here, sv->d_perm, d_y, d_yout, g_stream);
   LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+  check_aux_status(sv, "lsb_hip_solver_spmv_dev");
   return 0;
 }
 

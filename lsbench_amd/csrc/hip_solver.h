@@ -25,15 +25,26 @@
 #define LSB_INTERNAL __attribute__((visibility("hidden")))
 
 /* backend globals (defined in hip_cdna4.c; reference style, src/cusparse.c:33-36) */
+/* The streams, the communicator (hip_comm.c) and the last result are per host
+ * THREAD: a rank is a thread -- the caller's own when there is one GPU or one
+ * process per GPU, one of hip_multi.c's workers when hip_cdna4_bench drives
+ * several GPUs from the one caller process. */
 extern LSB_INTERNAL int lsb_initialized;
-extern LSB_INTERNAL hipStream_t g_stream, g_comm_stream; /* compute / halo exchange */
-extern LSB_INTERNAL struct lsb_hip_result g_last;
+extern LSB_INTERNAL __thread hipStream_t g_stream; /* compute */
+extern LSB_INTERNAL __thread struct lsb_hip_result g_last;
+LSB_INTERNAL hipStream_t comm_stream(void); /* halo exchange behind interior rows; made on first use */
+LSB_INTERNAL void rank_thread_attach(int device);
+LSB_INTERNAL void rank_thread_detach(void);
+/* hip_multi.c */
+LSB_INTERNAL int bench_multi(double *x, struct csr *A, const double *r, const struct lsbench *cb,
+                             const struct lsb_hip_opts *o, int ngpus);
 
 /* ------------------------------------------------------------------------ */
 /* solver object                                                             */
 /* ------------------------------------------------------------------------ */
 #define SCAL_STRIDE 8 /* doubles per shard in the scalar slab */
 #define MAX_SAMPLES 64
+#define LSB_NGRAPH 4 /* cached hipGraphs: whole-solve + continuation chunk, solve proper + correction */
 
 struct shard {
   unsigned row_begin, n;
@@ -67,6 +78,10 @@ struct shard {
   double *d_parts_pq, *d_parts2;
   double *d_scal; /* [0] p.q   [1] r.z'  [2] r.r   (multi-shard path) */
   struct lsb_pcg_state *d_st;
+  /* status word for communication steps that belong to no running solve (the
+   * SpMV entry point, the first all-reduce of a solve): a time-out of the direct
+   * xGMI path is recorded here and reported by the host (check_aux_status) */
+  struct lsb_pcg_state *d_st_aux;
   unsigned nblk, lanes;
   int variant;
   unsigned col_lo, col_hi; /* column hull referenced by the shard's rows */
@@ -95,9 +110,13 @@ struct lsb_hip_solver {
     hipGraphExec_t exec;
     int iters;
     double *x;
-  } gcache[2];
+  } gcache[LSB_NGRAPH];
   int gnext;
-  unsigned hint_iters; /* iterations of the previous solve, 0 = none yet */
+#define LSB_MAX_CORRECTIONS 4
+  unsigned hint_iters[LSB_MAX_CORRECTIONS + 1]; /* iterations of the previous solve and of each of
+                                                   its correction runs, 0 = none yet */
+  double tol_run;    /* tolerance of the CG run being enqueued (opts.tol, or a correction's) */
+  double *d_vr, *d_ve; /* opts.verify: right-hand side and solution of a correction run */
   unsigned agree_nnz, agree_n; /* distributed: largest shard, identical on all ranks */
   unsigned agree_halo;         /* largest halo (doubles) any shard receives from one peer */
   /* reordering: d_perm[new] = old; b and x are permuted through d_bp / d_xp */
@@ -142,11 +161,12 @@ LSB_INTERNAL void tune_spmv(lsb_hip_solver *sv, struct shard *s);
 LSB_INTERNAL void p2p_setup(lsb_hip_solver *sv);
 LSB_INTERNAL void exchange_on(lsb_hip_solver *sv, hipStream_t stream);
 LSB_INTERNAL void exchange_p(lsb_hip_solver *sv, int gated);
+LSB_INTERNAL void check_aux_status(lsb_hip_solver *sv, const char *where);
 LSB_INTERNAL void allreduce_scal(lsb_hip_solver *sv, unsigned off, unsigned cnt, int gated);
 LSB_INTERNAL void allreduce_pq(lsb_hip_solver *sv, unsigned cnt, int with2);
 LSB_INTERNAL int can_overlap(const lsb_hip_solver *sv);
 LSB_INTERNAL void exchange_and_spmv(lsb_hip_solver *sv, int sample);
-LSB_INTERNAL double true_relres(lsb_hip_solver *sv, const double *d_b, const double *d_x);
+LSB_INTERNAL double true_resid2(lsb_hip_solver *sv, const double *d_b, const double *d_x);
 /* hip_pcg.c */
 LSB_INTERNAL void drop_graphs(lsb_hip_solver *sv);
 LSB_INTERNAL int solve_core(lsb_hip_solver *sv, const double *d_b, double *d_x,

@@ -18,7 +18,7 @@
  * deliberate differences: --ordering/--precision/--verbose/--trials accept
  * "--flag value" as well as "--flag=value" (the reference segfaults on the
  * first form), --help prints the program name, and
- * --tol/--maxit/--operator/--nvirt/--krylov/--restart/--precond are new.
+ * --tol/--maxit/--operator/--nvirt/--krylov/--restart/--precond/--ngpus are new.
  */
 #define _GNU_SOURCE
 #include "lsb_impl.h"
@@ -80,6 +80,8 @@ static void usage(const char *prog) {
   printf("  --krylov <cg|cg1|auto|gmres> (hip) cg1 = single-reduction CG, gmres for --operator raw\n");
   printf("  --restart <M>        (hip) GMRES restart length, 1..32, default 30\n");
   printf("  --precond <jacobi|l1|none> (hip) diag(S), diag(sum_j |S_ij|), or none\n");
+  printf("  --ngpus <N>          (hip) row-partition the operator over N GPUs of this node\n");
+  printf("                       (0 = all visible), driven from this one process\n");
   printf("  --reorder            (hip) solve the RCM-permuted operator (any --ordering\n");
   printf("                       value maps to RCM; off by default because the reference's\n");
   printf("                       zero-filled default ordering IS RCM, src/lsbench.c:95)\n");
@@ -95,7 +97,7 @@ struct lsbench *lsbench_init(int argc, char *argv[]) {
       {"maxit", required_argument, 0, 81},    {"operator", required_argument, 0, 82},
       {"nvirt", required_argument, 0, 83},    {"krylov", required_argument, 0, 84},
       {"restart", required_argument, 0, 85},  {"reorder", no_argument, 0, 86},
-      {"precond", required_argument, 0, 87},
+      {"precond", required_argument, 0, 87},  {"ngpus", required_argument, 0, 88},
       {0, 0, 0, 0}};
 
   /* zero-filled => solver 0 (CUSOLVER), ordering 0 (RCM), FP64: the
@@ -161,6 +163,9 @@ struct lsbench *lsbench_init(int argc, char *argv[]) {
       o.precond = strcasecmp(optarg, "none") == 0 ? LSB_PRECOND_NONE
                   : strcasecmp(optarg, "l1") == 0 ? LSB_PRECOND_L1JACOBI
                                                   : LSB_PRECOND_JACOBI;
+      break;
+    case 88:
+      o.ngpus = atoi(optarg);
       break;
     default:
       usage(argv[0]);

@@ -29,7 +29,9 @@ struct lsb_pcg_state {
   int iters;       /* completed iterations                                   */
   int status;      /* LSB_STATUS_*; != 0 makes every later kernel a no-op    */
   int maxit;
-  int pad;
+  int pad;       /* single-reduction CG: 1 = the maxit-th update has run, the next
+                    launch turns it into the final status (never set and tested
+                    in the same launch)                                      */
 };
 
 /* ---- device-side GMRES(m) scalars ----------------------------------------- */

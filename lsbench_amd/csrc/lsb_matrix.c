@@ -270,9 +270,21 @@ static struct csr *cache_load(const char *cpath, const struct stat *src) {
         fread(A->offs, sizeof(unsigned), (size_t)h.nrows + 1, f) != (size_t)h.nrows + 1 ||
         fread(A->cols, sizeof(unsigned), (size_t)h.nnz, f) != (size_t)h.nnz ||
         fread(A->vals, sizeof(double), (size_t)h.nnz, f) != (size_t)h.nnz ||
-        A->offs[h.nrows] != h.nnz) {
+        A->offs[h.nrows] != h.nnz || h.base > 1 || A->offs[0] != 0) {
       lsbench_matrix_free(A); /* truncated or foreign file: parse the text instead */
       A = NULL;
+    }
+    /* a damaged file must not reach the operator build: offsets non-decreasing,
+     * columns at or above the base and strictly increasing inside a row (what
+     * the parser guarantees, src/lsbench-csr.c:54-63) */
+    for (unsigned i = 0; A && i < h.nrows; i++) {
+      int bad = A->offs[i] > A->offs[i + 1] || A->offs[i + 1] > h.nnz;
+      for (unsigned j = A->offs[i]; !bad && j < A->offs[i + 1]; j++)
+        bad = A->cols[j] < h.base || (j > A->offs[i] && A->cols[j] <= A->cols[j - 1]);
+      if (bad) {
+        lsbench_matrix_free(A);
+        A = NULL;
+      }
     }
   }
   fclose(f);

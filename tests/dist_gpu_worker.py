@@ -48,7 +48,11 @@ def main():
     # SpMV through the exchange as well
     d_v = torch.sin(torch.arange(r0, r1, dtype=torch.float64, device="cuda"))
     d_y = torch.empty_like(d_v)
-    s.spmv_dev(d_v, d_y)
+    # many in a row, nothing in between (regression, round-1 advisor: with the
+    # direct path a fast rank used to overwrite a halo region its peer was still
+    # copying); every call on another vector, the last one is checked
+    for k in range(30, -1, -1):
+        s.spmv_dev(d_v * float(k + 1) if k else d_v, d_y)
     np.save(os.path.join(outdir, "x%d.npy" % rank), d_x.cpu().numpy())
     np.save(os.path.join(outdir, "y%d.npy" % rank), d_y.cpu().numpy())
     np.save(os.path.join(outdir, "m%d.npy" % rank),

@@ -47,15 +47,30 @@ struct fake_comm {
   int local_sense;
 };
 
+static void die(const char *what);
 struct pending {
   int is_send, peer;
   void *buf;
   size_t bytes;
   hipStream_t stream;
 };
-static struct pending g_ops[4 * MAXR];
-static int g_nops = 0, g_group = 0;
-static struct fake_comm *g_group_comm = NULL;
+/* per thread: a rank may be a host thread of one process (hip_multi.c) */
+static __thread struct pending g_ops[4 * MAXR];
+static __thread int g_nops = 0, g_group = 0;
+static __thread struct fake_comm *g_group_comm = NULL;
+
+/* device <-> shared memory through the caller's stream (no null-stream copies:
+ * those would wait for every other rank-thread's stream of the same device) */
+static void d2h(void *dst, const void *src, size_t bytes, hipStream_t s) {
+  if (hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s) != hipSuccess ||
+      hipStreamSynchronize(s) != hipSuccess)
+    die("D2H");
+}
+static void h2d(void *dst, const void *src, size_t bytes, hipStream_t s) {
+  if (hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s) != hipSuccess ||
+      hipStreamSynchronize(s) != hipSuccess)
+    die("H2D");
+}
 
 static double now_s(void) {
   struct timespec ts;
@@ -102,7 +117,9 @@ const char *ncclGetErrorString(ncclResult_t r) { return r == ncclSuccess ? "ok" 
 
 ncclResult_t ncclGetUniqueId(ncclUniqueId *id) {
   memset(id, 0, sizeof *id);
-  snprintf(id->internal, sizeof id->internal, "/lsbfake_%d_%ld", (int)getpid(), (long)time(NULL));
+  static int serial = 0;
+  snprintf(id->internal, sizeof id->internal, "/lsbfake_%d_%ld_%d", (int)getpid(), (long)time(NULL),
+           __atomic_add_fetch(&serial, 1, __ATOMIC_RELAXED));
   return ncclSuccess;
 }
 
@@ -169,15 +186,30 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm) {
   return ncclSuccess;
 }
 
+/* FAKE_RCCL_STALL_RANK=r FAKE_RCCL_STALL_AFTER=k: rank r's all-reduces beyond the
+ * k-th behave like a collective whose peers never arrive -- the call returns at
+ * once (RCCL calls are asynchronous) and the STREAM stops making progress.  The
+ * product's host-side deadline has to notice. */
+static void stall_fn(void *arg) {
+  (void)arg;
+  sleep(45);
+}
+static __thread int g_allreduces = 0;
+
 ncclResult_t ncclAllReduce(const void *send, void *recv, size_t count, ncclDataType_t t,
                            ncclRedOp_t op, ncclComm_t comm, hipStream_t stream) {
   struct fake_comm *c = (struct fake_comm *)comm;
+  const char *sr = getenv("FAKE_RCCL_STALL_RANK"), *sa = getenv("FAKE_RCCL_STALL_AFTER");
+  if (sr && atoi(sr) == c->rank && ++g_allreduces > (sa ? atoi(sa) : 0)) {
+    if (hipLaunchHostFunc(stream, stall_fn, NULL) != hipSuccess)
+      die("hipLaunchHostFunc");
+    return ncclSuccess;
+  }
   if (t != ncclDouble || op != ncclSum || count * 8 > SLOT_BYTES)
     die("all-reduce: only sums of a few doubles");
   if (hipStreamSynchronize(stream) != hipSuccess)
     die("stream sync");
-  if (hipMemcpy(c->slots + (size_t)c->rank * SLOT_BYTES, send, count * 8, hipMemcpyDeviceToHost) != hipSuccess)
-    die("D2H");
+  d2h(c->slots + (size_t)c->rank * SLOT_BYTES, send, count * 8, stream);
   barrier(c);
   double acc[64];
   if (count > 64)
@@ -188,8 +220,7 @@ ncclResult_t ncclAllReduce(const void *send, void *recv, size_t count, ncclDataT
       acc[k] += ((double *)(c->slots + (size_t)q * SLOT_BYTES))[k];
   }
   barrier(c);
-  if (hipMemcpy(recv, acc, count * 8, hipMemcpyHostToDevice) != hipSuccess)
-    die("H2D");
+  h2d(recv, acc, count * 8, stream);
   return ncclSuccess;
 }
 
@@ -201,13 +232,10 @@ ncclResult_t ncclAllGather(const void *send, void *recv, size_t count, ncclDataT
     die("all-gather larger than the test double's slots");
   if (hipStreamSynchronize(stream) != hipSuccess)
     die("stream sync");
-  if (hipMemcpy(c->slots + (size_t)c->rank * SLOT_BYTES, send, b, hipMemcpyDeviceToHost) != hipSuccess)
-    die("D2H");
+  d2h(c->slots + (size_t)c->rank * SLOT_BYTES, send, b, stream);
   barrier(c);
   for (int q = 0; q < c->nranks; q++)
-    if (hipMemcpy((unsigned char *)recv + (size_t)q * b, c->slots + (size_t)q * SLOT_BYTES, b,
-                  hipMemcpyHostToDevice) != hipSuccess)
-      die("H2D");
+    h2d((unsigned char *)recv + (size_t)q * b, c->slots + (size_t)q * SLOT_BYTES, b, stream);
   barrier(c);
   return ncclSuccess;
 }
@@ -261,8 +289,7 @@ ncclResult_t ncclGroupEnd(void) {
     if (g_ops[i].is_send) {
       unsigned char *box = c->boxes + ((size_t)c->rank * c->nranks + g_ops[i].peer) * BOX_BYTES;
       memcpy(box, &g_ops[i].bytes, sizeof(size_t));
-      if (hipMemcpy(box + 64, g_ops[i].buf, g_ops[i].bytes, hipMemcpyDeviceToHost) != hipSuccess)
-        die("D2H");
+      d2h(box + 64, g_ops[i].buf, g_ops[i].bytes, g_ops[i].stream);
     }
   barrier(c);
   for (int i = 0; i < g_nops; i++)
@@ -272,8 +299,7 @@ ncclResult_t ncclGroupEnd(void) {
       memcpy(&got, box, sizeof got);
       if (got != g_ops[i].bytes)
         die("send/recv size mismatch between two ranks");
-      if (hipMemcpy(g_ops[i].buf, box + 64, g_ops[i].bytes, hipMemcpyHostToDevice) != hipSuccess)
-        die("H2D");
+      h2d(g_ops[i].buf, box + 64, g_ops[i].bytes, g_ops[i].stream);
     }
   barrier(c);
   g_nops = 0, g_group_comm = NULL;

@@ -14,6 +14,7 @@ import sys
 import numpy as np
 import pytest
 
+import lsbench_amd as la
 from conftest import ROOT
 from oracle import oracle as O
 
@@ -109,3 +110,73 @@ def test_bench_two_ranks_on_one_gpu():
     assert abs(two["config"]["iterations_per_solve"] - one["config"]["iterations_per_solve"]) <= 2
     assert two["config"]["relres"] <= 1e-8 and "single-reduction" in two["config"]["solver"]
     assert two["config"]["nnz"] == one["config"]["nnz"]
+
+
+@pytest.mark.parametrize("ngpus,comm,matrix", [
+    (2, "rccl", "xn3b_A_18"), (2, "p2p", "tj7a_A_18"), (3, "auto", "xn3b_A_12"),
+    (4, "rccl", "synth:lap3d:nx=40,ny=36,nz=30")])
+def test_driver_ngpus_from_one_process(ngpus, comm, matrix, matrix_path, golden_x):
+    """`driver --solver hip --ngpus N`: the row-partitioned solve BEHIND the
+    reference's backend contract -- one caller process, one hip_cdna4_bench call
+    (src/lsbench-impl.h:42-68, bin/driver.c:5-15); the backend starts one host
+    thread per GPU (hip_multi.c).  Rehearsed on the one GPU of this box: every
+    rank on the caller's device (LSBENCH_HIP_SHARE_DEVICE=1), RCCL's transport
+    under the nccl* symbols replaced by the test double, everything else --
+    operator build, partition, per-rank shard, exchange plan, collectives'
+    sequence, mailboxes reached through peer pointers, kernels, D2H of every
+    rank's rows into the caller's x -- the product's own code."""
+    drv = os.path.join(ROOT, "lsbench_amd", "csrc", "driver")
+    env = _env()
+    env.update(LSBENCH_HIP_SHARE_DEVICE="1", LSBENCH_HIP_COMM=comm, GPU_MAX_HW_QUEUES="8",
+               LSBENCH_HIP_P2P_TIMEOUT_MS="20000")
+    synth = matrix.startswith("synth:")
+    path = matrix if synth else matrix_path(matrix)
+    extra = ["--operator", "raw", "--tol", "1e-10"] if synth else []
+    outs = {}
+    for n in (1, ngpus):
+        r = subprocess.run([drv, "--solver", "hip", "--matrix", path, "--trials=2", "--verbose", "2",
+                            "--ngpus", str(n)] + extra, capture_output=True, text=True, env=env,
+                           timeout=600)
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+        lines = r.stdout.splitlines()
+        f = lines[lines.index("===matrix,n,nnz,trials,solver,ordering,elapsed===") + 1].split(",")
+        h = lines[lines.index("===hip_cdna4:iterations,relres,status,tol,solves_per_sec,nshards===") + 1].split(",")
+        x = np.array([float(l.split("=")[1]) for l in lines if l.startswith("x[")])
+        assert int(f[-4]) == 2 and int(f[-3]) == 6 and len(x) == int(f[-6])  # (a synth: name has commas)
+        assert int(h[2]) == 1 and int(h[5]) == n                   # converged; N shards
+        if n > 1:
+            k = lines.index("===hip_cdna4:ngpus,comm===")
+            got = lines[k + 1].split(",")
+            assert int(got[0]) == n
+            if comm == "rccl":
+                assert got[1] == "rccl"
+            if comm == "p2p":
+                assert got[1].startswith("direct-xgmi")
+        outs[n] = (x, int(h[0]))
+    x1, it1 = outs[1]
+    xn, itn = outs[ngpus]
+    assert abs(it1 - itn) <= max(3, it1 // 50)                      # cg vs single-reduction cg
+    if synth:
+        A = la.lsbench_matrix_synth(matrix[6:])
+        xo, _, _, _ = O.pcg_jacobi(A.offs, A.cols, A.vals, O.rhs(A.nrows), 1e-12)
+        assert np.linalg.norm(xn - xo) / np.linalg.norm(xo) <= 1e-8
+    else:
+        xg = golden_x(matrix)
+        assert np.linalg.norm(xn - xg) / np.linalg.norm(xg) <= 1e-10
+    assert np.linalg.norm(xn - x1) / np.linalg.norm(x1) <= 1e-8
+
+
+def test_hung_collective_ends_with_a_message():
+    """A rank that never shows up must not hang the node: the host-side deadline of
+    the sharded solve (opts.comm_deadline_s) turns it into exit code 1.  Here: two
+    ranks are announced, one of them never joins the all-reduce because the test
+    double is told to stall it."""
+    drv = os.path.join(ROOT, "lsbench_amd", "csrc", "driver")
+    env = _env()
+    env.update(LSBENCH_HIP_SHARE_DEVICE="1", LSBENCH_HIP_COMM="rccl", FAKE_RCCL_STALL_RANK="1",
+               FAKE_RCCL_STALL_AFTER="40", LSBENCH_HIP_COMM_DEADLINE_S="5")
+    r = subprocess.run([drv, "--solver", "hip", "--matrix", "synth:lap2d:nx=300,ny=200", "--operator", "raw",
+                        "--tol", "1e-10", "--trials=1", "--ngpus", "2"], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert r.returncode != 0
+    assert "hung" in r.stderr or "timed out" in r.stderr

@@ -116,3 +116,19 @@ def test_lap3d_64m_rows(hip):
     true = np.linalg.norm(b - O.spmv(A.offs, A.cols, A.vals, xs, threads=thr)) / np.linalg.norm(b)
     assert true <= 2e-6
     s.destroy()
+    del d_b, d_x
+    torch.cuda.empty_cache()
+    # config 4 AS BASELINE.json states it: row-partitioned 8 ways (50 planes of
+    # 400 x 400 per shard, one 1.28 MB plane per neighbour and exchange).  Eight
+    # row-range shards on the one device run the multi-GPU defaults (single-
+    # reduction PCG) over both transports; 30 iterations against the oracle's.
+    xo1, it1, rel1, _ = O.pcg1_jacobi(A.offs, A.cols, A.vals, b, 0.0, 30)
+    for comm in (hip.COMM_RCCL, hip.COMM_P2P):
+        sp = hip.Solver(A, hip.default_opts(op_mode=hip.OP_RAW, tol=0.0, maxit=30, nvirt=8, comm=comm,
+                                            krylov=hip.KRYLOV_AUTO))
+        assert sp.comm[0] == (1 if comm == hip.COMM_RCCL else 3)
+        xp, rp = sp.solve(b)
+        sp.destroy()
+        assert rp.iters == 30 and rp.status == hip.STATUS_MAXIT and it1 == 30
+        assert np.linalg.norm(xp - xo1) / np.linalg.norm(xo1) <= 1e-10
+        assert abs(rp.relres - rel1) <= 1e-9 * rel1

@@ -558,3 +558,21 @@ def test_two_launch_iteration_of_small_operators(hip, graph, matrix_path, golden
     assert np.linalg.norm(out[0][0] - out[1][0]) / np.linalg.norm(xg) <= 1e-11
     assert np.linalg.norm(out[0][2] - out[1][2]) <= 1e-12 * np.linalg.norm(out[1][2])
     assert abs(out[0][3] - out[1][3]) <= 1e-10 * out[1][3]
+
+
+def test_sampled_spmv_on_small_operators(hip, matrix_path, golden_x):
+    """Regression (round-1 advisor): sample_spmv > 0 with the sub-wavefront SpMV
+    used to read HIP events the two-launch iteration never recorded
+    (hipErrorInvalidHandle -> errx).  With sampling on, the solver keeps the
+    three-launch form and returns timed samples."""
+    A = hip.lsbench_matrix_read(matrix_path("xn3b_A_18"))
+    b = O.rhs(A.nrows)
+    xg = golden_x("xn3b_A_18")
+    for variant in (hip.SPMV_SUBWAVE, hip.SPMV_AUTO):
+        s = hip.Solver(A, hip.default_opts(spmv_variant=variant, sample_spmv=5, use_graph=0))
+        x, r = s.solve(b)
+        x2, r2 = s.solve(b)
+        s.destroy()
+        assert r.status == 1 and np.linalg.norm(x - xg) / np.linalg.norm(xg) <= 1e-10
+        assert r.spmv_samples > 10 and 0.0 < r.spmv_ms < 1.0
+        assert r2.iters == r.iters and np.array_equal(x, x2)

@@ -425,6 +425,17 @@ def test_binary_matrix_cache(tmp_path, matrix_path, monkeypatch):
     cache.write_bytes(cache.read_bytes()[:200])
     again = la.lsbench_matrix_read(str(src))
     assert np.array_equal(again.vals, plain.vals)
+    # right size, magic and source stamp, but offsets that go backwards / a column
+    # below the base: rejected like a truncated file, the text is parsed
+    good = cache.read_bytes()
+    hdr = 8 + 8 + 8 + 4 + 4 + 8
+    for pos, val in ((hdr + 4 * 7, np.uint32(plain.offs[9])),          # offs[7] > offs[8]
+                     (hdr + 4 * (plain.nrows + 1) + 4 * 3, np.uint32(0))):  # a column 0 in a base-1 matrix
+        raw = bytearray(good)
+        raw[pos:pos + 4] = val.tobytes()
+        cache.write_bytes(bytes(raw))
+        got = la.lsbench_matrix_read(str(src))
+        assert np.array_equal(got.offs, plain.offs) and np.array_equal(got.cols, plain.cols)
     # a cache directory
     d = tmp_path / "cache"
     d.mkdir()

@@ -134,3 +134,30 @@ def test_hip_pcg1_implicit_u_small_operator(hip, graph):
     _, it17, rel17, st17 = O.pcg1_jacobi(offs, cols, vals, b, tol=1e-12, maxit=17)
     assert r.status == hip.STATUS_MAXIT and r.iters == 17 and st17 == 3
     assert abs(r.relres - rel17) <= 1e-9 * rel17
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nvirt", [1, 3])
+def test_hip_pcg1_maxit_on_a_large_shard(hip, nvirt):
+    """Regression (round-1 advisor): the maxit-th update of the single-reduction
+    form must be applied by EVERY workgroup.  It used to publish LSB_STATUS_MAXIT
+    from inside that launch, so a workgroup starting late skipped its slice and x
+    was a mix of two iterates.  ~1000 workgroups per sweep here; x must be the
+    oracle's iterate at exactly maxit, bit for bit the same from run to run, and
+    the reported residual the one of the LAST update."""
+    L = hip.lsbench_matrix_synth("lap2d:nx=1600,ny=1300")   # 2.08 M rows
+    offs, cols, vals = O.lap2d(1600, 1300)
+    b = O.rhs(L.nrows)
+    for maxit in (7, 40):
+        xo, ito, relo, sto = O.pcg1_jacobi(offs, cols, vals, b, 1e-14, maxit)
+        s = hip.Solver(L, hip.default_opts(op_mode=hip.OP_RAW, krylov=hip.KRYLOV_PCG1, tol=1e-14,
+                                           maxit=maxit, use_graph=0, nvirt=nvirt))
+        xs = []
+        for _ in range(3):
+            x, res = s.solve(b)
+            assert res.status == hip.STATUS_MAXIT and res.iters == maxit == ito and sto == 3
+            assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-11
+            assert abs(res.relres - relo) <= 1e-8 * relo
+            xs.append(x)
+        s.destroy()
+        assert np.array_equal(xs[0], xs[1]) and np.array_equal(xs[0], xs[2])
