@@ -251,6 +251,29 @@ struct lsb_panel_csr {
 };
 struct lsb_panel_csr *lsb_csr_panelize(const struct csr *A, unsigned width);
 void lsb_panel_csr_free(struct lsb_panel_csr *P);
+/* Binned form of a CSR for LSB_SPMV_BINNED (scattered operators: the gather of a
+ * row strays over far more of x than an XCD's 4 MiB L2 holds, so a row-major
+ * sweep fetches a 128-byte line per non-zero).  The entries are binned by column
+ * panel -- `width` consecutive columns, an L2-sized window of x -- and sorted by
+ * row inside a bin (column order inside a row is kept); a bin is streamed as
+ * (row, col, value) triplets and every lane does the same work whatever the row
+ * lengths are.  A bin is cut into CHUNKS of whole (row, bin) runs holding at
+ * most LSB_BIN_CHUNK entries (a longer run is a chunk of its own), so that
+ * exactly one workgroup adds to a given y entry per bin: no atomics, results
+ * bit-identical from run to run. */
+#define LSB_BIN_CHUNK 2048
+struct lsb_binned {
+  unsigned nbins, width, nrows, nchunks;
+  unsigned long long nnz;
+  unsigned *bin_chunk;   /* nbins+1: first chunk of each bin                */
+  unsigned *chunk_begin; /* nchunks+1: first entry of each chunk            */
+  unsigned *rows;        /* nnz: row of each entry (local to A)             */
+  unsigned *cols;        /* nnz: 0-based column                             */
+  double *vals;
+};
+/* NULL when A or width is unusable, or the copy does not fit 32-bit offsets. */
+struct lsb_binned *lsb_csr_binize(const struct csr *A, unsigned width);
+void lsb_binned_free(struct lsb_binned *B);
 /* Sliced-ELL copy of a CSR for LSB_SPMV_SELL: rows in slices of LSB_SELL_ROWS,
  * every slice padded to its longest row and stored column-major (entry j of
  * row 128s+i at sptr[s] + 128j + i), so that a wavefront's lane l reads the

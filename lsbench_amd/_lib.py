@@ -21,6 +21,7 @@ PRECOND_JACOBI, PRECOND_NONE, PRECOND_L1JACOBI, PRECOND_CHEBYSHEV, PRECOND_BLOCK
 KRYLOV_PCG, KRYLOV_GMRES, KRYLOV_PCG1, KRYLOV_AUTO = 0, 1, 2, 3
 SPMV_AUTO, SPMV_ADAPTIVE, SPMV_SUBWAVE, SPMV_SCALAR, SPMV_PANEL, SPMV_SELL, SPMV_BINNED = 0, 1, 2, 3, 4, 5, 6
 SELL_ROWS = 128
+BIN_CHUNK = 2048
 SPMV_FLAG_PREFETCH, SPMV_FLAG_NT, SPMV_FLAG_C16 = 1, 2, 4
 STATUS_RUNNING, STATUS_CONVERGED, STATUS_BREAKDOWN, STATUS_MAXIT = 0, 1, 2, 3
 STATUS_COMM = 4
@@ -83,6 +84,14 @@ class Sell(C.Structure):
                 ("sbase", C.POINTER(C.c_int)), ("ncode_slots", C.c_uint)]
 
 
+class Binned(C.Structure):
+    """struct lsb_binned."""
+    _fields_ = [("nbins", C.c_uint), ("width", C.c_uint), ("nrows", C.c_uint), ("nchunks", C.c_uint),
+                ("nnz", C.c_ulonglong), ("bin_chunk", C.POINTER(C.c_uint)),
+                ("chunk_begin", C.POINTER(C.c_uint)), ("rows", C.POINTER(C.c_uint)),
+                ("cols", C.POINTER(C.c_uint)), ("vals", C.POINTER(C.c_double))]
+
+
 class Xfer(C.Structure):
     """struct lsb_xfer."""
     _fields_ = [("peer", C.c_int), ("offset", C.c_size_t), ("count", C.c_size_t)]
@@ -124,6 +133,8 @@ SIGNATURES = {
     "lsb_csr_bandwidth": (_u, [_csrp]),
     "lsb_csr_panelize": (C.POINTER(PanelCsr), [_csrp, _u]),
     "lsb_panel_csr_free": (None, [C.POINTER(PanelCsr)]),
+    "lsb_csr_binize": (C.POINTER(Binned), [_csrp, _u]),
+    "lsb_binned_free": (None, [C.POINTER(Binned)]),
     "lsb_csr_sell_stored": (C.c_ulonglong, [_csrp]),
     "lsb_csr_sellize": (C.POINTER(Sell), [_csrp]),
     "lsb_csr_sellize16": (C.POINTER(Sell), [_csrp, _u]),

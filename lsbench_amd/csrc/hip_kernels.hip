@@ -1134,9 +1134,170 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_sell16(
   }
 }
 
+// --------------------------------------------------------------------------
+// a2-1, binned form (LSB_SPMV_BINNED, host side lsb_csr_binize) -- for operators
+// whose rows scatter over far more of x than an XCD's L2 holds (power-law
+// config 5: PMC shows 2.7e8 L2 misses per launch of the row-major kernel, one
+// 128-byte line per non-zero, 34 GB of fabric traffic for 3.2 GB of algorithmic
+// bytes).  One launch per BIN = per 2 MiB window of x, so every gather of the
+// launch hits L2 after first touch; inside the bin the entries come as a
+// row-sorted (row, col, value) stream and are cut into chunks of whole rows.
+// A workgroup takes one chunk:
+//   1. all 256 lanes stream 8 entries each (coalesced), gather x, and park
+//      product and row id in LDS;
+//   2. lane t then owns the 8 CONSECUTIVE entries [8t, 8t+8): it adds up the
+//      runs of equal row ids in them -- a run that begins and ends inside is
+//      added to y at once -- and what is left open at either end goes through
+//      a segmented scan over the lanes (wavefront shuffles, then the four
+//      waves through LDS);
+//   3. the lane in which a multi-lane run ends adds carry + its own part to y.
+// Every lane does the same amount of work whatever the row lengths are (the
+// row-blocked kernel's reduce phase serialises on a block's longest row), each
+// y entry is touched by exactly one lane per launch (no atomics), and the order
+// of the additions is fixed by the layout alone: bit-identical run to run.
+// --------------------------------------------------------------------------
+#define BIN_U (LSB_BIN_CHUNK / WG)
+__device__ __forceinline__ unsigned bin_pad(unsigned i) { return i + (i >> 3); }
+
+template <int FLAGS>
+__global__ __launch_bounds__(WG) void k_spmv_binned(
+    const unsigned *__restrict__ chunk_begin, unsigned nchunk, const unsigned *__restrict__ rows,
+    const unsigned *__restrict__ cols, const double *__restrict__ vals,
+    const double *__restrict__ x, double *__restrict__ y, const lsb_pcg_state *__restrict__ st) {
+  __shared__ double sprod[LSB_BIN_CHUNK + LSB_BIN_CHUNK / 8 + 8];
+  __shared__ unsigned skey[LSB_BIN_CHUNK + LSB_BIN_CHUNK / 8 + 8];
+  __shared__ double swv[4];
+  __shared__ int swf[4];
+  __shared__ double sred[4];
+  const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  // XCD-contiguous chunk ids: an XCD's workgroups sweep neighbouring rows of y
+  const unsigned per = gridDim.x / NXCD;
+  const unsigned w = (blockIdx.x % NXCD) * per + blockIdx.x / NXCD;
+  if (w >= nchunk)
+    return;
+  const unsigned e0 = chunk_begin[w], cnt = chunk_begin[w + 1] - e0;
+  unsigned r[BIN_U], c[BIN_U];
+  double v[BIN_U];
+  if (cnt <= LSB_BIN_CHUNK) {
+#pragma unroll
+    for (int u = 0; u < BIN_U; u++) {
+      const unsigned t = tid + u * WG;
+      if (t < cnt) {
+        r[u] = stream_load<FLAGS>(rows + e0 + t);
+        c[u] = stream_load<FLAGS>(cols + e0 + t);
+        v[u] = stream_load<FLAGS>(vals + e0 + t);
+      }
+    }
+  }
+  if (st && st->status)
+    return;
+  if (cnt > LSB_BIN_CHUNK) { // ONE run longer than a chunk: the workgroup strides over it
+    double s[1] = {0.0};
+    for (unsigned j = e0 + tid; j < e0 + cnt; j += WG)
+      s[0] += vals[j] * x[cols[j]];
+    wg_sum<1>(s, sred);
+    if (tid == 0)
+      y[rows[e0]] += s[0];
+    return;
+  }
+#pragma unroll
+  for (int u = 0; u < BIN_U; u++) {
+    const unsigned t = tid + u * WG;
+    if (t < cnt) {
+      sprod[bin_pad(t)] = v[u] * x[c[u]];
+      skey[bin_pad(t)] = r[u];
+    }
+  }
+  __syncthreads();
+  // ---- lane t: entries [8t, 8t+8) -------------------------------------------
+  const unsigned i0 = tid * BIN_U;
+  const int nloc = i0 < cnt ? (int)min(cnt - i0, (unsigned)BIN_U) : 0;
+  double first_sum = 0.0, acc = 0.0;
+  unsigned first_key = 0, last_key = 0, prevk = 0xFFFFFFFFu, nextk = 0xFFFFFFFEu;
+  bool cont = false, has_boundary = false, closes = true;
+  if (nloc > 0) {
+    if (i0 > 0)
+      prevk = skey[bin_pad(i0 - 1)];
+    if (i0 + BIN_U < cnt)
+      nextk = skey[bin_pad(i0 + BIN_U)];
+    unsigned k[BIN_U];
+    double p[BIN_U];
+#pragma unroll
+    for (int j = 0; j < BIN_U; j++)
+      if (j < nloc) {
+        k[j] = skey[bin_pad(i0 + j)];
+        p[j] = sprod[bin_pad(i0 + j)];
+      }
+    cont = k[0] == prevk;
+    first_key = k[0];
+#pragma unroll
+    for (int j = 0; j < BIN_U; j++)
+      if (j < nloc) {
+        if (j > 0 && k[j] != k[j - 1]) { // the run of row k[j-1] ends here
+          if (!has_boundary) {
+            has_boundary = true;
+            first_sum = acc;
+            if (!cont)
+              y[k[j - 1]] += acc; // began at this lane's first entry: complete
+          } else {
+            y[k[j - 1]] += acc; // began and ended inside this lane
+          }
+          acc = 0.0;
+        }
+        acc += p[j];
+        last_key = k[j];
+      }
+    closes = last_key != nextk;
+    // the last run began in this lane and ends with it: complete
+    if (closes && (has_boundary || !cont))
+      y[last_key] += acc;
+  }
+  // ---- what is open at the lane ends: segmented scan over the lanes --------
+  // value = sum of the lane's last run, flag = "a run begins in this lane"
+  double sv = acc;
+  int sf = (has_boundary || !cont) ? 1 : 0;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const double v2 = __shfl_up(sv, d, 64);
+    const int f2 = __shfl_up(sf, d, 64);
+    if ((int)lane >= d) {
+      if (!sf)
+        sv += v2;
+      sf |= f2;
+    }
+  }
+  if (lane == 63)
+    swv[wave] = sv, swf[wave] = sf;
+  __syncthreads();
+  double carry_w = 0.0;
+  for (unsigned q = 0; q < wave; q++)
+    carry_w = swf[q] ? swv[q] : carry_w + swv[q];
+  const double incl = sv + (sf ? 0.0 : carry_w); // sum of the open run up to and including this lane
+  double carry_in = __shfl_up(incl, 1, 64);
+  if (lane == 0)
+    carry_in = carry_w;
+  if (nloc > 0 && cont && (has_boundary || closes))
+    y[first_key] += carry_in + (has_boundary ? first_sum : acc);
+}
+
 extern "C" {
 
 void lsb_k_set_blas1_nt(int on) { g_blas1_nt = on ? 1 : 0; }
+
+/* one bin of the binned form: chunks [c0, c0 + nchunk) */
+void lsb_k_spmv_binned(unsigned flags, const unsigned *chunk_begin, unsigned c0, unsigned nchunk,
+                       const unsigned *rows, const unsigned *cols, const double *vals,
+                       const double *x, double *y, const struct lsb_pcg_state *st, void *stream) {
+  if (!nchunk)
+    return;
+  const unsigned g = (nchunk + NXCD - 1) / NXCD * NXCD;
+  if (flags & SP_NT)
+    k_spmv_binned<SP_NT><<<g, WG, 0, (hipStream_t)stream>>>(chunk_begin + c0, nchunk, rows, cols,
+                                                            vals, x, y, st);
+  else
+    k_spmv_binned<0><<<g, WG, 0, (hipStream_t)stream>>>(chunk_begin + c0, nchunk, rows, cols, vals,
+                                                        x, y, st);
+}
 
 unsigned lsb_k_blas1_grid(unsigned n) {
   // 16 B/lane => WG*2 elements per workgroup per trip.  Up to 256 workgroups

@@ -26,6 +26,8 @@ void choose_spmv(struct shard *s, const struct lsb_hip_opts *o) {
     v = s->nnz <= 500000ull ? LSB_SPMV_SUBWAVE : LSB_SPMV_ADAPTIVE;
   if (v == LSB_SPMV_PANEL && !s->pn)
     v = LSB_SPMV_ADAPTIVE; /* the operator did not qualify for panels */
+  if (v == LSB_SPMV_BINNED && !s->bn)
+    v = LSB_SPMV_ADAPTIVE;
   if (v == LSB_SPMV_SELL && !s->d_sptr)
     v = LSB_SPMV_ADAPTIVE; /* no sliced-ELL copy (32-bit offsets exceeded) */
   s->variant = v;
@@ -75,6 +77,22 @@ static void shard_build_panels(struct shard *s, const struct csr *view, unsigned
   LSB_CHK_HIP(hipStreamSynchronize(g_stream));
   free(rball), free(lanes);
   lsb_panel_csr_free(P);
+}
+
+/* Binned form of the shard (lsb_csr_binize), uploaded as it is. */
+static void shard_build_bins(struct shard *s, const struct csr *view, unsigned width) {
+  struct lsb_binned *B = lsb_csr_binize(view, width);
+  if (!B)
+    return;
+  s->bn = B->nbins;
+  s->h_binchunk = (unsigned *)malloc(((size_t)B->nbins + 1) * sizeof(unsigned));
+  memcpy(s->h_binchunk, B->bin_chunk, ((size_t)B->nbins + 1) * sizeof(unsigned));
+  s->bd_chunk = (unsigned *)dev_upload(B->chunk_begin, ((size_t)B->nchunks + 1) * sizeof(unsigned));
+  s->bd_rows = (unsigned *)dev_upload(B->rows, (size_t)B->nnz * sizeof(unsigned));
+  s->bd_cols = (unsigned *)dev_upload(B->cols, (size_t)B->nnz * sizeof(unsigned));
+  s->bd_vals = (double *)dev_upload(B->vals, (size_t)B->nnz * sizeof(double));
+  LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+  lsb_binned_free(B);
 }
 
 /* Upload rows [r0,r1) of the 0-based operator `S` (global column ids) as one
@@ -148,8 +166,12 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
     const int forced = o->spmv_variant == LSB_SPMV_PANEL;
     const int scattered = s->nnz > 4000000ull && (double)(hi - lo) * 8.0 > 16.0e6 &&
                           lsb_csr_mean_scatter(&gview, row_begin) > 1.0e6;
-    if (width && (forced || (o->spmv_variant == LSB_SPMV_AUTO && scattered)))
+    if (width && (forced || (o->spmv_variant == LSB_SPMV_AUTO && scattered &&
+                             getenv("LSBENCH_HIP_PANELS")))) /* superseded by the binned form */
       shard_build_panels(s, &gview, width);
+    if (width && (o->spmv_variant == LSB_SPMV_BINNED ||
+                  (o->spmv_variant == LSB_SPMV_AUTO && scattered)))
+      shard_build_bins(s, &gview, width);
   }
   /* Near-uniform row lengths (stencils, meshes): also keep a sliced-ELL copy;
    * tune_spmv() keeps whichever kernel is faster on this shard. */
@@ -269,6 +291,9 @@ void shard_free(struct shard *s) {
   lsb_hip_free(s->d_sptr16), lsb_hip_free(s->d_scodes), lsb_hip_free(s->d_sbase);
   lsb_hip_free(s->d_svals16);
   free(s->h_pblk);
+  lsb_hip_free(s->bd_chunk), lsb_hip_free(s->bd_rows), lsb_hip_free(s->bd_cols);
+  lsb_hip_free(s->bd_vals);
+  free(s->h_binchunk);
   free(s->recv), free(s->send);
 }
 
@@ -548,6 +573,17 @@ void spmv_shard(struct shard *s, const double *xfull, double *y,
     sell_launch(s, 0, s->nslice, xfull, y, xdot, partials, np, st);
     return;
   }
+  if (s->variant == LSB_SPMV_BINNED) {
+    /* y = 0, then one launch per bin (= per L2-sized window of x) adds to it */
+    LSB_CHK_HIP(hipMemsetAsync(y, 0, (size_t)s->n * sizeof(double), g_stream));
+    for (unsigned b = 0; b < s->bn; b++)
+      lsb_k_spmv_binned(s->sp_flags, s->bd_chunk, s->h_binchunk[b],
+                        s->h_binchunk[b + 1] - s->h_binchunk[b], s->bd_rows, s->bd_cols, s->bd_vals,
+                        xfull, y, st, g_stream);
+    if (partials)
+      lsb_k_dot(s->n, y, xdot, partials, np, g_stream);
+    return;
+  }
   lsb_k_spmv(s->variant, s->n, s->d_offs, s->d_cols, s->d_vals, s->d_rowblk, s->d_blklanes,
              s->nblk, s->lanes, s->sp_flags, s->sp_grid, xfull, y, xdot, partials, np, st,
              NULL, g_stream);
@@ -578,7 +614,7 @@ void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
   if (s->variant == LSB_SPMV_SELL && !s->d_sptr)
     s->variant = LSB_SPMV_ADAPTIVE; /* the operator did not qualify for the copy */
   if ((s->variant != LSB_SPMV_ADAPTIVE && s->variant != LSB_SPMV_PANEL &&
-       s->variant != LSB_SPMV_SELL) ||
+       s->variant != LSB_SPMV_SELL && s->variant != LSB_SPMV_BINNED) ||
       s->nnz < 4000000ull)
     return; /* small operators are launch-latency bound: nothing to tune */
   float best = 1e30f;
@@ -592,7 +628,7 @@ void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
   struct {
     int v;
     unsigned f, g;
-  } cand[16];
+  } cand[20];
   int ncand = 0;
   const int any = o->spmv_variant == LSB_SPMV_AUTO;
   if (any || s->variant == LSB_SPMV_ADAPTIVE)
@@ -601,6 +637,10 @@ void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
   if (s->pn && (any || s->variant == LSB_SPMV_PANEL))
     for (unsigned f = 0; f < 4; f++)
       cand[ncand].v = LSB_SPMV_PANEL, cand[ncand].f = f, cand[ncand++].g = grid0;
+  if (s->bn && (any || s->variant == LSB_SPMV_BINNED)) {
+    cand[ncand].v = LSB_SPMV_BINNED, cand[ncand].f = LSB_SP_NT, cand[ncand++].g = grid0;
+    cand[ncand].v = LSB_SPMV_BINNED, cand[ncand].f = 0, cand[ncand++].g = grid0;
+  }
   if (s->d_sptr && (any || s->variant == LSB_SPMV_SELL))
     for (unsigned c16 = 0; c16 <= (s->d_scodes ? LSB_SP_C16 : 0u); c16 += LSB_SP_C16) {
       cand[ncand].v = LSB_SPMV_SELL, cand[ncand].f = c16 | LSB_SP_NT, cand[ncand++].g = grid0;
@@ -628,6 +668,11 @@ void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
   s->variant = bv;
   s->sp_flags = bf;
   /* the copies that lost are not kept */
+  if (any && bv != LSB_SPMV_BINNED && s->bn) {
+    lsb_hip_free(s->bd_chunk), lsb_hip_free(s->bd_rows), lsb_hip_free(s->bd_cols);
+    lsb_hip_free(s->bd_vals);
+    s->bd_chunk = s->bd_rows = s->bd_cols = NULL, s->bd_vals = NULL, s->bn = 0;
+  }
   if (!(bv == LSB_SPMV_SELL && (bf & LSB_SP_C16))) {
     lsb_hip_free(s->d_sptr16), lsb_hip_free(s->d_scodes), lsb_hip_free(s->d_sbase);
     lsb_hip_free(s->d_svals16);

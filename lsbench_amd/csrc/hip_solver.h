@@ -91,6 +91,11 @@ struct shard {
   int *pd_offs, *pd_cols, *pd_rowmap, *pd_rowblk;
   unsigned char *pd_blklanes;
   double *pd_vals;
+  /* binned form (LSB_SPMV_BINNED), built for scattered operators only */
+  unsigned bn;         /* bins, 0 = not built */
+  unsigned *h_binchunk; /* bn+1: first chunk of each bin (host) */
+  unsigned *bd_chunk, *bd_rows, *bd_cols;
+  double *bd_vals;
   struct lsb_xfer *recv, *send;
   int nrecv, nsend;
 };

@@ -481,6 +481,86 @@ void lsb_panel_csr_free(struct lsb_panel_csr *P) {
   free(P);
 }
 
+/* ------------------------------------------------------------------------ */
+/* Binned form (LSB_SPMV_BINNED): entries bin-major (bin = col / width), rows   */
+/* ascending inside a bin, column order of a row kept; chunks = whole (row,     */
+/* bin) runs, at most LSB_BIN_CHUNK entries unless one run alone is longer.     */
+/* ------------------------------------------------------------------------ */
+struct lsb_binned *lsb_csr_binize(const struct csr *A, unsigned width) {
+  if (!A || width == 0 || A->nrows == 0)
+    return NULL;
+  const unsigned n = A->nrows, base = A->base;
+  const unsigned long long nnz = A->offs[n];
+  unsigned lo, hi;
+  lsb_csr_col_hull(A, &lo, &hi);
+  const unsigned nb = hi ? (hi - 1) / width + 1 : 1;
+  if (nnz > 0x7FFFFFFEull)
+    return NULL;
+  unsigned long long *cnt = lsb_calloc(unsigned long long, (size_t)nb + 1);
+  for (unsigned long long j = 0; j < nnz; j++)
+    cnt[(A->cols[j] - base) / width + 1]++;
+  for (unsigned b = 0; b < nb; b++)
+    cnt[b + 1] += cnt[b];
+  struct lsb_binned *B = lsb_calloc(struct lsb_binned, 1);
+  B->nbins = nb, B->width = width, B->nrows = n, B->nnz = nnz;
+  B->rows = (unsigned *)malloc((size_t)(nnz ? nnz : 1) * sizeof(unsigned));
+  B->cols = (unsigned *)malloc((size_t)(nnz ? nnz : 1) * sizeof(unsigned));
+  B->vals = (double *)malloc((size_t)(nnz ? nnz : 1) * sizeof(double));
+  unsigned *cur = (unsigned *)malloc((size_t)nb * sizeof(unsigned));
+  if (!B->rows || !B->cols || !B->vals || !cur)
+    errx(EXIT_FAILURE, "out of host memory for the binned operator");
+  for (unsigned b = 0; b < nb; b++)
+    cur[b] = (unsigned)cnt[b];
+  for (unsigned i = 0; i < n; i++) /* row-major sweep: rows ascend inside every bin */
+    for (unsigned j = A->offs[i]; j < A->offs[i + 1]; j++) {
+      const unsigned c = A->cols[j] - base, e = cur[c / width]++;
+      B->rows[e] = i, B->cols[e] = c, B->vals[e] = A->vals[j];
+    }
+  free(cur);
+  /* chunks */
+  size_t cap = (size_t)(nnz / LSB_BIN_CHUNK) * 2 + 2 * (size_t)nb + 16, nc = 0;
+  B->chunk_begin = (unsigned *)malloc((cap + 1) * sizeof(unsigned));
+  B->bin_chunk = lsb_calloc(unsigned, (size_t)nb + 1);
+  for (unsigned b = 0; b < nb; b++) {
+    const unsigned e0 = (unsigned)cnt[b], e1 = (unsigned)cnt[b + 1];
+    B->bin_chunk[b] = (unsigned)nc;
+    unsigned e = e0;
+    while (e < e1) {
+      const unsigned start = e;
+      while (e < e1) {
+        unsigned re = e + 1;
+        while (re < e1 && B->rows[re] == B->rows[e])
+          re++;
+        if (re - start <= LSB_BIN_CHUNK || e == start) {
+          e = re;
+          if (e - start >= LSB_BIN_CHUNK)
+            break;
+        } else
+          break;
+      }
+      if (nc + 2 > cap) {
+        cap *= 2;
+        B->chunk_begin = (unsigned *)realloc(B->chunk_begin, (cap + 1) * sizeof(unsigned));
+        if (!B->chunk_begin)
+          errx(EXIT_FAILURE, "out of host memory for the binned operator");
+      }
+      B->chunk_begin[nc++] = start;
+    }
+  }
+  B->bin_chunk[nb] = (unsigned)nc;
+  B->chunk_begin[nc] = (unsigned)nnz;
+  B->nchunks = (unsigned)nc;
+  free(cnt);
+  return B;
+}
+
+void lsb_binned_free(struct lsb_binned *B) {
+  if (!B)
+    return;
+  free(B->bin_chunk), free(B->chunk_begin), free(B->rows), free(B->cols), free(B->vals);
+  free(B);
+}
+
 /* mean |col - row| over a sample of the rows: how far the gather of a row
  * strays from the diagonal (banded: ~bandwidth; scattered: ~n/3) */
 double lsb_csr_mean_scatter(const struct csr *A, unsigned row_begin) {

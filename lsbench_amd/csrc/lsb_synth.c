@@ -184,6 +184,82 @@ static struct csr *gen_powerlaw(unsigned long long n, double gamma, unsigned dma
   return A;
 }
 
+/* "spd=1": the symmetric positive definite operator SURVEY.md section 8(d) cfg5
+ * defines for CG runs on the power-law structure,
+ *     S = (B + B^T) + diag(1 + sum_j |(B + B^T)_ij|),
+ * strictly diagonally dominant with a positive diagonal.  A row of B^T needs
+ * every row of B, so the whole of B is generated (and freed) whatever the
+ * requested row range is; rows [r0, r1) of S are returned. */
+static struct csr *gen_powerlaw_spd(unsigned long long n, double gamma, unsigned dmax,
+                                    unsigned long long seed, unsigned long long r0,
+                                    unsigned long long r1) {
+  struct csr *B = gen_powerlaw(n, gamma, dmax, seed, 0, n);
+  const unsigned long long nnz = B->offs[n];
+  if (2 * nnz + n > 0xFFFFFFFEull)
+    errx(EXIT_FAILURE, "powerlaw spd=1: operator too large for 32-bit offsets");
+  /* B^T by counting sort: columns of a row of B^T come out ascending */
+  unsigned *toffs = lsb_calloc(unsigned, (size_t)n + 2);
+  for (unsigned long long j = 0; j < nnz; j++)
+    toffs[B->cols[j] + 2]++;
+  for (unsigned long long i = 0; i < n; i++)
+    toffs[i + 2] += toffs[i + 1];
+  unsigned *tcols = (unsigned *)malloc((size_t)(nnz ? nnz : 1) * sizeof(unsigned));
+  double *tvals = (double *)malloc((size_t)(nnz ? nnz : 1) * sizeof(double));
+  if (!tcols || !tvals)
+    errx(EXIT_FAILURE, "out of host memory for the transposed power-law operator");
+  for (unsigned long long i = 0; i < n; i++)
+    for (unsigned j = B->offs[i]; j < B->offs[i + 1]; j++) {
+      const unsigned e = toffs[B->cols[j] + 1]++;
+      tcols[e] = (unsigned)i, tvals[e] = B->vals[j];
+    }
+  /* toffs[i] .. toffs[i+1] is now row i of B^T */
+  struct csr *S = alloc_rows((unsigned)(r1 - r0));
+  unsigned long long *cnt = (unsigned long long *)malloc((size_t)(r1 - r0 + 1) * sizeof *cnt);
+#pragma omp parallel for schedule(dynamic, 4096)
+  for (long long rr = (long long)r0; rr < (long long)r1; rr++) {
+    unsigned a = B->offs[rr], ae = B->offs[rr + 1], b = toffs[rr], be = toffs[rr + 1];
+    unsigned long long c = 0;
+    int diag = 0;
+    while (a < ae || b < be) {
+      const unsigned ca = a < ae ? B->cols[a] : 0xFFFFFFFFu, cb = b < be ? tcols[b] : 0xFFFFFFFFu;
+      const unsigned col = ca < cb ? ca : cb;
+      a += ca == col, b += cb == col;
+      diag |= col == (unsigned)rr;
+      c++;
+    }
+    cnt[rr - (long long)r0] = c + !diag;
+  }
+  alloc_entries(S, cnt);
+  free(cnt);
+#pragma omp parallel for schedule(dynamic, 4096)
+  for (long long rr = (long long)r0; rr < (long long)r1; rr++) {
+    unsigned a = B->offs[rr], ae = B->offs[rr + 1], b = toffs[rr], be = toffs[rr + 1];
+    unsigned z = S->offs[rr - (long long)r0], zd = 0xFFFFFFFFu;
+    double sum = 0.0;
+    while (a < ae || b < be) {
+      const unsigned ca = a < ae ? B->cols[a] : 0xFFFFFFFFu, cb = b < be ? tcols[b] : 0xFFFFFFFFu;
+      const unsigned col = ca < cb ? ca : cb;
+      if (zd == 0xFFFFFFFFu && col > (unsigned)rr) /* the diagonal's place, if B + B^T has none */
+        zd = z, S->cols[z] = (unsigned)rr, S->vals[z++] = 0.0;
+      double v = 0.0;
+      if (ca == col)
+        v += B->vals[a++];
+      if (cb == col)
+        v += tvals[b++];
+      sum += fabs(v);
+      if (col == (unsigned)rr)
+        zd = z;
+      S->cols[z] = col, S->vals[z++] = v;
+    }
+    if (zd == 0xFFFFFFFFu)
+      zd = z, S->cols[z] = (unsigned)rr, S->vals[z++] = 0.0;
+    S->vals[zd] += 1.0 + sum;
+  }
+  free(toffs), free(tcols), free(tvals);
+  lsbench_matrix_free(B);
+  return S;
+}
+
 struct csr *lsbench_matrix_synth(const char *spec, unsigned r0, unsigned r1,
                                  unsigned *n_global) {
   double v;
@@ -233,6 +309,8 @@ struct csr *lsbench_matrix_synth(const char *spec, unsigned r0, unsigned r1,
     return NULL;
   if (n_global)
     *n_global = (unsigned)n;
+  if (kind == 3 && spec_get(spec, "spd", &v) && v != 0.0)
+    return gen_powerlaw_spd(n, gamma, dmax, seed, r0, r1);
   if (kind == 3)
     return gen_powerlaw(n, gamma, dmax, seed, r0, r1);
   return gen_lap(nx, ny, kind == 2 ? nz : 1, kind == 2, r0, r1);

@@ -442,3 +442,83 @@ def test_binary_matrix_cache(tmp_path, matrix_path, monkeypatch):
     monkeypatch.setenv("LSBENCH_MATRIX_CACHE", str(d))
     la.lsbench_matrix_read(str(src))
     assert (d / "m.txt.lsbcsr").exists()
+
+
+@pytest.mark.parametrize("spec,width", [("powerlaw:n=20000,gamma=1.2,max=3000,seed=7", 1024),
+                                        ("powerlaw:n=5000,gamma=1.585350372615855,max=4096,seed=3", 300),
+                                        ("lap2d:nx=70,ny=50", 512)])
+def test_binned_form(spec, width):
+    """lsb_csr_binize (LSB_SPMV_BINNED): a permutation of the entries, bin-major,
+    rows ascending inside a bin, column order of a row kept; chunks hold whole
+    (row, bin) runs, at most BIN_CHUNK entries unless one run alone is longer;
+    y = sum over bins reproduces A x."""
+    import ctypes as C
+    L = la._lib
+    A = la.lsbench_matrix_synth(spec)
+    B = L.load().lsb_csr_binize(A.ptr, width).contents
+    nnz = int(A.nnz)
+    assert (B.nnz, B.nrows, B.width) == (nnz, A.nrows, width)
+    rows = np.ctypeslib.as_array(B.rows, (nnz,)).copy()
+    cols = np.ctypeslib.as_array(B.cols, (nnz,)).copy()
+    vals = np.ctypeslib.as_array(B.vals, (nnz,)).copy()
+    cb = np.ctypeslib.as_array(B.chunk_begin, (B.nchunks + 1,)).copy()
+    bc = np.ctypeslib.as_array(B.bin_chunk, (B.nbins + 1,)).copy()
+    nbins, nchunks = int(B.nbins), int(B.nchunks)
+    L.load().lsb_binned_free(C.pointer(B))
+    offs = A.offs.astype(np.int64)
+    arow = np.repeat(np.arange(A.nrows), np.diff(offs))
+    # the same multiset of (row, col, value)
+    o1 = np.lexsort((A.cols, arow))
+    o2 = np.lexsort((cols, rows))
+    assert np.array_equal(arow[o1], rows[o2]) and np.array_equal(A.cols[o1], cols[o2])
+    assert np.array_equal(A.vals[o1], vals[o2])
+    bins = cols // width
+    assert np.all(np.diff(bins) >= 0)                                   # bin-major
+    same_bin = np.diff(bins) == 0
+    assert np.all(np.diff(rows)[same_bin] >= 0)                         # rows ascend inside a bin
+    same_run = same_bin & (np.diff(rows) == 0)
+    assert np.all(np.diff(cols.astype(np.int64))[same_run] > 0)         # column order kept
+    assert cb[0] == 0 and cb[-1] == nnz and np.all(np.diff(cb) > 0) and bc[0] == 0 and bc[-1] == nchunks
+    for b in range(nbins):                                             # chunks do not straddle bins
+        e0, e1 = cb[bc[b]], cb[bc[b + 1]]
+        assert e0 == e1 or (bins[e0] == b and bins[e1 - 1] == b)
+    for k in range(nchunks):
+        e0, e1 = cb[k], cb[k + 1]
+        if e0 > 0 and bins[e0 - 1] == bins[e0]:
+            assert rows[e0 - 1] != rows[e0]                            # boundary = run boundary
+        if e1 - e0 > L.BIN_CHUNK:
+            assert np.all(rows[e0:e1] == rows[e0])                     # one long run on its own
+    x = np.sin(np.arange(A.nrows, dtype=np.float64))
+    y = np.zeros(A.nrows)
+    np.add.at(y, rows, vals * x[cols])
+    assert np.allclose(y, O.spmv(A.offs, A.cols, A.vals, x), rtol=1e-12, atol=1e-12)
+
+
+def test_powerlaw_spd_variant():
+    """`powerlaw:...,spd=1` (SURVEY.md section 8(d), config 5 for CG runs):
+    S = (B + B^T) + diag(1 + sum_j |(B + B^T)_ij|) against a scipy construction
+    from the ORACLE's generator; any row range equals the rows of the whole."""
+    import scipy.sparse as sp
+    n, dmax, seed = 3000, 700, 11
+    gamma = 1.3
+    thr, _ = O.powerlaw_table(gamma, dmax)
+    o, c, v = O.powerlaw(n, thr, seed)
+    B = sp.csr_matrix((v, c, o.astype(np.int64)), shape=(n, n))
+    T = (B + B.T).tocsr()
+    T.sort_indices()
+    Sref = (T + sp.diags(1.0 + np.asarray(abs(T).sum(axis=1)).ravel())).tocsr()
+    Sref.sort_indices()
+    spec = "powerlaw:n=%d,gamma=%r,max=%d,seed=%d,spd=1" % (n, gamma, dmax, seed)
+    S = la.lsbench_matrix_synth(spec)
+    M = sp.csr_matrix((S.vals, S.cols.astype(np.int64), S.offs.astype(np.int64)), shape=(n, n))
+    assert M.has_sorted_indices and abs(M - M.T).max() == 0.0           # exactly symmetric
+    D = (M - Sref)
+    assert abs(D).max() <= 1e-12 * abs(Sref).max()
+    assert set(zip(*M.nonzero())) >= set(zip(*Sref.nonzero()))
+    d = M.diagonal()
+    assert np.all(d >= 1.0 + (abs(M).sum(axis=1).A1 - np.abs(d)) - 1e-9)  # strictly dominant
+    part = la.lsbench_matrix_synth(spec, 1000, 1800)
+    assert part.n_global == n and part.nrows == 800
+    assert np.array_equal(part.offs, S.offs[1000:1801] - S.offs[1000])
+    assert np.array_equal(part.cols, S.cols[S.offs[1000]:S.offs[1800]])
+    assert np.array_equal(part.vals, S.vals[S.offs[1000]:S.offs[1800]])
