@@ -208,9 +208,13 @@ int lsb_hip_device_count(void);
 /* Host-side matrix helpers (no GPU needed)                                  */
 /* ------------------------------------------------------------------------ */
 
+/* Frees a CSR made by any helper below or by lsbench_matrix_synth (the three
+ * arrays and the struct, like lsbench_matrix_free, src/lsbench-csr.c:101-108;
+ * the backend library does not export the reference's own symbols). */
+void lsb_csr_free(struct csr *A);
 /* The operator CHOLMOD factorises, as a full 0-based CSR (both triangles):
  * restates the triplet construction of src/cholmod-impl.h:5-21.  Caller frees
- * with lsbench_matrix_free. */
+ * with lsb_csr_free (or lsbench_matrix_free: same malloc'd layout). */
 struct csr *lsb_csr_symmetrize_upper(const struct csr *A);
 /* Deep copy with cols rebased to 0. */
 struct csr *lsb_csr_copy_base0(const struct csr *A);

@@ -10,7 +10,10 @@ import os
 import subprocess
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(_CSRC, "liblsbench_hip.so")
+LIB_PATH = os.path.join(_CSRC, "liblsbench_hip.so")    # the backend: the product
+CORE_PATH = os.path.join(_CSRC, "liblsbench_core.so")  # stand-in for the reference's liblsbench (CLI, loader, dispatch)
+CORE_SYMBOLS = ("lsbench_matrix_read", "lsbench_matrix_print", "lsbench_matrix_free", "lsbench_init",
+                "lsbench_get_matrix_name", "lsbench_bench", "lsbench_finalize")
 
 UNIQUE_ID_BYTES = 128
 
@@ -122,6 +125,7 @@ SIGNATURES = {
     "lsb_hip_last_result": (None, [C.POINTER(Result)]),
     "lsb_hip_device_count": (_i, []),
     # host helpers
+    "lsb_csr_free": (None, [_csrp]),
     "lsb_csr_symmetrize_upper": (_csrp, [_csrp]),
     "lsb_csr_copy_base0": (_csrp, [_csrp]),
     "lsb_csr_row_slice": (_csrp, [_csrp, _u, _u]),
@@ -213,10 +217,19 @@ def load():
         raise LsbenchHipError(
             "%s not built: run `make -C lsbench_amd/csrc` or __graft_entry__.build(); "
             "there is no fallback path" % LIB_PATH)
-    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    hip = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    core = C.CDLL(CORE_PATH, mode=C.RTLD_GLOBAL)
+
+    class _Both:
+        """the two libraries behind one namespace: a symbol of include/lsbench.h
+        comes from the stand-in core, everything else from the backend"""
+        pass
+    lib = _Both()
+    lib.hip, lib.core = hip, core
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)  # AttributeError = header/library mismatch
+        fn = getattr(core if name in CORE_SYMBOLS else hip, name)  # AttributeError = header/library mismatch
         fn.restype, fn.argtypes = res, args
+        setattr(lib, name, fn)
     _LIB = lib
     return lib
 

@@ -75,7 +75,7 @@ class Matrix:
 
     def free(self):
         if getattr(self, "_own", None) is None and self._h:
-            L.load().lsbench_matrix_free(self._h)
+            L.load().lsb_csr_free(self._h)
         self._h = None
 
     def __del__(self):

@@ -63,7 +63,7 @@ static void *mg_rank(void *argp) {
   const unsigned r0 = g->bounds[rank], r1 = g->bounds[rank + 1], nl = r1 - r0;
   struct csr *rows = lsb_csr_row_slice(g->S, r0, r1);
   lsb_hip_solver *sv = lsb_hip_solver_create_dist(rows, r0, g->S->nrows, &g->o);
-  lsbench_matrix_free(rows);
+  lsb_csr_free(rows);
   if (!sv)
     errx(EXIT_FAILURE, "hip_cdna4: rank %d cannot set up its shard", rank);
   const size_t bytes = (size_t)nl * sizeof(double);
@@ -169,7 +169,7 @@ int bench_multi(double *x, struct csr *A, const double *r, const struct lsbench 
          : g->comm_mode == 2 ? "direct-xgmi(allreduce)+rccl(halos)"
                              : "rccl");
   fflush(stdout);
-  lsbench_matrix_free(S);
+  lsb_csr_free(S);
   free(g);
   return 0;
 }

@@ -378,7 +378,7 @@ lsb_hip_solver *lsb_hip_solver_create(const struct csr *A,
     if (o.verbose)
       fprintf(stderr, "hip_cdna4: RCM bandwidth %u -> %u\n", lsb_csr_bandwidth(S),
               lsb_csr_bandwidth(Sp));
-    lsbench_matrix_free(S);
+    lsb_csr_free(S);
     S = Sp;
     sv->d_perm = (int *)dev_upload(perm, (size_t)S->nrows * sizeof(int));
     LSB_CHK_HIP(hipStreamSynchronize(g_stream));
@@ -403,7 +403,7 @@ lsb_hip_solver *lsb_hip_solver_create(const struct csr *A,
         sv->agree_halo = (unsigned)sv->sh[q].recv[k].count;
   }
   free(hull), free(bounds);
-  lsbench_matrix_free(S);
+  lsb_csr_free(S);
   solver_finish_setup(sv);
   return sv;
 }

@@ -21,6 +21,13 @@ static struct csr *csr_alloc(unsigned nrows, unsigned long long nnz) {
   return S;
 }
 
+void lsb_csr_free(struct csr *A) {
+  if (!A)
+    return;
+  free(A->offs), free(A->cols), free(A->vals);
+  free(A);
+}
+
 /*
  * The matrix CHOLMOD is given by the reference (src/cholmod-impl.h:5-21): of
  * each row i only the entries with column >= i are kept, as triplets of a

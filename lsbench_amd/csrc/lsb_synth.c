@@ -256,7 +256,7 @@ static struct csr *gen_powerlaw_spd(unsigned long long n, double gamma, unsigned
     S->vals[zd] += 1.0 + sum;
   }
   free(toffs), free(tcols), free(tvals);
-  lsbench_matrix_free(B);
+  lsb_csr_free(B);
   return S;
 }
 
