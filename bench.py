@@ -86,6 +86,17 @@ def parse():
                         "(7-point 400^3, 64 M rows) solved --cfg4-steps times on the same N GPUs -- the "
                         "workload the 8-vs-1 GPU target is stated on; 0 = skip it")
     p.add_argument("--cfg4-steps", type=int, default=2)
+    p.add_argument("--persistent", type=int, default=-1,
+                   help="launch-bound operators: 1 = the whole solve as one persistent launch, 0 = "
+                        "launch per kernel, -1 = whichever the creation-time timing finds faster")
+    p.add_argument("--precond", default="jacobi", choices=["jacobi", "l1", "none", "cheb", "bj"],
+                   help="preconditioner: Jacobi (headline), l1-Jacobi, none, Chebyshev polynomial "
+                        "(--cheb-degree), block-Jacobi (--block-size)")
+    p.add_argument("--cheb-degree", type=int, default=4)
+    p.add_argument("--block-size", type=int, default=8)
+    p.add_argument("--precision", default="fp64", choices=["fp64", "fp32"],
+                   help="fp32 = matrix values stored and streamed as fp32, fp64 vectors and "
+                        "accumulation, fp64 iterative refinement to the same tolerance")
     p.add_argument("--verify", type=int, default=1,
                    help="1 = a solve counts only once ||b - S x|| <= tol ||b|| holds for the residual "
                         "recomputed from x (correction solves inside the timed region if needed)")
@@ -277,7 +288,13 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
                            comm={"auto": la.COMM_AUTO, "rccl": la.COMM_RCCL, "p2p": la.COMM_P2P}[a.comm],
                            krylov={"cg": la.KRYLOV_PCG, "cg1": la.KRYLOV_PCG1,
                                    "auto": la.KRYLOV_AUTO}[a.krylov],
-                           precond=la.PRECOND_NONE if spmv_only else la.PRECOND_JACOBI,
+                           precond=la.PRECOND_NONE if spmv_only else {
+                               "jacobi": la.PRECOND_JACOBI, "l1": la.PRECOND_L1JACOBI,
+                               "none": la.PRECOND_NONE, "cheb": la.PRECOND_CHEBYSHEV,
+                               "bj": la.PRECOND_BLOCKJACOBI}[a.precond],
+                           cheb_degree=a.cheb_degree, block_size=a.block_size,
+                           precision=la.PREC_MIXED if a.precision == "fp32" else la.PREC_FP64,
+                           persistent=a.persistent,
                            verify=1 if (a.verify and a.fixed_iters == 0) else 0)
     if c.dist_on:
         solver = la.Solver(Aloc, opts, row_begin=r0, n_global=n)

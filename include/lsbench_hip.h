@@ -191,6 +191,9 @@ struct lsb_hip_result {
                             (restarts on the recomputed residual) it took   */
   double true_relres;    /* ||b - S x|| / ||b|| recomputed from x (fp64
                             operator); -1 when not computed                 */
+  unsigned spmvs;        /* multiplications by S the solve enqueued up to its
+                            last iteration (outer iterations x (1 + Chebyshev
+                            degree) + set-up ones)                          */
 };
 
 void lsb_hip_opts_default(struct lsb_hip_opts *o);

@@ -68,7 +68,7 @@ class Result(C.Structure):
     _fields_ = [("iters", C.c_uint), ("status", C.c_int), ("relres", C.c_double),
                 ("seconds", C.c_double), ("spmv_ms", C.c_double),
                 ("spmv_samples", C.c_uint), ("corrections", C.c_uint),
-                ("true_relres", C.c_double)]
+                ("true_relres", C.c_double), ("spmvs", C.c_uint)]
 
 
 class PanelCsr(C.Structure):

@@ -118,11 +118,13 @@ __device__ __forceinline__ T stream_load(const T *p) {
     }                                                                          \
   } while (0)
 
-template <int CAP, int FLAGS>
+// VT = double, or float: opts.precision = LSB_PREC_MIXED streams the matrix
+// values as fp32 (4 B instead of 8 B per entry); products and sums stay fp64.
+template <int CAP, int FLAGS, class VT = double>
 __global__ __launch_bounds__(WG, 8) void k_spmv_adaptive(
     const int *__restrict__ rowblk, const unsigned char *__restrict__ blklanes,
     unsigned nblk, const int *__restrict__ offs, const int *__restrict__ cols,
-    const double *__restrict__ vals, const double *__restrict__ x,
+    const VT *__restrict__ vals, const double *__restrict__ x,
     double *__restrict__ y, const double *__restrict__ xdot,
     double *__restrict__ partials, const lsb_pcg_state *__restrict__ st,
     const int *__restrict__ rowmap) {
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(WG, 8) void k_spmv_adaptive(
   constexpr int U = CAP / WG;
   double dot = 0.0;
   int c[U];
-  double v[U];
+  VT v[U];
   int r0 = 0, r1 = 0, j0 = 0, j1 = 0;
   unsigned k = kbeg + slot;
   if (k < kend)
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(WG, 8) void k_spmv_adaptive(
       for (int u = 0; u < U; u++) {
         const int t = (int)tid + u * WG;
         if (t < cnt)
-          sprod[t] = v[u] * x[c[u]];
+          sprod[t] = (double)v[u] * x[c[u]];
       }
       if ((FLAGS & SP_PREFETCH) && k + gx < kend)
         LSB_ISSUE_BLOCK(k + gx);
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(WG, 8) void k_spmv_adaptive(
       // common path 70 % (tests/test_build_resources.py guards that).
       double s[1] = {0.0};
       for (int j = cj0 + (int)tid; j < cj0 + cnt; j += WG)
-        s[0] += vals[j] * x[cols[j]];
+        s[0] += (double)vals[j] * x[cols[j]];
       wg_sum<1>(s, sred);
       if (tid == 0) {
         if (rowmap) {
@@ -229,10 +231,10 @@ __global__ __launch_bounds__(WG, 8) void k_spmv_adaptive(
 // one-wavefront-per-row kernel), rows dealt to workgroups in contiguous,
 // XCD-contiguous chunks; shuffle (DPP) reduction of the L partial sums.
 // --------------------------------------------------------------------------
-template <int L>
+template <int L, class VT = double>
 __global__ __launch_bounds__(WG) void k_spmv_subwave(
     unsigned n, unsigned rows_per_wg, const int *__restrict__ offs,
-    const int *__restrict__ cols, const double *__restrict__ vals,
+    const int *__restrict__ cols, const VT *__restrict__ vals,
     const double *__restrict__ x, double *__restrict__ y,
     const double *__restrict__ xdot, double *__restrict__ partials,
     const lsb_pcg_state *__restrict__ st) {
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(WG) void k_spmv_subwave(
       if (xdot)
         xd = xdot[r];
       for (int j = j0 + (int)l; j < j1; j += L)
-        s += vals[j] * x[cols[j]];
+        s += (double)vals[j] * x[cols[j]];
     }
 #pragma unroll
     for (int off = L >> 1; off > 0; off >>= 1)
@@ -977,10 +979,13 @@ static int g_blas1_nt = 1;
 typedef int i2v __attribute__((ext_vector_type(2)));
 typedef double sell_d2v __attribute__((ext_vector_type(2)));
 #define SELL_U 5
-template <int FLAGS>
+template <class VT> struct vt2;
+template <> struct vt2<double> { typedef double type __attribute__((ext_vector_type(2))); };
+template <> struct vt2<float> { typedef float type __attribute__((ext_vector_type(2))); };
+template <int FLAGS, class VT = double>
 __global__ __launch_bounds__(WG, 6) void k_spmv_sell(
     const unsigned *__restrict__ sptr, unsigned s0, unsigned ns, unsigned n,
-    const int *__restrict__ cols, const double *__restrict__ vals,
+    const int *__restrict__ cols, const VT *__restrict__ vals,
     const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ xdot,
     double *__restrict__ partials, const lsb_pcg_state *__restrict__ st) {
   __shared__ double sred[4];
@@ -995,12 +1000,13 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_sell(
     if (si < ns) {
       const unsigned s = s0 + si;
       const unsigned base = sptr[s], len = (sptr[s + 1] - base) / LSB_SELL_ROWS;
+      typedef typename vt2<VT>::type v2t;
       const i2v *cp = (const i2v *)(cols + base) + lane;
-      const sell_d2v *vp = (const sell_d2v *)(vals + base) + lane;
+      const v2t *vp = (const v2t *)(vals + base) + lane;
       double a0 = 0.0, a1 = 0.0;
       for (unsigned j0 = 0; j0 < len; j0 += SELL_U) {
         i2v c[SELL_U];
-        sell_d2v v[SELL_U];
+        v2t v[SELL_U];
 #pragma unroll
         for (int u = 0; u < SELL_U; u++)
           if (j0 + u < len) {
@@ -1017,8 +1023,8 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_sell(
 #pragma unroll
         for (int u = 0; u < SELL_U; u++)
           if (j0 + u < len) {
-            a0 += v[u].x * x[c[u].x];
-            a1 += v[u].y * x[c[u].y];
+            a0 += (double)v[u].x * x[c[u].x];
+            a1 += (double)v[u].y * x[c[u].y];
           }
       }
       const unsigned row = s * LSB_SELL_ROWS + 2 * lane;
@@ -1055,11 +1061,11 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_sell(
 // one diagonal band, so rows can have padding BETWEEN their entries; padding
 // has value 0 and is recognised by that (no gather, contributes an exact 0).
 typedef short s2v __attribute__((ext_vector_type(2)));
-template <int FLAGS>
+template <int FLAGS, class VT = double>
 __global__ __launch_bounds__(WG, 6) void k_spmv_sell16(
     const unsigned *__restrict__ sptr, unsigned s0, unsigned ns, unsigned n, unsigned row_begin,
     const short *__restrict__ codes, const int *__restrict__ sbase,
-    const double *__restrict__ vals, const double *__restrict__ x, double *__restrict__ y,
+    const VT *__restrict__ vals, const double *__restrict__ x, double *__restrict__ y,
     const double *__restrict__ xdot, double *__restrict__ partials,
     const lsb_pcg_state *__restrict__ st) {
   __shared__ double sred[4];
@@ -1073,15 +1079,16 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_sell16(
     const unsigned si = __builtin_amdgcn_readfirstlane(g * 4 + wave);
     if (si < ns) {
       const unsigned s = s0 + si;
+      typedef typename vt2<VT>::type v2t;
       const unsigned base = sptr[s], len = (sptr[s + 1] - base) / LSB_SELL_ROWS;
-      const sell_d2v *vp = (const sell_d2v *)(vals + base) + lane;
+      const v2t *vp = (const v2t *)(vals + base) + lane;
       const i2v *bp = (const i2v *)sbase + base / LSB_SELL_ROWS; // {base, code slot or -1}
       const unsigned row = s * LSB_SELL_ROWS + 2 * lane;
       const int grow = (int)(row + row_begin);
       double a0 = 0.0, a1 = 0.0;
       for (unsigned j0 = 0; j0 < len; j0 += SELL_U) {
         s2v c[SELL_U];
-        sell_d2v v[SELL_U];
+        v2t v[SELL_U];
         int b[SELL_U];
 #pragma unroll
         for (int u = 0; u < SELL_U; u++)
@@ -1103,11 +1110,11 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_sell16(
 #pragma unroll
         for (int u = 0; u < SELL_U; u++)
           if (j0 + u < len) {
-            const bool p0 = v[u].x != 0.0, p1 = v[u].y != 0.0;
+            const bool p0 = v[u].x != (VT)0, p1 = v[u].y != (VT)0;
             const double t0 = x[p0 ? grow + b[u] + (int)c[u].x : 0];
             const double t1 = x[p1 ? grow + 1 + b[u] + (int)c[u].y : 0];
-            a0 += v[u].x * (p0 ? t0 : 0.0);
-            a1 += v[u].y * (p1 ? t1 : 0.0);
+            a0 += (double)v[u].x * (p0 ? t0 : 0.0);
+            a1 += (double)v[u].y * (p1 ? t1 : 0.0);
           }
       }
       if (row + 1 < n) {
@@ -1204,7 +1211,16 @@ __global__ __launch_bounds__(WG) void k_spmv_binned(
   for (int u = 0; u < BIN_U; u++) {
     const unsigned t = tid + u * WG;
     if (t < cnt) {
-      sprod[bin_pad(t)] = v[u] * x[c[u]];
+      // how the window of x is gathered out of L2 is a tuning flag: plain loads
+      // fill a 128-byte L1 line per gather for 8 bytes used
+      double xv;
+      if (FLAGS & 8)
+        xv = __hip_atomic_load(x + c[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else if (FLAGS & 16)
+        xv = __builtin_nontemporal_load(x + c[u]);
+      else
+        xv = x[c[u]];
+      sprod[bin_pad(t)] = v[u] * xv;
       skey[bin_pad(t)] = r[u];
     }
   }
@@ -1213,44 +1229,58 @@ __global__ __launch_bounds__(WG) void k_spmv_binned(
   const unsigned i0 = tid * BIN_U;
   const int nloc = i0 < cnt ? (int)min(cnt - i0, (unsigned)BIN_U) : 0;
   double first_sum = 0.0, acc = 0.0;
-  unsigned first_key = 0, last_key = 0, prevk = 0xFFFFFFFFu, nextk = 0xFFFFFFFEu;
+  unsigned first_key = 0, prevk = 0xFFFFFFFFu, nextk = 0xFFFFFFFEu;
   bool cont = false, has_boundary = false, closes = true;
+  // runs that END inside this lane and did not begin in an earlier one are added
+  // to y by this lane alone: collect them first, then ALL the loads of y, then
+  // the stores -- a load-add-store chain per run would serialise up to eight
+  // memory round trips per lane (short rows: nearly every entry ends a run)
+  unsigned ok_[BIN_U];
+  double ov[BIN_U];
+  unsigned omask = 0;
   if (nloc > 0) {
     if (i0 > 0)
       prevk = skey[bin_pad(i0 - 1)];
     if (i0 + BIN_U < cnt)
       nextk = skey[bin_pad(i0 + BIN_U)];
-    unsigned k[BIN_U];
+    unsigned k[BIN_U + 1];
     double p[BIN_U];
 #pragma unroll
-    for (int j = 0; j < BIN_U; j++)
-      if (j < nloc) {
-        k[j] = skey[bin_pad(i0 + j)];
-        p[j] = sprod[bin_pad(i0 + j)];
-      }
+    for (int j = 0; j < BIN_U; j++) {
+      k[j] = j < nloc ? skey[bin_pad(i0 + j)] : 0u;
+      p[j] = j < nloc ? sprod[bin_pad(i0 + j)] : 0.0;
+    }
     cont = k[0] == prevk;
     first_key = k[0];
 #pragma unroll
     for (int j = 0; j < BIN_U; j++)
       if (j < nloc) {
-        if (j > 0 && k[j] != k[j - 1]) { // the run of row k[j-1] ends here
-          if (!has_boundary) {
-            has_boundary = true;
-            first_sum = acc;
-            if (!cont)
-              y[k[j - 1]] += acc; // began at this lane's first entry: complete
-          } else {
-            y[k[j - 1]] += acc; // began and ended inside this lane
-          }
-          acc = 0.0;
-        }
         acc += p[j];
-        last_key = k[j];
+        const bool last = j == nloc - 1;
+        const bool ends = last ? (k[j] != nextk) : (k[j + 1] != k[j]);
+        if (last)
+          closes = ends;
+        if (ends) {
+          if (cont && !has_boundary) {
+            first_sum = acc; // the head run: needs the carry of the lanes before
+          } else {
+            omask |= 1u << j;
+            ok_[j] = k[j], ov[j] = acc;
+          }
+          if (!last)
+            has_boundary = true, acc = 0.0;
+        }
       }
-    closes = last_key != nextk;
-    // the last run began in this lane and ends with it: complete
-    if (closes && (has_boundary || !cont))
-      y[last_key] += acc;
+    // (has_boundary = a run begins after this lane's first entry)
+    double yv[BIN_U];
+#pragma unroll
+    for (int j = 0; j < BIN_U; j++)
+      if (omask & (1u << j))
+        yv[j] = y[ok_[j]];
+#pragma unroll
+    for (int j = 0; j < BIN_U; j++)
+      if (omask & (1u << j))
+        y[ok_[j]] = yv[j] + ov[j];
   }
   // ---- what is open at the lane ends: segmented scan over the lanes --------
   // value = sum of the lane's last run, flag = "a run begins in this lane"
@@ -1276,8 +1306,10 @@ __global__ __launch_bounds__(WG) void k_spmv_binned(
   double carry_in = __shfl_up(incl, 1, 64);
   if (lane == 0)
     carry_in = carry_w;
+  // the head run of a lane that continues a run of the lanes before, where it ends
+  // in this lane (inside it, or with its last entry)
   if (nloc > 0 && cont && (has_boundary || closes))
-    y[first_key] += carry_in + (has_boundary ? first_sum : acc);
+    y[first_key] += carry_in + first_sum;
 }
 
 extern "C" {
@@ -1291,12 +1323,23 @@ void lsb_k_spmv_binned(unsigned flags, const unsigned *chunk_begin, unsigned c0,
   if (!nchunk)
     return;
   const unsigned g = (nchunk + NXCD - 1) / NXCD * NXCD;
-  if (flags & SP_NT)
+#define LSB_BINNED(FL)                                                                         \
+  case FL:                                                                                     \
+    k_spmv_binned<FL><<<g, WG, 0, (hipStream_t)stream>>>(chunk_begin + c0, nchunk, rows, cols, \
+                                                         vals, x, y, st);                      \
+    break;
+  switch (flags & (SP_NT | 8u | 16u)) {
+    LSB_BINNED(0)
+    LSB_BINNED(2)
+    LSB_BINNED(8)
+    LSB_BINNED(10)
+    LSB_BINNED(16)
+    LSB_BINNED(18)
+  default:
     k_spmv_binned<SP_NT><<<g, WG, 0, (hipStream_t)stream>>>(chunk_begin + c0, nchunk, rows, cols,
                                                             vals, x, y, st);
-  else
-    k_spmv_binned<0><<<g, WG, 0, (hipStream_t)stream>>>(chunk_begin + c0, nchunk, rows, cols, vals,
-                                                        x, y, st);
+  }
+#undef LSB_BINNED
 }
 
 unsigned lsb_k_blas1_grid(unsigned n) {
@@ -1358,16 +1401,22 @@ void lsb_k_spmv(int variant, unsigned n, const int *offs, const int *cols,
                 const double *x, double *y, const double *xdot,
                 double *partials, unsigned *npartials,
                 const struct lsb_pcg_state *st, const int *rowmap, void *stream) {
+  /* flags & LSB_SP_F32: `vals` points at fp32 values (mixed precision) */
   hipStream_t s = (hipStream_t)stream;
   const unsigned g = lsb_k_spmv_grid(variant, n, nblk, lanes_per_row, grid_cap);
+  const float *vals32 = (const float *)(const void *)vals;
+  const bool f32 = (flags & LSB_SP_F32) != 0;
   if (npartials)
     *npartials = g;
   if (variant == LSB_SPMV_ADAPTIVE) {
-#define LSB_ADAPTIVE(FL)                                                       \
-  case FL:                                                                     \
-    k_spmv_adaptive<LSB_BLOCK_NNZ, FL><<<g, WG, 0, s>>>(                       \
-        rowblk, blklanes, nblk, offs, cols, vals, x, y, xdot, partials, st,    \
-        rowmap);                                                               \
+#define LSB_ADAPTIVE(FL)                                                                 \
+  case FL:                                                                               \
+    if (f32)                                                                             \
+      k_spmv_adaptive<LSB_BLOCK_NNZ, FL, float><<<g, WG, 0, s>>>(                        \
+          rowblk, blklanes, nblk, offs, cols, vals32, x, y, xdot, partials, st, rowmap); \
+    else                                                                                 \
+      k_spmv_adaptive<LSB_BLOCK_NNZ, FL, double><<<g, WG, 0, s>>>(                       \
+          rowblk, blklanes, nblk, offs, cols, vals, x, y, xdot, partials, st, rowmap);   \
     break;
     switch (flags & 3u) {
       LSB_ADAPTIVE(0)
@@ -1380,10 +1429,14 @@ void lsb_k_spmv(int variant, unsigned n, const int *offs, const int *cols,
     const unsigned L = lanes_per_row;
     const unsigned slots = WG / L;
     const unsigned rpw = round_up(div_up(n, g), slots);
-#define LSB_SUBWAVE(LL)                                                        \
-  case LL:                                                                     \
-    k_spmv_subwave<LL><<<g, WG, 0, s>>>(n, rpw, offs, cols, vals, x, y, xdot,  \
-                                        partials, st);                         \
+#define LSB_SUBWAVE(LL)                                                                  \
+  case LL:                                                                               \
+    if (f32)                                                                             \
+      k_spmv_subwave<LL, float><<<g, WG, 0, s>>>(n, rpw, offs, cols, vals32, x, y, xdot, \
+                                                 partials, st);                          \
+    else                                                                                 \
+      k_spmv_subwave<LL, double><<<g, WG, 0, s>>>(n, rpw, offs, cols, vals, x, y, xdot,  \
+                                                  partials, st);                         \
     break;
     switch (L) {
       LSB_SUBWAVE(2)
@@ -1392,8 +1445,12 @@ void lsb_k_spmv(int variant, unsigned n, const int *offs, const int *cols,
       LSB_SUBWAVE(16)
       LSB_SUBWAVE(32)
     default:
-      k_spmv_subwave<64><<<g, WG, 0, s>>>(n, round_up(div_up(n, g), 4), offs, cols, vals,
-                                          x, y, xdot, partials, st);
+      if (f32)
+        k_spmv_subwave<64, float><<<g, WG, 0, s>>>(n, round_up(div_up(n, g), 4), offs, cols, vals32,
+                                                   x, y, xdot, partials, st);
+      else
+        k_spmv_subwave<64, double><<<g, WG, 0, s>>>(n, round_up(div_up(n, g), 4), offs, cols, vals,
+                                                    x, y, xdot, partials, st);
     }
 #undef LSB_SUBWAVE
   } else {
@@ -1445,19 +1502,34 @@ void lsb_k_spmv_sell(unsigned flags, unsigned grid_cap, const unsigned *sptr, un
   if (npartials)
     *npartials = g;
   const int nt = (flags & SP_NT) != 0;
-  if (flags & LSB_SP_C16) {
-    if (nt)
-      k_spmv_sell16<SP_NT><<<g, WG, 0, s>>>(sptr, s0, ns, n, row_begin, (const short *)cols,
-                                            sbase, vals, x, y, xdot, partials, st);
+  const float *vals32 = (const float *)(const void *)vals; /* flags & LSB_SP_F32 */
+#define LSB_SELL16(FL, VT, V)                                                                  \
+  k_spmv_sell16<FL, VT><<<g, WG, 0, s>>>(sptr, s0, ns, n, row_begin, (const short *)cols, sbase, \
+                                         V, x, y, xdot, partials, st)
+#define LSB_SELL32(FL, VT, V)                                                                  \
+  k_spmv_sell<FL, VT><<<g, WG, 0, s>>>(sptr, s0, ns, n, (const int *)cols, V, x, y, xdot,      \
+                                       partials, st)
+  if (flags & LSB_SP_F32) {
+    if (flags & LSB_SP_C16) {
+      if (nt)
+        LSB_SELL16(SP_NT, float, vals32);
+      else
+        LSB_SELL16(0, float, vals32);
+    } else if (nt)
+      LSB_SELL32(SP_NT, float, vals32);
     else
-      k_spmv_sell16<0><<<g, WG, 0, s>>>(sptr, s0, ns, n, row_begin, (const short *)cols, sbase,
-                                        vals, x, y, xdot, partials, st);
+      LSB_SELL32(0, float, vals32);
+  } else if (flags & LSB_SP_C16) {
+    if (nt)
+      LSB_SELL16(SP_NT, double, vals);
+    else
+      LSB_SELL16(0, double, vals);
   } else if (nt)
-    k_spmv_sell<SP_NT><<<g, WG, 0, s>>>(sptr, s0, ns, n, (const int *)cols, vals, x, y, xdot,
-                                        partials, st);
+    LSB_SELL32(SP_NT, double, vals);
   else
-    k_spmv_sell<0><<<g, WG, 0, s>>>(sptr, s0, ns, n, (const int *)cols, vals, x, y, xdot,
-                                    partials, st);
+    LSB_SELL32(0, double, vals);
+#undef LSB_SELL16
+#undef LSB_SELL32
 }
 
 void lsb_k_reduce_final(const double *partials, unsigned nparts, unsigned width,

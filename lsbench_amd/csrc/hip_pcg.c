@@ -18,7 +18,87 @@ static int fuse_p(const lsb_hip_solver *sv);
 static void cg1_enqueue_init(lsb_hip_solver *sv, const double *d_b, double *d_x);
 static void cg1_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int sample);
 
+/* ---- PCG with z = M^-1 r as a vector (Chebyshev, block-Jacobi) -------------
+ * The classic recurrences through the same sweeps: k_pcg_update_xr with a unit
+ * "diagonal" (its own r.r partial sums are superseded), the preconditioner's
+ * launches, k_dot2 for (r.z, r.r), k_pcg_update_p with z in the place of r. */
+static void gen_dot_and_reduce(lsb_hip_solver *sv, int gated, unsigned *np2_out) {
+  unsigned np2 = 0;
+  for (int i = 0; i < sv->nshard; i++) {
+    struct shard *s = &sv->sh[i];
+    lsb_k_dot2(s->n, s->d_r, s->d_z, s->d_parts2, &np2, gated ? s->d_st : NULL, g_stream);
+    if (sv->multi)
+      lsb_k_reduce_final(s->d_parts2, np2, 2, s->d_scal + 1, 0, gated ? s->d_st : NULL, g_stream);
+  }
+  if (sv->multi)
+    allreduce_scal(sv, 1, 2, gated);
+  *np2_out = np2;
+}
+
+static void gen_enqueue_init(lsb_hip_solver *sv, const double *d_b, double *d_x) {
+  unsigned np2 = 0;
+  for (int i = 0; i < sv->nshard; i++) {
+    struct shard *s = &sv->sh[i];
+    const size_t o = s->row_begin - sv->row_first;
+    /* x = 0, r = b (p = b for the moment) */
+    lsb_k_pcg_init(s->n, d_b + o, NULL, 1.0, d_x + o, s->d_r, s->d_pfull + s->row_begin,
+                   s->d_parts2, &np2, g_stream);
+    /* the state of the previous solve must not gate the preconditioner below */
+    LSB_CHK_HIP(hipMemsetAsync(&s->d_st->status, 0, sizeof(int), g_stream));
+  }
+  precond_apply(sv); /* z = M^-1 b */
+  for (int i = 0; i < sv->nshard; i++) {
+    struct shard *s = &sv->sh[i];
+    LSB_CHK_HIP(hipMemcpyAsync(s->d_pfull + s->row_begin, s->d_z, (size_t)s->n * sizeof(double),
+                               hipMemcpyDeviceToDevice, g_stream)); /* p = z */
+  }
+  gen_dot_and_reduce(sv, 0, &np2); /* (b.z, b.b) */
+  for (int i = 0; i < sv->nshard; i++) {
+    struct shard *s = &sv->sh[i];
+    lsb_k_pcg_init_state(s->d_st, sv->multi ? s->d_scal + 1 : s->d_parts2, sv->multi ? 1u : np2,
+                         sv->tol_run, (int)sv->o.maxit, g_stream);
+  }
+}
+
+static void gen_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int sample) {
+  unsigned npq = 0, np2 = 0;
+  if (sv->multi) {
+    exchange_and_spmv(sv, sample);
+    allreduce_pq(sv, 1, 0);
+  } else {
+    struct shard *s = &sv->sh[0];
+    if (sample >= 0)
+      LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample], g_stream));
+    spmv_shard(s, s->d_pfull, s->d_q, s->d_pfull + s->row_begin, s->d_parts_pq, &npq, s->d_st);
+    if (sample >= 0) {
+      LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 1], g_stream));
+      LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 2], g_stream));
+      LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 3], g_stream));
+    }
+  }
+  sv->nspmv++;
+  for (int i = 0; i < sv->nshard; i++) {
+    struct shard *s = &sv->sh[i];
+    const size_t o = s->row_begin - sv->row_first;
+    lsb_k_pcg_update_xr(s->n, s->d_pfull + s->row_begin, s->d_q, NULL, 1.0, d_x + o, s->d_r, s->d_st,
+                        parity, sv->multi ? s->d_scal : s->d_parts_pq, sv->multi ? 1u : npq,
+                        s->d_parts2, &np2, g_stream);
+  }
+  precond_apply(sv);
+  gen_dot_and_reduce(sv, 1, &np2);
+  for (int i = 0; i < sv->nshard; i++) {
+    struct shard *s = &sv->sh[i];
+    lsb_k_pcg_update_p(s->n, s->d_z, NULL, 1.0, s->d_pfull + s->row_begin, s->d_pfull + s->row_begin,
+                       s->d_st, parity, sv->multi ? s->d_scal + 1 : s->d_parts2,
+                       sv->multi ? 1u : np2, g_stream);
+  }
+}
+
 static void pcg_enqueue_init(lsb_hip_solver *sv, const double *d_b, double *d_x) {
+  if (generic_precond(sv)) {
+    gen_enqueue_init(sv, d_b, d_x);
+    return;
+  }
   if (use_cg1(sv)) {
     cg1_enqueue_init(sv, d_b, d_x);
     return;
@@ -54,8 +134,9 @@ static void pcg_enqueue_init(lsb_hip_solver *sv, const double *d_b, double *d_x)
 static int fuse_p(const lsb_hip_solver *sv) {
   /* (not while SpMV launches are being event-timed: the fused launch has no
    * SpMV of its own to bracket, and solve_core reads the sample events) */
-  return !sv->multi && !use_cg1(sv) && sv->sh[0].variant == LSB_SPMV_SUBWAVE &&
-         sv->o.sample_spmv <= 0 && !getenv("LSBENCH_HIP_NO_FUSE_P");
+  return !sv->multi && !use_cg1(sv) && !generic_precond(sv) && !sv->sh[0].mixed &&
+         sv->sh[0].variant == LSB_SPMV_SUBWAVE && sv->o.sample_spmv <= 0 &&
+         !getenv("LSBENCH_HIP_NO_FUSE_P");
 }
 
 static void fused_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int pos) {
@@ -82,6 +163,10 @@ static void fused_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int 
  * events 4*sample .. 4*sample+3.  pos: bit 0 = first, bit 1 = last iteration of
  * the run being enqueued. */
 static void pcg_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int sample, int pos) {
+  if (generic_precond(sv)) {
+    gen_enqueue_iter(sv, d_x, parity, sample);
+    return;
+  }
   if (use_cg1(sv)) {
     cg1_enqueue_iter(sv, d_x, parity, sample);
     return;
@@ -133,6 +218,8 @@ static void pcg_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int sa
 
 /* ---- single-reduction CG (LSB_KRYLOV_PCG1): see k_cg1_update -------------- */
 static int use_cg1(const lsb_hip_solver *sv) {
+  if (generic_precond(sv)) /* z = M^-1 r as a vector: the classic form, see gen_enqueue_iter */
+    return 0;
   if (sv->o.krylov == LSB_KRYLOV_PCG1)
     return 1;
   if (sv->o.krylov != LSB_KRYLOV_AUTO)
@@ -340,7 +427,7 @@ double true_resid2(lsb_hip_solver *sv, const double *d_b, const double *d_x) {
     struct shard *s = &sv->sh[i];
     const size_t o = s->row_begin - sv->row_first;
     unsigned np = 0;
-    spmv_shard(s, s->d_pfull, s->d_q, s->d_pfull + s->row_begin, s->d_parts_pq, &s->npq, NULL);
+    spmv_shard_exact(s, s->d_pfull, s->d_q, s->d_pfull + s->row_begin, s->d_parts_pq, &s->npq, NULL);
     lsb_k_axpy(s->n, s->d_scal + 5, d_b + o, s->d_q, g_stream); /* q = S x - b */
     lsb_k_dot(s->n, s->d_q, s->d_q, s->d_parts_pq, &np, g_stream);
     lsb_k_reduce_final(s->d_parts_pq, np, 1, s->d_scal + 4, 0, NULL, g_stream);
@@ -369,6 +456,113 @@ int lsb_hip_solver_solve_dev(lsb_hip_solver *sv, const double *d_b, double *d_x,
   return rc;
 }
 
+/* ------------------------------------------------------------------------ */
+/* launch-bound operators: one persistent launch per solve (hip_persist.hip)   */
+/* ------------------------------------------------------------------------ */
+static int persist_run(lsb_hip_solver *sv, const double *d_b, double *d_x, double tol, int maxit) {
+  struct shard *s = &sv->sh[0];
+  int dev = 0, khz = 100000;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0)
+    khz = 100000, (void)hipGetLastError();
+  LSB_CHK_HIP(hipMemsetAsync(sv->ps.d_shared, 0, 64, g_stream));
+  return lsb_k_pcg_persist(s->n, sv->ps.G, sv->ps.stride, sv->ps.d_wgrow, s->d_offs, s->d_cols,
+                           s->d_vals, s->d_dinv, d_b, d_x, sv->ps.d_ug, sv->ps.d_shared, s->d_st, tol,
+                           maxit, sv->ps.lanes, 2000ll * khz, g_stream);
+}
+
+/* Does the operator qualify, how are its rows dealt to the workgroups, and (opts.
+ * persistent = -1) which form is faster on THIS operator: 40 iterations each way,
+ * timed at creation -- setup is untimed, like the reference's csr_init. */
+void persist_setup(lsb_hip_solver *sv) {
+  const struct lsb_hip_opts *o = &sv->o;
+  struct shard *s = &sv->sh[0];
+  unsigned nzmax, rmax, gmax;
+  const unsigned nmax = lsb_k_persist_limits(&nzmax, &rmax, &gmax);
+  if (sv->multi || sv->nshard != 1 || o->persistent == 0 || o->sample_spmv > 0 ||
+      o->krylov == LSB_KRYLOV_GMRES || s->n > nmax || s->n < 2 ||
+      (o->precond != LSB_PRECOND_JACOBI && o->precond != LSB_PRECOND_NONE &&
+       o->precond != LSB_PRECOND_L1JACOBI) ||
+      o->precision != LSB_PREC_FP64)
+    return;
+  const char *e = getenv("LSBENCH_HIP_PERSIST_WGS");
+  unsigned G = e ? (unsigned)atoi(e) : 32u;
+  const unsigned need = (unsigned)((s->nnz + nzmax * 3 / 4 - 1) / (nzmax * 3 / 4));
+  if (G < need)
+    G = need;
+  if (G < (s->n + rmax - 1) / rmax)
+    G = (s->n + rmax - 1) / rmax;
+  if (G > s->n / 2)
+    G = s->n / 2 ? s->n / 2 : 1;
+  if (G > gmax || G < 1)
+    return;
+  /* rows to workgroups: contiguous, balanced by non-zeros */
+  int *offs = (int *)malloc(((size_t)s->n + 1) * sizeof(int));
+  unsigned *row = (unsigned *)malloc(((size_t)G + 1) * sizeof(unsigned));
+  LSB_CHK_HIP(hipMemcpy(offs, s->d_offs, ((size_t)s->n + 1) * sizeof(int), hipMemcpyDeviceToHost));
+  int ok = 1;
+  row[0] = 0;
+  for (unsigned g = 1, r = 0; g <= G; g++) {
+    const unsigned long long want = s->nnz * g / G;
+    while (r < s->n && (unsigned long long)offs[r + 1] <= want && s->n - (r + 1) >= G - g)
+      r++;
+    if (g < G && r <= row[g - 1])
+      r = row[g - 1] + 1; /* at least one row each */
+    row[g] = g == G ? s->n : r;
+    ok &= row[g] - row[g - 1] <= rmax && row[g] > row[g - 1] &&
+          (unsigned)(offs[row[g]] - offs[row[g - 1]]) <= nzmax;
+  }
+  free(offs);
+  if (!ok) {
+    free(row);
+    return;
+  }
+  sv->ps.G = G;
+  e = getenv("LSBENCH_HIP_PERSIST_STRIDE"); /* 8: the working workgroups share one XCD */
+  sv->ps.stride = e ? (unsigned)atoi(e) : 1u;
+  if (sv->ps.stride < 1)
+    sv->ps.stride = 1;
+  sv->ps.lanes = s->lanes > 32 ? 32 : s->lanes;
+  sv->ps.d_wgrow = (unsigned *)dev_upload(row, ((size_t)G + 1) * sizeof(unsigned));
+  LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+  free(row);
+  sv->ps.d_ug = (double *)lsb_hip_malloc((size_t)s->n * sizeof(double));
+  sv->ps.d_shared = lsb_hip_malloc(lsb_k_persist_shared_bytes());
+  sv->ps.ok = 1;
+  if (o->persistent > 0) {
+    sv->ps.use = 1;
+    return;
+  }
+  /* auto: 40 iterations of each form on b_i = i, best of 3 */
+  double *d_b = (double *)lsb_hip_malloc((size_t)s->n * sizeof(double));
+  double *d_x = (double *)lsb_hip_malloc((size_t)s->n * sizeof(double));
+  lsb_k_fill_index(s->n, s->row_begin + 1, d_b, g_stream);
+  const struct lsb_hip_opts keep = sv->o;
+  sv->o.tol = 0.0, sv->o.maxit = 40, sv->o.verify = 0;
+  double best[2] = {1e30, 1e30};
+  for (int form = 0; form < 2; form++) {
+    sv->ps.use = form;
+    for (int rep = 0; rep < 4; rep++) {
+      struct lsb_hip_result r;
+      solve_core(sv, d_b, d_x, &r);
+      if (rep && r.seconds < best[form])
+        best[form] = r.seconds;
+      if (form == 1 && r.status == LSB_STATUS_COMM)
+        best[1] = 1e30;
+    }
+  }
+  sv->o = keep;
+  memset(sv->hint_iters, 0, sizeof sv->hint_iters);
+  drop_graphs(sv);
+  sv->ps.us_launches = best[0] * 1e6, sv->ps.us_persist = best[1] * 1e6;
+  sv->ps.use = best[1] < best[0];
+  if (o->verbose)
+    fprintf(stderr, "hip_cdna4: 40 iterations: %.1f us as one persistent launch (%u workgroups), "
+                    "%.1f us as launches -> %s\n", best[1] * 1e6, G, best[0] * 1e6,
+            sv->ps.use ? "persistent" : "launches");
+  lsb_hip_free(d_b), lsb_hip_free(d_x);
+}
+
 /* One CG run from x0 = 0 to sv->tol_run; `round` = 0 for the solve proper, k for
  * its k-th correction run (each keeps its own iteration-count hint: the
  * benchmark protocol repeats the same sequence trial after trial). */
@@ -382,6 +576,29 @@ static int pcg_run(lsb_hip_solver *sv, const double *d_b, double *d_x, struct ls
   unsigned done_iters = 0;
   struct lsb_pcg_state *hst = sv->h_st; /* two pinned slots */
   double t0 = wall_seconds();
+  if (sv->ps.use) {
+    /* one launch, one look at the state it leaves */
+    if (persist_run(sv, d_b, d_x, sv->tol_run, (int)sv->o.maxit) != 0)
+      errx(EXIT_FAILURE, "hip_cdna4: the persistent solve kernel could not be launched");
+    LSB_CHK_HIP(hipMemcpyAsync(&hst[0], sv->sh[0].d_st, sizeof(struct lsb_pcg_state),
+                               hipMemcpyDeviceToHost, g_stream));
+    LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+    if (hst[0].status == LSB_STATUS_COMM) {
+      warnx("hip_cdna4: the persistent solve's workgroups did not all arrive (the device is "
+            "shared?); using the launch-per-kernel form from here on");
+      sv->ps.use = 0;
+      return pcg_run(sv, d_b, d_x, res, round);
+    }
+    struct lsb_hip_result r;
+    memset(&r, 0, sizeof r);
+    r.iters = (unsigned)hst[0].iters, r.status = hst[0].status;
+    r.relres = hst[0].bb > 0.0 ? sqrt(hst[0].rr / hst[0].bb) : 0.0;
+    r.seconds = wall_seconds() - t0, r.true_relres = -1.0;
+    *hint = r.iters;
+    if (res)
+      *res = r;
+    return 0;
+  }
 
 #define ENQUEUE_ITERS(count)                                                   \
   do {                                                                         \
@@ -500,7 +717,17 @@ int solve_core(lsb_hip_solver *sv, const double *d_b, double *d_x,
     return gmres_solve_dev(sv, d_b, d_x, res);
   const double t0 = wall_seconds();
   struct lsb_hip_result r;
-  sv->tol_run = sv->o.tol;
+  /* Mixed precision: the CG runs see S~ = fp32(S) (fp64 vectors and sums) and
+   * are the inner solves of an iterative refinement on the fp64 operator,
+   * x += S~^-1 (b - S x); each is asked for no more than the rounding of the
+   * values lets it deliver (where rounding changed no value -- the Laplacians --
+   * S~ = S and the first run is the whole solve). */
+  const int refine = sv->sh[0].mixed && sv->o.tol > 0.0;
+  int inexact = 0;
+  for (int i = 0; i < sv->nshard; i++)
+    inexact |= sv->sh[i].mixed && !sv->sh[i].exact32;
+  const double floor_tol = inexact ? LSB_MIXED_INNER_TOL : 0.0;
+  sv->tol_run = fmax(sv->o.tol, floor_tol);
   pcg_run(sv, d_b, d_x, &r, 0);
   const double bb = sv->h_st->bb;
   if (sv->p2p_on) {
@@ -518,7 +745,7 @@ int solve_core(lsb_hip_solver *sv, const double *d_b, double *d_x,
       return solve_core(sv, d_b, d_x, res);
     }
   }
-  if (sv->o.verify && r.status == LSB_STATUS_CONVERGED && sv->o.tol > 0.0 && bb > 0.0) {
+  if ((sv->o.verify || refine) && r.status == LSB_STATUS_CONVERGED && sv->o.tol > 0.0 && bb > 0.0) {
     for (int round = 1;; round++) {
       if (r.true_relres < 0.0 || round > 1)
         r.true_relres = sqrt(true_resid2(sv, d_b, d_x) / bb);
@@ -536,7 +763,7 @@ int solve_core(lsb_hip_solver *sv, const double *d_b, double *d_x,
                                    g_stream));
       }
       struct lsb_hip_result rc;
-      sv->tol_run = 0.7 * sv->o.tol / r.true_relres; /* relative to ||S x - b|| */
+      sv->tol_run = fmax(0.7 * sv->o.tol / r.true_relres, floor_tol); /* relative to ||S x - b|| */
       pcg_run(sv, sv->d_vr, sv->d_ve, &rc, round);
       for (int i = 0; i < sv->nshard; i++) {
         struct shard *s = &sv->sh[i];
@@ -556,6 +783,11 @@ int solve_core(lsb_hip_solver *sv, const double *d_b, double *d_x,
     drain_stream(sv, "correction");
   }
   r.seconds = wall_seconds() - t0;
+  {
+    const unsigned m = sv->o.precond == LSB_PRECOND_CHEBYSHEV ? (unsigned)sv->cheb_m : 0u;
+    r.spmvs = r.iters * (1u + m) + (1u + r.corrections) * (m + (use_cg1(sv) || sv->ps.use ? 1u : 0u)) +
+              (r.true_relres >= 0.0 ? 1u + r.corrections : 0u);
+  }
   if (res)
     *res = r;
   g_last = r;

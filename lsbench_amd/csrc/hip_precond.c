@@ -1,0 +1,203 @@
+/*
+ * Host side of the preconditioners that are not a diagonal scaling (kernels:
+ * hip_precond_k.hip): set-up at solver creation
+ * (untimed, like the reference's csr_init / CHOLMOD's factorisation,
+ * src/cholmod-impl.h:25-26) and the launches of one application z = M^-1 r.
+ */
+#define _GNU_SOURCE
+#include "hip_solver.h"
+
+#define DINV(s) ((s)->dinv_uniform ? NULL : (s)->d_dinv), (s)->dinv_const
+
+int generic_precond(const lsb_hip_solver *sv) {
+  return sv->o.precond == LSB_PRECOND_CHEBYSHEV || sv->o.precond == LSB_PRECOND_BLOCKJACOBI;
+}
+
+/* ---- block-Jacobi: dense diagonal blocks out of the shard's rows ------------ */
+/* offs/cols: the shard's local CSR with GLOBAL column ids; blocks are runs of bs
+ * consecutive rows of the shard (a block never reaches into another shard). */
+void precond_shard_blocks(struct shard *s, const int *offs, const int *cols, const double *vals,
+                          const struct lsb_hip_opts *o) {
+  if (o->precond != LSB_PRECOND_BLOCKJACOBI)
+    return;
+  unsigned bs = o->block_size < 1 ? 1u : (unsigned)o->block_size;
+  if (bs > s->n)
+    bs = s->n;
+  if ((unsigned long long)s->n * bs > (1ull << 31))
+    errx(EXIT_FAILURE, "hip_cdna4: block-Jacobi with %u-row blocks on %u rows needs %.1f GB; "
+                       "choose a smaller --block-size", bs, s->n, (double)s->n * bs * 8e-9);
+  const size_t total = (size_t)s->n * bs;
+  double *blk = (double *)calloc(total ? total : 1, sizeof(double));
+  if (!blk)
+    errx(EXIT_FAILURE, "hip_cdna4: out of host memory for the block-Jacobi blocks");
+  for (unsigned i = 0; i < s->n; i++) {
+    const unsigned k = i / bs, il = i % bs, m = s->n - k * bs < bs ? s->n - k * bs : bs;
+    const long long c0 = (long long)s->row_begin + (long long)k * bs;
+    for (int j = offs[i]; j < offs[i + 1]; j++) {
+      const long long c = (long long)cols[j] - c0;
+      if (c >= 0 && c < (long long)m)
+        blk[(size_t)k * bs * bs + (size_t)il * m + (size_t)c] = vals[j];
+    }
+  }
+  for (unsigned i = 0; i < s->n; i++) { /* an empty diagonal would make a block singular */
+    const unsigned k = i / bs, il = i % bs, m = s->n - k * bs < bs ? s->n - k * bs : bs;
+    if (blk[(size_t)k * bs * bs + (size_t)il * m + il] == 0.0)
+      errx(EXIT_FAILURE, "hip_cdna4: row %u has no non-zero diagonal entry; block-Jacobi needs one",
+           s->row_begin + i);
+  }
+  s->bj_bs = bs;
+  s->d_binv = (double *)dev_upload(blk, total * sizeof(double));
+  double *scratch = (double *)lsb_hip_malloc(2 * (size_t)s->n * sizeof(double));
+  lsb_k_bj_invert(s->n, bs, s->d_binv, scratch, g_stream);
+  LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+  lsb_hip_free(scratch);
+  free(blk);
+  const unsigned nch = lsb_k_bj_chunks(bs);
+  if (nch)
+    s->d_bjpart = (double *)lsb_hip_malloc((size_t)nch * s->n * sizeof(double));
+}
+
+/* sum over all shards (of all ranks) of a_i . b_i, on the host; set-up only */
+static double global_dot(lsb_hip_solver *sv, double *const *a, double *const *b) {
+  for (int i = 0; i < sv->nshard; i++) {
+    struct shard *s = &sv->sh[i];
+    unsigned np = 0;
+    lsb_k_dot(s->n, a[i], b[i], s->d_parts_pq, &np, g_stream);
+    lsb_k_reduce_final(s->d_parts_pq, np, 1, s->d_scal + 4, 0, NULL, g_stream);
+  }
+  const int on = sv->p2p_on, halo = sv->p2p_halo;
+  sv->p2p_on = sv->p2p_halo = 0; /* set-up talks over RCCL / device copies */
+  allreduce_scal(sv, 4, 1, 0);
+  sv->p2p_on = on, sv->p2p_halo = halo;
+  double v = 0.0;
+  LSB_CHK_HIP(hipMemcpyAsync(&v, sv->sh[0].d_scal + 4, sizeof v, hipMemcpyDeviceToHost, g_stream));
+  LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+  return v;
+}
+
+/* exchange + SpMV on the gather vector `full` of every shard (own rows at
+ * full + row_begin): y_i = (S v)_i */
+static void op_apply(lsb_hip_solver *sv, int which_z, double *const *y, int gated) {
+  /* the exchange routines work on shard.d_pfull: lend them the other vector */
+  for (int i = 0; i < sv->nshard && which_z; i++) {
+    double *t = sv->sh[i].d_pfull;
+    sv->sh[i].d_pfull = sv->sh[i].d_zfull, sv->sh[i].d_zfull = t;
+  }
+  if (sv->multi) {
+    const int on = sv->p2p_on, halo = sv->p2p_halo;
+    if (!gated)
+      sv->p2p_on = sv->p2p_halo = 0;
+    exchange_p(sv, gated);
+    sv->p2p_on = on, sv->p2p_halo = halo;
+  }
+  for (int i = 0; i < sv->nshard; i++) {
+    struct shard *s = &sv->sh[i];
+    spmv_shard(s, s->d_pfull, y[i], NULL, NULL, NULL, gated ? s->d_st : NULL);
+  }
+  for (int i = 0; i < sv->nshard && which_z; i++) {
+    double *t = sv->sh[i].d_pfull;
+    sv->sh[i].d_pfull = sv->sh[i].d_zfull, sv->sh[i].d_zfull = t;
+  }
+}
+
+#define CHEB_POWER_ITS 20
+#define CHEB_SAFETY 1.1
+#define CHEB_RATIO 30.0
+
+void precond_setup(lsb_hip_solver *sv) {
+  if (!generic_precond(sv))
+    return;
+  for (int i = 0; i < sv->nshard; i++) {
+    struct shard *s = &sv->sh[i];
+    /* z lives in a gather vector of its own: Chebyshev multiplies it by S */
+    const size_t len = sv->o.precond == LSB_PRECOND_CHEBYSHEV ? (size_t)sv->n_glob : (size_t)s->n;
+    s->d_zfull = (double *)lsb_hip_malloc(len * sizeof(double));
+    LSB_CHK_HIP(hipMemsetAsync(s->d_zfull, 0, len * sizeof(double), g_stream));
+    s->d_z = sv->o.precond == LSB_PRECOND_CHEBYSHEV ? s->d_zfull + s->row_begin : s->d_zfull;
+    if (sv->o.precond == LSB_PRECOND_CHEBYSHEV)
+      s->d_chd = (double *)lsb_hip_malloc((size_t)s->n * sizeof(double));
+  }
+  if (sv->o.precond != LSB_PRECOND_CHEBYSHEV)
+    return;
+  int m = sv->o.cheb_degree;
+  m = m < 1 ? 1 : (m > LSB_CHEB_MAX ? LSB_CHEB_MAX : m);
+  sv->cheb_m = m;
+  /* lmax of D^-1 S by power iteration: v <- D^-1 S v / ||.||, 20 steps from a
+   * fixed start vector, then 10 % on top (an underestimate would make the
+   * polynomial grow beyond the interval) */
+  double **v = lsb_calloc(double *, sv->nshard), **w = lsb_calloc(double *, sv->nshard);
+  for (int i = 0; i < sv->nshard; i++) {
+    struct shard *s = &sv->sh[i];
+    v[i] = s->d_z, w[i] = s->d_q;
+    lsb_k_power_start(s->n, s->row_begin, v[i], g_stream);
+  }
+  double lam = 1.0, vv = global_dot(sv, v, v);
+  for (int it = 0; it < CHEB_POWER_ITS; it++) {
+    op_apply(sv, 1, w, 0);
+    for (int i = 0; i < sv->nshard; i++) /* w <- D^-1 w, in place through the scaling kernel */
+      lsb_k_scale_dinv(sv->sh[i].n, 1.0, sv->sh[i].d_dinv, w[i], w[i], g_stream);
+    const double ww = global_dot(sv, w, w);
+    if (!(ww > 0.0) || !(vv > 0.0))
+      break;
+    lam = sqrt(ww / vv);
+    const double c = 1.0 / sqrt(ww);
+    for (int i = 0; i < sv->nshard; i++) { /* v = w / ||w|| */
+      struct shard *s = &sv->sh[i];
+      LSB_CHK_HIP(hipMemcpyAsync(v[i], w[i], (size_t)s->n * sizeof(double), hipMemcpyDeviceToDevice,
+                                 g_stream));
+      lsb_k_scale_vec(s->n, c, v[i], g_stream);
+    }
+    vv = 1.0;
+  }
+  free(v), free(w);
+  sv->cheb_lmax = CHEB_SAFETY * lam, sv->cheb_lmin = sv->cheb_lmax / CHEB_RATIO;
+  const double theta = 0.5 * (sv->cheb_lmax + sv->cheb_lmin), delta = 0.5 * (sv->cheb_lmax - sv->cheb_lmin);
+  const double sigma = theta / delta;
+  double rho = 1.0 / sigma;
+  sv->cheb_c0 = 1.0 / theta;
+  for (int k = 0; k < m; k++) {
+    const double rho_new = 1.0 / (2.0 * sigma - rho);
+    sv->cheb_a[k] = rho_new * rho, sv->cheb_b[k] = 2.0 * rho_new / delta;
+    rho = rho_new;
+  }
+  if (sv->o.verbose)
+    fprintf(stderr, "hip_cdna4: Chebyshev preconditioner, degree %d on [%.4g, %.4g] (lmax of D^-1 S by "
+                    "%d power iterations: %.6g)\n", m, sv->cheb_lmin, sv->cheb_lmax, CHEB_POWER_ITS, lam);
+  for (int i = 0; i < sv->nshard; i++)
+    LSB_CHK_HIP(hipMemsetAsync(sv->sh[i].d_zfull, 0, (size_t)sv->n_glob * sizeof(double), g_stream));
+  LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+}
+
+/* z = M^-1 r on every shard (r = shard.d_r, z = shard.d_z); part of a running
+ * solve: launches no-op once its state has left RUNNING */
+void precond_apply(lsb_hip_solver *sv) {
+  if (sv->o.precond == LSB_PRECOND_BLOCKJACOBI) {
+    for (int i = 0; i < sv->nshard; i++) {
+      struct shard *s = &sv->sh[i];
+      lsb_k_bj_apply(s->n, s->bj_bs, s->d_binv, s->d_r, s->d_z, s->d_bjpart, s->d_st, g_stream);
+    }
+    return;
+  }
+  for (int i = 0; i < sv->nshard; i++) {
+    struct shard *s = &sv->sh[i];
+    lsb_k_cheb_first(s->n, s->d_r, DINV(s), sv->cheb_c0, s->d_chd, s->d_z, s->d_st, g_stream);
+  }
+  double *w[64];
+  if (sv->nshard > 64)
+    errx(EXIT_FAILURE, "hip_cdna4: more than 64 shards");
+  for (int i = 0; i < sv->nshard; i++)
+    w[i] = sv->sh[i].d_q;
+  for (int k = 0; k < sv->cheb_m; k++) {
+    op_apply(sv, 1, w, 1);
+    sv->nspmv++;
+    for (int i = 0; i < sv->nshard; i++) {
+      struct shard *s = &sv->sh[i];
+      lsb_k_cheb_step(s->n, s->d_r, s->d_q, DINV(s), sv->cheb_a[k], sv->cheb_b[k], s->d_chd, s->d_z,
+                      s->d_st, g_stream);
+    }
+  }
+}
+
+void precond_free_shard(struct shard *s) {
+  lsb_hip_free(s->d_binv), lsb_hip_free(s->d_bjpart), lsb_hip_free(s->d_zfull), lsb_hip_free(s->d_chd);
+}

@@ -95,6 +95,25 @@ static void shard_build_bins(struct shard *s, const struct csr *view, unsigned w
   lsb_binned_free(B);
 }
 
+/* fp32 copy of a value array on the device; *exact &= "no value changed" */
+static float *upload_f32(const double *v, size_t cnt, int *exact) {
+  float *f = (float *)malloc((cnt ? cnt : 1) * sizeof(float));
+  if (!f)
+    errx(EXIT_FAILURE, "hip_cdna4: out of host memory for the fp32 matrix values");
+  int same = 1;
+#pragma omp parallel for reduction(& : same) schedule(static)
+  for (long long i = 0; i < (long long)cnt; i++) {
+    f[i] = (float)v[i];
+    same &= (double)f[i] == v[i];
+  }
+  if (exact)
+    *exact &= same;
+  float *d = (float *)dev_upload(f, (cnt ? cnt : 1) * sizeof(float));
+  LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+  free(f);
+  return d;
+}
+
 /* Upload rows [r0,r1) of the 0-based operator `S` (global column ids) as one
  * shard.  When `S` holds only the shard's rows, pass local=1. */
 void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
@@ -127,6 +146,9 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
   s->d_offs = (int *)dev_upload(offs, ((size_t)n + 1) * sizeof(int));
   s->d_cols = (int *)dev_upload(cols, (size_t)s->nnz * sizeof(int));
   s->d_vals = (double *)dev_upload(S->vals + j0, (size_t)s->nnz * sizeof(double));
+  s->mixed = o->precision == LSB_PREC_MIXED, s->exact32 = 1;
+  if (s->mixed)
+    s->d_vals32 = upload_f32(S->vals + j0, (size_t)s->nnz, &s->exact32);
   /* row blocks of the adaptive kernel, on the local offsets */
   struct csr view = {n, 0, (unsigned *)offs, NULL, NULL};
   unsigned *rb = NULL;
@@ -186,7 +208,8 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
       s->nslice = E->nslice;
       s->d_sptr = (unsigned *)dev_upload(E->sptr, ((size_t)E->nslice + 1) * sizeof(unsigned));
       s->d_scols = (int *)dev_upload(E->cols, ((size_t)E->stored + LSB_SELL_ROWS) * sizeof(int));
-      s->d_svals = (double *)dev_upload(E->vals, ((size_t)E->stored + LSB_SELL_ROWS) * sizeof(double));
+      s->d_svals = s->mixed ? (double *)upload_f32(E->vals, (size_t)E->stored + LSB_SELL_ROWS, NULL)
+                            : (double *)dev_upload(E->vals, ((size_t)E->stored + LSB_SELL_ROWS) * sizeof(double));
       const int row_end = (int)(row_begin + n);
       unsigned s1 = 0, s2 = E->nslice;
       int ok = 1;
@@ -217,12 +240,14 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
         s->d_sptr16 = (unsigned *)dev_upload(H->sptr, ((size_t)H->nslice + 1) * sizeof(unsigned));
         s->d_scodes = (short *)dev_upload(H->codes, ((size_t)H->ncode_slots + 1) * LSB_SELL_ROWS * sizeof(short));
         s->d_sbase = (int *)dev_upload(H->sbase, 2 * ((size_t)H->stored / LSB_SELL_ROWS + 1) * sizeof(int));
-        s->d_svals16 = (double *)dev_upload(H->vals, ((size_t)H->stored + LSB_SELL_ROWS) * sizeof(double));
+        s->d_svals16 = s->mixed ? (double *)upload_f32(H->vals, (size_t)H->stored + LSB_SELL_ROWS, NULL)
+                                : (double *)dev_upload(H->vals, ((size_t)H->stored + LSB_SELL_ROWS) * sizeof(double));
         LSB_CHK_HIP(hipStreamSynchronize(g_stream));
         lsb_sell_free(H);
       }
     }
   }
+  precond_shard_blocks(s, offs, cols, S->vals + j0, o); /* block-Jacobi: dense diagonal blocks */
   LSB_CHK_HIP(hipStreamSynchronize(g_stream)); /* host staging is freed next */
   free(rb), free(offs), free(cols), free(lanes);
 
@@ -241,7 +266,8 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
   LSB_CHK_HIP(hipMemsetAsync(s->d_st_aux, 0, sizeof(struct lsb_pcg_state), g_stream));
   choose_spmv(s, o);
 
-  if (o->precond == LSB_PRECOND_JACOBI || o->precond == LSB_PRECOND_L1JACOBI) {
+  if (o->precond == LSB_PRECOND_JACOBI || o->precond == LSB_PRECOND_L1JACOBI ||
+      o->precond == LSB_PRECOND_CHEBYSHEV) { /* Chebyshev is a polynomial in D^-1 S */
     int *d_nz = (int *)lsb_hip_malloc(sizeof(int)), nz = 0;
     LSB_CHK_HIP(hipMemsetAsync(d_nz, 0, sizeof(int), g_stream));
     if (o->precond == LSB_PRECOND_L1JACOBI)
@@ -279,7 +305,7 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
 }
 
 void shard_free(struct shard *s) {
-  lsb_hip_free(s->d_offs), lsb_hip_free(s->d_cols), lsb_hip_free(s->d_vals);
+  lsb_hip_free(s->d_offs), lsb_hip_free(s->d_cols), lsb_hip_free(s->d_vals), lsb_hip_free(s->d_vals32);
   lsb_hip_free(s->d_rowblk), lsb_hip_free(s->d_blklanes);
   lsb_hip_free(s->d_dinv), lsb_hip_free(s->d_r);
   lsb_hip_free(s->d_q), lsb_hip_free(s->d_pfull), lsb_hip_free(s->d_parts_pq);
@@ -294,6 +320,7 @@ void shard_free(struct shard *s) {
   lsb_hip_free(s->bd_chunk), lsb_hip_free(s->bd_rows), lsb_hip_free(s->bd_cols);
   lsb_hip_free(s->bd_vals);
   free(s->h_binchunk);
+  precond_free_shard(s);
   free(s->recv), free(s->send);
 }
 
@@ -350,7 +377,9 @@ void solver_finish_setup(lsb_hip_solver *sv) {
     }
     sv->cg1_implicit = same;
   }
+  precond_setup(sv);
   p2p_setup(sv);
+  persist_setup(sv);
 }
 
 lsb_hip_solver *lsb_hip_solver_create(const struct csr *A,
@@ -504,6 +533,7 @@ void lsb_hip_solver_destroy(lsb_hip_solver *sv) {
   }
   lsb_hip_free(sv->d_scal_all), lsb_hip_free(sv->d_tmp);
   lsb_hip_free(sv->d_vr), lsb_hip_free(sv->d_ve);
+  lsb_hip_free(sv->ps.d_wgrow), lsb_hip_free(sv->ps.d_ug), lsb_hip_free(sv->ps.d_shared);
   lsb_hip_free(sv->d_perm), lsb_hip_free(sv->d_bp), lsb_hip_free(sv->d_xp);
   for (int i = 0; sv->gm && i < sv->nshard; i++) {
     lsb_hip_free(sv->gm[i].V), lsb_hip_free(sv->gm[i].parts);
@@ -543,11 +573,12 @@ int lsb_hip_solver_comm(const lsb_hip_solver *s, double *p2p_us, double *rccl_us
 void sell_launch(struct shard *s, unsigned s0, unsigned ns, const double *xfull, double *y,
                         const double *xdot, double *partials, unsigned *np,
                         const struct lsb_pcg_state *st) {
+  const unsigned f32 = s->mixed ? LSB_SP_F32 : 0u; /* the value arrays hold floats then */
   if ((s->sp_flags & LSB_SP_C16) && s->d_scodes)
-    lsb_k_spmv_sell(s->sp_flags, s->sp_grid, s->d_sptr16, s0, ns, s->n, s->row_begin, s->d_scodes,
+    lsb_k_spmv_sell(s->sp_flags | f32, s->sp_grid, s->d_sptr16, s0, ns, s->n, s->row_begin, s->d_scodes,
                     s->d_sbase, s->d_svals16, xfull, y, xdot, partials, np, st, g_stream);
   else
-    lsb_k_spmv_sell(s->sp_flags & ~LSB_SP_C16, s->sp_grid, s->d_sptr, s0, ns, s->n, s->row_begin,
+    lsb_k_spmv_sell((s->sp_flags & ~LSB_SP_C16) | f32, s->sp_grid, s->d_sptr, s0, ns, s->n, s->row_begin,
                     s->d_scols, NULL, s->d_svals, xfull, y, xdot, partials, np, st, g_stream);
 }
 
@@ -584,9 +615,22 @@ void spmv_shard(struct shard *s, const double *xfull, double *y,
       lsb_k_dot(s->n, y, xdot, partials, np, g_stream);
     return;
   }
-  lsb_k_spmv(s->variant, s->n, s->d_offs, s->d_cols, s->d_vals, s->d_rowblk, s->d_blklanes,
-             s->nblk, s->lanes, s->sp_flags, s->sp_grid, xfull, y, xdot, partials, np, st,
-             NULL, g_stream);
+  const int f32 = s->mixed && (s->variant == LSB_SPMV_ADAPTIVE || s->variant == LSB_SPMV_SUBWAVE);
+  lsb_k_spmv(s->variant, s->n, s->d_offs, s->d_cols, f32 ? (const double *)s->d_vals32 : s->d_vals,
+             s->d_rowblk, s->d_blklanes, s->nblk, s->lanes, s->sp_flags | (f32 ? LSB_SP_F32 : 0u),
+             s->sp_grid, xfull, y, xdot, partials, np, st, NULL, g_stream);
+}
+
+void spmv_shard_exact(struct shard *s, const double *xfull, double *y, const double *xdot,
+                      double *partials, unsigned *np, const struct lsb_pcg_state *st) {
+  if (!s->mixed) {
+    spmv_shard(s, xfull, y, xdot, partials, np, st);
+    return;
+  }
+  /* the CSR arrays always stay: row-blocked kernel (sub-wavefront for small operators) */
+  const int v = s->nnz <= 500000ull ? LSB_SPMV_SUBWAVE : LSB_SPMV_ADAPTIVE;
+  lsb_k_spmv(v, s->n, s->d_offs, s->d_cols, s->d_vals, s->d_rowblk, s->d_blklanes, s->nblk, s->lanes,
+             LSB_SP_PREFETCH | LSB_SP_NT, 0, xfull, y, xdot, partials, np, st, NULL, g_stream);
 }
 
 /*
@@ -608,7 +652,8 @@ void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
   s->sp_flags = LSB_SP_PREFETCH | LSB_SP_NT;
   s->sp_grid = o->spmv_grid > 0 ? (unsigned)o->spmv_grid : LSB_MAX_PARTIALS;
   if (o->spmv_tune >= 0) {
-    s->sp_flags = (unsigned)o->spmv_tune & 7u; /* bit 2: 16-bit codes, where that copy exists */
+    s->sp_flags = (unsigned)o->spmv_tune & 31u; /* bit 2: 16-bit codes, where that copy exists;
+                                                   bits 3, 4: binned form's gather flavour */
     return;
   }
   if (s->variant == LSB_SPMV_SELL && !s->d_sptr)
@@ -628,7 +673,7 @@ void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
   struct {
     int v;
     unsigned f, g;
-  } cand[20];
+  } cand[24];
   int ncand = 0;
   const int any = o->spmv_variant == LSB_SPMV_AUTO;
   if (any || s->variant == LSB_SPMV_ADAPTIVE)
@@ -638,8 +683,10 @@ void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
     for (unsigned f = 0; f < 4; f++)
       cand[ncand].v = LSB_SPMV_PANEL, cand[ncand].f = f, cand[ncand++].g = grid0;
   if (s->bn && (any || s->variant == LSB_SPMV_BINNED)) {
-    cand[ncand].v = LSB_SPMV_BINNED, cand[ncand].f = LSB_SP_NT, cand[ncand++].g = grid0;
-    cand[ncand].v = LSB_SPMV_BINNED, cand[ncand].f = 0, cand[ncand++].g = grid0;
+    /* stream loads {nontemporal, plain} x gather of x {plain, L1-bypassing, nontemporal} */
+    static const unsigned bf[] = {LSB_SP_NT, 0, LSB_SP_NT | 8u, 8u, LSB_SP_NT | 16u};
+    for (unsigned k = 0; k < sizeof bf / sizeof bf[0]; k++)
+      cand[ncand].v = LSB_SPMV_BINNED, cand[ncand].f = bf[k], cand[ncand++].g = grid0;
   }
   if (s->d_sptr && (any || s->variant == LSB_SPMV_SELL))
     for (unsigned c16 = 0; c16 <= (s->d_scodes ? LSB_SP_C16 : 0u); c16 += LSB_SP_C16) {
@@ -707,7 +754,7 @@ int lsb_hip_solver_spmv_dev(lsb_hip_solver *sv, const double *d_x, double *d_y) 
     exchange_p(sv, 0);
   for (int i = 0; i < sv->nshard; i++) {
     struct shard *s = &sv->sh[i];
-    spmv_shard(s, s->d_pfull, d_y + (s->row_begin - sv->row_first), NULL, NULL, NULL, NULL);
+    spmv_shard_exact(s, s->d_pfull, d_y + (s->row_begin - sv->row_first), NULL, NULL, NULL, NULL);
   }
   if (d_yout)
     lsb_k_perm_scatter(sv->n_here, sv->d_perm, d_y, d_yout, g_stream);

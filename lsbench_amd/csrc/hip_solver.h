@@ -91,6 +91,16 @@ struct shard {
   int *pd_offs, *pd_cols, *pd_rowmap, *pd_rowblk;
   unsigned char *pd_blklanes;
   double *pd_vals;
+  /* opts.precision = LSB_PREC_MIXED: the SpMV forms stream fp32 values (the sliced-
+   * ELL value arrays then HOLD floats; d_vals32 is the CSR's copy); d_vals stays
+   * fp64 for the residual of the refinement.  exact32: rounding changed nothing */
+  int mixed, exact32;
+  float *d_vals32;
+  /* preconditioners that produce z = M^-1 r as a vector (hip_precond.c) */
+  double *d_zfull, *d_z; /* z: a gather vector of its own (Chebyshev), or n doubles */
+  double *d_chd;         /* Chebyshev: the recurrence's direction vector */
+  double *d_binv, *d_bjpart; /* block-Jacobi: inverted diagonal blocks; chunk partial sums */
+  unsigned bj_bs;
   /* binned form (LSB_SPMV_BINNED), built for scattered operators only */
   unsigned bn;         /* bins, 0 = not built */
   unsigned *h_binchunk; /* bn+1: first chunk of each bin (host) */
@@ -117,7 +127,8 @@ struct lsb_hip_solver {
     double *x;
   } gcache[LSB_NGRAPH];
   int gnext;
-#define LSB_MAX_CORRECTIONS 4
+#define LSB_MAX_CORRECTIONS 6
+#define LSB_MIXED_INNER_TOL 1e-5 /* what an inner solve on fp32-rounded values is asked for */
   unsigned hint_iters[LSB_MAX_CORRECTIONS + 1]; /* iterations of the previous solve and of each of
                                                    its correction runs, 0 = none yet */
   double tol_run;    /* tolerance of the CG run being enqueued (opts.tol, or a correction's) */
@@ -146,6 +157,19 @@ struct lsb_hip_solver {
    * rank has the same constant Jacobi diagonal (k_cg1_update<UI>) */
   int cg1_implicit;
   int pcur; /* launch-bound fused path: which direction buffer is current */
+#define LSB_CHEB_MAX 16
+  int cheb_m;
+  double cheb_lmin, cheb_lmax, cheb_c0, cheb_a[LSB_CHEB_MAX], cheb_b[LSB_CHEB_MAX];
+  unsigned nspmv; /* SpMV launches (per shard) of the solve being enqueued */
+  /* launch-bound operators: the whole solve as one persistent launch (hip_persist.hip) */
+  struct {
+    int ok, use;          /* qualifies / chosen */
+    unsigned G, stride, lanes;
+    unsigned *d_wgrow;    /* G+1 row bounds of the workgroups */
+    double *d_ug;         /* the shared vector u */
+    void *d_shared;       /* barrier counter + partial records */
+    double us_persist, us_launches; /* creation-time timing of 40 iterations each way */
+  } ps;
   struct lsb_p2p **p2p;
   int p2p_on, p2p_halo;
   double p2p_us, rccl_us; /* self-test: one exchange + all-reduce, each way */
@@ -161,6 +185,9 @@ LSB_INTERNAL void sell_launch(struct shard *s, unsigned s0, unsigned ns, const d
                               const struct lsb_pcg_state *st);
 LSB_INTERNAL void spmv_shard(struct shard *s, const double *xfull, double *y, const double *xdot,
                              double *partials, unsigned *np, const struct lsb_pcg_state *st);
+/* the same with the fp64 values whatever opts.precision says (residuals, y = Op x) */
+LSB_INTERNAL void spmv_shard_exact(struct shard *s, const double *xfull, double *y, const double *xdot,
+                                   double *partials, unsigned *np, const struct lsb_pcg_state *st);
 LSB_INTERNAL void tune_spmv(lsb_hip_solver *sv, struct shard *s);
 /* hip_dist.c */
 LSB_INTERNAL void p2p_setup(lsb_hip_solver *sv);
@@ -174,8 +201,16 @@ LSB_INTERNAL void exchange_and_spmv(lsb_hip_solver *sv, int sample);
 LSB_INTERNAL double true_resid2(lsb_hip_solver *sv, const double *d_b, const double *d_x);
 /* hip_pcg.c */
 LSB_INTERNAL void drop_graphs(lsb_hip_solver *sv);
+LSB_INTERNAL void persist_setup(lsb_hip_solver *sv);
 LSB_INTERNAL int solve_core(lsb_hip_solver *sv, const double *d_b, double *d_x,
                             struct lsb_hip_result *res);
+/* hip_precond.c */
+LSB_INTERNAL int generic_precond(const lsb_hip_solver *sv);
+LSB_INTERNAL void precond_shard_blocks(struct shard *s, const int *offs, const int *cols,
+                                       const double *vals, const struct lsb_hip_opts *o);
+LSB_INTERNAL void precond_setup(lsb_hip_solver *sv);
+LSB_INTERNAL void precond_apply(lsb_hip_solver *sv);
+LSB_INTERNAL void precond_free_shard(struct shard *s);
 /* hip_gmres_drv.c */
 LSB_INTERNAL int gmres_solve_dev(lsb_hip_solver *sv, const double *d_b, double *d_x,
                                  struct lsb_hip_result *res);

@@ -174,8 +174,14 @@ struct lsbench *lsbench_init(int argc, char *argv[]) {
   }
   if (cb->matrix == NULL) /* src/lsbench.c:138-139 */
     errx(EXIT_FAILURE, "Input matrix file not provided. Try `--help`.");
-  if (cb->precision != LSBENCH_PRECISION_FP64) /* :140-141 */
-    errx(EXIT_FAILURE, "Precisions other than FP64 are not implemented yet.");
+  /* src/lsbench.c:140-141 rejects everything but FP64; the hip backend takes
+   * FP32 as "fp32 matrix values, fp64 vectors and refinement" (SURVEY.md 8(f)-4:
+   * the reference's AMG paths already run fp32, src/amgx.c:91) */
+  if (cb->precision == LSBENCH_PRECISION_FP32 && cb->solver == LSBENCH_SOLVER_HIP)
+    o.precision = LSB_PREC_MIXED;
+  else if (cb->precision != LSBENCH_PRECISION_FP64)
+    errx(EXIT_FAILURE, "Precisions other than FP64 are not implemented yet%s.",
+         cb->solver == LSBENCH_SOLVER_HIP ? " (hip: FP64, FP32)" : "");
   o.verbose = (int)cb->verbose;
   lsb_hip_set_opts(&o);
 

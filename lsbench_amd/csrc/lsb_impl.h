@@ -68,6 +68,7 @@ unsigned lsb_k_spmv_grid(int variant, unsigned n, unsigned nblk,
 #define LSB_SP_PREFETCH 1u
 #define LSB_SP_NT 2u
 #define LSB_SP_C16 4u /* sliced-ELL only: 16-bit column codes */
+#define LSB_SP_F32 32u /* the values pointer holds fp32 (opts.precision = LSB_PREC_MIXED) */
 void lsb_k_spmv_sell(unsigned flags, unsigned grid_cap, const unsigned *sptr, unsigned s0,
                      unsigned ns, unsigned n, unsigned row_begin, const void *cols,
                      const int *sbase, const double *vals, const double *x, double *y,
@@ -152,6 +153,32 @@ void lsb_k_gm_hess(struct lsb_gmres_state *st, int j, const double *h, const dou
                    const double *partials, unsigned nparts, void *stream);
 void lsb_k_gm_finish_cycle(unsigned n, const double *V, size_t ld, const double *dinv, double *x,
                            struct lsb_gmres_state *st, void *stream);
+
+/* ---- preconditioners with z as a vector (hip_precond_k.hip) -------------------- */
+void lsb_k_dot2(unsigned n, const double *r, const double *z, double *partials2,
+                unsigned *npartials, const struct lsb_pcg_state *st, void *stream);
+void lsb_k_cheb_first(unsigned n, const double *r, const double *dinv, double dc, double c0,
+                      double *d, double *z, const struct lsb_pcg_state *st, void *stream);
+void lsb_k_cheb_step(unsigned n, const double *r, const double *w, const double *dinv, double dc,
+                     double a, double b, double *d, double *z, const struct lsb_pcg_state *st,
+                     void *stream);
+void lsb_k_scale_dinv(unsigned n, double c, const double *dinv, const double *w, double *v,
+                      void *stream);
+void lsb_k_scale_vec(unsigned n, double c, double *v, void *stream);
+void lsb_k_power_start(unsigned n, unsigned first, double *v, void *stream);
+void lsb_k_bj_invert(unsigned n, unsigned bs, double *binv, double *scratch, void *stream);
+void lsb_k_bj_apply(unsigned n, unsigned bs, const double *binv, const double *r, double *z,
+                    double *part, const struct lsb_pcg_state *st, void *stream);
+unsigned lsb_k_bj_chunks(unsigned bs);
+
+/* ---- one-launch solve of launch-bound operators (hip_persist.hip) ------------ */
+size_t lsb_k_persist_shared_bytes(void);
+unsigned lsb_k_persist_limits(unsigned *nzmax, unsigned *rmax, unsigned *gmax);
+int lsb_k_pcg_persist(unsigned n, unsigned G, unsigned stride, const unsigned *wg_row,
+                      const int *offs, const int *cols, const double *vals, const double *dinv,
+                      const double *b, double *x, double *ug, void *shared,
+                      struct lsb_pcg_state *st, double tol, int maxit, unsigned lanes,
+                      long long timeout_ticks, void *stream);
 
 /* ---- direct xGMI path (hip_p2p.hip) ---------------------------------------- */
 struct lsb_p2p;

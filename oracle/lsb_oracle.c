@@ -340,6 +340,185 @@ done:
 }
 
 /*
+ * PCG with a preconditioner applied as a vector operation z = M^-1 r -- textbook
+ * restatement of what lsbench_amd/csrc/hip_precond.c enqueues (no reference
+ * source: the nearest statements are the smoother set-ups of src/hypre.c:126-158,
+ * src/amgx.c:78-85 and the Jacobi preconditioner of src/ginkgo.cpp:57-58).
+ *   kind 3  Chebyshev polynomial of degree `param` in D^-1 A on [lmax/30, lmax],
+ *           lmax = 1.1 x the estimate of 20 power iterations from the start vector
+ *           v_i = 1 + ((7919 i) mod 1024) / 1024:
+ *              theta = (lmax+lmin)/2, delta = (lmax-lmin)/2, sigma = theta/delta, rho = 1/sigma
+ *              d = D^-1 r / theta ; z = d
+ *              k = 1..param: rho' = 1/(2 sigma - rho)
+ *                            d = rho' rho d + (2 rho'/delta) D^-1 (r - A z) ; z += d ; rho = rho'
+ *   kind 4  block-Jacobi: z_B = A_BB^-1 r_B for blocks B of `param` consecutive rows
+ *           (the last one shorter), each solved by a dense Cholesky factorisation
+ *           -- a different algorithm from the product's in-place Gauss-Jordan inverse.
+ * Recurrences and stop rule as orc_pcg_jacobi.  *spmv_out counts A-multiplications.
+ */
+static void orc_chol_blocks(uint64_t n, uint32_t bs, const uint64_t *offs, const uint32_t *cols,
+                            const double *vals, double *L) {
+  for (uint64_t b0 = 0, k = 0; b0 < n; b0 += bs, k++) {
+    const uint32_t m = (uint32_t)(n - b0 < bs ? n - b0 : bs);
+    double *B = L + k * (uint64_t)bs * bs;
+    for (uint32_t i = 0; i < m; i++)
+      for (uint64_t j = offs[b0 + i]; j < offs[b0 + i + 1]; j++)
+        if (cols[j] >= b0 && cols[j] < b0 + m)
+          B[(uint64_t)i * m + (cols[j] - b0)] = vals[j];
+    for (uint32_t j = 0; j < m; j++) { /* B = L L^T, lower triangle in place */
+      double d = B[(uint64_t)j * m + j];
+      for (uint32_t t = 0; t < j; t++)
+        d -= B[(uint64_t)j * m + t] * B[(uint64_t)j * m + t];
+      d = sqrt(d);
+      B[(uint64_t)j * m + j] = d;
+      for (uint32_t i = j + 1; i < m; i++) {
+        double v = B[(uint64_t)i * m + j];
+        for (uint32_t t = 0; t < j; t++)
+          v -= B[(uint64_t)i * m + t] * B[(uint64_t)j * m + t];
+        B[(uint64_t)i * m + j] = v / d;
+      }
+    }
+  }
+}
+
+static void orc_chol_solve(uint64_t n, uint32_t bs, const double *L, const double *r, double *z) {
+  for (uint64_t b0 = 0, k = 0; b0 < n; b0 += bs, k++) {
+    const uint32_t m = (uint32_t)(n - b0 < bs ? n - b0 : bs);
+    const double *B = L + k * (uint64_t)bs * bs;
+    double *y = z + b0;
+    for (uint32_t i = 0; i < m; i++) { /* L y = r */
+      double v = r[b0 + i];
+      for (uint32_t t = 0; t < i; t++)
+        v -= B[(uint64_t)i * m + t] * y[t];
+      y[i] = v / B[(uint64_t)i * m + i];
+    }
+    for (uint32_t ii = m; ii-- > 0;) { /* L^T z = y */
+      double v = y[ii];
+      for (uint32_t t = ii + 1; t < m; t++)
+        v -= B[(uint64_t)t * m + ii] * y[t];
+      y[ii] = v / B[(uint64_t)ii * m + ii];
+    }
+  }
+}
+
+int orc_pcg_prec(uint64_t n, const uint64_t *offs, const uint32_t *cols, const double *vals,
+                 const double *b, double *x, double tol, uint32_t maxit, int kind, uint32_t param,
+                 uint32_t *iters_out, double *relres_out, uint32_t *spmv_out, double *lmax_out) {
+  double *r = (double *)malloc(n * sizeof(double)), *p = (double *)malloc(n * sizeof(double));
+  double *q = (double *)malloc(n * sizeof(double)), *z = (double *)malloc(n * sizeof(double));
+  double *d = (double *)calloc(n, sizeof(double)), *dinv = (double *)malloc(n * sizeof(double));
+  double *L = NULL;
+  uint32_t it = 0, nspmv = 0;
+  int status = 3;
+  double lmax = 0.0, theta = 0.0, delta = 0.0, sigma = 0.0;
+  for (uint64_t i = 0; i < n; i++) {
+    double dd = 0.0;
+    for (uint64_t j = offs[i]; j < offs[i + 1]; j++)
+      if (cols[j] == i)
+        dd = vals[j];
+    dinv[i] = dd != 0.0 ? 1.0 / dd : 0.0;
+  }
+  if (kind == 3) {
+    double vv = 0.0, lam = 1.0;
+    for (uint64_t i = 0; i < n; i++) {
+      z[i] = 1.0 + (double)(((uint32_t)i * 7919u) % 1024u) / 1024.0;
+      vv += z[i] * z[i];
+    }
+    for (int k = 0; k < 20; k++) {
+      orc_spmv(n, offs, cols, vals, z, q);
+      double ww = 0.0;
+      for (uint64_t i = 0; i < n; i++) {
+        q[i] *= dinv[i];
+        ww += q[i] * q[i];
+      }
+      if (!(ww > 0.0) || !(vv > 0.0))
+        break;
+      lam = sqrt(ww / vv);
+      const double c = 1.0 / sqrt(ww);
+      for (uint64_t i = 0; i < n; i++)
+        z[i] = c * q[i];
+      vv = 1.0;
+    }
+    lmax = 1.1 * lam;
+    const double lmin = lmax / 30.0;
+    theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
+  } else if (kind == 4) {
+    const uint64_t nb = (n + param - 1) / param;
+    L = (double *)calloc(nb * (uint64_t)param * param, sizeof(double));
+    orc_chol_blocks(n, param, offs, cols, vals, L);
+  }
+#define ORC_PREC()                                                                       \
+  do {                                                                                   \
+    if (kind == 4) {                                                                     \
+      orc_chol_solve(n, param, L, r, z);                                                 \
+    } else {                                                                             \
+      double rho = 1.0 / sigma;                                                          \
+      for (uint64_t i = 0; i < n; i++)                                                   \
+        d[i] = (1.0 / theta) * (dinv[i] * r[i]), z[i] = d[i];                            \
+      for (uint32_t k = 0; k < param; k++) {                                             \
+        const double rho_new = 1.0 / (2.0 * sigma - rho);                                \
+        const double ca = rho_new * rho, cb = 2.0 * rho_new / delta;                     \
+        orc_spmv(n, offs, cols, vals, z, q);                                             \
+        nspmv++;                                                                         \
+        for (uint64_t i = 0; i < n; i++) {                                               \
+          d[i] = ca * d[i] + cb * (dinv[i] * (r[i] - q[i]));                             \
+          z[i] += d[i];                                                                  \
+        }                                                                                \
+        rho = rho_new;                                                                   \
+      }                                                                                  \
+    }                                                                                    \
+  } while (0)
+  double bb = 0.0;
+  for (uint64_t i = 0; i < n; i++)
+    x[i] = 0.0, r[i] = b[i], bb += b[i] * b[i];
+  double rr = bb, rz = 0.0;
+  const double thresh2 = tol * tol * bb;
+  if (bb == 0.0) {
+    status = 1;
+    goto done;
+  }
+  ORC_PREC();
+  for (uint64_t i = 0; i < n; i++)
+    p[i] = z[i], rz += r[i] * z[i];
+  while (it < maxit) {
+    orc_spmv(n, offs, cols, vals, p, q);
+    nspmv++;
+    const double pq = orc_dot(n, p, q);
+    if (!(pq != 0.0) || !isfinite(pq)) {
+      status = 2;
+      break;
+    }
+    const double alpha = rz / pq;
+    rr = 0.0;
+    for (uint64_t i = 0; i < n; i++) {
+      x[i] += alpha * p[i];
+      r[i] -= alpha * q[i];
+      rr += r[i] * r[i];
+    }
+    it++;
+    if (rr <= thresh2) {
+      status = 1;
+      break;
+    }
+    ORC_PREC();
+    double rz_new = 0.0;
+    for (uint64_t i = 0; i < n; i++)
+      rz_new += r[i] * z[i];
+    const double beta = rz_new / rz;
+    rz = rz_new;
+    for (uint64_t i = 0; i < n; i++)
+      p[i] = z[i] + beta * p[i];
+  }
+#undef ORC_PREC
+done:
+  *iters_out = it, *relres_out = bb > 0.0 ? sqrt(rr / bb) : 0.0, *spmv_out = nspmv;
+  if (lmax_out)
+    *lmax_out = lmax;
+  free(r), free(p), free(q), free(z), free(d), free(dinv), free(L);
+  return status;
+}
+
+/*
  * Single-reduction CG (Chronopoulos & Gear 1989), Jacobi-preconditioned,
  * x0 = 0 -- the recurrences of k_cg1_update in lsbench_amd/csrc/hip_kernels.hip,
  * stated sequentially:

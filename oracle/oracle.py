@@ -183,6 +183,26 @@ def pcg1_jacobi(offs, cols, vals, b, tol=1e-12, maxit=20000):
     return x, it.value, rel.value, st
 
 
+def pcg_prec(offs, cols, vals, b, tol=1e-12, maxit=20000, kind="cheb", param=4):
+    """PCG with z = M^-1 r as a vector operation: kind "cheb" = Chebyshev polynomial
+    of degree `param` in D^-1 A, "bj" = block-Jacobi with `param`-row blocks (dense
+    Cholesky per block).  Returns (x, iters, relres, status, spmvs, lmax)."""
+    L = lib()
+    L.orc_set_threads(1)
+    n = len(offs) - 1
+    x = np.zeros(n, np.float64)
+    it, rel, nsp, lmax = C.c_uint32(), C.c_double(), C.c_uint32(), C.c_double()
+    L.orc_pcg_prec.restype = C.c_int
+    L.orc_pcg_prec.argtypes = [C.c_uint64, _u64p, _u32p, _f64p, _f64p, _f64p, C.c_double, C.c_uint32,
+                               C.c_int, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_double),
+                               C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
+    st = L.orc_pcg_prec(n, _as64(offs), np.ascontiguousarray(cols, np.uint32),
+                        np.ascontiguousarray(vals, np.float64), np.ascontiguousarray(b, np.float64),
+                        x, tol, maxit, {"cheb": 3, "bj": 4}[kind], int(param), C.byref(it),
+                        C.byref(rel), C.byref(nsp), C.byref(lmax))
+    return x, it.value, rel.value, st, nsp.value, lmax.value
+
+
 def gmres_jacobi(offs, cols, vals, b, tol=1e-10, maxit=20000, restart=30):
     """Restarted GMRES(m) with right Jacobi preconditioning (sequential).
     Returns (x, inner iterations, relres estimate, status)."""

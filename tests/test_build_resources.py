@@ -37,7 +37,7 @@ def test_hot_kernels_have_no_spills_and_full_occupancy(tmp_path):
             info[name][m.group(1).strip()] = int(m.group(2))
     hot = {k: v for k, v in info.items()
            if re.search(r"k_spmv_adaptive|k_pcg_update_xr|k_pcg_update_p|k_pcg_init", k)}
-    assert len([k for k in hot if "k_spmv_adaptive" in k]) == 4  # the four flavours
+    assert len([k for k in hot if "k_spmv_adaptive" in k]) == 8  # four flavours x {fp64, fp32 values}
     for k, v in hot.items():
         assert v["ScratchSize"] == 0, (k, v)
         assert v["VGPRs"] <= 64, (k, v)
@@ -45,7 +45,7 @@ def test_hot_kernels_have_no_spills_and_full_occupancy(tmp_path):
         if "k_spmv_adaptive" in k:
             assert v["LDS Size"] <= 16 * 1024 + 64, (k, v)
     sell = {k: v for k, v in info.items() if "k_spmv_sell" in k}
-    assert len(sell) == 4                                         # {32-bit, 16-bit columns} x {plain, nontemporal}
+    assert len(sell) == 8                     # {32-bit, 16-bit columns} x {plain, nontemporal} x {fp64, fp32}
     for k, v in sell.items():                                     # no LDS staging, >= 6 workgroups per CU
         assert v["ScratchSize"] == 0 and v["VGPRs"] <= 80 and v["Occupancy"] >= 6, (k, v)
         assert v["LDS Size"] <= 64, (k, v)

@@ -1,0 +1,110 @@
+"""Preconditioners beyond the diagonal ones:
+Chebyshev polynomial in D^-1 S and block-Jacobi with dense inverted blocks.
+CPU: the oracle's restatement reaches the golden solutions and cuts the outer
+iterations.  GPU: the HIP path follows the oracle's iteration counts and reaches
+the same solutions on all seven SPD reference matrices, alone and over shards."""
+import numpy as np
+import pytest
+
+from conftest import SPD
+from oracle import oracle as O
+
+
+@pytest.mark.parametrize("name", SPD)
+def test_oracle_preconditioners_reach_golden(name, matrix_path, golden_x):
+    S = O.operator_upper(O.matrix_read(matrix_path(name)))
+    b = O.rhs(len(S.offs) - 1)
+    xg = golden_x(name)
+    _, itj, _, stj = O.pcg_jacobi(S.offs, S.cols, S.vals, b, 1e-12)
+    for kind, param in (("cheb", 2), ("cheb", 6), ("bj", 4), ("bj", 64)):
+        x, it, rel, st, nsp, lmax = O.pcg_prec(S.offs, S.cols, S.vals, b, 1e-12, kind=kind, param=param)
+        assert st == 1 and np.linalg.norm(x - xg) / np.linalg.norm(xg) <= 1e-10
+        if kind == "cheb":
+            # a degree-m polynomial: the outer iterations (= pairs of reductions) drop by
+            # about m + 1 while the multiplications by S stay within ~40 % of Jacobi's
+            assert it <= 1.35 * itj / (param + 1) + 5 and nsp == it * (param + 1)
+            assert nsp <= 1.5 * itj and 1.0 < lmax < 10.0
+        else:
+            assert it <= itj + 5 and nsp == it
+    if name in ("xn3b_A_18", "tj7a_A_18"):   # (dense n^3 Cholesky in the oracle: the two smallest only)
+        # one block as large as the operator = the exact inverse: one iteration, or a
+        # second one where cond(S) eps is not far below the tolerance
+        x, it, rel, st, nsp, _ = O.pcg_prec(S.offs, S.cols, S.vals, b, 1e-12, kind="bj",
+                                            param=len(S.offs) - 1)
+        assert st == 1 and it <= 2 and np.linalg.norm(x - xg) / np.linalg.norm(xg) <= 1e-10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SPD)
+def test_hip_preconditioners_follow_the_oracle(hip, name, matrix_path, golden_x):
+    A = hip.lsbench_matrix_read(matrix_path(name))
+    S = O.operator_upper(O.matrix_read(matrix_path(name)))
+    b = O.rhs(A.nrows)
+    xg = golden_x(name)
+    for kind, precond, key, param in (("cheb", hip.PRECOND_CHEBYSHEV, "cheb_degree", 4),
+                                      ("cheb", hip.PRECOND_CHEBYSHEV, "cheb_degree", 1),
+                                      ("bj", hip.PRECOND_BLOCKJACOBI, "block_size", 8),
+                                      ("bj", hip.PRECOND_BLOCKJACOBI, "block_size", 100)):
+        xo, ito, relo, sto, nspo, _ = O.pcg_prec(S.offs, S.cols, S.vals, b, 1e-12, kind=kind, param=param)
+        for graph in (0, 1):
+            s = hip.Solver(A, hip.default_opts(precond=precond, use_graph=graph, **{key: param}))
+            x, r = s.solve(b)
+            x2, r2 = s.solve(b)
+            s.destroy()
+            assert r.status == hip.STATUS_CONVERGED and sto == 1
+            assert abs(int(r.iters) - ito) <= max(2, ito // 25)
+            assert r2.iters == r.iters and np.array_equal(x, x2)
+            assert np.linalg.norm(x - xg) / np.linalg.norm(xg) <= 1e-10
+            if kind == "cheb":
+                assert r.spmvs == r.iters * (param + 1) + param
+
+
+@pytest.mark.gpu
+def test_hip_preconditioners_variants(hip, matrix_path, golden_x):
+    name = "xn3b_A_12"
+    A = hip.lsbench_matrix_read(matrix_path(name))
+    S = O.operator_upper(O.matrix_read(matrix_path(name)))
+    b = O.rhs(A.nrows)
+    xg = golden_x(name)
+    # over virtual shards: the Chebyshev steps exchange halos, no reduction inside
+    ref = None
+    for nv, comm in ((1, hip.COMM_AUTO), (3, hip.COMM_AUTO), (4, hip.COMM_P2P)):
+        s = hip.Solver(A, hip.default_opts(precond=hip.PRECOND_CHEBYSHEV, cheb_degree=3, nvirt=nv, comm=comm))
+        x, r = s.solve(b)
+        s.destroy()
+        assert r.status == 1 and np.linalg.norm(x - xg) / np.linalg.norm(xg) <= 1e-10
+        ref = ref or int(r.iters)
+        assert abs(int(r.iters) - ref) <= 2
+    s = hip.Solver(A, hip.default_opts(precond=hip.PRECOND_BLOCKJACOBI, block_size=16, nvirt=3))
+    x, r = s.solve(b)
+    s.destroy()
+    assert r.status == 1 and np.linalg.norm(x - xg) / np.linalg.norm(xg) <= 1e-10
+    # one block as large as the operator: a cached dense inverse, one or two iterations
+    s = hip.Solver(A, hip.default_opts(precond=hip.PRECOND_BLOCKJACOBI, block_size=1 << 20))
+    x, r = s.solve(b)
+    s.destroy()
+    assert r.status == 1 and r.iters <= 3 and np.linalg.norm(x - xg) / np.linalg.norm(xg) <= 1e-10
+    # MAXIT and b = 0 through the generic sweeps; with verification on top
+    xo, ito, relo, sto, _, _ = O.pcg_prec(S.offs, S.cols, S.vals, b, 1e-12, 9, kind="cheb", param=2)
+    s = hip.Solver(A, hip.default_opts(precond=hip.PRECOND_CHEBYSHEV, cheb_degree=2, maxit=9))
+    x, r = s.solve(b)
+    assert (r.status, r.iters, sto, ito) == (hip.STATUS_MAXIT, 9, 3, 9)
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-9 and abs(r.relres - relo) <= 1e-7 * relo
+    x0, r0 = s.solve(np.zeros_like(b))
+    s.destroy()
+    assert r0.status == 1 and r0.iters == 0 and not x0.any()
+    s = hip.Solver(A, hip.default_opts(precond=hip.PRECOND_CHEBYSHEV, cheb_degree=4, verify=1, tol=1e-11))
+    x, r = s.solve(b)
+    s.destroy()
+    assert r.status == 1 and 0 <= r.true_relres <= 1e-11
+    # a stencil through the sliced-ELL SpMV and the constant diagonal
+    L = hip.lsbench_matrix_synth("lap2d:nx=900,ny=700")
+    offs, cols, vals = O.lap2d(900, 700)
+    bl = O.rhs(L.nrows)
+    xo, ito, _, sto, nspo, _ = O.pcg_prec(offs, cols, vals, bl, 1e-9, kind="cheb", param=4)
+    s = hip.Solver(L, hip.default_opts(op_mode=hip.OP_RAW, precond=hip.PRECOND_CHEBYSHEV, cheb_degree=4,
+                                       tol=1e-9, use_graph=0))
+    x, r = s.solve(bl)
+    s.destroy()
+    assert r.status == 1 and abs(int(r.iters) - ito) <= 3
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-7
