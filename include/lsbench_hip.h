@@ -271,6 +271,8 @@ void lsb_panel_csr_free(struct lsb_panel_csr *P);
 #define LSB_BIN_CHUNK 2048
 struct lsb_binned {
   unsigned nbins, width, nrows, nchunks;
+  unsigned chunk_cap;    /* entries a chunk holds at most: LSB_BIN_CHUNK, or 1024 /
+                            1536 / 2048 from LSBENCH_HIP_BIN_CHUNK (tuning)   */
   unsigned long long nnz;
   unsigned *bin_chunk;   /* nbins+1: first chunk of each bin                */
   unsigned *chunk_begin; /* nchunks+1: first entry of each chunk            */

@@ -90,7 +90,7 @@ class Sell(C.Structure):
 class Binned(C.Structure):
     """struct lsb_binned."""
     _fields_ = [("nbins", C.c_uint), ("width", C.c_uint), ("nrows", C.c_uint), ("nchunks", C.c_uint),
-                ("nnz", C.c_ulonglong), ("bin_chunk", C.POINTER(C.c_uint)),
+                ("chunk_cap", C.c_uint), ("nnz", C.c_ulonglong), ("bin_chunk", C.POINTER(C.c_uint)),
                 ("chunk_begin", C.POINTER(C.c_uint)), ("rows", C.POINTER(C.c_uint)),
                 ("cols", C.POINTER(C.c_uint)), ("vals", C.POINTER(C.c_double))]
 

@@ -1163,16 +1163,16 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_sell16(
 // y entry is touched by exactly one lane per launch (no atomics), and the order
 // of the additions is fixed by the layout alone: bit-identical run to run.
 // --------------------------------------------------------------------------
-#define BIN_U (LSB_BIN_CHUNK / WG)
 __device__ __forceinline__ unsigned bin_pad(unsigned i) { return i + (i >> 3); }
 
-template <int FLAGS>
+template <int FLAGS, int BIN_U>
 __global__ __launch_bounds__(WG) void k_spmv_binned(
     const unsigned *__restrict__ chunk_begin, unsigned nchunk, const unsigned *__restrict__ rows,
     const unsigned *__restrict__ cols, const double *__restrict__ vals,
     const double *__restrict__ x, double *__restrict__ y, const lsb_pcg_state *__restrict__ st) {
-  __shared__ double sprod[LSB_BIN_CHUNK + LSB_BIN_CHUNK / 8 + 8];
-  __shared__ unsigned skey[LSB_BIN_CHUNK + LSB_BIN_CHUNK / 8 + 8];
+  constexpr unsigned CHUNK = BIN_U * WG; // entries of a chunk: 1024, 1536 or 2048
+  __shared__ double sprod[CHUNK + CHUNK / 8 + 8];
+  __shared__ unsigned skey[CHUNK + CHUNK / 8 + 8];
   __shared__ double swv[4];
   __shared__ int swf[4];
   __shared__ double sred[4];
@@ -1185,7 +1185,7 @@ __global__ __launch_bounds__(WG) void k_spmv_binned(
   const unsigned e0 = chunk_begin[w], cnt = chunk_begin[w + 1] - e0;
   unsigned r[BIN_U], c[BIN_U];
   double v[BIN_U];
-  if (cnt <= LSB_BIN_CHUNK) {
+  if (cnt <= CHUNK) {
 #pragma unroll
     for (int u = 0; u < BIN_U; u++) {
       const unsigned t = tid + u * WG;
@@ -1198,7 +1198,7 @@ __global__ __launch_bounds__(WG) void k_spmv_binned(
   }
   if (st && st->status)
     return;
-  if (cnt > LSB_BIN_CHUNK) { // ONE run longer than a chunk: the workgroup strides over it
+  if (cnt > CHUNK) { // ONE run longer than a chunk: the workgroup strides over it
     double s[1] = {0.0};
     for (unsigned j = e0 + tid; j < e0 + cnt; j += WG)
       s[0] += vals[j] * x[cols[j]];
@@ -1317,16 +1317,23 @@ extern "C" {
 void lsb_k_set_blas1_nt(int on) { g_blas1_nt = on ? 1 : 0; }
 
 /* one bin of the binned form: chunks [c0, c0 + nchunk) */
-void lsb_k_spmv_binned(unsigned flags, const unsigned *chunk_begin, unsigned c0, unsigned nchunk,
-                       const unsigned *rows, const unsigned *cols, const double *vals,
+void lsb_k_spmv_binned(unsigned flags, unsigned chunk_cap, const unsigned *chunk_begin, unsigned c0,
+                       unsigned nchunk, const unsigned *rows, const unsigned *cols, const double *vals,
                        const double *x, double *y, const struct lsb_pcg_state *st, void *stream) {
   if (!nchunk)
     return;
   const unsigned g = (nchunk + NXCD - 1) / NXCD * NXCD;
+#define LSB_BINNED_U(FL, U)                                                                    \
+  k_spmv_binned<FL, U><<<g, WG, 0, (hipStream_t)stream>>>(chunk_begin + c0, nchunk, rows, cols,   \
+                                                          vals, x, y, st)
 #define LSB_BINNED(FL)                                                                         \
   case FL:                                                                                     \
-    k_spmv_binned<FL><<<g, WG, 0, (hipStream_t)stream>>>(chunk_begin + c0, nchunk, rows, cols, \
-                                                         vals, x, y, st);                      \
+    if (chunk_cap == 1024)                                                                     \
+      LSB_BINNED_U(FL, 4);                                                                     \
+    else if (chunk_cap == 1536)                                                                \
+      LSB_BINNED_U(FL, 6);                                                                     \
+    else                                                                                       \
+      LSB_BINNED_U(FL, 8);                                                                     \
     break;
   switch (flags & (SP_NT | 8u | 16u)) {
     LSB_BINNED(0)
@@ -1336,9 +1343,9 @@ void lsb_k_spmv_binned(unsigned flags, const unsigned *chunk_begin, unsigned c0,
     LSB_BINNED(16)
     LSB_BINNED(18)
   default:
-    k_spmv_binned<SP_NT><<<g, WG, 0, (hipStream_t)stream>>>(chunk_begin + c0, nchunk, rows, cols,
-                                                            vals, x, y, st);
+    LSB_BINNED_U(SP_NT, 8);
   }
+#undef LSB_BINNED_U
 #undef LSB_BINNED
 }
 

@@ -84,7 +84,7 @@ static void shard_build_bins(struct shard *s, const struct csr *view, unsigned w
   struct lsb_binned *B = lsb_csr_binize(view, width);
   if (!B)
     return;
-  s->bn = B->nbins;
+  s->bn = B->nbins, s->bcap = B->chunk_cap;
   s->h_binchunk = (unsigned *)malloc(((size_t)B->nbins + 1) * sizeof(unsigned));
   memcpy(s->h_binchunk, B->bin_chunk, ((size_t)B->nbins + 1) * sizeof(unsigned));
   s->bd_chunk = (unsigned *)dev_upload(B->chunk_begin, ((size_t)B->nchunks + 1) * sizeof(unsigned));
@@ -608,7 +608,7 @@ void spmv_shard(struct shard *s, const double *xfull, double *y,
     /* y = 0, then one launch per bin (= per L2-sized window of x) adds to it */
     LSB_CHK_HIP(hipMemsetAsync(y, 0, (size_t)s->n * sizeof(double), g_stream));
     for (unsigned b = 0; b < s->bn; b++)
-      lsb_k_spmv_binned(s->sp_flags, s->bd_chunk, s->h_binchunk[b],
+      lsb_k_spmv_binned(s->sp_flags, s->bcap, s->bd_chunk, s->h_binchunk[b],
                         s->h_binchunk[b + 1] - s->h_binchunk[b], s->bd_rows, s->bd_cols, s->bd_vals,
                         xfull, y, st, g_stream);
     if (partials)

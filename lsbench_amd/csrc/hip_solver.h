@@ -102,7 +102,7 @@ struct shard {
   double *d_binv, *d_bjpart; /* block-Jacobi: inverted diagonal blocks; chunk partial sums */
   unsigned bj_bs;
   /* binned form (LSB_SPMV_BINNED), built for scattered operators only */
-  unsigned bn;         /* bins, 0 = not built */
+  unsigned bn, bcap;   /* bins (0 = not built), entries per chunk */
   unsigned *h_binchunk; /* bn+1: first chunk of each bin (host) */
   unsigned *bd_chunk, *bd_rows, *bd_cols;
   double *bd_vals;

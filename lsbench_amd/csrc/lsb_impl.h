@@ -74,8 +74,8 @@ void lsb_k_spmv_sell(unsigned flags, unsigned grid_cap, const unsigned *sptr, un
                      const int *sbase, const double *vals, const double *x, double *y,
                      const double *xdot, double *partials, unsigned *npartials,
                      const struct lsb_pcg_state *st, void *stream);
-void lsb_k_spmv_binned(unsigned flags, const unsigned *chunk_begin, unsigned c0, unsigned nchunk,
-                       const unsigned *rows, const unsigned *cols, const double *vals,
+void lsb_k_spmv_binned(unsigned flags, unsigned chunk_cap, const unsigned *chunk_begin, unsigned c0,
+                       unsigned nchunk, const unsigned *rows, const unsigned *cols, const double *vals,
                        const double *x, double *y, const struct lsb_pcg_state *st, void *stream);
 void lsb_k_reduce_final(const double *partials, unsigned nparts, unsigned width,
                         double *out, int take_sqrt,

@@ -510,6 +510,9 @@ struct lsb_binned *lsb_csr_binize(const struct csr *A, unsigned width) {
     cnt[b + 1] += cnt[b];
   struct lsb_binned *B = lsb_calloc(struct lsb_binned, 1);
   B->nbins = nb, B->width = width, B->nrows = n, B->nnz = nnz;
+  const char *ce = getenv("LSBENCH_HIP_BIN_CHUNK");
+  const unsigned CAP = ce && (atoi(ce) == 1024 || atoi(ce) == 1536) ? (unsigned)atoi(ce) : LSB_BIN_CHUNK;
+  B->chunk_cap = CAP;
   B->rows = (unsigned *)malloc((size_t)(nnz ? nnz : 1) * sizeof(unsigned));
   B->cols = (unsigned *)malloc((size_t)(nnz ? nnz : 1) * sizeof(unsigned));
   B->vals = (double *)malloc((size_t)(nnz ? nnz : 1) * sizeof(double));
@@ -525,7 +528,7 @@ struct lsb_binned *lsb_csr_binize(const struct csr *A, unsigned width) {
     }
   free(cur);
   /* chunks */
-  size_t cap = (size_t)(nnz / LSB_BIN_CHUNK) * 2 + 2 * (size_t)nb + 16, nc = 0;
+  size_t cap = (size_t)(nnz / CAP) * 2 + 2 * (size_t)nb + 16, nc = 0;
   B->chunk_begin = (unsigned *)malloc((cap + 1) * sizeof(unsigned));
   B->bin_chunk = lsb_calloc(unsigned, (size_t)nb + 1);
   for (unsigned b = 0; b < nb; b++) {
@@ -538,9 +541,9 @@ struct lsb_binned *lsb_csr_binize(const struct csr *A, unsigned width) {
         unsigned re = e + 1;
         while (re < e1 && B->rows[re] == B->rows[e])
           re++;
-        if (re - start <= LSB_BIN_CHUNK || e == start) {
+        if (re - start <= CAP || e == start) {
           e = re;
-          if (e - start >= LSB_BIN_CHUNK)
+          if (e - start >= CAP)
             break;
         } else
           break;
