@@ -315,7 +315,7 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
     bytes_spmv = 12 * nnz_loc + 20 * nl + 4
     kernel = {la.SPMV_ADAPTIVE: "k_spmv_adaptive", la.SPMV_SUBWAVE: "k_spmv_subwave",
               la.SPMV_SCALAR: "k_spmv_scalar", la.SPMV_PANEL: "k_spmv_adaptive",
-              la.SPMV_BINNED: "k_spmv_binned",
+              la.SPMV_BINNED: "k_spmv_binned", la.SPMV_TWOPHASE: "k_pb_products + k_pb_reduce",
               la.SPMV_SELL: "k_spmv_sell16" if solver.spmv_flags & la.SPMV_FLAG_C16 else "k_spmv_sell"
               }.get(solver.spmv_variant, "?")
     traffic, traffic_src = pmc_traffic(key if world == 1 else None, kernel)

@@ -116,6 +116,9 @@ enum { LSB_SPMV_AUTO = 0,     /* pick by mean row length                    */
        LSB_SPMV_SELL = 5,     /* sliced-ELL copy of the rows (lsb_csr_sellize):
                                  128-row slices stored column-major, two rows
                                  per lane, no LDS; for near-uniform row lengths */
+       LSB_SPMV_TWOPHASE = 7, /* scattered operators: products streamed out by
+                                 column chunk (x window in LDS), added up by row
+                                 bin (y rows in LDS): lsb_csr_pbize             */
        LSB_SPMV_BINNED = 6 }; /* scattered operators: entries binned by column
                                  panel (an L2-sized window of x) and sorted by
                                  row inside a bin, streamed as (row, col, value)
@@ -283,6 +286,37 @@ struct lsb_binned {
 /* NULL when A or width is unusable, or the copy does not fit 32-bit offsets. */
 struct lsb_binned *lsb_csr_binize(const struct csr *A, unsigned width);
 void lsb_binned_free(struct lsb_binned *B);
+/* Two-phase form of a CSR for LSB_SPMV_TWOPHASE (scattered operators; "propagation
+ * blocking"): no gather ever leaves a compute unit.
+ *   phase 1  the entries are cut by COLUMN into chunks of LSB_PB_COLS columns; a
+ *            workgroup copies its chunk's window of x into LDS and streams its
+ *            entries -- value (8 B) + column inside the window (2 B) -- writing
+ *            one product per entry, in entry order (8 B, coalesced);
+ *   phase 2  inside a chunk the entries are ordered by ROW BIN (LSB_PB_ROWS rows)
+ *            and by row inside a bin, so every (chunk, bin) pair is one contiguous,
+ *            row-sorted RUN of products.  A workgroup owns a bin: its four
+ *            wavefronts take the bin's runs in turn (run k to wave k mod 4), add
+ *            them -- product (8 B) + row inside the bin (2 B) -- into a private
+ *            LDS copy of the bin's rows, and the four copies are summed in a
+ *            fixed order into y (each y entry is written once, by one lane).
+ * 28 bytes of streaming traffic per non-zero instead of a 128-byte line per
+ * gather, no atomics, bit-identical from run to run. */
+#define LSB_PB_COLS 8192
+#define LSB_PB_ROWS 2048
+struct lsb_pb {
+  unsigned nrows, ncols_lo, nchunks, nbins, nitems;
+  unsigned long long nnz;
+  unsigned long long nruns;
+  double *vals;            /* nnz, in (chunk, bin, row, col) order            */
+  unsigned short *colw;    /* nnz: column - (ncols_lo + chunk * LSB_PB_COLS)  */
+  unsigned short *roww;    /* nnz: row - bin * LSB_PB_ROWS                    */
+  unsigned *item;          /* 3 * nitems: {chunk, first entry, end entry} of
+                              the phase-1 work items (<= 32768 entries each)  */
+  unsigned *bin_run;       /* nbins + 1: first run of each bin                */
+  unsigned *run;           /* 2 * nruns: {first entry, length}, chunk order   */
+};
+struct lsb_pb *lsb_csr_pbize(const struct csr *A);
+void lsb_pb_free(struct lsb_pb *P);
 /* Sliced-ELL copy of a CSR for LSB_SPMV_SELL: rows in slices of LSB_SELL_ROWS,
  * every slice padded to its longest row and stored column-major (entry j of
  * row 128s+i at sptr[s] + 128j + i), so that a wavefront's lane l reads the

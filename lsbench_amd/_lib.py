@@ -22,9 +22,10 @@ SOLVER_HIP = 6
 OP_CHOLMOD_UPPER, OP_RAW = 0, 1
 PRECOND_JACOBI, PRECOND_NONE, PRECOND_L1JACOBI, PRECOND_CHEBYSHEV, PRECOND_BLOCKJACOBI = 0, 1, 2, 3, 4
 KRYLOV_PCG, KRYLOV_GMRES, KRYLOV_PCG1, KRYLOV_AUTO = 0, 1, 2, 3
-SPMV_AUTO, SPMV_ADAPTIVE, SPMV_SUBWAVE, SPMV_SCALAR, SPMV_PANEL, SPMV_SELL, SPMV_BINNED = 0, 1, 2, 3, 4, 5, 6
+SPMV_AUTO, SPMV_ADAPTIVE, SPMV_SUBWAVE, SPMV_SCALAR, SPMV_PANEL, SPMV_SELL, SPMV_BINNED, SPMV_TWOPHASE = 0, 1, 2, 3, 4, 5, 6, 7
 SELL_ROWS = 128
 BIN_CHUNK = 2048
+PB_COLS, PB_ROWS = 8192, 2048
 SPMV_FLAG_PREFETCH, SPMV_FLAG_NT, SPMV_FLAG_C16 = 1, 2, 4
 STATUS_RUNNING, STATUS_CONVERGED, STATUS_BREAKDOWN, STATUS_MAXIT = 0, 1, 2, 3
 STATUS_COMM = 4
@@ -95,6 +96,15 @@ class Binned(C.Structure):
                 ("cols", C.POINTER(C.c_uint)), ("vals", C.POINTER(C.c_double))]
 
 
+class Pb(C.Structure):
+    """struct lsb_pb."""
+    _fields_ = [("nrows", C.c_uint), ("ncols_lo", C.c_uint), ("nchunks", C.c_uint), ("nbins", C.c_uint),
+                ("nitems", C.c_uint), ("nnz", C.c_ulonglong), ("nruns", C.c_ulonglong),
+                ("vals", C.POINTER(C.c_double)), ("colw", C.POINTER(C.c_ushort)),
+                ("roww", C.POINTER(C.c_ushort)), ("item", C.POINTER(C.c_uint)),
+                ("bin_run", C.POINTER(C.c_uint)), ("run", C.POINTER(C.c_uint))]
+
+
 class Xfer(C.Structure):
     """struct lsb_xfer."""
     _fields_ = [("peer", C.c_int), ("offset", C.c_size_t), ("count", C.c_size_t)]
@@ -137,6 +147,8 @@ SIGNATURES = {
     "lsb_csr_bandwidth": (_u, [_csrp]),
     "lsb_csr_panelize": (C.POINTER(PanelCsr), [_csrp, _u]),
     "lsb_panel_csr_free": (None, [C.POINTER(PanelCsr)]),
+    "lsb_csr_pbize": (C.POINTER(Pb), [_csrp]),
+    "lsb_pb_free": (None, [C.POINTER(Pb)]),
     "lsb_csr_binize": (C.POINTER(Binned), [_csrp, _u]),
     "lsb_binned_free": (None, [C.POINTER(Binned)]),
     "lsb_csr_sell_stored": (C.c_ulonglong, [_csrp]),

@@ -28,6 +28,8 @@ void choose_spmv(struct shard *s, const struct lsb_hip_opts *o) {
     v = LSB_SPMV_ADAPTIVE; /* the operator did not qualify for panels */
   if (v == LSB_SPMV_BINNED && !s->bn)
     v = LSB_SPMV_ADAPTIVE;
+  if (v == LSB_SPMV_TWOPHASE && !s->tp_bins)
+    v = LSB_SPMV_ADAPTIVE;
   if (v == LSB_SPMV_SELL && !s->d_sptr)
     v = LSB_SPMV_ADAPTIVE; /* no sliced-ELL copy (32-bit offsets exceeded) */
   s->variant = v;
@@ -114,6 +116,24 @@ static float *upload_f32(const double *v, size_t cnt, int *exact) {
   return d;
 }
 
+/* Two-phase form of the shard (lsb_csr_pbize), uploaded as it is. */
+static void shard_build_twophase(struct shard *s, const struct csr *view, unsigned n_glob) {
+  struct lsb_pb *P = lsb_csr_pbize(view);
+  if (!P)
+    return;
+  s->tp_items = P->nitems, s->tp_bins = P->nbins, s->tp_col_lo = P->ncols_lo, s->tp_xlen = n_glob;
+  s->tp_item = (unsigned *)dev_upload(P->item, (size_t)P->nitems * 3 * sizeof(unsigned));
+  s->tp_binrun = (unsigned *)dev_upload(P->bin_run, ((size_t)P->nbins + 1) * sizeof(unsigned));
+  s->tp_run = (unsigned *)dev_upload(P->run, (size_t)(P->nruns ? P->nruns : 1) * 2 * sizeof(unsigned));
+  s->tp_colw = (unsigned short *)dev_upload(P->colw, (size_t)P->nnz * sizeof(unsigned short));
+  s->tp_roww = (unsigned short *)dev_upload(P->roww, (size_t)P->nnz * sizeof(unsigned short));
+  s->tp_vals = (double *)dev_upload(P->vals, (size_t)P->nnz * sizeof(double));
+  s->tp_prod = (double *)lsb_hip_malloc((size_t)P->nnz * sizeof(double));
+  s->tp_binparts = (double *)lsb_hip_malloc((size_t)P->nbins * sizeof(double));
+  LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+  lsb_pb_free(P);
+}
+
 /* Upload rows [r0,r1) of the 0-based operator `S` (global column ids) as one
  * shard.  When `S` holds only the shard's rows, pass local=1. */
 void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
@@ -184,7 +204,11 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
   {
     struct csr gview = {n, 0, (unsigned *)offs, (unsigned *)cols, (double *)(S->vals + j0)};
     const char *e = getenv("LSBENCH_HIP_PANEL_COLS");
-    const unsigned width = e ? (unsigned)strtoul(e, NULL, 10) : 262144u; /* 2 MiB of x */
+    /* window of x one bin / panel gathers from: 4 MiB = an XCD's whole L2.  Measured
+     * on the 8 M-row power-law operator (binned form): 1 MiB 3.71 ms, 2 MiB 3.05,
+     * 3 MiB 2.85, 4 MiB 2.80, 8 MiB 3.21 -- fewer passes over y win until the
+     * window no longer fits */
+    const unsigned width = e ? (unsigned)strtoul(e, NULL, 10) : 524288u;
     const int forced = o->spmv_variant == LSB_SPMV_PANEL;
     const int scattered = s->nnz > 4000000ull && (double)(hi - lo) * 8.0 > 16.0e6 &&
                           lsb_csr_mean_scatter(&gview, row_begin) > 1.0e6;
@@ -194,6 +218,12 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
     if (width && (o->spmv_variant == LSB_SPMV_BINNED ||
                   (o->spmv_variant == LSB_SPMV_AUTO && scattered)))
       shard_build_bins(s, &gview, width);
+    /* on request only: measured slower than the binned form on the 8 M-row power-law
+     * operator (4.16 vs 2.78 ms: both phases are latency-bound at the two workgroups
+     * per CU their 64 KB of LDS allow), DESIGN.md section 4 */
+    if (o->spmv_variant == LSB_SPMV_TWOPHASE ||
+        (o->spmv_variant == LSB_SPMV_AUTO && scattered && getenv("LSBENCH_HIP_TRY_TWOPHASE")))
+      shard_build_twophase(s, &gview, n_glob);
   }
   /* Near-uniform row lengths (stencils, meshes): also keep a sliced-ELL copy;
    * tune_spmv() keeps whichever kernel is faster on this shard. */
@@ -320,6 +350,9 @@ void shard_free(struct shard *s) {
   lsb_hip_free(s->bd_chunk), lsb_hip_free(s->bd_rows), lsb_hip_free(s->bd_cols);
   lsb_hip_free(s->bd_vals);
   free(s->h_binchunk);
+  lsb_hip_free(s->tp_item), lsb_hip_free(s->tp_binrun), lsb_hip_free(s->tp_run);
+  lsb_hip_free(s->tp_colw), lsb_hip_free(s->tp_roww), lsb_hip_free(s->tp_vals);
+  lsb_hip_free(s->tp_prod), lsb_hip_free(s->tp_binparts);
   precond_free_shard(s);
   free(s->recv), free(s->send);
 }
@@ -604,6 +637,12 @@ void spmv_shard(struct shard *s, const double *xfull, double *y,
     sell_launch(s, 0, s->nslice, xfull, y, xdot, partials, np, st);
     return;
   }
+  if (s->variant == LSB_SPMV_TWOPHASE) {
+    lsb_k_spmv_twophase(s->tp_items, s->tp_item, s->tp_vals, s->tp_colw, s->tp_roww, s->tp_col_lo,
+                        s->tp_bins, s->tp_binrun, s->tp_run, s->tp_prod, s->n, xfull, s->tp_xlen, y,
+                        xdot, partials, np, s->tp_binparts, st, g_stream);
+    return;
+  }
   if (s->variant == LSB_SPMV_BINNED) {
     /* y = 0, then one launch per bin (= per L2-sized window of x) adds to it */
     LSB_CHK_HIP(hipMemsetAsync(y, 0, (size_t)s->n * sizeof(double), g_stream));
@@ -659,7 +698,8 @@ void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
   if (s->variant == LSB_SPMV_SELL && !s->d_sptr)
     s->variant = LSB_SPMV_ADAPTIVE; /* the operator did not qualify for the copy */
   if ((s->variant != LSB_SPMV_ADAPTIVE && s->variant != LSB_SPMV_PANEL &&
-       s->variant != LSB_SPMV_SELL && s->variant != LSB_SPMV_BINNED) ||
+       s->variant != LSB_SPMV_SELL && s->variant != LSB_SPMV_BINNED &&
+       s->variant != LSB_SPMV_TWOPHASE) ||
       s->nnz < 4000000ull)
     return; /* small operators are launch-latency bound: nothing to tune */
   float best = 1e30f;
@@ -682,9 +722,13 @@ void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
   if (s->pn && (any || s->variant == LSB_SPMV_PANEL))
     for (unsigned f = 0; f < 4; f++)
       cand[ncand].v = LSB_SPMV_PANEL, cand[ncand].f = f, cand[ncand++].g = grid0;
+  if (s->tp_bins && (any || s->variant == LSB_SPMV_TWOPHASE))
+    cand[ncand].v = LSB_SPMV_TWOPHASE, cand[ncand].f = 0, cand[ncand++].g = grid0;
   if (s->bn && (any || s->variant == LSB_SPMV_BINNED)) {
-    /* stream loads {nontemporal, plain} x gather of x {plain, L1-bypassing, nontemporal} */
-    static const unsigned bf[] = {LSB_SP_NT, 0, LSB_SP_NT | 8u, 8u, LSB_SP_NT | 16u};
+    /* stream loads {nontemporal, plain}; the gather of x stays a plain load: L1-
+     * bypassing (sc1) gathers measured the same, nontemporal ones 1.7x slower
+     * (flags 8 / 16, kept for experiments through opts.spmv_tune) */
+    static const unsigned bf[] = {LSB_SP_NT, 0};
     for (unsigned k = 0; k < sizeof bf / sizeof bf[0]; k++)
       cand[ncand].v = LSB_SPMV_BINNED, cand[ncand].f = bf[k], cand[ncand++].g = grid0;
   }
@@ -715,6 +759,13 @@ void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
   s->variant = bv;
   s->sp_flags = bf;
   /* the copies that lost are not kept */
+  if (any && bv != LSB_SPMV_TWOPHASE && s->tp_bins) {
+    lsb_hip_free(s->tp_item), lsb_hip_free(s->tp_binrun), lsb_hip_free(s->tp_run);
+    lsb_hip_free(s->tp_colw), lsb_hip_free(s->tp_roww), lsb_hip_free(s->tp_vals);
+    lsb_hip_free(s->tp_prod), lsb_hip_free(s->tp_binparts);
+    s->tp_item = s->tp_binrun = s->tp_run = NULL, s->tp_colw = s->tp_roww = NULL;
+    s->tp_vals = s->tp_prod = s->tp_binparts = NULL, s->tp_bins = 0;
+  }
   if (any && bv != LSB_SPMV_BINNED && s->bn) {
     lsb_hip_free(s->bd_chunk), lsb_hip_free(s->bd_rows), lsb_hip_free(s->bd_cols);
     lsb_hip_free(s->bd_vals);

@@ -106,6 +106,11 @@ struct shard {
   unsigned *h_binchunk; /* bn+1: first chunk of each bin (host) */
   unsigned *bd_chunk, *bd_rows, *bd_cols;
   double *bd_vals;
+  /* two-phase form (LSB_SPMV_TWOPHASE), built for scattered operators only */
+  unsigned tp_items, tp_bins, tp_col_lo, tp_xlen; /* tp_bins = 0: not built */
+  unsigned *tp_item, *tp_binrun, *tp_run;
+  unsigned short *tp_colw, *tp_roww;
+  double *tp_vals, *tp_prod, *tp_binparts;
   struct lsb_xfer *recv, *send;
   int nrecv, nsend;
 };

@@ -77,6 +77,12 @@ void lsb_k_spmv_sell(unsigned flags, unsigned grid_cap, const unsigned *sptr, un
 void lsb_k_spmv_binned(unsigned flags, unsigned chunk_cap, const unsigned *chunk_begin, unsigned c0,
                        unsigned nchunk, const unsigned *rows, const unsigned *cols, const double *vals,
                        const double *x, double *y, const struct lsb_pcg_state *st, void *stream);
+void lsb_k_spmv_twophase(unsigned nitems, const unsigned *item, const double *vals,
+                         const unsigned short *colw, const unsigned short *roww, unsigned col_lo,
+                         unsigned nbins, const unsigned *bin_run, const unsigned *run, double *prod,
+                         unsigned n, const double *x, unsigned xlen, double *y, const double *xdot,
+                         double *partials, unsigned *npartials, double *binparts,
+                         const struct lsb_pcg_state *st, void *stream);
 void lsb_k_reduce_final(const double *partials, unsigned nparts, unsigned width,
                         double *out, int take_sqrt,
                         const struct lsb_pcg_state *st, void *stream);

@@ -571,6 +571,105 @@ void lsb_binned_free(struct lsb_binned *B) {
   free(B);
 }
 
+/* ------------------------------------------------------------------------ */
+/* Two-phase form (LSB_SPMV_TWOPHASE): see include/lsbench_hip.h.             */
+/* ------------------------------------------------------------------------ */
+#define PB_ITEM 32768u
+struct lsb_pb *lsb_csr_pbize(const struct csr *A) {
+  if (!A || A->nrows == 0)
+    return NULL;
+  const unsigned n = A->nrows, base = A->base;
+  const unsigned long long nnz = A->offs[n];
+  if (nnz == 0 || nnz > 0x7FFFFFFEull)
+    return NULL;
+  unsigned lo, hi;
+  lsb_csr_col_hull(A, &lo, &hi);
+  lo -= lo % LSB_PB_COLS; /* windows start on a multiple of the chunk width */
+  const unsigned nch = (hi - lo + LSB_PB_COLS - 1) / LSB_PB_COLS;
+  const unsigned nb = (n + LSB_PB_ROWS - 1) / LSB_PB_ROWS;
+  const unsigned long long nbuck = (unsigned long long)nch * nb;
+  if (nbuck > (1ull << 31))
+    return NULL;
+  /* counting sort by (chunk, bin); the row-major sweep keeps rows, then columns,
+   * ascending inside a bucket */
+  unsigned *cnt = lsb_calloc(unsigned, (size_t)nbuck + 1);
+  if (!cnt)
+    errx(EXIT_FAILURE, "out of host memory for the two-phase operator");
+  for (unsigned i = 0; i < n; i++) {
+    const unsigned b = i / LSB_PB_ROWS;
+    for (unsigned j = A->offs[i]; j < A->offs[i + 1]; j++)
+      cnt[(size_t)((A->cols[j] - base - lo) / LSB_PB_COLS) * nb + b + 1]++;
+  }
+  unsigned long long nruns = 0;
+  for (unsigned long long k = 0; k < nbuck; k++) {
+    nruns += cnt[k + 1] != 0;
+    cnt[k + 1] += cnt[k];
+  }
+  struct lsb_pb *P = lsb_calloc(struct lsb_pb, 1);
+  P->nrows = n, P->ncols_lo = lo, P->nchunks = nch, P->nbins = nb, P->nnz = nnz, P->nruns = nruns;
+  P->vals = (double *)malloc((size_t)nnz * sizeof(double));
+  P->colw = (unsigned short *)malloc((size_t)nnz * sizeof(unsigned short));
+  P->roww = (unsigned short *)malloc((size_t)nnz * sizeof(unsigned short));
+  P->bin_run = lsb_calloc(unsigned, (size_t)nb + 1);
+  P->run = (unsigned *)malloc((size_t)(nruns ? nruns : 1) * 2 * sizeof(unsigned));
+  if (!P->vals || !P->colw || !P->roww || !P->run)
+    errx(EXIT_FAILURE, "out of host memory for the two-phase operator");
+  /* runs of a bin, in chunk order */
+  for (unsigned b = 0; b < nb; b++)
+    for (unsigned c = 0; c < nch; c++)
+      P->bin_run[b + 1] += cnt[(size_t)c * nb + b + 1] != cnt[(size_t)c * nb + b];
+  for (unsigned b = 0; b < nb; b++)
+    P->bin_run[b + 1] += P->bin_run[b];
+  {
+    unsigned *cur = (unsigned *)malloc((size_t)nb * sizeof(unsigned));
+    for (unsigned b = 0; b < nb; b++)
+      cur[b] = P->bin_run[b];
+    for (unsigned c = 0; c < nch; c++)
+      for (unsigned b = 0; b < nb; b++) {
+        const unsigned e0 = cnt[(size_t)c * nb + b], e1 = cnt[(size_t)c * nb + b + 1];
+        if (e1 > e0) {
+          P->run[2 * (size_t)cur[b]] = e0, P->run[2 * (size_t)cur[b] + 1] = e1 - e0;
+          cur[b]++;
+        }
+      }
+    free(cur);
+  }
+  /* phase-1 work items: slices of a chunk */
+  {
+    size_t cap = (size_t)(nnz / PB_ITEM) + nch + 8, ni = 0;
+    P->item = (unsigned *)malloc(cap * 3 * sizeof(unsigned));
+    for (unsigned c = 0; c < nch; c++) {
+      const unsigned e0 = cnt[(size_t)c * nb], e1 = cnt[(size_t)(c + 1) * nb];
+      for (unsigned e = e0; e < e1; e += PB_ITEM) {
+        P->item[3 * ni] = c, P->item[3 * ni + 1] = e;
+        P->item[3 * ni + 2] = e + PB_ITEM < e1 ? e + PB_ITEM : e1;
+        ni++;
+      }
+    }
+    P->nitems = (unsigned)ni;
+  }
+  /* scatter (cnt[k] is the cursor of bucket k from here on) */
+  for (unsigned i = 0; i < n; i++) {
+    const unsigned b = i / LSB_PB_ROWS;
+    for (unsigned j = A->offs[i]; j < A->offs[i + 1]; j++) {
+      const unsigned c = A->cols[j] - base - lo, ch = c / LSB_PB_COLS;
+      const unsigned e = cnt[(size_t)ch * nb + b]++;
+      P->vals[e] = A->vals[j];
+      P->colw[e] = (unsigned short)(c % LSB_PB_COLS);
+      P->roww[e] = (unsigned short)(i % LSB_PB_ROWS);
+    }
+  }
+  free(cnt);
+  return P;
+}
+
+void lsb_pb_free(struct lsb_pb *P) {
+  if (!P)
+    return;
+  free(P->vals), free(P->colw), free(P->roww), free(P->item), free(P->bin_run), free(P->run);
+  free(P);
+}
+
 /* mean |col - row| over a sample of the rows: how far the gather of a row
  * strays from the diagonal (banded: ~bandwidth; scattered: ~n/3) */
 double lsb_csr_mean_scatter(const struct csr *A, unsigned row_begin) {

@@ -91,7 +91,7 @@ def test_powerlaw_8m_rows_spmv(hip):
     d = np.diff(A.offs.astype(np.int64))
     assert d.max() <= 4096 and d.min() >= 1 and 31 < d.mean() < 33
     x = np.random.default_rng(1).standard_normal(A.nrows)
-    for variant in (hip.SPMV_BINNED, hip.SPMV_ADAPTIVE, hip.SPMV_SUBWAVE):
+    for variant in (hip.SPMV_TWOPHASE, hip.SPMV_BINNED, hip.SPMV_ADAPTIVE, hip.SPMV_SUBWAVE):
         s = hip.Solver(A, hip.default_opts(op_mode=hip.OP_RAW, precond=hip.PRECOND_NONE,
                                            spmv_variant=variant))
         _spmv_check(hip, A, s, x, thr)

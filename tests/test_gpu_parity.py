@@ -627,3 +627,62 @@ def test_binned_spmv(hip, width, monkeypatch):
     x, res = s.solve(bb)
     s.destroy()
     assert res.status == 1 and np.linalg.norm(bb - M @ x) / np.linalg.norm(bb) <= 2e-10
+
+
+def test_twophase_spmv(hip):
+    """LSB_SPMV_TWOPHASE (hip_pb.hip): products by column chunk with the window of
+    x in LDS, sums by row bin with the bin's rows in LDS.  Element-wise oracle bound
+    on scattered, ragged, banded and tiny operators, over shards; bit-identical
+    from run to run; fused dot product; PCG and GMRES on top."""
+    import torch
+    import scipy.sparse as sp
+    rng = np.random.default_rng(11)
+    for spec in ("powerlaw:n=60000,gamma=%r,max=4096,seed=4" % GAMMA, "powerlaw:n=6500,gamma=1.05,max=4096,seed=9",
+                 "lap2d:nx=300,ny=170", "lap2d:nx=3,ny=2", "powerlaw:n=300000,gamma=2.2,max=64,seed=5"):
+        A = hip.lsbench_matrix_synth(spec)
+        for nvirt in (1, 3):
+            if nvirt > 1 and A.nrows < 100:
+                continue
+            s = hip.Solver(A, hip.default_opts(op_mode=hip.OP_RAW, precond=hip.PRECOND_NONE,
+                                               spmv_variant=hip.SPMV_TWOPHASE, nvirt=nvirt))
+            assert s.spmv_variant == hip.SPMV_TWOPHASE
+            x = rng.standard_normal(A.nrows)
+            ys = []
+            for _ in range(2):
+                d_y = torch.full((A.nrows,), float("nan"), dtype=torch.float64, device="cuda:0")
+                s.spmv_dev(_dev(x), d_y)
+                ys.append(d_y.cpu().numpy())
+            _check_spmv(A, x, ys[0])
+            assert np.array_equal(ys[0], ys[1])
+            s.destroy()
+    L = hip.lsbench_matrix_synth("lap2d:nx=150,ny=120")
+    b = O.rhs(L.nrows)
+    xo, ito, _, _ = O.pcg_jacobi(L.offs, L.cols, L.vals, b, 1e-10)
+    for kry in (hip.KRYLOV_PCG, hip.KRYLOV_PCG1):
+        s = hip.Solver(L, hip.default_opts(op_mode=hip.OP_RAW, spmv_variant=hip.SPMV_TWOPHASE, tol=1e-10,
+                                           krylov=kry))
+        x, res = s.solve(b)
+        s.destroy()
+        assert res.status == 1 and abs(int(res.iters) - ito) <= 3
+        assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-9
+    # the SPD power-law operator of config 5 (spd=1), CG through the two-phase SpMV
+    S = hip.lsbench_matrix_synth("powerlaw:n=40000,gamma=1.4,max=512,seed=2,spd=1")
+    bs = O.rhs(S.nrows)
+    xo, ito, _, sto = O.pcg_jacobi(S.offs, S.cols, S.vals, bs, 1e-10)
+    s = hip.Solver(S, hip.default_opts(op_mode=hip.OP_RAW, spmv_variant=hip.SPMV_TWOPHASE, tol=1e-10))
+    x, res = s.solve(bs)
+    s.destroy()
+    assert sto == 1 and res.status == 1 and abs(int(res.iters) - ito) <= 2
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-9
+    thr, _ = O.powerlaw_table(GAMMA, 256)
+    o, c, v = O.powerlaw(20000, thr, 3)
+    B = sp.csr_matrix((v, c, o.astype(np.int64)), shape=(20000, 20000))
+    M = (B + sp.diags(1.0 + np.asarray(abs(B).sum(axis=1)).ravel())).tocsr()
+    M.sort_indices()
+    bb = O.rhs(20000)
+    s = hip.Solver(hip.Matrix.from_arrays(M.indptr, M.indices, M.data),
+                   hip.default_opts(op_mode=hip.OP_RAW, spmv_variant=hip.SPMV_TWOPHASE, tol=1e-10,
+                                    krylov=hip.KRYLOV_GMRES))
+    x, res = s.solve(bb)
+    s.destroy()
+    assert res.status == 1 and np.linalg.norm(bb - M @ x) / np.linalg.norm(bb) <= 2e-10

@@ -522,3 +522,58 @@ def test_powerlaw_spd_variant():
     assert np.array_equal(part.offs, S.offs[1000:1801] - S.offs[1000])
     assert np.array_equal(part.cols, S.cols[S.offs[1000]:S.offs[1800]])
     assert np.array_equal(part.vals, S.vals[S.offs[1000]:S.offs[1800]])
+
+
+@pytest.mark.parametrize("spec", ["powerlaw:n=30000,gamma=1.2,max=3000,seed=7",
+                                  "powerlaw:n=5000,gamma=1.585350372615855,max=4096,seed=3",
+                                  "lap2d:nx=170,ny=150"])
+def test_twophase_form(spec):
+    """lsb_csr_pbize (LSB_SPMV_TWOPHASE): a permutation of the entries ordered by
+    (column chunk, row bin, row, column); every (chunk, bin) pair one run, the runs
+    of a bin listed in chunk order; phase-1 items tile the entries chunk by chunk;
+    products summed through the run table reproduce A x."""
+    import ctypes as C
+    L = la._lib
+    A = la.lsbench_matrix_synth(spec)
+    P = L.load().lsb_csr_pbize(A.ptr).contents
+    nnz, nb, nch, ni, nr = int(P.nnz), int(P.nbins), int(P.nchunks), int(P.nitems), int(P.nruns)
+    assert nnz == A.nnz and P.nrows == A.nrows and nb == (A.nrows + L.PB_ROWS - 1) // L.PB_ROWS
+    vals = np.ctypeslib.as_array(P.vals, (nnz,)).copy()
+    colw = np.ctypeslib.as_array(P.colw, (nnz,)).astype(np.int64)
+    roww = np.ctypeslib.as_array(P.roww, (nnz,)).astype(np.int64)
+    item = np.ctypeslib.as_array(P.item, (3 * ni,)).reshape(ni, 3).astype(np.int64)
+    binrun = np.ctypeslib.as_array(P.bin_run, (nb + 1,)).astype(np.int64)
+    run = np.ctypeslib.as_array(P.run, (2 * nr,)).reshape(nr, 2).astype(np.int64)
+    col_lo = int(P.ncols_lo)
+    L.load().lsb_pb_free(C.pointer(P))
+    assert col_lo % L.PB_COLS == 0 and colw.max() < L.PB_COLS and roww.max() < L.PB_ROWS
+    # items: contiguous, in order, <= 32768 entries, one chunk each
+    assert item[0, 1] == 0 and item[-1, 2] == nnz and np.all(item[1:, 1] == item[:-1, 2])
+    assert np.all(item[:, 2] - item[:, 1] <= 32768) and np.all(np.diff(item[:, 0]) >= 0)
+    chunk_of = np.repeat(item[:, 0], item[:, 2] - item[:, 1])
+    # runs: every entry in exactly one run; a bin's runs in chunk (= entry) order
+    cover = np.zeros(nnz, np.int64)
+    bin_of = np.empty(nnz, np.int64)
+    for b in range(nb):
+        rr = run[binrun[b]:binrun[b + 1]]
+        assert np.all(np.diff(rr[:, 0]) > 0)
+        for s0, ln in rr:
+            cover[s0:s0 + ln] += 1
+            bin_of[s0:s0 + ln] = b
+            assert len(set(chunk_of[s0:s0 + ln])) == 1 and np.all(np.diff(roww[s0:s0 + ln]) >= 0)
+    assert np.all(cover == 1)
+    rows = bin_of * L.PB_ROWS + roww
+    cols = col_lo + chunk_of * L.PB_COLS + colw
+    offs = A.offs.astype(np.int64)
+    arow = np.repeat(np.arange(A.nrows), np.diff(offs))
+    o1 = np.lexsort((A.cols, arow))
+    o2 = np.lexsort((cols, rows))
+    assert np.array_equal(arow[o1], rows[o2]) and np.array_equal(A.cols[o1].astype(np.int64), cols[o2])
+    assert np.array_equal(A.vals[o1], vals[o2])
+    key = (chunk_of * nb + bin_of) * (1 << 40) + rows * (1 << 20) + (cols - col_lo) % (1 << 20)
+    assert np.all(np.diff(chunk_of * nb + bin_of) >= 0)            # (chunk, bin)-major
+    x = np.sin(np.arange(max(A.nrows, int(cols.max()) + 1), dtype=np.float64))
+    y = np.zeros(A.nrows)
+    np.add.at(y, rows, vals * x[cols])
+    assert np.allclose(y, O.spmv(A.offs, A.cols, A.vals, x[:A.nrows] if cols.max() < A.nrows else x),
+                       rtol=1e-12, atol=1e-12)

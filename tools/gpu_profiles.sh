@@ -1,15 +1,34 @@
 #!/bin/bash
-# Round profiles: kernel-trace stats of the default bench + PMC passes (own runs).
+# Round profiles: the default bench, kernel-trace stats and PMC passes (their own runs,
+# --kernel-trace only next to --pmc) for configs 3, 4, 5; config 2 and the optional
+# forms as bench lines.  Condensed into profiles/ by tools/summarize_profiles.py.
 cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=gpurun_out/${1:-profiles}; mkdir -p $OUT; export TMPDIR=/tmp
 step() { local name=$1 secs=$2; shift 2
   echo "=== $name"; timeout -k 10 "$secs" "$@" > "$OUT/$name.log" 2>&1; local rc=$?
   echo "rc=$rc"; if [ $rc -ge 124 ]; then echo "step $name killed: stopping"; exit $rc; fi; }
-step bench 400 python bench.py
-step trace 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --steps 1 --warmup 0 --cpu-seconds 0
-step pmc_fetch 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py --fixed-iters 60 --steps 1 --warmup 0 --cpu-seconds 0
-step pmc_write 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -- python3 bench.py --fixed-iters 60 --steps 1 --warmup 0 --cpu-seconds 0
-step trace_lap3d 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_lap3d" -- python3 bench.py --workload lap3d --fixed-iters 100 --steps 1 --warmup 0 --cpu-seconds 0
-step trace_cfg2 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_cfg2" -- python3 bench.py --workload file:tests/golden/matrices/xn3b_A_18.txt.gz --tol 1e-12 --steps 20 --warmup 2 --cpu-seconds 0
+Q="--cpu-seconds 0 --cfg4 0"
+F=file:tests/golden/matrices/xn3b_A_18.txt.gz
+step bench 500 python bench.py
+step trace 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --steps 1 --warmup 0 $Q
+step pmc_fetch 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py --fixed-iters 60 --steps 1 --warmup 0 $Q
+step pmc_write 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -- python3 bench.py --fixed-iters 60 --steps 1 --warmup 0 $Q
+step trace_lap3d 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_lap3d" -- python3 bench.py --workload lap3d --fixed-iters 100 --steps 1 --warmup 0 $Q
+step pmc_fetch_lap3d 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch_lap3d" -- python3 bench.py --workload lap3d --fixed-iters 40 --steps 1 --warmup 0 $Q
+step pmc_write_lap3d 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write_lap3d" -- python3 bench.py --workload lap3d --fixed-iters 40 --steps 1 --warmup 0 $Q
+step bench_powerlaw 400 python bench.py --workload powerlaw $Q
+step trace_powerlaw 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_powerlaw" -- python3 bench.py --workload powerlaw --steps 1 $Q
+step pmc_fetch_powerlaw 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch_powerlaw" -- python3 bench.py --workload powerlaw --steps 1 $Q
+step pmc_write_powerlaw 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write_powerlaw" -- python3 bench.py --workload powerlaw --steps 1 $Q
+for v in 6 1; do step bench_powerlaw_v$v 400 python bench.py --workload powerlaw --spmv $v $Q; done
+step trace_cfg2 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_cfg2" -- python3 bench.py --workload $F --tol 1e-12 --steps 20 --warmup 2 --persistent 0 $Q
+C2="--workload $F --tol 1e-12 --steps 100 --warmup 5 --cfg4 0 --verify 0"
+step cfg2_launches 300 python bench.py $C2 --persistent 0
+step cfg2_persistent 300 python bench.py $C2 --persistent 1 --cpu-seconds 0
+step cfg2_dense_inverse 300 python bench.py $C2 --persistent 0 --precond bj --block-size 1000000 --cpu-seconds 0
+step cfg2_cheb4 300 python bench.py $C2 --persistent 0 --precond cheb --cheb-degree 4 --cpu-seconds 0
+step cfg3_fp32 400 python bench.py --precision fp32 --steps 2 $Q
+step cfg3_cheb4 400 python bench.py --precond cheb --cheb-degree 4 --steps 2 $Q
+step cfg3_bj8 400 python bench.py --precond bj --block-size 8 --steps 2 $Q
 find "$OUT" -name '*kernel_trace.csv' -size +12M -delete 2>/dev/null
 tail -n 3 $OUT/bench.log

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Condense gpurun_out/<dir> (tools/gpu_profiles.sh) into profiles/<round>_*:
 kernel-trace stats, PMC traffic per launch (FETCH_SIZE corrected x2 for gfx950
-as MI355X_MICROARCH.md section HBM prescribes; WRITE_SIZE as read), and
-profiles/pmc_traffic.json that bench.py reads for roofline.traffic."""
+as MI355X_MICROARCH.md section HBM prescribes; WRITE_SIZE as read), the bench
+lines, and profiles/pmc_traffic.json that bench.py reads for roofline.traffic
+(bytes per launch of the dominant kernel, per workload)."""
 import collections, csv, glob, json, os, shutil, sys
 
 src, rnd = sys.argv[1], sys.argv[2]
@@ -16,47 +17,67 @@ def one(pattern):
     return g[-1] if g else None  # newest run wins
 
 
-for tag in ("trace", "trace_lap3d", "trace_cfg2"):
+for tag in ("trace", "trace_lap3d", "trace_cfg2", "trace_powerlaw"):
     f = one(tag + "/*/*kernel_stats.csv")
     if f:
         shutil.copyfile(f, os.path.join(out, "%s_%s_kernel_stats.csv" % (rnd, tag)))
 
-pmc = {}
-for cname, tag in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
-    f = one(tag + "/*/*counter_collection.csv")
-    if not f:
-        continue
-    agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] == cname:
-            agg[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
-    for k, v in agg.items():
-        v.sort()
-        pmc.setdefault(k, {})[cname + "_KB_median"] = v[len(v) // 2]
-        pmc[k]["launches_" + cname] = len(v)
-
-lines = ["kernel,launches,FETCH_SIZE_KB(median),fetch_bytes_corrected_x2,WRITE_SIZE_KB(median),write_bytes,hbm_bytes_per_launch"]
 traffic = {}
-for k, d in sorted(pmc.items()):
-    if "FETCH_SIZE_KB_median" not in d or "WRITE_SIZE_KB_median" not in d:
+for wl, suffix in (("lap2d", ""), ("lap3d", "_lap3d"), ("powerlaw", "_powerlaw")):
+    pmc = {}
+    for cname, tag in (("FETCH_SIZE", "pmc_fetch" + suffix), ("WRITE_SIZE", "pmc_write" + suffix)):
+        f = one(tag + "/*/*counter_collection.csv")
+        if not f:
+            continue
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == cname:
+                agg[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+        for k, v in agg.items():
+            v.sort()
+            pmc.setdefault(k, {})[cname + "_KB_median"] = v[len(v) // 2]
+            pmc[k][cname + "_KB_sum"] = sum(v)
+            pmc[k]["launches_" + cname] = len(v)
+    if not pmc:
         continue
-    fb = 2 * d["FETCH_SIZE_KB_median"] * 1024  # gfx950: FETCH_SIZE reads half the bytes
-    wb = d["WRITE_SIZE_KB_median"] * 1024
-    lines.append("%s,%d,%.1f,%.0f,%.1f,%.0f,%.0f" % (k, d["launches_FETCH_SIZE"], d["FETCH_SIZE_KB_median"], fb,
-                                                     d["WRITE_SIZE_KB_median"], wb, fb + wb))
-    if "k_spmv_" in k and d["launches_FETCH_SIZE"] > 20:
-        # the SpMV kernel the solve ran (the timing pass at setup launches the
-        # other forms a few times each)
-        name = k.split("<")[0].split()[-1]
-        if d["launches_FETCH_SIZE"] > traffic.get("lap2d", {}).get("launches", 0):
-            traffic["lap2d"] = {"bytes": fb + wb, "kernel": name, "launches": d["launches_FETCH_SIZE"]}
-open(os.path.join(out, "%s_pmc_traffic_lap2d.csv" % rnd), "w").write("\n".join(lines) + "\n")
+    lines = ["kernel,launches,FETCH_SIZE_KB(median),fetch_bytes_corrected_x2,WRITE_SIZE_KB(median),write_bytes,hbm_bytes_per_launch"]
+    best = None
+    for k, d in sorted(pmc.items()):
+        if "FETCH_SIZE_KB_median" not in d or "WRITE_SIZE_KB_median" not in d:
+            continue
+        fb = 2 * d["FETCH_SIZE_KB_median"] * 1024  # gfx950: FETCH_SIZE reads half the bytes
+        wb = d["WRITE_SIZE_KB_median"] * 1024
+        lines.append("%s,%d,%.1f,%.0f,%.1f,%.0f,%.0f" % (k, d["launches_FETCH_SIZE"], d["FETCH_SIZE_KB_median"], fb,
+                                                         d["WRITE_SIZE_KB_median"], wb, fb + wb))
+        if ("k_spmv_" in k or "k_pb_" in k) and d["launches_FETCH_SIZE"] > 20:
+            name = k.split("<")[0].split()[-1]
+            if best is None or d["launches_FETCH_SIZE"] > best[1]:
+                best = (name, d["launches_FETCH_SIZE"], fb + wb)
+    if wl == "powerlaw":
+        # one SpMV = the two phases' launches together: median products launch + median reduce launch
+        tot = sum(2 * d["FETCH_SIZE_KB_median"] * 1024 + d["WRITE_SIZE_KB_median"] * 1024
+                  for k, d in pmc.items() if "k_pb_" in k and "FETCH_SIZE_KB_median" in d and "WRITE_SIZE_KB_median" in d)
+        if tot:
+            best = ("k_pb_products + k_pb_reduce", best[1] if best else 0, tot)
+    open(os.path.join(out, "%s_pmc_traffic_%s.csv" % (rnd, wl)), "w").write("\n".join(lines) + "\n")
+    if best:
+        traffic[wl] = {"bytes": best[2], "kernel": best[0], "launches": best[1],
+                       "source": "profiles/%s_pmc_traffic_%s.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                                 "separate passes of this command; FETCH_SIZE x 2)" % (rnd, wl)}
+    print(wl)
+    print("\n".join(lines))
 if traffic:
     json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
-for tag in ("bench",):
-    f = os.path.join(src, tag + ".log")
-    if os.path.exists(f):
-        with open(f) as fi, open(os.path.join(out, "%s_%s.jsonl" % (rnd, tag)), "w") as fo:
-            fo.writelines(l for l in fi if l.startswith("{"))
-print("\n".join(lines))
+# bench lines
+names = ["bench", "bench_powerlaw", "bench_powerlaw_v6", "bench_powerlaw_v1", "cfg2_launches", "cfg2_persistent",
+         "cfg2_dense_inverse", "cfg2_cheb4", "cfg3_fp32", "cfg3_cheb4", "cfg3_bj8"]
+with open(os.path.join(out, "%s_bench.jsonl" % rnd), "w") as fo:
+    for tag in names:
+        f = os.path.join(src, tag + ".log")
+        if os.path.exists(f):
+            for l in open(f):
+                if l.startswith("{"):
+                    d = json.loads(l)
+                    d["_run"] = tag
+                    fo.write(json.dumps(d) + "\n")
 print(traffic)
