@@ -86,7 +86,7 @@ def parse():
                         "(7-point 400^3, 64 M rows) solved --cfg4-steps times on the same N GPUs -- the "
                         "workload the 8-vs-1 GPU target is stated on; 0 = skip it")
     p.add_argument("--cfg4-steps", type=int, default=2)
-    p.add_argument("--persistent", type=int, default=-1,
+    p.add_argument("--persistent", type=int, default=0,
                    help="launch-bound operators: 1 = the whole solve as one persistent launch, 0 = "
                         "launch per kernel, -1 = whichever the creation-time timing finds faster")
     p.add_argument("--precond", default="jacobi", choices=["jacobi", "l1", "none", "cheb", "bj"],

@@ -175,8 +175,11 @@ struct lsb_hip_opts {
                         same tolerance on the fp64 operator's residual   [FP64] */
   int persistent;    /* launch-bound operators (everything fits one XCD's L2):
                         the whole solve as ONE launch confined to one XCD;
-                        -1 = where the creation-time timing says it is faster,
-                        0 off, 1 on                                       [-1] */
+                        1 on, 0 off, -1 = time both forms at solver creation
+                        and keep the faster (which form runs then depends on
+                        a timing: iterates differ in the last bits between
+                        the forms).  Measured 2x slower than the two-launch
+                        iteration on tests/xn3b_A_18.txt, hence             [0] */
   double comm_deadline_s; /* sharded solves: the host gives a poll of the device
                         state at most this long before it reports a hung
                         collective and exits non-zero                    [120] */
