@@ -97,6 +97,7 @@ def parse():
     p.add_argument("--precision", default="fp64", choices=["fp64", "fp32"],
                    help="fp32 = matrix values stored and streamed as fp32, fp64 vectors and "
                         "accumulation, fp64 iterative refinement to the same tolerance")
+    p.add_argument("--verbose", type=int, default=0, help="library verbosity (2: the timing pass's lines)")
     p.add_argument("--verify", type=int, default=1,
                    help="1 = a solve counts only once ||b - S x|| <= tol ||b|| holds for the residual "
                         "recomputed from x (correction solves inside the timed region if needed)")
@@ -294,7 +295,7 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
                                "bj": la.PRECOND_BLOCKJACOBI}[a.precond],
                            cheb_degree=a.cheb_degree, block_size=a.block_size,
                            precision=la.PREC_MIXED if a.precision == "fp32" else la.PREC_FP64,
-                           persistent=a.persistent,
+                           persistent=a.persistent, verbose=a.verbose,
                            verify=1 if (a.verify and a.fixed_iters == 0) else 0)
     if c.dist_on:
         solver = la.Solver(Aloc, opts, row_begin=r0, n_global=n)
@@ -423,7 +424,7 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
                              "8-10 B per entry, so frac exceeds frac_hbm (PMC bytes / time / peak)",
                      "kernel": kernel + (" (panels)" if solver.spmv_variant == la.SPMV_PANEL else "") + " (fused p.q)",
                      "launch_ms": spmv_avg_ms, "back_to_back_launch_ms": b2b_ms,
-                     "spmv_flags": solver.spmv_flags,
+                     "spmv_flags": solver.spmv_flags, "xcd_period_slices": solver.spmv_period,
                      "algorithmic_bytes": bytes_spmv, "measured": how},
     }
     if a.fixed_iters > 0:
@@ -450,7 +451,8 @@ def main():
                                            "setup_seconds", "comm")}
         line["cfg4"]["config"] = r4["config"]
         line["cfg4"]["spmv"] = {k: r4["roofline"][k] for k in ("kernel", "launch_ms", "achieved", "frac",
-                                                               "algorithmic_bytes")}
+                                                               "algorithmic_bytes", "traffic", "frac_hbm",
+                                                               "xcd_period_slices", "spmv_flags")}
         line["cfg4"]["note"] = ("BASELINE.json configs[3] on the same %d GPU(s): strong scaling of ONE 64 M-row "
                                 "operator; the >= 6x target is cfg4.value(N=8) / cfg4.value(N=1)" % c.world)
     if c.rank == 0:

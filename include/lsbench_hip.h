@@ -429,6 +429,9 @@ int lsb_hip_solver_spmv_variant(const lsb_hip_solver *s);
  * bit 1 nontemporal) and the workgroup cap of the SpMV launch. */
 unsigned lsb_hip_solver_spmv_flags(const lsb_hip_solver *s);
 unsigned lsb_hip_solver_spmv_grid(const lsb_hip_solver *s);
+/* sliced-ELL: slices per plane the XCD dealing follows (every XCD the same eighth
+ * of every plane of a 3-D stencil), 0 = contiguous eighths of the rows. */
+unsigned lsb_hip_solver_spmv_period(const lsb_hip_solver *s);
 /* 1 when the halo exchange of this solver runs behind its interior rows. */
 int lsb_hip_solver_overlaps(const lsb_hip_solver *s);
 /* 0 one shard; 1 RCCL (device copies between virtual shards); 2 direct xGMI

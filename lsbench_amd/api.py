@@ -303,6 +303,10 @@ class Solver:
         return L.load().lsb_hip_solver_spmv_grid(self._h)
 
     @property
+    def spmv_period(self):
+        return L.load().lsb_hip_solver_spmv_period(self._h)
+
+    @property
     def comm(self):
         """(mode, p2p_us, rccl_us): mode 0 = one shard, 1 = RCCL / device copies,
         2 = direct xGMI stores for the all-reduces, 3 = and for the halos; the

@@ -976,6 +976,44 @@ static int g_blas1_nt = 1;
 // (tools/spmv_lab.hip).  Groups of four slices are dealt to the XCDs like the
 // row blocks of k_spmv_adaptive.  [s0, s0+ns) = the slices of this launch.
 // --------------------------------------------------------------------------
+// Which slice does wave `wave` of this workgroup take in its turn `it`?
+// period = 0: the slices [0, ns) are cut into 8 contiguous chunks, one per XCD,
+// groups of four dealt cyclically to the XCD's workgroups (turns it = slot,
+// slot + gx, ... < turns).  period = P > 0 (slices per plane of a 3-D stencil,
+// ns a multiple of P): XCD k takes the SAME eighth [P k/8, P (k+1)/8) of every
+// plane, plane after plane -- the +-plane gathers of its resident workgroups
+// then stay inside ~8 of its own sections (64 M-row 7-point: 1.4 MB of x instead
+// of 3.6 MB next to the matrix stream in a 4 MiB L2; PMC 5.59 -> see DESIGN.md).
+// Placement is a speed matter only; every slice is taken exactly once.
+struct sell_deal {
+  unsigned turns, base, L, period;
+};
+__device__ __forceinline__ sell_deal sell_deal_init(unsigned ns, unsigned period, unsigned xcd) {
+  sell_deal d;
+  d.period = period;
+  if (!period) {
+    const unsigned ngrp = (ns + 3) / 4, chunk = (ngrp + NXCD - 1) / NXCD;
+    const unsigned g0 = min(xcd * chunk, ngrp), g1 = min(g0 + chunk, ngrp);
+    d.base = g0 * 4, d.turns = g1 - g0, d.L = 0;
+  } else {
+    const unsigned qlo = period * xcd / NXCD, qhi = period * (xcd + 1) / NXCD;
+    d.L = qhi - qlo, d.base = qlo;
+    d.turns = (d.L * (ns / period) + 3) / 4;
+  }
+  return d;
+}
+__device__ __forceinline__ unsigned sell_deal_slice(const sell_deal &d, unsigned it, unsigned wave,
+                                                    unsigned ns) {
+  if (!d.period) {
+    const unsigned si = d.base + it * 4 + wave;
+    return si < ns ? si : 0xFFFFFFFFu;
+  }
+  const unsigned m = it * 4 + wave;
+  if (m >= d.L * (ns / d.period))
+    return 0xFFFFFFFFu;
+  return (m / d.L) * d.period + d.base + m % d.L;
+}
+
 typedef int i2v __attribute__((ext_vector_type(2)));
 typedef double sell_d2v __attribute__((ext_vector_type(2)));
 #define SELL_U 5
@@ -984,20 +1022,19 @@ template <> struct vt2<double> { typedef double type __attribute__((ext_vector_t
 template <> struct vt2<float> { typedef float type __attribute__((ext_vector_type(2))); };
 template <int FLAGS, class VT = double>
 __global__ __launch_bounds__(WG, 6) void k_spmv_sell(
-    const unsigned *__restrict__ sptr, unsigned s0, unsigned ns, unsigned n,
+    const unsigned *__restrict__ sptr, unsigned s0, unsigned ns, unsigned period, unsigned n,
     const int *__restrict__ cols, const VT *__restrict__ vals,
     const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ xdot,
     double *__restrict__ partials, const lsb_pcg_state *__restrict__ st) {
   __shared__ double sred[4];
   const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const unsigned gx = gridDim.x / NXCD, xcd = blockIdx.x % NXCD, slot = blockIdx.x / NXCD;
-  const unsigned ngrp = (ns + 3) / 4, chunk = (ngrp + NXCD - 1) / NXCD;
-  const unsigned g0 = xcd * chunk, g1 = min(g0 + chunk, ngrp);
+  const sell_deal deal = sell_deal_init(ns, period, xcd);
   const int stopped = st ? st->status : 0; // tested behind the first loads
   double dot = 0.0;
-  for (unsigned g = g0 + slot; g < g1; g += gx) {
-    const unsigned si = __builtin_amdgcn_readfirstlane(g * 4 + wave);
-    if (si < ns) {
+  for (unsigned g = slot; g < deal.turns; g += gx) {
+    const unsigned si = __builtin_amdgcn_readfirstlane(sell_deal_slice(deal, g, wave, ns));
+    if (si != 0xFFFFFFFFu) {
       const unsigned s = s0 + si;
       const unsigned base = sptr[s], len = (sptr[s + 1] - base) / LSB_SELL_ROWS;
       typedef typename vt2<VT>::type v2t;
@@ -1063,21 +1100,20 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_sell(
 typedef short s2v __attribute__((ext_vector_type(2)));
 template <int FLAGS, class VT = double>
 __global__ __launch_bounds__(WG, 6) void k_spmv_sell16(
-    const unsigned *__restrict__ sptr, unsigned s0, unsigned ns, unsigned n, unsigned row_begin,
-    const short *__restrict__ codes, const int *__restrict__ sbase,
+    const unsigned *__restrict__ sptr, unsigned s0, unsigned ns, unsigned period, unsigned n,
+    unsigned row_begin, const short *__restrict__ codes, const int *__restrict__ sbase,
     const VT *__restrict__ vals, const double *__restrict__ x, double *__restrict__ y,
     const double *__restrict__ xdot, double *__restrict__ partials,
     const lsb_pcg_state *__restrict__ st) {
   __shared__ double sred[4];
   const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const unsigned gx = gridDim.x / NXCD, xcd = blockIdx.x % NXCD, slot = blockIdx.x / NXCD;
-  const unsigned ngrp = (ns + 3) / 4, chunk = (ngrp + NXCD - 1) / NXCD;
-  const unsigned g0 = xcd * chunk, g1 = min(g0 + chunk, ngrp);
+  const sell_deal deal = sell_deal_init(ns, period, xcd);
   const int stopped = st ? st->status : 0; // tested behind the first loads
   double dot = 0.0;
-  for (unsigned g = g0 + slot; g < g1; g += gx) {
-    const unsigned si = __builtin_amdgcn_readfirstlane(g * 4 + wave);
-    if (si < ns) {
+  for (unsigned g = slot; g < deal.turns; g += gx) {
+    const unsigned si = __builtin_amdgcn_readfirstlane(sell_deal_slice(deal, g, wave, ns));
+    if (si != 0xFFFFFFFFu) {
       const unsigned s = s0 + si;
       typedef typename vt2<VT>::type v2t;
       const unsigned base = sptr[s], len = (sptr[s + 1] - base) / LSB_SELL_ROWS;
@@ -1499,8 +1535,8 @@ void lsb_k_spmv_subwave_p(unsigned n, const int *offs, const int *cols, const do
 /* Sliced-ELL launch over the slices [s0, s0+ns).  flags & LSB_SP_C16: `cols` is
  * the 16-bit code array and `sbase` the slot bases (row_begin = global index
  * of local row 0); else `cols` holds 32-bit column ids and sbase is unused. */
-void lsb_k_spmv_sell(unsigned flags, unsigned grid_cap, const unsigned *sptr, unsigned s0,
-                     unsigned ns, unsigned n, unsigned row_begin, const void *cols,
+void lsb_k_spmv_sell(unsigned flags, unsigned grid_cap, unsigned period, const unsigned *sptr,
+                     unsigned s0, unsigned ns, unsigned n, unsigned row_begin, const void *cols,
                      const int *sbase, const double *vals, const double *x, double *y,
                      const double *xdot, double *partials, unsigned *npartials,
                      const struct lsb_pcg_state *st, void *stream) {
@@ -1510,11 +1546,13 @@ void lsb_k_spmv_sell(unsigned flags, unsigned grid_cap, const unsigned *sptr, un
     *npartials = g;
   const int nt = (flags & SP_NT) != 0;
   const float *vals32 = (const float *)(const void *)vals; /* flags & LSB_SP_F32 */
+  if (period && (ns % period || period < NXCD))
+    period = 0; /* a sub-range that is not whole planes: contiguous dealing */
 #define LSB_SELL16(FL, VT, V)                                                                  \
-  k_spmv_sell16<FL, VT><<<g, WG, 0, s>>>(sptr, s0, ns, n, row_begin, (const short *)cols, sbase, \
-                                         V, x, y, xdot, partials, st)
+  k_spmv_sell16<FL, VT><<<g, WG, 0, s>>>(sptr, s0, ns, period, n, row_begin, (const short *)cols, \
+                                         sbase, V, x, y, xdot, partials, st)
 #define LSB_SELL32(FL, VT, V)                                                                  \
-  k_spmv_sell<FL, VT><<<g, WG, 0, s>>>(sptr, s0, ns, n, (const int *)cols, V, x, y, xdot,      \
+  k_spmv_sell<FL, VT><<<g, WG, 0, s>>>(sptr, s0, ns, period, n, (const int *)cols, V, x, y, xdot, \
                                        partials, st)
   if (flags & LSB_SP_F32) {
     if (flags & LSB_SP_C16) {

@@ -235,6 +235,22 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
     if (stored && (forced || (o->spmv_variant == LSB_SPMV_AUTO && stored <= s->nnz + s->nnz / 8)))
       E = lsb_csr_sellize(&gview);
     if (E) {
+      /* 3-D stencil?  the largest |col - row| a multiple of the slice height and
+       * the slices whole planes: candidate period of the XCD dealing */
+      {
+        unsigned bw = 0;
+        for (unsigned i = 0; i < n; i++)
+          if (offs[i + 1] > offs[i]) {
+            const long long g = (long long)row_begin + i;
+            const long long a = g - cols[offs[i]], b = (long long)cols[offs[i + 1] - 1] - g;
+            if (a > (long long)bw)
+              bw = (unsigned)a;
+            if (b > (long long)bw)
+              bw = (unsigned)b;
+          }
+        if (bw >= 64 * LSB_SELL_ROWS && bw % LSB_SELL_ROWS == 0 && E->nslice % (bw / LSB_SELL_ROWS) == 0)
+          s->sell_period = bw / LSB_SELL_ROWS;
+      }
       s->nslice = E->nslice;
       s->d_sptr = (unsigned *)dev_upload(E->sptr, ((size_t)E->nslice + 1) * sizeof(unsigned));
       s->d_scols = (int *)dev_upload(E->cols, ((size_t)E->stored + LSB_SELL_ROWS) * sizeof(int));
@@ -592,6 +608,7 @@ unsigned lsb_hip_solver_nblocks(const lsb_hip_solver *s) { return s->sh[0].nblk;
 int lsb_hip_solver_spmv_variant(const lsb_hip_solver *s) { return s->sh[0].variant; }
 unsigned lsb_hip_solver_spmv_flags(const lsb_hip_solver *s) { return s->sh[0].sp_flags; }
 unsigned lsb_hip_solver_spmv_grid(const lsb_hip_solver *s) { return s->sh[0].sp_grid; }
+unsigned lsb_hip_solver_spmv_period(const lsb_hip_solver *s) { return s->sh[0].sp_period; }
 int can_overlap(const lsb_hip_solver *sv);
 int lsb_hip_solver_overlaps(const lsb_hip_solver *s) { return can_overlap(s); }
 int lsb_hip_solver_comm(const lsb_hip_solver *s, double *p2p_us, double *rccl_us) {
@@ -608,10 +625,10 @@ void sell_launch(struct shard *s, unsigned s0, unsigned ns, const double *xfull,
                         const struct lsb_pcg_state *st) {
   const unsigned f32 = s->mixed ? LSB_SP_F32 : 0u; /* the value arrays hold floats then */
   if ((s->sp_flags & LSB_SP_C16) && s->d_scodes)
-    lsb_k_spmv_sell(s->sp_flags | f32, s->sp_grid, s->d_sptr16, s0, ns, s->n, s->row_begin, s->d_scodes,
+    lsb_k_spmv_sell(s->sp_flags | f32, s->sp_grid, s->sp_period, s->d_sptr16, s0, ns, s->n, s->row_begin, s->d_scodes,
                     s->d_sbase, s->d_svals16, xfull, y, xdot, partials, np, st, g_stream);
   else
-    lsb_k_spmv_sell((s->sp_flags & ~LSB_SP_C16) | f32, s->sp_grid, s->d_sptr, s0, ns, s->n, s->row_begin,
+    lsb_k_spmv_sell((s->sp_flags & ~LSB_SP_C16) | f32, s->sp_grid, s->sp_period, s->d_sptr, s0, ns, s->n, s->row_begin,
                     s->d_scols, NULL, s->d_svals, xfull, y, xdot, partials, np, st, g_stream);
 }
 
@@ -706,14 +723,15 @@ void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
   unsigned bf = s->sp_flags, np;
   int bv = s->variant;
   const unsigned grid0 = s->sp_grid;
-  unsigned bg = grid0;
+  unsigned bg = grid0, bp = 0;
   /* candidates {form, flags, grid}: the form asked for, or (auto) every form
    * this shard has; the sliced-ELL kernels have no prefetch flavour, they try
    * 6 instead of 8 resident workgroups per CU instead */
   struct {
     int v;
-    unsigned f, g;
-  } cand[24];
+    unsigned f, g, p;
+  } cand[32];
+  memset(cand, 0, sizeof cand);
   int ncand = 0;
   const int any = o->spmv_variant == LSB_SPMV_AUTO;
   if (any || s->variant == LSB_SPMV_ADAPTIVE)
@@ -738,24 +756,40 @@ void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
       cand[ncand].v = LSB_SPMV_SELL, cand[ncand].f = c16, cand[ncand++].g = grid0;
       if (o->spmv_grid <= 0)
         cand[ncand].v = LSB_SPMV_SELL, cand[ncand].f = c16 | LSB_SP_NT, cand[ncand++].g = 1536;
+      if (s->sell_period && !getenv("LSBENCH_HIP_NO_PERIOD")) { /* every XCD an eighth of every plane */
+        cand[ncand].v = LSB_SPMV_SELL, cand[ncand].f = c16 | LSB_SP_NT, cand[ncand].p = s->sell_period,
+        cand[ncand++].g = grid0;
+        cand[ncand].v = LSB_SPMV_SELL, cand[ncand].f = c16, cand[ncand].p = s->sell_period,
+        cand[ncand++].g = grid0;
+      }
     }
   for (int ci = 0; ci < ncand; ci++) {
-    s->variant = cand[ci].v, s->sp_flags = cand[ci].f, s->sp_grid = cand[ci].g;
+    s->variant = cand[ci].v, s->sp_flags = cand[ci].f, s->sp_grid = cand[ci].g, s->sp_period = cand[ci].p;
     spmv_shard(s, s->d_pfull, s->d_q, s->d_pfull + s->row_begin, s->d_parts_pq, &np, NULL);
     LSB_CHK_HIP(hipEventRecord(sv->ev_t0, g_stream));
-    for (int r = 0; r < 3; r++)
+    const int reps = 5;
+    for (int r = 0; r < reps; r++)
       spmv_shard(s, s->d_pfull, s->d_q, s->d_pfull + s->row_begin, s->d_parts_pq, &np, NULL);
     LSB_CHK_HIP(hipEventRecord(sv->ev_t1, g_stream));
     LSB_CHK_HIP(hipEventSynchronize(sv->ev_t1));
     float ms = 0.f;
     LSB_CHK_HIP(hipEventElapsedTime(&ms, sv->ev_t0, sv->ev_t1));
+    ms *= 3.0f / reps; /* (the verbose line below quotes per-launch time as ms / 3) */
     if (o->verbose > 1)
-      fprintf(stderr, "hip_cdna4: spmv tune form=%d flags=%u grid=%u: %.1f us\n", s->variant,
-              s->sp_flags, s->sp_grid, ms * 1e3f / 3);
+      fprintf(stderr, "hip_cdna4: spmv tune form=%d flags=%u grid=%u period=%u: %.1f us\n", s->variant,
+              s->sp_flags, s->sp_grid, s->sp_period, ms * 1e3f / 3);
+    /* back-to-back launches flatter plain stream loads: inside a solve the sweeps'
+     * vectors compete for the Infinity Cache with the matrix stream and the
+     * nontemporal flavour runs 5-10 % faster than its timing here says (64 M-row
+     * 7-point: 0.914 ms against 0.966-1.03 ms in the solve at equal times back to
+     * back) -- a plain flavour has to win by 3 % to be taken */
+    if (!(s->sp_flags & LSB_SP_NT))
+      ms *= 1.03f;
     if (ms < best)
-      best = ms, bf = s->sp_flags, bv = s->variant, bg = s->sp_grid;
+      best = ms, bf = s->sp_flags, bv = s->variant, bg = s->sp_grid, bp = s->sp_period;
   }
   s->sp_grid = bg;
+  s->sp_period = bp;
   s->variant = bv;
   s->sp_flags = bf;
   /* the copies that lost are not kept */

@@ -52,6 +52,8 @@ struct shard {
   int *d_offs, *d_cols, *d_rowblk;
   unsigned char *d_blklanes;
   unsigned sp_flags, sp_grid; /* adaptive-SpMV flavour, picked by tune_spmv() */
+  unsigned sp_period, sell_period; /* sliced-ELL: slices per plane the XCD dealing follows (0 =
+                                      contiguous eighths); candidate found at upload */
   double *d_vals, *d_dinv, *d_r, *d_q, *d_pfull;
   double *d_p1, *d_s1; /* single-reduction CG: p and s = S p (pfull then holds u) */
   unsigned npq, np2;   /* partial counts of the SpMV / sweep launches */

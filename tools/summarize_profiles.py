@@ -54,11 +54,16 @@ for wl, suffix in (("lap2d", ""), ("lap3d", "_lap3d"), ("powerlaw", "_powerlaw")
             if best is None or d["launches_FETCH_SIZE"] > best[1]:
                 best = (name, d["launches_FETCH_SIZE"], fb + wb)
     if wl == "powerlaw":
-        # one SpMV = the two phases' launches together: median products launch + median reduce launch
-        tot = sum(2 * d["FETCH_SIZE_KB_median"] * 1024 + d["WRITE_SIZE_KB_median"] * 1024
-                  for k, d in pmc.items() if "k_pb_" in k and "FETCH_SIZE_KB_median" in d and "WRITE_SIZE_KB_median" in d)
-        if tot:
-            best = ("k_pb_products + k_pb_reduce", best[1] if best else 0, tot)
+        # one SpMV of the binned form = one launch per window of x: all launches of the kernel
+        # summed, divided by the number of SpMVs (launches / windows; 8 M columns, 524288 per window)
+        nbins = -(-8000000 // 524288)
+        for k, d in pmc.items():
+            if "k_spmv_binned<2" in k and "FETCH_SIZE_KB_sum" in d and "WRITE_SIZE_KB_sum" in d:
+                nspmv = d["launches_FETCH_SIZE"] / nbins
+                tot = (2 * d["FETCH_SIZE_KB_sum"] + d["WRITE_SIZE_KB_sum"]) * 1024 / nspmv
+                best = ("k_spmv_binned", d["launches_FETCH_SIZE"], tot)
+                lines.append("# k_spmv_binned per SpMV (%d launches = %d windows x %.0f SpMVs): %.0f bytes"
+                             % (d["launches_FETCH_SIZE"], nbins, nspmv, tot))
     open(os.path.join(out, "%s_pmc_traffic_%s.csv" % (rnd, wl)), "w").write("\n".join(lines) + "\n")
     if best:
         traffic[wl] = {"bytes": best[2], "kernel": best[0], "launches": best[1],
