@@ -440,6 +440,10 @@ lsb_hip_solver *lsb_hip_solver_create(const struct csr *A,
     o = *o_in;
   else
     lsb_hip_get_opts(&o);
+  if (o.precision == LSB_PREC_MIXED && o.krylov == LSB_KRYLOV_GMRES) {
+    warnx("hip_cdna4: mixed precision is an iterative refinement around CG; GMRES runs in fp64");
+    o.precision = LSB_PREC_FP64;
+  }
   /* the operator, 0-based, both triangles */
   struct csr *S = o.op_mode == LSB_OP_CHOLMOD_UPPER ? lsb_csr_symmetrize_upper(A)
                                                     : lsb_csr_copy_base0(A);
@@ -497,6 +501,8 @@ lsb_hip_solver *lsb_hip_solver_create_dist(const struct csr *A_rows,
     o = *o_in;
   else
     lsb_hip_get_opts(&o);
+  if (o.precision == LSB_PREC_MIXED && o.krylov == LSB_KRYLOV_GMRES)
+    o.precision = LSB_PREC_FP64; /* as in lsb_hip_solver_create */
   const int P = lsb_hip_comm_size(), me = lsb_hip_comm_rank();
   lsb_hip_solver *sv = solver_alloc(1, &o);
   sv->n_glob = n_global, sv->n_here = A_rows->nrows, sv->row_first = row_begin;
