@@ -90,7 +90,7 @@ def test_bench_two_ranks_on_one_gpu():
     """bench.py's N > 1 branch end to end (gloo for torch.distributed, the test
     double for the library's collectives): same iteration count as N = 1."""
     common = ["--workload", "lap2d:nx=700,ny=500", "--tol", "1e-8", "--steps", "2", "--warmup", "1",
-              "--cpu-seconds", "0"]
+              "--cpu-seconds", "0", "--cfg4", "0"]
     env = _env()
     env["LSB_BENCH_BACKEND"] = "gloo"
     env["LSB_BENCH_ONE_GPU"] = "1"

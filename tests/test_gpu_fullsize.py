@@ -132,3 +132,40 @@ def test_lap3d_64m_rows(hip):
         assert rp.iters == 30 and rp.status == hip.STATUS_MAXIT and it1 == 30
         assert np.linalg.norm(xp - xo1) / np.linalg.norm(xo1) <= 1e-10
         assert abs(rp.relres - rel1) <= 1e-9 * rel1
+
+
+def test_bench_line_contract():
+    """`python bench.py` end to end at full size (config 3 + the cfg4 sub-record):
+    ONE JSON line with the contract's keys, the roofline and cpu_baseline objects,
+    a solve that is converged on the residual recomputed from x."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1",
+                        "--cpu-seconds", "3", "--cfg4-steps", "1"], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "cfg4"):
+        assert k in d, k
+    assert d["metric"] == "cg_solves_per_sec" and d["unit"] == "solves/s" and d["n_gpus"] == 1
+    assert d["dtype"] == "f64" and d["vs_baseline"] is None and d["higher_is_better"] is True
+    assert d["config"]["workload"].startswith("lap2d:nx=3162") and d["config"]["rows"] == 9998244
+    assert d["config"]["true_relres"] <= d["config"]["tol"] * (1 + 1e-6)
+    assert abs(d["value"] - d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) <= 1e-9 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0.5 < rf["frac"] < 1.2
+    assert rf["algorithmic_bytes"] == 12 * 49978572 + 20 * 9998244 + 4
+    assert rf["traffic"] is None or (0.3 < rf["frac_hbm"] < 1.0 and rf["traffic_source"])
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    c4 = d["cfg4"]
+    assert c4["config"]["rows"] == 64000000 and c4["config"]["nnz"] == 447040000 and c4["value"] > 0
+    assert c4["config"]["true_relres"] <= c4["config"]["tol"] * (1 + 1e-6) and c4["n_gpus"] == 1
+    assert "pcg_iteration_GBps" not in d
