@@ -1,0 +1,44 @@
+/* Host-side format builders under AddressSanitizer + UBSan (tests/test_sanitizers.py):
+ * every layout the backend builds on the host (binned, two-phase, sliced-ELL, operator,
+ * RCM, partition, synthetic generators incl. spd=1) on small inputs, leaks counted. */
+#include "lsbench_hip.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <math.h>
+int main(void) {
+  const char *specs[] = {"powerlaw:n=30000,gamma=1.2,max=3000,seed=7", "powerlaw:n=5000,gamma=1.585350372615855,max=4096,seed=3",
+                         "lap2d:nx=170,ny=150", "lap3d:nx=20,ny=17,nz=11", "powerlaw:n=3000,gamma=1.3,max=700,seed=11,spd=1",
+                         "lap2d:nx=3,ny=2", "powerlaw:n=40,gamma=1.0,max=40,seed=1"};
+  for (unsigned k = 0; k < sizeof specs / sizeof specs[0]; k++) {
+    unsigned n;
+    struct csr *A = lsbench_matrix_synth(specs[k], 0, 0, &n);
+    if (!A) { printf("bad %s\n", specs[k]); return 1; }
+    unsigned widths[] = {7, 300, 1024, 262144};
+    for (int w = 0; w < 4; w++) {
+      struct lsb_binned *B = lsb_csr_binize(A, widths[w]);
+      unsigned long long s = 0;
+      for (unsigned c = 0; c < B->nchunks; c++) s += B->chunk_begin[c + 1] - B->chunk_begin[c];
+      if (s != B->nnz) { printf("binize mismatch\n"); return 1; }
+      lsb_binned_free(B);
+    }
+    struct lsb_pb *P = lsb_csr_pbize(A);
+    unsigned long long s = 0;
+    for (unsigned long long r = 0; r < P->nruns; r++) s += P->run[2 * r + 1];
+    if (s != P->nnz) { printf("pbize mismatch\n"); return 1; }
+    lsb_pb_free(P);
+    struct lsb_sell *E = lsb_csr_sellize(A); lsb_sell_free(E);
+    E = lsb_csr_sellize16(A, 0); lsb_sell_free(E);
+    struct csr *S = lsb_csr_symmetrize_upper(A);
+    unsigned *perm = malloc(sizeof(unsigned) * S->nrows);
+    lsb_csr_rcm(S, perm);
+    struct csr *Sp = lsb_csr_permute_sym(S, perm);
+    unsigned b[5]; lsb_csr_partition_rows(S, 4, b);
+    struct csr *R = lsb_csr_row_slice(S, b[1], b[2]);
+    lsb_csr_free(R); lsb_csr_free(Sp); lsb_csr_free(S); free(perm);
+    struct csr *part = lsbench_matrix_synth(specs[k], n / 3, n / 2, &n);
+    lsb_csr_free(part);
+    lsb_csr_free(A);
+    printf("ok %s\n", specs[k]);
+  }
+  return 0;
+}
