@@ -293,30 +293,35 @@ void lsb_binned_free(struct lsb_binned *B);
  * blocking"): no gather ever leaves a compute unit.
  *   phase 1  the entries are cut by COLUMN into chunks of LSB_PB_COLS columns; a
  *            workgroup copies its chunk's window of x into LDS and streams its
- *            entries -- value (8 B) + column inside the window (2 B) -- writing
- *            one product per entry, in entry order (8 B, coalesced);
- *   phase 2  inside a chunk the entries are ordered by ROW BIN (LSB_PB_ROWS rows)
- *            and by row inside a bin, so every (chunk, bin) pair is one contiguous,
- *            row-sorted RUN of products.  A workgroup owns a bin: its four
- *            wavefronts take the bin's runs in turn (run k to wave k mod 4), add
- *            them -- product (8 B) + row inside the bin (2 B) -- into a private
- *            LDS copy of the bin's rows, and the four copies are summed in a
- *            fixed order into y (each y entry is written once, by one lane).
- * 28 bytes of streaming traffic per non-zero instead of a 128-byte line per
- * gather, no atomics, bit-identical from run to run. */
-#define LSB_PB_COLS 8192
+ *            entries -- value (8 B), column inside the window (2 B), target slot
+ *            (4 B) -- writing each product into its slot of the product array;
+ *   phase 2  the product array is ROW-BIN major (LSB_PB_ROWS rows per bin): a
+ *            workgroup owns a bin and streams its slots -- product (8 B) + row
+ *            inside the bin (2 B) -- adding them into LDS copies of the bin's
+ *            rows, one copy per wavefront, summed in a fixed order into y.
+ * The host lays a bin's slots out in steps of 64 in which EQUAL ROWS ARE NEIGHBOURS
+ * (an entry whose row is already in the step under construction, but not in the
+ * slot before it, is deferred to the end of the bin, where the deferred ones are
+ * placed sorted by row; a step that cannot take the next one is padded): a
+ * wavefront combines neighbouring equal rows by a segmented shuffle scan and then
+ * ONE lane per row adds to LDS -- no conflicts, no atomics, and the order of the
+ * additions is fixed by the layout: bit-identical from run to run.  Inside a bin
+ * the slots follow the chunk order, so the products of one (chunk, bin) pair land
+ * in consecutive slots: phase 1's stores are contiguous pieces.
+ * 22 B read + 8 B written per non-zero instead of a 128-byte line per gather. */
+#define LSB_PB_COLS 4096
 #define LSB_PB_ROWS 2048
 struct lsb_pb {
   unsigned nrows, ncols_lo, nchunks, nbins, nitems;
   unsigned long long nnz;
-  unsigned long long nruns;
-  double *vals;            /* nnz, in (chunk, bin, row, col) order            */
-  unsigned short *colw;    /* nnz: column - (ncols_lo + chunk * LSB_PB_COLS)  */
-  unsigned short *roww;    /* nnz: row - bin * LSB_PB_ROWS                    */
+  unsigned long long nslots; /* slots of the product array = bin_ptr[nbins]      */
+  double *vals;            /* nnz, in (chunk, bin, row, col) order              */
+  unsigned short *colw;    /* nnz: column - (ncols_lo + chunk * LSB_PB_COLS)    */
+  unsigned *pos;           /* nnz: slot of the entry's product                  */
   unsigned *item;          /* 3 * nitems: {chunk, first entry, end entry} of
-                              the phase-1 work items (<= 32768 entries each)  */
-  unsigned *bin_run;       /* nbins + 1: first run of each bin                */
-  unsigned *run;           /* 2 * nruns: {first entry, length}, chunk order   */
+                              the phase-1 work items (<= 32768 entries each)    */
+  unsigned *bin_ptr;       /* nbins + 1: first slot of each bin (multiples of 64) */
+  unsigned short *roww;    /* nslots: row - bin * LSB_PB_ROWS, 0xFFFF = padding */
 };
 struct lsb_pb *lsb_csr_pbize(const struct csr *A);
 void lsb_pb_free(struct lsb_pb *P);

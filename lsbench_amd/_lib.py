@@ -25,7 +25,7 @@ KRYLOV_PCG, KRYLOV_GMRES, KRYLOV_PCG1, KRYLOV_AUTO = 0, 1, 2, 3
 SPMV_AUTO, SPMV_ADAPTIVE, SPMV_SUBWAVE, SPMV_SCALAR, SPMV_PANEL, SPMV_SELL, SPMV_BINNED, SPMV_TWOPHASE = 0, 1, 2, 3, 4, 5, 6, 7
 SELL_ROWS = 128
 BIN_CHUNK = 2048
-PB_COLS, PB_ROWS = 8192, 2048
+PB_COLS, PB_ROWS = 4096, 2048
 SPMV_FLAG_PREFETCH, SPMV_FLAG_NT, SPMV_FLAG_C16 = 1, 2, 4
 STATUS_RUNNING, STATUS_CONVERGED, STATUS_BREAKDOWN, STATUS_MAXIT = 0, 1, 2, 3
 STATUS_COMM = 4
@@ -99,10 +99,10 @@ class Binned(C.Structure):
 class Pb(C.Structure):
     """struct lsb_pb."""
     _fields_ = [("nrows", C.c_uint), ("ncols_lo", C.c_uint), ("nchunks", C.c_uint), ("nbins", C.c_uint),
-                ("nitems", C.c_uint), ("nnz", C.c_ulonglong), ("nruns", C.c_ulonglong),
+                ("nitems", C.c_uint), ("nnz", C.c_ulonglong), ("nslots", C.c_ulonglong),
                 ("vals", C.POINTER(C.c_double)), ("colw", C.POINTER(C.c_ushort)),
-                ("roww", C.POINTER(C.c_ushort)), ("item", C.POINTER(C.c_uint)),
-                ("bin_run", C.POINTER(C.c_uint)), ("run", C.POINTER(C.c_uint))]
+                ("pos", C.POINTER(C.c_uint)), ("item", C.POINTER(C.c_uint)),
+                ("bin_ptr", C.POINTER(C.c_uint)), ("roww", C.POINTER(C.c_ushort))]
 
 
 class Xfer(C.Structure):

@@ -123,12 +123,13 @@ static void shard_build_twophase(struct shard *s, const struct csr *view, unsign
     return;
   s->tp_items = P->nitems, s->tp_bins = P->nbins, s->tp_col_lo = P->ncols_lo, s->tp_xlen = n_glob;
   s->tp_item = (unsigned *)dev_upload(P->item, (size_t)P->nitems * 3 * sizeof(unsigned));
-  s->tp_binrun = (unsigned *)dev_upload(P->bin_run, ((size_t)P->nbins + 1) * sizeof(unsigned));
-  s->tp_run = (unsigned *)dev_upload(P->run, (size_t)(P->nruns ? P->nruns : 1) * 2 * sizeof(unsigned));
+  s->tp_binptr = (unsigned *)dev_upload(P->bin_ptr, ((size_t)P->nbins + 1) * sizeof(unsigned));
+  s->tp_pos = (unsigned *)dev_upload(P->pos, (size_t)P->nnz * sizeof(unsigned));
   s->tp_colw = (unsigned short *)dev_upload(P->colw, (size_t)P->nnz * sizeof(unsigned short));
-  s->tp_roww = (unsigned short *)dev_upload(P->roww, (size_t)P->nnz * sizeof(unsigned short));
+  s->tp_roww = (unsigned short *)dev_upload(P->roww, (size_t)P->nslots * sizeof(unsigned short));
   s->tp_vals = (double *)dev_upload(P->vals, (size_t)P->nnz * sizeof(double));
-  s->tp_prod = (double *)lsb_hip_malloc((size_t)P->nnz * sizeof(double));
+  s->tp_prod = (double *)lsb_hip_malloc((size_t)P->nslots * sizeof(double));
+  LSB_CHK_HIP(hipMemsetAsync(s->tp_prod, 0, (size_t)P->nslots * sizeof(double), g_stream));
   s->tp_binparts = (double *)lsb_hip_malloc((size_t)P->nbins * sizeof(double));
   LSB_CHK_HIP(hipStreamSynchronize(g_stream));
   lsb_pb_free(P);
@@ -366,7 +367,7 @@ void shard_free(struct shard *s) {
   lsb_hip_free(s->bd_chunk), lsb_hip_free(s->bd_rows), lsb_hip_free(s->bd_cols);
   lsb_hip_free(s->bd_vals);
   free(s->h_binchunk);
-  lsb_hip_free(s->tp_item), lsb_hip_free(s->tp_binrun), lsb_hip_free(s->tp_run);
+  lsb_hip_free(s->tp_item), lsb_hip_free(s->tp_binptr), lsb_hip_free(s->tp_pos);
   lsb_hip_free(s->tp_colw), lsb_hip_free(s->tp_roww), lsb_hip_free(s->tp_vals);
   lsb_hip_free(s->tp_prod), lsb_hip_free(s->tp_binparts);
   precond_free_shard(s);
@@ -661,8 +662,8 @@ void spmv_shard(struct shard *s, const double *xfull, double *y,
     return;
   }
   if (s->variant == LSB_SPMV_TWOPHASE) {
-    lsb_k_spmv_twophase(s->tp_items, s->tp_item, s->tp_vals, s->tp_colw, s->tp_roww, s->tp_col_lo,
-                        s->tp_bins, s->tp_binrun, s->tp_run, s->tp_prod, s->n, xfull, s->tp_xlen, y,
+    lsb_k_spmv_twophase(s->tp_items, s->tp_item, s->tp_vals, s->tp_colw, s->tp_pos, s->tp_roww,
+                        s->tp_col_lo, s->tp_bins, s->tp_binptr, s->tp_prod, s->n, xfull, s->tp_xlen, y,
                         xdot, partials, np, s->tp_binparts, st, g_stream);
     return;
   }
@@ -800,10 +801,10 @@ void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
   s->sp_flags = bf;
   /* the copies that lost are not kept */
   if (any && bv != LSB_SPMV_TWOPHASE && s->tp_bins) {
-    lsb_hip_free(s->tp_item), lsb_hip_free(s->tp_binrun), lsb_hip_free(s->tp_run);
+    lsb_hip_free(s->tp_item), lsb_hip_free(s->tp_binptr), lsb_hip_free(s->tp_pos);
     lsb_hip_free(s->tp_colw), lsb_hip_free(s->tp_roww), lsb_hip_free(s->tp_vals);
     lsb_hip_free(s->tp_prod), lsb_hip_free(s->tp_binparts);
-    s->tp_item = s->tp_binrun = s->tp_run = NULL, s->tp_colw = s->tp_roww = NULL;
+    s->tp_item = s->tp_binptr = s->tp_pos = NULL, s->tp_colw = s->tp_roww = NULL;
     s->tp_vals = s->tp_prod = s->tp_binparts = NULL, s->tp_bins = 0;
   }
   if (any && bv != LSB_SPMV_BINNED && s->bn) {

@@ -110,7 +110,7 @@ struct shard {
   double *bd_vals;
   /* two-phase form (LSB_SPMV_TWOPHASE), built for scattered operators only */
   unsigned tp_items, tp_bins, tp_col_lo, tp_xlen; /* tp_bins = 0: not built */
-  unsigned *tp_item, *tp_binrun, *tp_run;
+  unsigned *tp_item, *tp_binptr, *tp_pos;
   unsigned short *tp_colw, *tp_roww;
   double *tp_vals, *tp_prod, *tp_binparts;
   struct lsb_xfer *recv, *send;

@@ -78,8 +78,8 @@ void lsb_k_spmv_binned(unsigned flags, unsigned chunk_cap, const unsigned *chunk
                        unsigned nchunk, const unsigned *rows, const unsigned *cols, const double *vals,
                        const double *x, double *y, const struct lsb_pcg_state *st, void *stream);
 void lsb_k_spmv_twophase(unsigned nitems, const unsigned *item, const double *vals,
-                         const unsigned short *colw, const unsigned short *roww, unsigned col_lo,
-                         unsigned nbins, const unsigned *bin_run, const unsigned *run, double *prod,
+                         const unsigned short *colw, const unsigned *pos, const unsigned short *roww,
+                         unsigned col_lo, unsigned nbins, const unsigned *bin_ptr, double *prod,
                          unsigned n, const double *x, unsigned xlen, double *y, const double *xdot,
                          double *partials, unsigned *npartials, double *binparts,
                          const struct lsb_pcg_state *st, void *stream);

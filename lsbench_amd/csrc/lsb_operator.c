@@ -580,7 +580,7 @@ struct lsb_pb *lsb_csr_pbize(const struct csr *A) {
     return NULL;
   const unsigned n = A->nrows, base = A->base;
   const unsigned long long nnz = A->offs[n];
-  if (nnz == 0 || nnz > 0x7FFFFFFEull)
+  if (nnz == 0 || nnz > 0x7FFFFFF0ull)
     return NULL;
   unsigned lo, hi;
   lsb_csr_col_hull(A, &lo, &hi);
@@ -600,40 +600,17 @@ struct lsb_pb *lsb_csr_pbize(const struct csr *A) {
     for (unsigned j = A->offs[i]; j < A->offs[i + 1]; j++)
       cnt[(size_t)((A->cols[j] - base - lo) / LSB_PB_COLS) * nb + b + 1]++;
   }
-  unsigned long long nruns = 0;
-  for (unsigned long long k = 0; k < nbuck; k++) {
-    nruns += cnt[k + 1] != 0;
+  for (unsigned long long k = 0; k < nbuck; k++)
     cnt[k + 1] += cnt[k];
-  }
   struct lsb_pb *P = lsb_calloc(struct lsb_pb, 1);
-  P->nrows = n, P->ncols_lo = lo, P->nchunks = nch, P->nbins = nb, P->nnz = nnz, P->nruns = nruns;
+  P->nrows = n, P->ncols_lo = lo, P->nchunks = nch, P->nbins = nb, P->nnz = nnz;
   P->vals = (double *)malloc((size_t)nnz * sizeof(double));
   P->colw = (unsigned short *)malloc((size_t)nnz * sizeof(unsigned short));
-  P->roww = (unsigned short *)malloc((size_t)nnz * sizeof(unsigned short));
-  P->bin_run = lsb_calloc(unsigned, (size_t)nb + 1);
-  P->run = (unsigned *)malloc((size_t)(nruns ? nruns : 1) * 2 * sizeof(unsigned));
-  if (!P->vals || !P->colw || !P->roww || !P->run)
+  P->pos = (unsigned *)malloc((size_t)nnz * sizeof(unsigned));
+  P->bin_ptr = lsb_calloc(unsigned, (size_t)nb + 1);
+  unsigned short *rw = (unsigned short *)malloc((size_t)nnz * sizeof(unsigned short));
+  if (!P->vals || !P->colw || !P->pos || !rw)
     errx(EXIT_FAILURE, "out of host memory for the two-phase operator");
-  /* runs of a bin, in chunk order */
-  for (unsigned b = 0; b < nb; b++)
-    for (unsigned c = 0; c < nch; c++)
-      P->bin_run[b + 1] += cnt[(size_t)c * nb + b + 1] != cnt[(size_t)c * nb + b];
-  for (unsigned b = 0; b < nb; b++)
-    P->bin_run[b + 1] += P->bin_run[b];
-  {
-    unsigned *cur = (unsigned *)malloc((size_t)nb * sizeof(unsigned));
-    for (unsigned b = 0; b < nb; b++)
-      cur[b] = P->bin_run[b];
-    for (unsigned c = 0; c < nch; c++)
-      for (unsigned b = 0; b < nb; b++) {
-        const unsigned e0 = cnt[(size_t)c * nb + b], e1 = cnt[(size_t)c * nb + b + 1];
-        if (e1 > e0) {
-          P->run[2 * (size_t)cur[b]] = e0, P->run[2 * (size_t)cur[b] + 1] = e1 - e0;
-          cur[b]++;
-        }
-      }
-    free(cur);
-  }
   /* phase-1 work items: slices of a chunk */
   {
     size_t cap = (size_t)(nnz / PB_ITEM) + nch + 8, ni = 0;
@@ -648,7 +625,7 @@ struct lsb_pb *lsb_csr_pbize(const struct csr *A) {
     }
     P->nitems = (unsigned)ni;
   }
-  /* scatter (cnt[k] is the cursor of bucket k from here on) */
+  /* scatter into (chunk, bin, row, col) order; afterwards cnt[k] = END of bucket k */
   for (unsigned i = 0; i < n; i++) {
     const unsigned b = i / LSB_PB_ROWS;
     for (unsigned j = A->offs[i]; j < A->offs[i + 1]; j++) {
@@ -656,17 +633,107 @@ struct lsb_pb *lsb_csr_pbize(const struct csr *A) {
       const unsigned e = cnt[(size_t)ch * nb + b]++;
       P->vals[e] = A->vals[j];
       P->colw[e] = (unsigned short)(c % LSB_PB_COLS);
-      P->roww[e] = (unsigned short)(i % LSB_PB_ROWS);
+      rw[e] = (unsigned short)(i % LSB_PB_ROWS);
     }
   }
-  free(cnt);
+  /* Slots of every bin: pieces in chunk order, steps of 64 slots in which EQUAL
+   * ROWS ARE NEIGHBOURS (a row may repeat only in consecutive slots: phase 2
+   * combines neighbours by a segmented scan, then one lane adds per row).  An
+   * entry whose row is already in the step under construction, but not in the
+   * slot before it, is deferred to the end of the bin, where the deferred ones are
+   * placed sorted by row under the same rule.  pos[e] holds the slot INSIDE the
+   * bin first. */
+  unsigned *blen = lsb_calloc(unsigned, (size_t)nb + 1);
+#pragma omp parallel
+  {
+    unsigned *stamp = lsb_calloc(unsigned, LSB_PB_ROWS);
+    unsigned *defer = NULL, *dsort = NULL, *dcount = lsb_calloc(unsigned, LSB_PB_ROWS + 1);
+    size_t dcap = 0;
+#pragma omp for schedule(dynamic, 16)
+    for (long long bb = 0; bb < (long long)nb; bb++) {
+      const unsigned b = (unsigned)bb;
+      memset(stamp, 0, LSB_PB_ROWS * sizeof(unsigned));
+      unsigned step = 1, fill = 0, last = 0xFFFFFFFFu; /* stamp[row] == step: row is in the step */
+      size_t nd = 0;
+#define PB_PLACE(e_)                                                           \
+  do {                                                                         \
+    stamp[rw[e_]] = step, last = rw[e_];                                       \
+    P->pos[e_] = (step - 1) * 64 + fill;                                       \
+    if (++fill == 64)                                                          \
+      fill = 0, step++, last = 0xFFFFFFFFu;                                    \
+  } while (0)
+      for (unsigned c = 0; c < nch; c++) {
+        const size_t k = (size_t)c * nb + b;
+        const unsigned e0 = k ? cnt[k - 1] : 0, e1 = cnt[k];
+        for (unsigned e = e0; e < e1; e++) {
+          if (stamp[rw[e]] == step && rw[e] != last) {
+            if (nd == dcap) {
+              dcap = dcap ? 2 * dcap : 1024;
+              defer = (unsigned *)realloc(defer, dcap * sizeof(unsigned));
+              dsort = (unsigned *)realloc(dsort, dcap * sizeof(unsigned));
+              if (!defer || !dsort)
+                errx(EXIT_FAILURE, "out of host memory for the two-phase operator");
+            }
+            defer[nd++] = e;
+            continue;
+          }
+          PB_PLACE(e);
+        }
+      }
+      if (nd) { /* counting sort of the deferred entries by row: equal rows become neighbours */
+        memset(dcount, 0, (LSB_PB_ROWS + 1) * sizeof(unsigned));
+        for (size_t q = 0; q < nd; q++)
+          dcount[rw[defer[q]] + 1]++;
+        for (unsigned r = 0; r < LSB_PB_ROWS; r++)
+          dcount[r + 1] += dcount[r];
+        for (size_t q = 0; q < nd; q++)
+          dsort[dcount[rw[defer[q]]]++] = defer[q];
+      }
+      size_t q0 = 0;
+      while (q0 < nd) { /* in row order; what collides with the current step closes it */
+        const unsigned e = dsort[q0];
+        if (stamp[rw[e]] == step && rw[e] != last) {
+          fill = 0, step++, last = 0xFFFFFFFFu; /* pad the rest of this step */
+          continue;
+        }
+        PB_PLACE(e);
+        q0++;
+      }
+#undef PB_PLACE
+      blen[b] = (step - 1) * 64 + (fill ? 64 : 0);
+    }
+    free(stamp), free(defer), free(dsort), free(dcount);
+  }
+  unsigned long long tot = 0;
+  for (unsigned b = 0; b < nb; b++) {
+    P->bin_ptr[b] = (unsigned)tot;
+    tot += blen[b];
+  }
+  if (tot > 0xFFFFFFF0ull)
+    errx(EXIT_FAILURE, "two-phase operator too large for 32-bit slots");
+  P->bin_ptr[nb] = (unsigned)tot, P->nslots = tot;
+  P->roww = (unsigned short *)malloc((size_t)(tot ? tot : 1) * sizeof(unsigned short));
+  if (!P->roww)
+    errx(EXIT_FAILURE, "out of host memory for the two-phase operator");
+  memset(P->roww, 0xFF, (size_t)tot * sizeof(unsigned short));
+#pragma omp parallel for schedule(dynamic, 16)
+  for (long long bb = 0; bb < (long long)nb; bb++)
+    for (unsigned c = 0; c < nch; c++) {
+      const size_t k = (size_t)c * nb + (size_t)bb;
+      const unsigned e0 = k ? cnt[k - 1] : 0, e1 = cnt[k];
+      for (unsigned e = e0; e < e1; e++) {
+        P->pos[e] += P->bin_ptr[bb];
+        P->roww[P->pos[e]] = rw[e];
+      }
+    }
+  free(blen), free(rw), free(cnt);
   return P;
 }
 
 void lsb_pb_free(struct lsb_pb *P) {
   if (!P)
     return;
-  free(P->vals), free(P->colw), free(P->roww), free(P->item), free(P->bin_run), free(P->run);
+  free(P->vals), free(P->colw), free(P->pos), free(P->item), free(P->bin_ptr), free(P->roww);
   free(P);
 }
 

@@ -23,8 +23,9 @@ int main(void) {
     }
     struct lsb_pb *P = lsb_csr_pbize(A);
     unsigned long long s = 0;
-    for (unsigned long long r = 0; r < P->nruns; r++) s += P->run[2 * r + 1];
-    if (s != P->nnz) { printf("pbize mismatch\n"); return 1; }
+    for (unsigned long long q = 0; q < P->nslots; q++) s += P->roww[q] != 0xFFFFu;
+    for (unsigned long long e = 0; e < P->nnz; e++) if (P->pos[e] >= P->nslots) s = 0;
+    if (s != P->nnz || P->bin_ptr[P->nbins] != P->nslots) { printf("pbize mismatch\n"); return 1; }
     lsb_pb_free(P);
     struct lsb_sell *E = lsb_csr_sellize(A); lsb_sell_free(E);
     E = lsb_csr_sellize16(A, 0); lsb_sell_free(E);

@@ -526,54 +526,62 @@ def test_powerlaw_spd_variant():
 
 @pytest.mark.parametrize("spec", ["powerlaw:n=30000,gamma=1.2,max=3000,seed=7",
                                   "powerlaw:n=5000,gamma=1.585350372615855,max=4096,seed=3",
-                                  "lap2d:nx=170,ny=150"])
+                                  "lap2d:nx=170,ny=150", "powerlaw:n=2500,gamma=0.3,max=2500,seed=5"])
 def test_twophase_form(spec):
-    """lsb_csr_pbize (LSB_SPMV_TWOPHASE): a permutation of the entries ordered by
-    (column chunk, row bin, row, column); every (chunk, bin) pair one run, the runs
-    of a bin listed in chunk order; phase-1 items tile the entries chunk by chunk;
-    products summed through the run table reproduce A x."""
+    """lsb_csr_pbize (LSB_SPMV_TWOPHASE): entries ordered by (column chunk, row bin,
+    row, column) with a target slot each; the slots are row-bin major, a bin a whole
+    number of 64-slot steps in which EQUAL ROWS ARE NEIGHBOURS (the property phase 2
+    relies on: segmented scan, then one lane per LDS word), padding marked 0xFFFF; phase-1
+    items tile the entries chunk by chunk; products summed slot by slot give A x."""
     import ctypes as C
     L = la._lib
     A = la.lsbench_matrix_synth(spec)
     P = L.load().lsb_csr_pbize(A.ptr).contents
-    nnz, nb, nch, ni, nr = int(P.nnz), int(P.nbins), int(P.nchunks), int(P.nitems), int(P.nruns)
+    nnz, nb, nch, ni, nsl = int(P.nnz), int(P.nbins), int(P.nchunks), int(P.nitems), int(P.nslots)
     assert nnz == A.nnz and P.nrows == A.nrows and nb == (A.nrows + L.PB_ROWS - 1) // L.PB_ROWS
     vals = np.ctypeslib.as_array(P.vals, (nnz,)).copy()
     colw = np.ctypeslib.as_array(P.colw, (nnz,)).astype(np.int64)
-    roww = np.ctypeslib.as_array(P.roww, (nnz,)).astype(np.int64)
+    pos = np.ctypeslib.as_array(P.pos, (nnz,)).astype(np.int64)
     item = np.ctypeslib.as_array(P.item, (3 * ni,)).reshape(ni, 3).astype(np.int64)
-    binrun = np.ctypeslib.as_array(P.bin_run, (nb + 1,)).astype(np.int64)
-    run = np.ctypeslib.as_array(P.run, (2 * nr,)).reshape(nr, 2).astype(np.int64)
+    binptr = np.ctypeslib.as_array(P.bin_ptr, (nb + 1,)).astype(np.int64)
+    roww = np.ctypeslib.as_array(P.roww, (nsl,)).astype(np.int64)
     col_lo = int(P.ncols_lo)
     L.load().lsb_pb_free(C.pointer(P))
-    assert col_lo % L.PB_COLS == 0 and colw.max() < L.PB_COLS and roww.max() < L.PB_ROWS
-    # items: contiguous, in order, <= 32768 entries, one chunk each
+    assert col_lo % L.PB_COLS == 0 and colw.max() < L.PB_COLS
     assert item[0, 1] == 0 and item[-1, 2] == nnz and np.all(item[1:, 1] == item[:-1, 2])
     assert np.all(item[:, 2] - item[:, 1] <= 32768) and np.all(np.diff(item[:, 0]) >= 0)
     chunk_of = np.repeat(item[:, 0], item[:, 2] - item[:, 1])
-    # runs: every entry in exactly one run; a bin's runs in chunk (= entry) order
-    cover = np.zeros(nnz, np.int64)
-    bin_of = np.empty(nnz, np.int64)
-    for b in range(nb):
-        rr = run[binrun[b]:binrun[b + 1]]
-        assert np.all(np.diff(rr[:, 0]) > 0)
-        for s0, ln in rr:
-            cover[s0:s0 + ln] += 1
-            bin_of[s0:s0 + ln] = b
-            assert len(set(chunk_of[s0:s0 + ln])) == 1 and np.all(np.diff(roww[s0:s0 + ln]) >= 0)
-    assert np.all(cover == 1)
-    rows = bin_of * L.PB_ROWS + roww
+    # slots: bins are whole steps, every entry has its own slot, the rest is padding
+    assert binptr[0] == 0 and binptr[-1] == nsl and np.all(binptr % 64 == 0) and np.all(np.diff(binptr) >= 0)
+    assert len(np.unique(pos)) == nnz and pos.max() < nsl
+    used = np.zeros(nsl, bool)
+    used[pos] = True
+    assert np.all(roww[~used] == 0xFFFF) and np.all(roww[used] < L.PB_ROWS)
+    assert nsl - nnz <= 64 * nb + nnz // 20                            # little padding
+    bin_of_slot = np.searchsorted(binptr, np.arange(nsl), side="right") - 1
+    rows = bin_of_slot[pos] * L.PB_ROWS + roww[pos]
     cols = col_lo + chunk_of * L.PB_COLS + colw
+    # inside a step of 64 slots equal rows are neighbours (one contiguous run per row)
+    steps = roww.reshape(-1, 64)
+    for k in range(steps.shape[0]):
+        live = steps[k][steps[k] != 0xFFFF]
+        runs = 1 + int(np.count_nonzero(np.diff(live))) if len(live) else 0
+        assert runs == len(np.unique(live))
+    # the same multiset of (row, col, value); (chunk, bin)-major entry order
     offs = A.offs.astype(np.int64)
     arow = np.repeat(np.arange(A.nrows), np.diff(offs))
     o1 = np.lexsort((A.cols, arow))
     o2 = np.lexsort((cols, rows))
     assert np.array_equal(arow[o1], rows[o2]) and np.array_equal(A.cols[o1].astype(np.int64), cols[o2])
     assert np.array_equal(A.vals[o1], vals[o2])
-    key = (chunk_of * nb + bin_of) * (1 << 40) + rows * (1 << 20) + (cols - col_lo) % (1 << 20)
-    assert np.all(np.diff(chunk_of * nb + bin_of) >= 0)            # (chunk, bin)-major
+    assert np.all(np.diff(chunk_of * nb + rows // L.PB_ROWS) >= 0)
+    # products of one (chunk, bin) pair mostly land in consecutive slots
+    same_pair = np.diff(chunk_of * nb + rows // L.PB_ROWS) == 0
+    assert np.mean(np.diff(pos)[same_pair] == 1) > 0.8
     x = np.sin(np.arange(max(A.nrows, int(cols.max()) + 1), dtype=np.float64))
+    prod = np.zeros(nsl)
+    prod[pos] = vals * x[cols]
     y = np.zeros(A.nrows)
-    np.add.at(y, rows, vals * x[cols])
-    assert np.allclose(y, O.spmv(A.offs, A.cols, A.vals, x[:A.nrows] if cols.max() < A.nrows else x),
-                       rtol=1e-12, atol=1e-12)
+    sl = np.nonzero(used)[0]
+    np.add.at(y, bin_of_slot[sl] * L.PB_ROWS + roww[sl], prod[sl])
+    assert np.allclose(y, O.spmv(A.offs, A.cols, A.vals, x[:A.nrows]), rtol=1e-12, atol=1e-12)
