@@ -46,7 +46,7 @@ static void gen_enqueue_init(lsb_hip_solver *sv, const double *d_b, double *d_x)
     /* the state of the previous solve must not gate the preconditioner below */
     LSB_CHK_HIP(hipMemsetAsync(&s->d_st->status, 0, sizeof(int), g_stream));
   }
-  precond_apply(sv); /* z = M^-1 b */
+  precond_apply(sv, 0); /* z = M^-1 b */
   for (int i = 0; i < sv->nshard; i++) {
     struct shard *s = &sv->sh[i];
     LSB_CHK_HIP(hipMemcpyAsync(s->d_pfull + s->row_begin, s->d_z, (size_t)s->n * sizeof(double),
@@ -83,8 +83,9 @@ static void gen_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int sa
     lsb_k_pcg_update_xr(s->n, s->d_pfull + s->row_begin, s->d_q, NULL, 1.0, d_x + o, s->d_r, s->d_st,
                         parity, sv->multi ? s->d_scal : s->d_parts_pq, sv->multi ? 1u : npq,
                         s->d_parts2, &np2, g_stream);
+    s->np2 = np2;
   }
-  precond_apply(sv);
+  precond_apply(sv, 1);
   gen_dot_and_reduce(sv, 1, &np2);
   for (int i = 0; i < sv->nshard; i++) {
     struct shard *s = &sv->sh[i];

@@ -170,11 +170,13 @@ void precond_setup(lsb_hip_solver *sv) {
 
 /* z = M^-1 r on every shard (r = shard.d_r, z = shard.d_z); part of a running
  * solve: launches no-op once its state has left RUNNING */
-void precond_apply(lsb_hip_solver *sv) {
+void precond_apply(lsb_hip_solver *sv, int after_update) {
   if (sv->o.precond == LSB_PRECOND_BLOCKJACOBI) {
     for (int i = 0; i < sv->nshard; i++) {
       struct shard *s = &sv->sh[i];
-      lsb_k_bj_apply(s->n, s->bj_bs, s->d_binv, s->d_r, s->d_z, s->d_bjpart, s->d_st, g_stream);
+      /* after_update: k_pcg_update_xr's r.r partial sums are in d_parts2 (s->np2 records) */
+      lsb_k_bj_apply(s->n, s->bj_bs, s->d_binv, s->d_r, s->d_z, s->d_bjpart, s->d_st,
+                     after_update && !sv->multi ? s->d_parts2 : NULL, s->np2, g_stream);
     }
     return;
   }

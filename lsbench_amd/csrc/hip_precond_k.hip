@@ -164,6 +164,20 @@ __global__ __launch_bounds__(WG) void k_gj_update(unsigned n, unsigned bs, unsig
   }
 }
 
+// "The residual already meets the tolerance": the sweep before the preconditioner
+// (k_pcg_update_xr) left partial sums of r.r; when they add up to <= thresh2 the
+// iteration will end in k_pcg_update_p anyway and z is never used -- a dense block
+// need not be streamed for it (one shard only: over shards r.r needs an all-reduce).
+__device__ __forceinline__ bool bj_residual_small(const double *__restrict__ parts2, unsigned np2,
+                                                  const lsb_pcg_state *__restrict__ st,
+                                                  double *sred) {
+  double v[2] = {0.0, 0.0};
+  for (unsigned i = threadIdx.x; i < np2; i += WG)
+    v[1] += parts2[2 * (size_t)i + 1];
+  pwg_sum2(v, sred);
+  return v[1] <= st->thresh2;
+}
+
 // z = Binv r, one thread per row, small blocks (bs <= 64): reads bs entries
 __global__ __launch_bounds__(WG) void k_bj_apply(unsigned n, unsigned bs,
                                                  const double *__restrict__ binv,
@@ -191,8 +205,13 @@ __global__ __launch_bounds__(WG) void k_bj_apply_part(unsigned n, unsigned bs, u
                                                       const double *__restrict__ binv,
                                                       const double *__restrict__ r,
                                                       double *__restrict__ part,
-                                                      const lsb_pcg_state *__restrict__ st) {
+                                                      const lsb_pcg_state *__restrict__ st,
+                                                      const double *__restrict__ skip2,
+                                                      unsigned nskip) {
+  __shared__ double sred[8];
   if (st && st->status)
+    return;
+  if (skip2 && bj_residual_small(skip2, nskip, st, sred))
     return;
   const size_t i = (size_t)blockIdx.x * WG + threadIdx.x;
   const unsigned ch = blockIdx.y;
@@ -278,14 +297,16 @@ void lsb_k_bj_invert(unsigned n, unsigned bs, double *binv, double *scratch, voi
 }
 
 void lsb_k_bj_apply(unsigned n, unsigned bs, const double *binv, const double *r, double *z,
-                    double *part, const struct lsb_pcg_state *st, void *stream) {
+                    double *part, const struct lsb_pcg_state *st, const double *skip2,
+                    unsigned nskip, void *stream) {
   if (bs <= 64 || !part) {
     k_bj_apply<<<pgrid(n), WG, 0, (hipStream_t)stream>>>(n, bs, binv, r, z, st);
     return;
   }
   const unsigned nch = (bs + BJ_CH - 1) / BJ_CH;
   dim3 grid((n + WG - 1) / WG, nch);
-  k_bj_apply_part<<<grid, WG, 0, (hipStream_t)stream>>>(n, bs, nch, binv, r, part, st);
+  k_bj_apply_part<<<grid, WG, 0, (hipStream_t)stream>>>(n, bs, nch, binv, r, part, st,
+                                                        st ? skip2 : NULL, nskip);
   k_bj_sum<<<pgrid(n), WG, 0, (hipStream_t)stream>>>(n, nch, part, z, st);
 }
 

@@ -216,7 +216,7 @@ LSB_INTERNAL int generic_precond(const lsb_hip_solver *sv);
 LSB_INTERNAL void precond_shard_blocks(struct shard *s, const int *offs, const int *cols,
                                        const double *vals, const struct lsb_hip_opts *o);
 LSB_INTERNAL void precond_setup(lsb_hip_solver *sv);
-LSB_INTERNAL void precond_apply(lsb_hip_solver *sv);
+LSB_INTERNAL void precond_apply(lsb_hip_solver *sv, int after_update);
 LSB_INTERNAL void precond_free_shard(struct shard *s);
 /* hip_gmres_drv.c */
 LSB_INTERNAL int gmres_solve_dev(lsb_hip_solver *sv, const double *d_b, double *d_x,

@@ -174,7 +174,8 @@ void lsb_k_scale_vec(unsigned n, double c, double *v, void *stream);
 void lsb_k_power_start(unsigned n, unsigned first, double *v, void *stream);
 void lsb_k_bj_invert(unsigned n, unsigned bs, double *binv, double *scratch, void *stream);
 void lsb_k_bj_apply(unsigned n, unsigned bs, const double *binv, const double *r, double *z,
-                    double *part, const struct lsb_pcg_state *st, void *stream);
+                    double *part, const struct lsb_pcg_state *st, const double *skip2,
+                    unsigned nskip, void *stream);
 unsigned lsb_k_bj_chunks(unsigned bs);
 
 /* ---- one-launch solve of launch-bound operators (hip_persist.hip) ------------ */

@@ -169,3 +169,24 @@ def test_bench_line_contract():
     assert c4["config"]["rows"] == 64000000 and c4["config"]["nnz"] == 447040000 and c4["value"] > 0
     assert c4["config"]["true_relres"] <= c4["config"]["tol"] * (1 + 1e-6) and c4["n_gpus"] == 1
     assert "pcg_iteration_GBps" not in d
+
+
+def test_powerlaw_spd_8m_rows_cg(hip):
+    """config 5 as SURVEY 8(d) defines it for CG runs: S = (B + B^T) + diag(1 + sum|row|)
+    on the 8 M-row power-law structure (521 M non-zeros), Jacobi-PCG through the SpMV
+    the timing pass picks for scattered rows; the oracle's iterates and stop."""
+    import torch
+    thr = min(O.max_threads(), 16)
+    A = hip.lsbench_matrix_synth("powerlaw:n=8000000,gamma=%r,max=4096,seed=20240607,spd=1" % GAMMA)
+    assert A.nrows == 8000000 and 5.0e8 < A.nnz < 5.4e8
+    b = O.rhs(A.nrows)
+    xo, ito, relo, sto = O.pcg_jacobi(A.offs, A.cols, A.vals, b, 1e-10, threads=thr)
+    s = hip.Solver(A, hip.default_opts(op_mode=hip.OP_RAW, tol=1e-10, use_graph=0, verify=1))
+    assert s.spmv_variant in (hip.SPMV_BINNED, hip.SPMV_TWOPHASE, hip.SPMV_ADAPTIVE)
+    d_b, d_x = _dev(b), torch.empty(A.nrows, dtype=torch.float64, device="cuda:0")
+    res = s.solve_dev(d_b, d_x)
+    x = d_x.cpu().numpy()
+    s.destroy()
+    assert sto == 1 and res.status == hip.STATUS_CONVERGED and abs(int(res.iters) - ito) <= 1
+    assert 0 <= res.true_relres <= 1e-10
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-9
