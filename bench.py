@@ -319,7 +319,8 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
               la.SPMV_BINNED: "k_spmv_binned", la.SPMV_TWOPHASE: "k_pb_products + k_pb_reduce",
               la.SPMV_SELL: "k_spmv_sell16" if solver.spmv_flags & la.SPMV_FLAG_C16 else "k_spmv_sell"
               }.get(solver.spmv_variant, "?")
-    traffic, traffic_src = pmc_traffic(key if world == 1 else None, kernel)
+    # (the committed PMC profile is of the fp64 forms: no traffic figure for fp32 values)
+    traffic, traffic_src = pmc_traffic(key if world == 1 and a.precision == "fp64" else None, kernel)
 
     if spmv_only:
         # config 5: SpMV throughput only (the operator is unsymmetric)
