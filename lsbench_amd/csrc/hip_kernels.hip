@@ -986,19 +986,24 @@ static int g_blas1_nt = 1;
 // of 3.6 MB next to the matrix stream in a 4 MiB L2; PMC 5.59 -> see DESIGN.md).
 // Placement is a speed matter only; every slice is taken exactly once.
 struct sell_deal {
-  unsigned turns, base, L, period;
+  unsigned turns, base, L, period, full, total;
 };
 __device__ __forceinline__ sell_deal sell_deal_init(unsigned ns, unsigned period, unsigned xcd) {
   sell_deal d;
-  d.period = period;
+  d.period = period, d.full = 0, d.total = 0;
   if (!period) {
     const unsigned ngrp = (ns + 3) / 4, chunk = (ngrp + NXCD - 1) / NXCD;
     const unsigned g0 = min(xcd * chunk, ngrp), g1 = min(g0 + chunk, ngrp);
     d.base = g0 * 4, d.turns = g1 - g0, d.L = 0;
   } else {
+    // whole planes first, then this XCD's part of the ragged last one (a shard
+    // need not hold whole planes)
     const unsigned qlo = period * xcd / NXCD, qhi = period * (xcd + 1) / NXCD;
+    const unsigned planes = ns / period, rem = ns % period;
     d.L = qhi - qlo, d.base = qlo;
-    d.turns = (d.L * (ns / period) + 3) / 4;
+    d.full = d.L * planes;
+    d.total = d.full + (rem > qlo ? min(qhi, rem) - qlo : 0u);
+    d.turns = (d.total + 3) / 4;
   }
   return d;
 }
@@ -1009,9 +1014,11 @@ __device__ __forceinline__ unsigned sell_deal_slice(const sell_deal &d, unsigned
     return si < ns ? si : 0xFFFFFFFFu;
   }
   const unsigned m = it * 4 + wave;
-  if (m >= d.L * (ns / d.period))
+  if (m >= d.total)
     return 0xFFFFFFFFu;
-  return (m / d.L) * d.period + d.base + m % d.L;
+  if (m < d.full)
+    return (m / d.L) * d.period + d.base + m % d.L;
+  return (ns / d.period) * d.period + d.base + (m - d.full);
 }
 
 typedef int i2v __attribute__((ext_vector_type(2)));
@@ -1546,8 +1553,8 @@ void lsb_k_spmv_sell(unsigned flags, unsigned grid_cap, unsigned period, const u
     *npartials = g;
   const int nt = (flags & SP_NT) != 0;
   const float *vals32 = (const float *)(const void *)vals; /* flags & LSB_SP_F32 */
-  if (period && (ns % period || period < NXCD))
-    period = 0; /* a sub-range that is not whole planes: contiguous dealing */
+  if (period && (period < NXCD || ns < period))
+    period = 0; /* less than a plane: contiguous dealing */
 #define LSB_SELL16(FL, VT, V)                                                                  \
   k_spmv_sell16<FL, VT><<<g, WG, 0, s>>>(sptr, s0, ns, period, n, row_begin, (const short *)cols, \
                                          sbase, V, x, y, xdot, partials, st)

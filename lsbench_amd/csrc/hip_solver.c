@@ -249,7 +249,7 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
             if (b > (long long)bw)
               bw = (unsigned)b;
           }
-        if (bw >= 64 * LSB_SELL_ROWS && bw % LSB_SELL_ROWS == 0 && E->nslice % (bw / LSB_SELL_ROWS) == 0)
+        if (bw >= 64 * LSB_SELL_ROWS && bw % LSB_SELL_ROWS == 0 && E->nslice >= 2 * (bw / LSB_SELL_ROWS))
           s->sell_period = bw / LSB_SELL_ROWS;
       }
       s->nslice = E->nslice;
@@ -714,6 +714,8 @@ void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
   const struct lsb_hip_opts *o = &sv->o;
   s->sp_flags = LSB_SP_PREFETCH | LSB_SP_NT;
   s->sp_grid = o->spmv_grid > 0 ? (unsigned)o->spmv_grid : LSB_MAX_PARTIALS;
+  if (getenv("LSBENCH_HIP_FORCE_PERIOD")) /* tests: the plane-periodic dealing on small operators */
+    s->sp_period = s->sell_period;
   if (o->spmv_tune >= 0) {
     s->sp_flags = (unsigned)o->spmv_tune & 31u; /* bit 2: 16-bit codes, where that copy exists;
                                                    bits 3, 4: binned form's gather flavour */

@@ -173,3 +173,40 @@ def test_tuning_pass_picks_among_forms(hip):
     s = hip.Solver(P, hip.default_opts(op_mode=hip.OP_RAW, precond=hip.PRECOND_NONE))
     assert s.spmv_variant != hip.SPMV_SELL
     s.destroy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nvirt,overlap,comm", [(1, 0, 0), (4, 0, 1), (4, 1, 1), (4, 1, 2), (2, 1, 2)])
+def test_plane_periodic_dealing_of_a_3d_stencil(hip, nvirt, overlap, comm, monkeypatch):
+    """sell_deal (hip_kernels.hip): every XCD takes the same eighth of every plane of a
+    3-D stencil instead of a contiguous eighth of the rows.  A placement matter only:
+    the same SpMV element for element and the same solve, on one shard, over row-range
+    shards (whole planes each) and with the SpMV split into interior and boundary
+    launches around the halo exchange -- the form config 4 runs in at 8 GPUs."""
+    import torch
+    monkeypatch.setenv("LSBENCH_HIP_FORCE_PERIOD", "1")
+    A = hip.lsbench_matrix_synth("lap3d:nx=128,ny=64,nz=64")        # plane = 8192 rows = 64 slices
+    offs, cols, vals = O.lap3d(128, 64, 64)
+    b = O.rhs(A.nrows)
+    xo, ito, relo, sto = O.pcg_jacobi(offs, cols, vals, b, 1e-10)
+    s = hip.Solver(A, hip.default_opts(op_mode=hip.OP_RAW, spmv_variant=hip.SPMV_SELL, nvirt=nvirt,
+                                       overlap=overlap, comm=comm, tol=1e-10, use_graph=0))
+    assert s.spmv_period == 64 and s.spmv_variant == hip.SPMV_SELL
+    assert bool(s.overlaps) == bool(overlap)
+    x = np.random.default_rng(3).standard_normal(A.nrows)
+    d_y = torch.full((A.nrows,), float("nan"), dtype=torch.float64, device="cuda:0")
+    s.spmv_dev(torch.from_numpy(x).to("cuda:0"), d_y)
+    y = d_y.cpu().numpy()
+    yo = O.spmv(offs, cols, vals, x)
+    assert np.all(np.abs(y - yo) <= 4 * np.finfo(float).eps * 7 * O.spmv(offs, cols, np.abs(vals), np.abs(x)))
+    xs, r = s.solve(b)
+    s.destroy()
+    assert r.status == 1 and abs(int(r.iters) - ito) <= 3
+    assert np.linalg.norm(xs - xo) / np.linalg.norm(xo) <= 1e-9
+    monkeypatch.delenv("LSBENCH_HIP_FORCE_PERIOD")
+    s = hip.Solver(A, hip.default_opts(op_mode=hip.OP_RAW, spmv_variant=hip.SPMV_SELL, tol=1e-10, use_graph=0))
+    assert s.spmv_period == 0
+    d_y0 = torch.empty_like(d_y)
+    s.spmv_dev(torch.from_numpy(x).to("cuda:0"), d_y0)
+    s.destroy()
+    assert np.array_equal(d_y0.cpu().numpy(), y)          # a row's sum does not depend on the dealing
