@@ -92,9 +92,11 @@ static void opts_from_env(struct lsb_hip_opts *o) {
   if ((e = getenv("LSBENCH_HIP_SPMV")))
     o->spmv_variant = atoi(e);
   if ((e = getenv("LSBENCH_HIP_PRECOND")))
-    o->precond = !strcasecmp(e, "none") ? LSB_PRECOND_NONE
-                 : !strcasecmp(e, "l1")  ? LSB_PRECOND_L1JACOBI
-                                         : LSB_PRECOND_JACOBI;
+    o->precond = !strcasecmp(e, "none")   ? LSB_PRECOND_NONE
+                 : !strcasecmp(e, "l1")   ? LSB_PRECOND_L1JACOBI
+                 : !strcasecmp(e, "cheb") ? LSB_PRECOND_CHEBYSHEV
+                 : !strcasecmp(e, "bj")   ? LSB_PRECOND_BLOCKJACOBI
+                                          : LSB_PRECOND_JACOBI;
   if ((e = getenv("LSBENCH_HIP_COMM")))
     o->comm = !strcmp(e, "rccl") ? LSB_COMM_RCCL : !strcmp(e, "p2p") ? LSB_COMM_P2P : LSB_COMM_AUTO;
   if ((e = getenv("LSBENCH_HIP_OVERLAP")))

@@ -18,7 +18,8 @@
  * deliberate differences: --ordering/--precision/--verbose/--trials accept
  * "--flag value" as well as "--flag=value" (the reference segfaults on the
  * first form), --help prints the program name, and
- * --tol/--maxit/--operator/--nvirt/--krylov/--restart/--precond/--ngpus are new.
+ * --tol/--maxit/--operator/--nvirt/--krylov/--restart/--precond/--cheb-degree/
+ * --block-size/--ngpus are new.
  */
 #define _GNU_SOURCE
 #include "lsb_impl.h"
@@ -79,7 +80,10 @@ static void usage(const char *prog) {
   printf("  --nvirt <P>          (hip) P row-range shards on one device (test)\n");
   printf("  --krylov <cg|cg1|auto|gmres> (hip) cg1 = single-reduction CG, gmres for --operator raw\n");
   printf("  --restart <M>        (hip) GMRES restart length, 1..32, default 30\n");
-  printf("  --precond <jacobi|l1|none> (hip) diag(S), diag(sum_j |S_ij|), or none\n");
+  printf("  --precond <jacobi|l1|none|cheb|bj> (hip) diag(S); diag(sum_j |S_ij|); none; Chebyshev\n");
+  printf("                       polynomial in D^-1 S (--cheb-degree M, default 4); block-Jacobi with\n");
+  printf("                       dense inverted blocks of --block-size B rows (default 8; B >= n = a\n");
+  printf("                       cached dense inverse, for operators of a few thousand rows)\n");
   printf("  --ngpus <N>          (hip) row-partition the operator over N GPUs of this node\n");
   printf("                       (0 = all visible), driven from this one process\n");
   printf("  --reorder            (hip) solve the RCM-permuted operator (any --ordering\n");
@@ -98,6 +102,7 @@ struct lsbench *lsbench_init(int argc, char *argv[]) {
       {"nvirt", required_argument, 0, 83},    {"krylov", required_argument, 0, 84},
       {"restart", required_argument, 0, 85},  {"reorder", no_argument, 0, 86},
       {"precond", required_argument, 0, 87},  {"ngpus", required_argument, 0, 88},
+      {"cheb-degree", required_argument, 0, 89}, {"block-size", required_argument, 0, 90},
       {0, 0, 0, 0}};
 
   /* zero-filled => solver 0 (CUSOLVER), ordering 0 (RCM), FP64: the
@@ -160,9 +165,17 @@ struct lsbench *lsbench_init(int argc, char *argv[]) {
       o.reorder = 1;
       break;
     case 87:
-      o.precond = strcasecmp(optarg, "none") == 0 ? LSB_PRECOND_NONE
-                  : strcasecmp(optarg, "l1") == 0 ? LSB_PRECOND_L1JACOBI
-                                                  : LSB_PRECOND_JACOBI;
+      o.precond = strcasecmp(optarg, "none") == 0   ? LSB_PRECOND_NONE
+                  : strcasecmp(optarg, "l1") == 0   ? LSB_PRECOND_L1JACOBI
+                  : strcasecmp(optarg, "cheb") == 0 ? LSB_PRECOND_CHEBYSHEV
+                  : strcasecmp(optarg, "bj") == 0   ? LSB_PRECOND_BLOCKJACOBI
+                                                    : LSB_PRECOND_JACOBI;
+      break;
+    case 89:
+      o.cheb_degree = atoi(optarg);
+      break;
+    case 90:
+      o.block_size = atoi(optarg);
       break;
     case 88:
       o.ngpus = atoi(optarg);

@@ -108,3 +108,25 @@ def test_hip_preconditioners_variants(hip, matrix_path, golden_x):
     s.destroy()
     assert r.status == 1 and abs(int(r.iters) - ito) <= 3
     assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-7
+
+
+@pytest.mark.gpu
+def test_preconditioners_through_the_driver(hip, matrix_path, golden_x):
+    """`driver --solver hip --precond bj --block-size N` / `--precond cheb --cheb-degree M`:
+    the options behind the reference's CLI; one block as large as the operator is the
+    cached dense inverse (one iteration)."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    drv = os.path.join(ROOT, "lsbench_amd", "csrc", "driver")
+    xg = golden_x("xn3b_A_18")
+    for extra, itmax in ((["--precond", "bj", "--block-size", "100000"], 2),
+                         (["--precond", "cheb", "--cheb-degree", "4"], 70)):
+        r = subprocess.run([drv, "--solver", "hip", "--matrix", matrix_path("xn3b_A_18"), "--trials=3",
+                            "--verbose", "2"] + extra, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        lines = r.stdout.splitlines()
+        h = lines[lines.index("===hip_cdna4:iterations,relres,status,tol,solves_per_sec,nshards===") + 1].split(",")
+        x = np.array([float(l.split("=")[1]) for l in lines if l.startswith("x[")])
+        assert int(h[2]) == 1 and int(h[0]) <= itmax
+        assert np.linalg.norm(x - xg) / np.linalg.norm(xg) <= 1e-10

@@ -59,11 +59,13 @@ for wl, suffix in (("lap2d", ""), ("lap3d", "_lap3d"), ("powerlaw", "_powerlaw")
         nbins = -(-8000000 // 524288)
         for k, d in pmc.items():
             if "k_spmv_binned<2" in k and "FETCH_SIZE_KB_sum" in d and "WRITE_SIZE_KB_sum" in d:
-                nspmv = d["launches_FETCH_SIZE"] / nbins
-                tot = (2 * d["FETCH_SIZE_KB_sum"] + d["WRITE_SIZE_KB_sum"]) * 1024 / nspmv
-                best = ("k_spmv_binned", d["launches_FETCH_SIZE"], tot)
-                lines.append("# k_spmv_binned per SpMV (%d launches = %d windows x %.0f SpMVs): %.0f bytes"
-                             % (d["launches_FETCH_SIZE"], nbins, nspmv, tot))
+                # (the two passes are separate runs and may hold different numbers of launches of
+                # this flavour -- the start-up timing pass picks it or its plain-load twin)
+                nf, nw = d["launches_FETCH_SIZE"], d["launches_WRITE_SIZE"]
+                tot = (2 * d["FETCH_SIZE_KB_sum"] / nf + d["WRITE_SIZE_KB_sum"] / nw) * 1024 * nbins
+                best = ("k_spmv_binned", nf, tot)
+                lines.append("# k_spmv_binned per SpMV = %d windows x mean launch (%d launches in the FETCH "
+                             "pass, %d in the WRITE pass): %.0f bytes" % (nbins, nf, nw, tot))
     open(os.path.join(out, "%s_pmc_traffic_%s.csv" % (rnd, wl)), "w").write("\n".join(lines) + "\n")
     if best:
         traffic[wl] = {"bytes": best[2], "kernel": best[0], "launches": best[1],
