@@ -154,7 +154,7 @@ struct lsb_hip_opts {
   int spmv_grid;     /* workgroup cap of the SpMV launch, 0 = tuned     [0] */
   int reorder;       /* 1: solve P S P^T with P = reverse Cuthill-McKee, permute
                         b, un-permute x (single shard)                  [0] */
-  int krylov;        /* LSB_KRYLOV_*                                  [PCG] */
+  int krylov;        /* LSB_KRYLOV_*                                 [AUTO] */
   int restart;       /* GMRES restart length m, 1..32                  [30] */
   int verbose;
   int ngpus;         /* hip_cdna4_bench only: row-partition the operator over

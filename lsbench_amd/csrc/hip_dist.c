@@ -163,17 +163,72 @@ void spmv_range(struct shard *s, int part, double *y, double *partials, unsigned
   if (b1 > b0)
     lsb_k_spmv(LSB_SPMV_ADAPTIVE, s->n, s->d_offs, s->d_cols, s->d_vals, s->d_rowblk + b0,
                s->d_blklanes + b0, b1 - b0, s->lanes, s->sp_flags, s->sp_grid, s->d_pfull, y,
-               s->d_pfull + s->row_begin, partials, np, st, NULL, g_stream);
+               s->d_pfull + s->row_begin, partials, np, st, NULL, &s->tail, g_stream);
+}
+
+/* rows of the split SpMV's part (see spmv_range) */
+static unsigned range_len(const struct shard *s, int part) {
+  const unsigned a = s->variant == LSB_SPMV_SELL ? s->ov_s1 : s->ov_b1;
+  const unsigned b = s->variant == LSB_SPMV_SELL ? s->ov_s2 : s->ov_b2;
+  const unsigned e = s->variant == LSB_SPMV_SELL ? s->nslice : s->nblk;
+  return part == 0 ? (b > a ? b - a : 0) : part == 1 ? a : (e > b ? e - b : 0);
+}
+
+/* The all-reduce of {w.u; the sweep's r.u, r.r} folded into neighbouring
+ * launches (hip_ar.h): the next SpMV launch of shard i is the last one of this
+ * iteration's SpMV -- it carries the contribute phase; `before` dot partials of
+ * earlier launches precede its own in d_parts_pq. */
+static void arm_tail(lsb_hip_solver *sv, int i, unsigned before) {
+  struct shard *s = &sv->sh[i];
+  if (s->ar2_width != 2)
+    errx(EXIT_FAILURE, "hip_cdna4: the folded all-reduce carries {w.u; r.u, r.r} only");
+  lsb_p2p_fold_contribute(sv->p2p[i], &s->tail);
+  s->tail.parts = s->d_parts_pq, s->tail.nparts_before = before;
+  s->tail.parts2 = s->ar2_parts, s->tail.nparts2 = s->ar2_n, s->tail.width2 = s->ar2_width;
+}
+
+/* How single-reduction CG over the direct path runs its all-reduce (hip_ar.h):
+ *   0  k_p2p_allreduce, one launch: contribute, wait, collect
+ *   1  contribute in a launch of its own that waits for nobody; the wait and the
+ *      collect at the head of the next k_cg1_update, behind its first loads (default)
+ *   2  the contribute phase in the tail of the SpMV's last launch as well: no launch
+ *      at all, but 13 us slower per iteration at 1.25 M rows -- the workgroups'
+ *      hand-ins are ~1500 atomic adds to one word that all arrive when the launch
+ *      ends (profiles/r02_shard_floor.txt); kept for that measurement
+ * LSBENCH_HIP_AR_FOLD picks one; ranks need not agree (same stores, same order). */
+int can_fold_allreduce(const lsb_hip_solver *sv) {
+  const char *e = getenv("LSBENCH_HIP_AR_FOLD");
+  int mode = e ? atoi(e) : 1;
+  if (!sv->multi || !sv->p2p_on || mode <= 0)
+    return 0;
+  for (int i = 0; i < sv->nshard && mode == 2; i++)
+    if (!lsb_k_spmv_has_tail(sv->sh[i].variant) || sv->sh[i].n == 0)
+      mode = 1;
+  return mode > 2 ? 1 : mode;
+}
+
+/* mode 1: this shard's sums to every rank's mailbox; nobody is waited for */
+void allreduce_pq_contribute(lsb_hip_solver *sv) {
+  for (int i = 0; i < sv->nshard; i++) {
+    struct shard *s = &sv->sh[i];
+    lsb_p2p_allreduce(sv->p2p[i], s->d_parts_pq, s->npq, 1, s->ar2_parts, s->ar2_n, s->ar2_width,
+                      NULL, 0, s->d_scal, s->d_st, 1, g_stream);
+  }
 }
 
 void exchange_and_spmv(lsb_hip_solver *sv, int sample) {
+  const int fold = sv->fold_next;
+  sv->fold_next = 0;
   if (!can_overlap(sv)) {
     exchange_p(sv, 1);
     for (int i = 0; i < sv->nshard; i++) {
       struct shard *s = &sv->sh[i];
       if (i == 0 && sample >= 0)
         LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample], g_stream));
+      if (fold)
+        arm_tail(sv, i, 0);
       spmv_shard(s, s->d_pfull, s->d_q, s->d_pfull + s->row_begin, s->d_parts_pq, &s->npq, s->d_st);
+      s->tail.counter = NULL;
       if (i == 0 && sample >= 0) {
         LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 1], g_stream));
         LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 2], g_stream));
@@ -196,7 +251,10 @@ void exchange_and_spmv(lsb_hip_solver *sv, int sample) {
   unsigned na, nb, nc;
   for (int i = 0; i < sv->nshard; i++) {                         /* interior: no halo     */
     struct shard *s = &sv->sh[i];
+    if (fold && !range_len(s, 1) && !range_len(s, 2))
+      arm_tail(sv, i, 0);
     spmv_range(s, 0, s->d_q, s->d_parts_pq, &na, s->d_st);
+    s->tail.counter = NULL;
     s->npq = na;
   }
   if (sv->p2p_halo) {
@@ -206,8 +264,14 @@ void exchange_and_spmv(lsb_hip_solver *sv, int sample) {
     LSB_CHK_HIP(hipStreamWaitEvent(g_stream, sv->ev_halo, 0));
   for (int i = 0; i < sv->nshard; i++) {                         /* boundary rows         */
     struct shard *s = &sv->sh[i];
+    if (fold && range_len(s, 1) && !range_len(s, 2))
+      arm_tail(sv, i, s->npq);
     spmv_range(s, 1, s->d_q, s->d_parts_pq + s->npq, &nb, s->d_st);
+    s->tail.counter = NULL;
+    if (fold && range_len(s, 2))
+      arm_tail(sv, i, s->npq + nb);
     spmv_range(s, 2, s->d_q, s->d_parts_pq + s->npq + nb, &nc, s->d_st);
+    s->tail.counter = NULL;
     s->npq += nb + nc;
   }
   if (sample >= 0) {

@@ -18,10 +18,13 @@
 // window a row block gathers from is re-used out of one XCD's L2.  No MFMA.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
+#include "hip_ar.h"
 #include "lsb_impl.h"
 
 #define WG 256      // threads per workgroup = 4 wavefronts of 64
+static_assert(WG == AR_WG, "the folded all-reduce phases assume this workgroup size");
 #define NXCD 8      // XCDs per MI355X; blocks are dealt round-robin over them
 
 // --------------------------------------------------------------------------
@@ -64,6 +67,21 @@ __device__ __forceinline__ void wg_sum_partials(const double *__restrict__ parts
       v[k] += parts[(size_t)i * W + k];
   }
   wg_sum<W>(v, sred);
+}
+
+// End of an SpMV launch with the fused dot: the workgroup's partial sum goes to
+// partials[blockIdx.x]; with a tail (sharded solve over the direct xGMI path)
+// the workgroup that hands in last also runs the all-reduce's contribute phase.
+__device__ __forceinline__ void spmv_publish(double *__restrict__ partials, double dot,
+                                             double *sred, const lsb_ar_tail &tail) {
+  if (!partials)
+    return;
+  double d[1] = {dot};
+  wg_sum<1>(d, sred);
+  if (tail.counter)
+    ar_tail(partials, d[0], tail);
+  else if (threadIdx.x == 0)
+    partials[blockIdx.x] = d[0];
 }
 
 // Logical workgroup id such that each XCD owns a contiguous range of logical
@@ -127,7 +145,7 @@ __global__ __launch_bounds__(WG, 8) void k_spmv_adaptive(
     const VT *__restrict__ vals, const double *__restrict__ x,
     double *__restrict__ y, const double *__restrict__ xdot,
     double *__restrict__ partials, const lsb_pcg_state *__restrict__ st,
-    const int *__restrict__ rowmap) {
+    const int *__restrict__ rowmap, const lsb_ar_tail tail) {
   // rowmap != NULL: column-panel mode -- the CSR's rows are (row, panel) pairs,
   // row r of it accumulates into y[rowmap[r]] (one launch per panel, so a y
   // entry is touched by one lane per launch; lsb_csr_panelize)
@@ -217,12 +235,7 @@ __global__ __launch_bounds__(WG, 8) void k_spmv_adaptive(
     if (!(FLAGS & SP_PREFETCH) && k + gx < kend)
       LSB_ISSUE_BLOCK(k + gx);
   }
-  if (partials) {
-    double d[1] = {dot};
-    wg_sum<1>(d, sred);
-    if (tid == 0)
-      partials[blockIdx.x] = d[0];
-  }
+  spmv_publish(partials, dot, sred, tail);
 }
 #undef LSB_ISSUE_BLOCK
 
@@ -814,7 +827,8 @@ __global__ __launch_bounds__(WG) void k_cg1_update(
     const double *__restrict__ dinv, double dc, double *__restrict__ p, double *__restrict__ sv,
     double *__restrict__ x, double *__restrict__ r, lsb_pcg_state *__restrict__ st,
     int parity, const double *__restrict__ parts_gr, unsigned ngr,
-    const double *__restrict__ parts_d, unsigned nd, double *__restrict__ partials2) {
+    const double *__restrict__ parts_d, unsigned nd, const lsb_ar_collect col,
+    double *__restrict__ partials2) {
   __shared__ double sred[8];
   const size_t gtid = (size_t)blockIdx.x * WG + threadIdx.x;
   const size_t gsz = (size_t)gridDim.x * WG;
@@ -842,10 +856,32 @@ __global__ __launch_bounds__(WG) void k_cg1_update(
       uv = ld2<NT>(u2 + gtid);
   }
   double gr[2], dd[1];
-  wg_sum_partials<2>(parts_gr, ngr, gr, sred);
-  wg_sum_partials<1>(parts_d, nd, dd, sred);
-  if (stopped)
-    return;
+  if (col.mbox) {
+    // sharded solve over the direct xGMI path: the SpMV launch in front of this
+    // one sent this rank's sums to every rank; take w.u, r.u, r.r from the
+    // mailbox (rank order: the same bits everywhere) -- hip_ar.h
+    if (stopped)
+      return;
+    if (threadIdx.x < 64) {
+      double v[3];
+      const bool ok = ar_collect<false>(col.mbox, col.R, col.epoch, col.timeout, 3, v);
+      if (threadIdx.x == 0)
+        sred[0] = v[0], sred[1] = v[1], sred[2] = v[2], sred[3] = ok ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    dd[0] = sred[0], gr[0] = sred[1], gr[1] = sred[2];
+    if (sred[3] == 0.0) { // a peer did not arrive: every workgroup that notices says so
+      if (threadIdx.x == 0)
+        __hip_atomic_store(&st->status, (int)LSB_STATUS_COMM, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+  } else {
+    wg_sum_partials<2>(parts_gr, ngr, gr, sred);
+    wg_sum_partials<1>(parts_d, nd, dd, sred);
+    if (stopped)
+      return;
+  }
   const double g_new = gr[0], rr = gr[1], delta = UI ? dc * dc * dd[0] : dd[0];
   const bool leader = blockIdx.x == 0 && threadIdx.x == 0;
   if (rr <= thresh2 || pend) { // r of the previous update meets the tolerance, or it was the last allowed
@@ -1032,7 +1068,7 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_sell(
     const unsigned *__restrict__ sptr, unsigned s0, unsigned ns, unsigned period, unsigned n,
     const int *__restrict__ cols, const VT *__restrict__ vals,
     const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ xdot,
-    double *__restrict__ partials, const lsb_pcg_state *__restrict__ st) {
+    double *__restrict__ partials, const lsb_pcg_state *__restrict__ st, const lsb_ar_tail tail) {
   __shared__ double sred[4];
   const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const unsigned gx = gridDim.x / NXCD, xcd = blockIdx.x % NXCD, slot = blockIdx.x / NXCD;
@@ -1088,12 +1124,7 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_sell(
   }
   if (stopped)
     return;
-  if (partials) {
-    double d[1] = {dot};
-    wg_sum<1>(d, sred);
-    if (tid == 0)
-      partials[blockIdx.x] = d[0];
-  }
+  spmv_publish(partials, dot, sred, tail);
 }
 
 // The same with 16-bit column codes (lsb_csr_sellize16): the column of the entry
@@ -1111,7 +1142,7 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_sell16(
     unsigned row_begin, const short *__restrict__ codes, const int *__restrict__ sbase,
     const VT *__restrict__ vals, const double *__restrict__ x, double *__restrict__ y,
     const double *__restrict__ xdot, double *__restrict__ partials,
-    const lsb_pcg_state *__restrict__ st) {
+    const lsb_pcg_state *__restrict__ st, const lsb_ar_tail tail) {
   __shared__ double sred[4];
   const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const unsigned gx = gridDim.x / NXCD, xcd = blockIdx.x % NXCD, slot = blockIdx.x / NXCD;
@@ -1176,12 +1207,7 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_sell16(
   }
   if (stopped)
     return;
-  if (partials) {
-    double d[1] = {dot};
-    wg_sum<1>(d, sred);
-    if (tid == 0)
-      partials[blockIdx.x] = d[0];
-  }
+  spmv_publish(partials, dot, sred, tail);
 }
 
 // --------------------------------------------------------------------------
@@ -1444,15 +1470,32 @@ unsigned lsb_k_spmv_grid(int variant, unsigned n, unsigned nblk,
   return g;
 }
 
+/* the kernels with spmv_publish at their end */
+int lsb_k_spmv_has_tail(int variant) { return variant == LSB_SPMV_ADAPTIVE || variant == LSB_SPMV_SELL; }
+
+static lsb_ar_tail tail_for(const struct lsb_ar_tail *t, const double *partials) {
+  lsb_ar_tail none;
+  memset(&none, 0, sizeof none);
+  if (!t || !t->counter)
+    return none;
+  if (!partials)
+    errx(EXIT_FAILURE, "an SpMV launch without dot partials cannot carry the all-reduce");
+  return *t;
+}
+
 void lsb_k_spmv(int variant, unsigned n, const int *offs, const int *cols,
                 const double *vals, const int *rowblk,
                 const unsigned char *blklanes, unsigned nblk,
                 unsigned lanes_per_row, unsigned flags, unsigned grid_cap,
                 const double *x, double *y, const double *xdot,
                 double *partials, unsigned *npartials,
-                const struct lsb_pcg_state *st, const int *rowmap, void *stream) {
+                const struct lsb_pcg_state *st, const int *rowmap,
+                const struct lsb_ar_tail *tail_in, void *stream) {
   /* flags & LSB_SP_F32: `vals` points at fp32 values (mixed precision) */
   hipStream_t s = (hipStream_t)stream;
+  const lsb_ar_tail tail = tail_for(tail_in, partials);
+  if (tail.counter && !lsb_k_spmv_has_tail(variant))
+    errx(EXIT_FAILURE, "lsb_k_spmv: SpMV form %d cannot carry the all-reduce", variant);
   const unsigned g = lsb_k_spmv_grid(variant, n, nblk, lanes_per_row, grid_cap);
   const float *vals32 = (const float *)(const void *)vals;
   const bool f32 = (flags & LSB_SP_F32) != 0;
@@ -1463,10 +1506,12 @@ void lsb_k_spmv(int variant, unsigned n, const int *offs, const int *cols,
   case FL:                                                                               \
     if (f32)                                                                             \
       k_spmv_adaptive<LSB_BLOCK_NNZ, FL, float><<<g, WG, 0, s>>>(                        \
-          rowblk, blklanes, nblk, offs, cols, vals32, x, y, xdot, partials, st, rowmap); \
+          rowblk, blklanes, nblk, offs, cols, vals32, x, y, xdot, partials, st, rowmap,  \
+          tail);                                                                         \
     else                                                                                 \
       k_spmv_adaptive<LSB_BLOCK_NNZ, FL, double><<<g, WG, 0, s>>>(                       \
-          rowblk, blklanes, nblk, offs, cols, vals, x, y, xdot, partials, st, rowmap);   \
+          rowblk, blklanes, nblk, offs, cols, vals, x, y, xdot, partials, st, rowmap,    \
+          tail);                                                                         \
     break;
     switch (flags & 3u) {
       LSB_ADAPTIVE(0)
@@ -1546,8 +1591,9 @@ void lsb_k_spmv_sell(unsigned flags, unsigned grid_cap, unsigned period, const u
                      unsigned s0, unsigned ns, unsigned n, unsigned row_begin, const void *cols,
                      const int *sbase, const double *vals, const double *x, double *y,
                      const double *xdot, double *partials, unsigned *npartials,
-                     const struct lsb_pcg_state *st, void *stream) {
+                     const struct lsb_pcg_state *st, const struct lsb_ar_tail *tail_in, void *stream) {
   hipStream_t s = (hipStream_t)stream;
+  const lsb_ar_tail tail = tail_for(tail_in, partials);
   const unsigned g = lsb_k_spmv_grid(LSB_SPMV_SELL, n, ns, 0, grid_cap ? grid_cap : 1536);
   if (npartials)
     *npartials = g;
@@ -1557,10 +1603,10 @@ void lsb_k_spmv_sell(unsigned flags, unsigned grid_cap, unsigned period, const u
     period = 0; /* less than a plane: contiguous dealing */
 #define LSB_SELL16(FL, VT, V)                                                                  \
   k_spmv_sell16<FL, VT><<<g, WG, 0, s>>>(sptr, s0, ns, period, n, row_begin, (const short *)cols, \
-                                         sbase, V, x, y, xdot, partials, st)
+                                         sbase, V, x, y, xdot, partials, st, tail)
 #define LSB_SELL32(FL, VT, V)                                                                  \
   k_spmv_sell<FL, VT><<<g, WG, 0, s>>>(sptr, s0, ns, period, n, (const int *)cols, V, x, y, xdot, \
-                                       partials, st)
+                                       partials, st, tail)
   if (flags & LSB_SP_F32) {
     if (flags & LSB_SP_C16) {
       if (nt)
@@ -1704,15 +1750,20 @@ void lsb_k_cg1_update(unsigned n, double *u, const double *w, const double *dinv
                       double *p,
                       double *s, double *x, double *r, struct lsb_pcg_state *st, int parity,
                       const double *parts_gr, unsigned ngr, const double *parts_d, unsigned nd,
-                      double *partials2, unsigned *npartials, void *stream) {
+                      const struct lsb_ar_collect *collect, double *partials2,
+                      unsigned *npartials, void *stream) {
   const unsigned g = lsb_k_blas1_grid(n);
   *npartials = g;
   hipStream_t hs = (hipStream_t)stream;
+  lsb_ar_collect col;
+  memset(&col, 0, sizeof col);
+  if (collect)
+    col = *collect;
   const bool v2 = aligned16(u) && aligned16(w) && aligned16(dinv) && aligned16(p) &&
                   aligned16(s) && aligned16(x) && aligned16(r);
 #define LSB_CG1(V, N, U)                                                                  \
   k_cg1_update<V, N, U><<<g, WG, 0, hs>>>(n, u, w, dinv, dc, p, s, x, r, st, parity, parts_gr, \
-                                          ngr, parts_d, nd, partials2)
+                                          ngr, parts_d, nd, col, partials2)
   if (!u) { /* implicit u = dc r: r is the gather vector (needs the constant diagonal) */
     if (dinv)
       errx(EXIT_FAILURE, "lsb_k_cg1_update: implicit u needs a constant diagonal");

@@ -43,14 +43,15 @@
 #include <stdint.h>
 #include <string.h>
 
+#include "hip_ar.h"
 #include "lsb_impl.h"
 
-#define P2P_MAX_RANKS 64
+#define P2P_MAX_RANKS AR_MAX_RANKS
 #define P2P_AR_BYTES 4096u   // 2 parities x 64 ranks x 32 B
 #define P2P_FLAG_BYTES 4096u // 64 ranks x one 64-B line
 #define P2P_HEADER (P2P_AR_BYTES + P2P_FLAG_BYTES)
 #define P2P_NONE 0xFFFFFFFFu
-#define P2P_WG 256
+#define P2P_WG AR_WG
 
 typedef unsigned long long u64;
 
@@ -80,29 +81,17 @@ struct lsb_p2p {
   p2p_send_ent *d_send;
   p2p_recv_ent *d_recv;
   unsigned *d_counters;
+  unsigned *d_tail; // hand-in counter of an all-reduce folded into an SpMV launch (hip_ar.h)
   int nsend, nrecv;
   unsigned send_grid, recv_grid;
 };
 
 // --------------------------------------------------------------------------
-__device__ __forceinline__ u64 ld_sys(const u64 *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ double ld_sys(const double *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-// true when *flag reached `epoch` before the deadline.  Epochs only grow, so
-// "reached" is >=: a waiter that arrives late for epoch k must not spin on a
-// flag its peer has meanwhile moved on to k+1.
+// (flag waits, slots and the two all-reduce phases: hip_ar.h, shared with the
+// kernels the phases can be folded into)
+__device__ __forceinline__ double ld_sys(const double *p) { return ar_ld_sys(p); }
 __device__ __forceinline__ bool wait_flag(const u64 *flag, u64 epoch, long long timeout) {
-  const long long t0 = wall_clock64();
-  while (ld_sys(flag) < epoch) {
-    __builtin_amdgcn_s_sleep(1);
-    if (wall_clock64() - t0 > timeout)
-      return false;
-  }
-  return true;
+  return ar_wait_flag(flag, epoch, timeout);
 }
 
 __device__ __forceinline__ void p2p_send_body(const p2p_send_ent *__restrict__ ents, int nent,
@@ -188,11 +177,6 @@ __global__ __launch_bounds__(P2P_WG) void k_p2p_sendrecv(
     p2p_recv_body(recvs, nrecv, blockIdx.x - send_grid, full, epoch, st, timeout);
 }
 
-// slot of rank r, parity b, inside a mailbox: 3 doubles + the epoch
-__device__ __forceinline__ char *ar_slot(char *mbox, unsigned b, int r) {
-  return mbox + ((size_t)b * P2P_MAX_RANKS + (size_t)r) * 32;
-}
-
 __global__ __launch_bounds__(P2P_WG) void k_p2p_allreduce(
     const double *__restrict__ parts, unsigned nparts, unsigned width,
     const double *__restrict__ parts2, unsigned nparts2, unsigned width2,
@@ -203,65 +187,21 @@ __global__ __launch_bounds__(P2P_WG) void k_p2p_allreduce(
     return;
   __shared__ double sred[3 * (P2P_WG / 64)];
   __shared__ double sval[3];
-  const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const unsigned nvals = width + width2 + nextra, b = (unsigned)(epoch & 1);
-  if (phases & 1) {
-    // my partial sums, fixed order; all (up to three) columns in ONE pass and one
-    // workgroup reduction -- this kernel sits on the critical path of every
-    // sharded iteration
-    double v[3] = {0.0, 0.0, 0.0};
-    for (unsigned i = tid; i < nparts; i += P2P_WG)
-      for (unsigned c = 0; c < width; c++)
-        v[c] += parts[(size_t)i * width + c];
-    for (unsigned i = tid; i < nparts2; i += P2P_WG)
-      for (unsigned c = 0; c < width2; c++)
-        v[width + c] += parts2[(size_t)i * width2 + c];
-#pragma unroll
-    for (int k = 0; k < 3; k++)
-      for (int off = 32; off > 0; off >>= 1)
-        v[k] += __shfl_xor(v[k], off, 64);
-    if (lane == 0)
-      for (int k = 0; k < 3; k++)
-        sred[wave * 3 + k] = v[k];
-    __syncthreads();
-    if (tid < 3) {
-      double t = 0.0;
-      for (unsigned w = 0; w < P2P_WG / 64; w++)
-        t += sred[w * 3 + tid];
-      sval[tid] = t;
-    }
-    __syncthreads();
-    if (tid < nextra)
-      sval[width + width2 + tid] = extra[tid];
-    __syncthreads();
-    if (tid < (unsigned)R) { // lane r serves peer r (own mailbox included)
-      double *slot = (double *)ar_slot(peer[tid], b, me);
-      for (unsigned k = 0; k < nvals; k++)
-        slot[k] = sval[k];
-      __threadfence_system();
-      __hip_atomic_store((u64 *)(slot + 3), epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
-  if ((phases & 2) && wave == 0) {
-    const double *slot = (const double *)ar_slot(peer[me], b, lane < (unsigned)R ? (int)lane : 0);
-    bool ok = true;
-    if (lane < (unsigned)R)
-      ok = wait_flag((const u64 *)(slot + 3), epoch, timeout);
-    if (!__all(ok)) {
-      if (lane == 0 && st)
+  const unsigned nvals = width + width2 + nextra;
+  if (phases & 1)
+    ar_contribute<false, false>(parts, nparts, width, parts2, nparts2, width2, extra, nextra, peer, R, me,
+                         epoch, sred, sval);
+  if ((phases & 2) && threadIdx.x < 64) {
+    double v[3];
+    if (!ar_collect<true>(peer[me], R, epoch, timeout, nvals, v)) {
+      if (threadIdx.x == 0 && st)
         __hip_atomic_store(&st->status, (int)LSB_STATUS_COMM, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
       return;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-    for (unsigned k = 0; k < nvals; k++) {
-      const double a = lane < (unsigned)R ? ld_sys(slot + k) : 0.0;
-      double s = 0.0;
-      for (int r = 0; r < R; r++) // rank order: identical bits on every rank
-        s += __shfl(a, r, 64);
-      if (lane == 0)
-        out[k] = s;
-    }
+    if (threadIdx.x == 0)
+      for (unsigned k = 0; k < nvals; k++)
+        out[k] = v[k];
   }
 }
 
@@ -354,6 +294,9 @@ static int p2p_connect(struct lsb_p2p *p, const unsigned *tab, const unsigned *h
   if (hipMalloc((void **)&p->d_peer, sizeof(char *) * R) != hipSuccess ||
       hipMemcpy(p->d_peer, p->peer, sizeof(char *) * R, hipMemcpyHostToDevice) != hipSuccess)
     return 1;
+  if (hipMalloc((void **)&p->d_tail, sizeof(unsigned)) != hipSuccess ||
+      hipMemset(p->d_tail, 0, sizeof(unsigned)) != hipSuccess)
+    return 1;
   if (!p->halo)
     return 0;
   p2p_send_ent hs[P2P_MAX_RANKS];
@@ -399,7 +342,7 @@ extern "C" void lsb_p2p_destroy(struct lsb_p2p *p) {
     if (p->opened[q])
       (void)hipIpcCloseMemHandle(p->peer[q]);
   (void)hipFree(p->d_peer), (void)hipFree(p->d_send), (void)hipFree(p->d_recv);
-  (void)hipFree(p->d_counters), (void)hipFree(p->mbox);
+  (void)hipFree(p->d_counters), (void)hipFree(p->d_tail), (void)hipFree(p->mbox);
   (void)hipGetLastError();
   free(p);
 }
@@ -568,6 +511,19 @@ extern "C" void lsb_p2p_allreduce(struct lsb_p2p *p, const double *parts, unsign
   k_p2p_allreduce<<<1, P2P_WG, 0, (hipStream_t)stream>>>(
       parts, nparts, width, parts2, nparts2, width2, extra, nextra, out, p->d_peer, p->R, p->me,
       p->epoch_r, st, phases, p->timeout_ticks);
+}
+
+/* The same all-reduce with its two phases folded into neighbouring launches
+ * (hip_ar.h): lsb_p2p_fold_contribute opens epoch k and fills what the SpMV
+ * launcher needs for the tail (the caller adds the partial-sum arrays);
+ * lsb_p2p_fold_collect describes the matching collect for k_cg1_update. */
+extern "C" void lsb_p2p_fold_contribute(struct lsb_p2p *p, struct lsb_ar_tail *t) {
+  p->epoch_r++;
+  t->counter = p->d_tail;
+  t->peer = p->d_peer, t->R = p->R, t->me = p->me, t->epoch = p->epoch_r;
+}
+extern "C" void lsb_p2p_fold_collect(const struct lsb_p2p *p, struct lsb_ar_collect *c) {
+  c->mbox = p->mbox, c->R = p->R, c->epoch = p->epoch_r, c->timeout = p->timeout_ticks;
 }
 
 /* self-test pieces (hip_cdna4.c drives them) */

@@ -232,6 +232,7 @@ static int use_cg1(const lsb_hip_solver *sv) {
 }
 
 static void cg1_enqueue_init(lsb_hip_solver *sv, const double *d_b, double *d_x) {
+  sv->ar_fold = can_fold_allreduce(sv), sv->ar_pending = 0, sv->fold_next = 0;
   for (int i = 0; i < sv->nshard; i++) {
     struct shard *s = &sv->sh[i];
     const size_t o = s->row_begin - sv->row_first, bytes = (size_t)s->n * sizeof(double);
@@ -281,18 +282,23 @@ static void cg1_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int sa
     double *gr_in = s->d_parts2 + (size_t)parity * 2 * LSB_MAX_PARTIALS;
     double *gr_out = s->d_parts2 + (size_t)(parity ^ 1) * 2 * LSB_MAX_PARTIALS;
     unsigned np2 = 0;
+    struct lsb_ar_collect col;
+    if (sv->ar_pending) /* the SpMV before this launch sent the sums to every rank's mailbox */
+      lsb_p2p_fold_collect(sv->p2p[i], &col);
     lsb_k_cg1_update(s->n, sv->cg1_implicit ? NULL : s->d_pfull + s->row_begin, s->d_q, DINV(s),
                      s->d_p1, s->d_s1, d_x + o,
                      sv->cg1_implicit ? s->d_pfull + s->row_begin : s->d_r, s->d_st, parity,
                      sv->multi ? s->d_scal + 1 : gr_in,
                      sv->multi ? 1u : s->np2, sv->multi ? s->d_scal : s->d_parts_pq,
-                     sv->multi ? 1u : s->npq, gr_out, &np2, g_stream);
+                     sv->multi ? 1u : s->npq, sv->ar_pending ? &col : NULL, gr_out, &np2, g_stream);
     /* reduced together with the SpMV's partial sums, in the all-reduce's launch
      * (direct path) or in the one reduction launch in front of it (RCCL) */
     s->ar2_parts = gr_out, s->ar2_n = np2, s->ar2_width = 2;
   }
-  if (sv->multi)
+  if (sv->multi) {
+    sv->fold_next = sv->ar_fold == 2;
     exchange_and_spmv(sv, sample);
+  }
   for (int i = 0; i < sv->nshard; i++) {
     struct shard *s = &sv->sh[i];
     if (!sv->multi) {
@@ -307,8 +313,14 @@ static void cg1_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int sa
       }
     }
   }
-  if (sv->multi)
-    allreduce_pq(sv, 3, 1); /* w.u, r.u, r.r in ONE collective */
+  /* w.u, r.u, r.r in ONE collective -- over the direct path sent by a launch that waits
+   * for nobody (or by the SpMV's last workgroup) and collected by the next k_cg1_update */
+  if (sv->multi && sv->ar_fold) {
+    if (sv->ar_fold == 1)
+      allreduce_pq_contribute(sv);
+    sv->ar_pending = 1;
+  } else if (sv->multi)
+    allreduce_pq(sv, 3, 1);
 }
 
 static int auto_chunk(const lsb_hip_solver *sv) {

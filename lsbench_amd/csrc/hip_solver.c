@@ -507,7 +507,12 @@ lsb_hip_solver *lsb_hip_solver_create_dist(const struct csr *A_rows,
   const int P = lsb_hip_comm_size(), me = lsb_hip_comm_rank();
   lsb_hip_solver *sv = solver_alloc(1, &o);
   sv->n_glob = n_global, sv->n_here = A_rows->nrows, sv->row_first = row_begin;
-  sv->dist = P > 1, sv->multi = P > 1;
+  /* LSBENCH_HIP_DIST_ALONE=1: a communicator of ONE rank still runs the sharded
+   * iteration -- exchange, all-reduce, single-reduction CG -- so that one GPU can time
+   * what a rank's share costs with the communication launches in place
+   * (tools/gpu_shard_floor.py) */
+  const char *alone = getenv("LSBENCH_HIP_DIST_ALONE");
+  sv->dist = sv->multi = P > 1 || (alone && atoi(alone) > 0);
   shard_upload(&sv->sh[0], A_rows, 0, 0, 1, row_begin, n_global, &o);
   unsigned mine[4] = {row_begin, A_rows->nrows, sv->sh[0].col_lo, sv->sh[0].col_hi};
   unsigned *hull = lsb_calloc(unsigned, 4 * (size_t)P);
@@ -633,10 +638,10 @@ void sell_launch(struct shard *s, unsigned s0, unsigned ns, const double *xfull,
   const unsigned f32 = s->mixed ? LSB_SP_F32 : 0u; /* the value arrays hold floats then */
   if ((s->sp_flags & LSB_SP_C16) && s->d_scodes)
     lsb_k_spmv_sell(s->sp_flags | f32, s->sp_grid, s->sp_period, s->d_sptr16, s0, ns, s->n, s->row_begin, s->d_scodes,
-                    s->d_sbase, s->d_svals16, xfull, y, xdot, partials, np, st, g_stream);
+                    s->d_sbase, s->d_svals16, xfull, y, xdot, partials, np, st, &s->tail, g_stream);
   else
     lsb_k_spmv_sell((s->sp_flags & ~LSB_SP_C16) | f32, s->sp_grid, s->sp_period, s->d_sptr, s0, ns, s->n, s->row_begin,
-                    s->d_scols, NULL, s->d_svals, xfull, y, xdot, partials, np, st, g_stream);
+                    s->d_scols, NULL, s->d_svals, xfull, y, xdot, partials, np, st, &s->tail, g_stream);
 }
 
 void spmv_shard(struct shard *s, const double *xfull, double *y,
@@ -651,7 +656,7 @@ void spmv_shard(struct shard *s, const double *xfull, double *y,
       if (nb)
         lsb_k_spmv(LSB_SPMV_ADAPTIVE, s->n, s->pd_offs, s->pd_cols, s->pd_vals,
                    s->pd_rowblk + b0, s->pd_blklanes + b0, nb, s->lanes, s->sp_flags,
-                   s->sp_grid, xfull, y, NULL, NULL, NULL, st, s->pd_rowmap, g_stream);
+                   s->sp_grid, xfull, y, NULL, NULL, NULL, st, s->pd_rowmap, NULL, g_stream);
     }
     if (partials)
       lsb_k_dot(s->n, y, xdot, partials, np, g_stream);
@@ -681,7 +686,7 @@ void spmv_shard(struct shard *s, const double *xfull, double *y,
   const int f32 = s->mixed && (s->variant == LSB_SPMV_ADAPTIVE || s->variant == LSB_SPMV_SUBWAVE);
   lsb_k_spmv(s->variant, s->n, s->d_offs, s->d_cols, f32 ? (const double *)s->d_vals32 : s->d_vals,
              s->d_rowblk, s->d_blklanes, s->nblk, s->lanes, s->sp_flags | (f32 ? LSB_SP_F32 : 0u),
-             s->sp_grid, xfull, y, xdot, partials, np, st, NULL, g_stream);
+             s->sp_grid, xfull, y, xdot, partials, np, st, NULL, &s->tail, g_stream);
 }
 
 void spmv_shard_exact(struct shard *s, const double *xfull, double *y, const double *xdot,
@@ -693,7 +698,7 @@ void spmv_shard_exact(struct shard *s, const double *xfull, double *y, const dou
   /* the CSR arrays always stay: row-blocked kernel (sub-wavefront for small operators) */
   const int v = s->nnz <= 500000ull ? LSB_SPMV_SUBWAVE : LSB_SPMV_ADAPTIVE;
   lsb_k_spmv(v, s->n, s->d_offs, s->d_cols, s->d_vals, s->d_rowblk, s->d_blklanes, s->nblk, s->lanes,
-             LSB_SP_PREFETCH | LSB_SP_NT, 0, xfull, y, xdot, partials, np, st, NULL, g_stream);
+             LSB_SP_PREFETCH | LSB_SP_NT, 0, xfull, y, xdot, partials, np, st, NULL, NULL, g_stream);
 }
 
 /*

@@ -59,6 +59,8 @@ struct shard {
   unsigned npq, np2;   /* partial counts of the SpMV / sweep launches */
   const double *ar2_parts; /* sweep partials the next all-reduce folds in */
   unsigned ar2_n, ar2_width;
+  struct lsb_ar_tail tail; /* counter != NULL: the next SpMV launch of this shard carries the
+                              all-reduce's contribute phase (exchange_and_spmv arms and clears it) */
   /* rows that reference other shards' columns sit in row blocks [0,ov_b1) and
    * [ov_b2,nblk); the blocks in between need no halo (0,0 = not separable) */
   unsigned ov_b1, ov_b2;
@@ -179,6 +181,11 @@ struct lsb_hip_solver {
   } ps;
   struct lsb_p2p **p2p;
   int p2p_on, p2p_halo;
+  /* single-reduction CG over the direct path: the all-reduce's collect phase rides at the
+   * head of k_cg1_update (ar_fold = 1), its contribute phase in the SpMV's last launch too
+   * (ar_fold = 2) -- hip_ar.h, can_fold_allreduce.  fold_next: the next exchange_and_spmv
+   * arms the tails; ar_pending: a contribution is out, the next k_cg1_update collects it */
+  int ar_fold, fold_next, ar_pending;
   double p2p_us, rccl_us; /* self-test: one exchange + all-reduce, each way */
 };
 
@@ -204,6 +211,8 @@ LSB_INTERNAL void check_aux_status(lsb_hip_solver *sv, const char *where);
 LSB_INTERNAL void allreduce_scal(lsb_hip_solver *sv, unsigned off, unsigned cnt, int gated);
 LSB_INTERNAL void allreduce_pq(lsb_hip_solver *sv, unsigned cnt, int with2);
 LSB_INTERNAL int can_overlap(const lsb_hip_solver *sv);
+LSB_INTERNAL int can_fold_allreduce(const lsb_hip_solver *sv);
+LSB_INTERNAL void allreduce_pq_contribute(lsb_hip_solver *sv);
 LSB_INTERNAL void exchange_and_spmv(lsb_hip_solver *sv, int sample);
 LSB_INTERNAL double true_resid2(lsb_hip_solver *sv, const double *d_b, const double *d_x);
 /* hip_pcg.c */

@@ -34,6 +34,28 @@ struct lsb_pcg_state {
                     in the same launch)                                      */
 };
 
+/* ---- the direct-xGMI all-reduce folded into neighbouring launches (hip_ar.h) ---
+ * lsb_ar_tail: handed BY VALUE to the SpMV launch that writes the last dot
+ * partials of an iteration; counter == NULL: no tail.  lsb_ar_collect: handed
+ * to k_cg1_update, which then takes w.u, r.u, r.r from the mailbox instead of
+ * from reduced scalars; mbox == NULL: off.  Filled by lsb_p2p_fold_*. */
+struct lsb_ar_tail {
+  unsigned *counter;          /* workgroups of the launch that have handed in */
+  const double *parts;        /* ALL dot partials of this SpMV: the earlier launches' of a
+                                 split SpMV first, then this launch's (one per workgroup) */
+  const double *parts2;       /* the sweep's records: nparts2 of width2 */
+  char *const *peer;          /* mailboxes of all ranks (device array) */
+  unsigned long long epoch;
+  unsigned nparts_before, nparts2, width2;
+  int R, me;
+};
+struct lsb_ar_collect {
+  char *mbox; /* the own mailbox */
+  unsigned long long epoch;
+  long long timeout; /* wall_clock64 ticks */
+  int R;
+};
+
 /* ---- device-side GMRES(m) scalars ----------------------------------------- */
 #define LSB_GMRES_MAX_RESTART 32
 #define LSB_GMRES_PARTIALS 512
@@ -61,7 +83,9 @@ void lsb_k_spmv(int variant, unsigned n, const int *offs, const int *cols,
                 unsigned lanes_per_row, unsigned flags, unsigned grid_cap,
                 const double *x, double *y, const double *xdot,
                 double *partials, unsigned *npartials,
-                const struct lsb_pcg_state *st, const int *rowmap, void *stream);
+                const struct lsb_pcg_state *st, const int *rowmap,
+                const struct lsb_ar_tail *tail, void *stream);
+int lsb_k_spmv_has_tail(int variant); /* the variant's kernel can carry an lsb_ar_tail */
 unsigned lsb_k_spmv_grid(int variant, unsigned n, unsigned nblk,
                          unsigned lanes_per_row, unsigned grid_cap);
 /* flags of the adaptive SpMV (picked by the timing pass at solver creation) */
@@ -73,7 +97,7 @@ void lsb_k_spmv_sell(unsigned flags, unsigned grid_cap, unsigned period, const u
                      unsigned s0, unsigned ns, unsigned n, unsigned row_begin, const void *cols,
                      const int *sbase, const double *vals, const double *x, double *y,
                      const double *xdot, double *partials, unsigned *npartials,
-                     const struct lsb_pcg_state *st, void *stream);
+                     const struct lsb_pcg_state *st, const struct lsb_ar_tail *tail, void *stream);
 void lsb_k_spmv_binned(unsigned flags, unsigned chunk_cap, const unsigned *chunk_begin, unsigned c0,
                        unsigned nchunk, const unsigned *rows, const unsigned *cols, const double *vals,
                        const double *x, double *y, const struct lsb_pcg_state *st, void *stream);
@@ -130,7 +154,8 @@ void lsb_k_cg1_update(unsigned n, double *u, const double *w, const double *dinv
                       double *p,
                       double *s, double *x, double *r, struct lsb_pcg_state *st, int parity,
                       const double *parts_gr, unsigned ngr, const double *parts_d, unsigned nd,
-                      double *partials2, unsigned *npartials, void *stream);
+                      const struct lsb_ar_collect *collect, double *partials2, unsigned *npartials,
+                      void *stream);
 unsigned lsb_k_blas1_grid(unsigned n);
 void lsb_k_set_blas1_nt(int on);
 void lsb_k_fill_index(unsigned n, unsigned first, double *v, void *stream);
@@ -203,6 +228,8 @@ void lsb_p2p_allreduce(struct lsb_p2p *p, const double *parts, unsigned nparts, 
                        const double *parts2, unsigned nparts2, unsigned width2,
                        const double *extra, unsigned nextra, double *out,
                        struct lsb_pcg_state *st, int phases, void *stream);
+void lsb_p2p_fold_contribute(struct lsb_p2p *p, struct lsb_ar_tail *t);
+void lsb_p2p_fold_collect(const struct lsb_p2p *p, struct lsb_ar_collect *c);
 void lsb_p2p_test_pattern(double *d_full, size_t goff, size_t n, unsigned round, void *stream);
 void lsb_p2p_test_check_range(const double *d_full, size_t goff, size_t n, unsigned round,
                               unsigned *d_bad, void *stream);

@@ -188,21 +188,31 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm) {
 
 /* FAKE_RCCL_STALL_RANK=r FAKE_RCCL_STALL_AFTER=k: rank r's all-reduces beyond the
  * k-th behave like a collective whose peers never arrive -- the call returns at
- * once (RCCL calls are asynchronous) and the STREAM stops making progress.  The
- * product's host-side deadline has to notice. */
+ * once (RCCL calls are asynchronous) and the STREAM stops making progress; so do
+ * all of that rank's later collectives (a real hung stream never gets to them).
+ * The product's host-side deadline has to notice.  The sleeping host functions
+ * end as soon as the process starts exiting, so that the runtime's teardown
+ * does not wait for them. */
+static volatile int g_exiting = 0;
+static void note_exit(void) { g_exiting = 1; }
 static void stall_fn(void *arg) {
   (void)arg;
-  sleep(45);
+  for (int i = 0; i < 450 && !g_exiting; i++)
+    usleep(100000);
 }
-static __thread int g_allreduces = 0;
+static __thread int g_allreduces = 0, g_stalled = 0;
 
 ncclResult_t ncclAllReduce(const void *send, void *recv, size_t count, ncclDataType_t t,
                            ncclRedOp_t op, ncclComm_t comm, hipStream_t stream) {
   struct fake_comm *c = (struct fake_comm *)comm;
   const char *sr = getenv("FAKE_RCCL_STALL_RANK"), *sa = getenv("FAKE_RCCL_STALL_AFTER");
   if (sr && atoi(sr) == c->rank && ++g_allreduces > (sa ? atoi(sa) : 0)) {
-    if (hipLaunchHostFunc(stream, stall_fn, NULL) != hipSuccess)
+    static int registered = 0;
+    if (!__atomic_exchange_n(&registered, 1, __ATOMIC_ACQ_REL))
+      atexit(note_exit);
+    if (!g_stalled && hipLaunchHostFunc(stream, stall_fn, NULL) != hipSuccess)
       die("hipLaunchHostFunc");
+    g_stalled = 1;
     return ncclSuccess;
   }
   if (t != ncclDouble || op != ncclSum || count * 8 > SLOT_BYTES)
@@ -228,6 +238,8 @@ ncclResult_t ncclAllGather(const void *send, void *recv, size_t count, ncclDataT
                            ncclComm_t comm, hipStream_t stream) {
   struct fake_comm *c = (struct fake_comm *)comm;
   const size_t b = count * type_bytes(t);
+  if (g_stalled)
+    return ncclSuccess;
   if (b > SLOT_BYTES)
     die("all-gather larger than the test double's slots");
   if (hipStreamSynchronize(stream) != hipSuccess)
@@ -274,6 +286,10 @@ ncclResult_t ncclGroupEnd(void) {
   if (--g_group > 0)
     return ncclSuccess;
   struct fake_comm *c = g_group_comm;
+  if (g_stalled) { /* behind a hung collective on this rank's stream: never runs */
+    g_nops = 0, g_group_comm = NULL;
+    return ncclSuccess;
+  }
   if (!c) { /* an empty group still has to keep the ranks in step?  No: ranks with
                nothing to exchange make no call at all in hip_comm.c */
     g_nops = 0;

@@ -83,3 +83,35 @@ def test_overlap_is_automatic_for_large_halos(hip):
         s1.destroy()
         assert r.iters == r1.iters == 40
         assert np.linalg.norm(x - x1) / np.linalg.norm(x1) <= 1e-11
+
+
+@pytest.mark.parametrize("variant,nvirt,overlap", [("SELL", 4, 0), ("SELL", 3, 1), ("ADAPTIVE", 5, 1),
+                                                   ("ADAPTIVE", 2, 0), ("SUBWAVE", 3, 0)])
+def test_allreduce_folded_into_spmv_and_sweep(hip, monkeypatch, variant, nvirt, overlap):
+    """Single-reduction CG over the direct path: the all-reduce's collect phase at
+    the head of k_cg1_update (LSBENCH_HIP_AR_FOLD=1, the default), its contribute
+    phase in the tail of the SpMV's last launch as well (=2) -- hip_ar.h --
+    bit-identical iterates to the stand-alone all-reduce launch (=0), for the
+    whole and the split (interior / boundary) SpMV; a form whose kernel cannot
+    carry the tail keeps the contribute launch."""
+    A = hip.lsbench_matrix_synth("lap3d:nx=48,ny=40,nz=36")
+    b = O.rhs(A.nrows)
+    out = {}
+    for fold in ("0", "1", "2"):
+        monkeypatch.setenv("LSBENCH_HIP_AR_FOLD", fold)
+        s = hip.Solver(A, hip.default_opts(op_mode=hip.OP_RAW, nvirt=nvirt, overlap=overlap, tol=1e-11,
+                                           krylov=hip.KRYLOV_PCG1, comm=hip.COMM_P2P, verify=0,
+                                           spmv_variant=getattr(hip, "SPMV_" + variant)))
+        assert s.comm[0] == 3 and s.overlaps == bool(overlap)
+        x, r = s.solve(b)
+        x2, r2 = s.solve(b)            # hinted run: epochs keep counting across solves
+        s.destroy()
+        assert r.status == 1 and r2.iters == r.iters and np.array_equal(x, x2)
+        out[fold] = (x, int(r.iters), r.relres)
+    for fold in ("1", "2"):
+        assert out["0"][1] == out[fold][1] and out["0"][2] == out[fold][2]
+        assert np.array_equal(out["0"][0], out[fold][0])
+    offs, cols, vals = O.lap3d(48, 40, 36)
+    xo, ito, _, _ = O.pcg1_jacobi(offs, cols, vals, b, tol=1e-11)
+    assert abs(out["1"][1] - ito) <= 3
+    assert np.linalg.norm(out["1"][0] - xo) / np.linalg.norm(xo) <= 1e-9
