@@ -291,38 +291,42 @@ struct lsb_binned *lsb_csr_binize(const struct csr *A, unsigned width);
 void lsb_binned_free(struct lsb_binned *B);
 /* Two-phase form of a CSR for LSB_SPMV_TWOPHASE (scattered operators; "propagation
  * blocking"): no gather ever leaves a compute unit.
- *   phase 1  the entries are cut by COLUMN into chunks of LSB_PB_COLS columns; a
- *            workgroup copies its chunk's window of x into LDS and streams its
- *            entries -- value (8 B), column inside the window (2 B), target slot
- *            (4 B) -- writing each product into its slot of the product array;
- *   phase 2  the product array is ROW-BIN major (LSB_PB_ROWS rows per bin): a
- *            workgroup owns a bin and streams its slots -- product (8 B) + row
- *            inside the bin (2 B) -- adding them into LDS copies of the bin's
- *            rows, one copy per wavefront, summed in a fixed order into y.
- * The host lays a bin's slots out in steps of 64 in which EQUAL ROWS ARE NEIGHBOURS
- * (an entry whose row is already in the step under construction, but not in the
- * slot before it, is deferred to the end of the bin, where the deferred ones are
- * placed sorted by row; a step that cannot take the next one is padded): a
- * wavefront combines neighbouring equal rows by a segmented shuffle scan and then
- * ONE lane per row adds to LDS -- no conflicts, no atomics, and the order of the
- * additions is fixed by the layout: bit-identical from run to run.  Inside a bin
- * the slots follow the chunk order, so the products of one (chunk, bin) pair land
- * in consecutive slots: phase 1's stores are contiguous pieces.
- * 22 B read + 8 B written per non-zero instead of a 128-byte line per gather. */
-#define LSB_PB_COLS 4096
+ *   phase 1  the entries are cut by COLUMN into chunks of `cols` columns; a
+ *            workgroup copies its chunk's window of x into LDS (8 * cols bytes)
+ *            and streams its entries -- value (8 B), column inside the window
+ *            (2 B) -- writing each product into the product array;
+ *   phase 2  the product array is ROW-BIN major (`rows` rows per bin): a WAVEFRONT
+ *            owns a bin, streams its slots -- product (8 B) + row inside the bin
+ *            (2 B) -- and adds them into its LDS copy of the bin's rows
+ *            (ds_add_f64, the wavefront's own 8 * rows bytes: nobody else touches
+ *            them, so the order of the additions is the wavefront's program
+ *            order), then writes the rows of y, coalesced.
+ * Both orders keep the entries of one (chunk, bin) pair -- a PIECE -- together and in
+ * the same order, chunk-major for phase 1 and bin-major for phase 2, so the slot of
+ * a product is its entry index plus a per-piece constant (`delta`); which piece an
+ * entry belongs to is read off two words per group of 64 entries (`grp_first`,
+ * `grp_mask`).  The entries of a chunk start on a multiple of 64 (vals = 0 in the
+ * gaps, never read).  18.2 B read/written per non-zero in phase 1, 10 B in phase 2,
+ * instead of a 128-byte line per gather. */
+#define LSB_PB_COLS 8192 /* defaults; LSBENCH_HIP_PB_COLS / _ROWS (<= 16384 / <= 4096) */
 #define LSB_PB_ROWS 2048
 struct lsb_pb {
-  unsigned nrows, ncols_lo, nchunks, nbins, nitems;
-  unsigned long long nnz;
-  unsigned long long nslots; /* slots of the product array = bin_ptr[nbins]      */
-  double *vals;            /* nnz, in (chunk, bin, row, col) order              */
-  unsigned short *colw;    /* nnz: column - (ncols_lo + chunk * LSB_PB_COLS)    */
-  unsigned *pos;           /* nnz: slot of the entry's product                  */
+  unsigned nrows, ncols_lo, nchunks, nbins, nitems, npieces;
+  unsigned cols, rows;     /* chunk width (columns), bin height (rows)          */
+  unsigned long long nnz;  /* = slots of the product array                      */
+  unsigned long long nent; /* length of the phase-1 arrays (a multiple of 64)   */
+  double *vals;            /* nent, in (chunk, bin, row, col) order             */
+  unsigned short *colw;    /* nent: column - (ncols_lo + chunk * cols)          */
+  unsigned *grp_first;     /* nent / 64: piece of the group's first entry       */
+  unsigned long long *grp_mask; /* nent / 64: bit j > 0: entry j starts a piece */
+  unsigned *delta;         /* npieces: slot - entry index, mod 2^32             */
   unsigned *item;          /* 3 * nitems: {chunk, first entry, end entry} of
-                              the phase-1 work items (<= 32768 entries each)    */
-  unsigned *bin_ptr;       /* nbins + 1: first slot of each bin (multiples of 64) */
-  unsigned short *roww;    /* nslots: row - bin * LSB_PB_ROWS, 0xFFFF = padding */
+                              the phase-1 work items                            */
+  unsigned *bin_ptr;       /* nbins + 1: first slot of each bin                 */
+  unsigned short *roww;    /* nnz: row - bin * rows, in slot order              */
 };
+/* cols, rows: 0 = the defaults */
+struct lsb_pb *lsb_csr_pbize2(const struct csr *A, unsigned cols, unsigned rows);
 struct lsb_pb *lsb_csr_pbize(const struct csr *A);
 void lsb_pb_free(struct lsb_pb *P);
 /* Sliced-ELL copy of a CSR for LSB_SPMV_SELL: rows in slices of LSB_SELL_ROWS,

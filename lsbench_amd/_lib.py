@@ -25,7 +25,7 @@ KRYLOV_PCG, KRYLOV_GMRES, KRYLOV_PCG1, KRYLOV_AUTO = 0, 1, 2, 3
 SPMV_AUTO, SPMV_ADAPTIVE, SPMV_SUBWAVE, SPMV_SCALAR, SPMV_PANEL, SPMV_SELL, SPMV_BINNED, SPMV_TWOPHASE = 0, 1, 2, 3, 4, 5, 6, 7
 SELL_ROWS = 128
 BIN_CHUNK = 2048
-PB_COLS, PB_ROWS = 4096, 2048
+PB_COLS, PB_ROWS = 8192, 2048
 SPMV_FLAG_PREFETCH, SPMV_FLAG_NT, SPMV_FLAG_C16 = 1, 2, 4
 STATUS_RUNNING, STATUS_CONVERGED, STATUS_BREAKDOWN, STATUS_MAXIT = 0, 1, 2, 3
 STATUS_COMM = 4
@@ -99,9 +99,11 @@ class Binned(C.Structure):
 class Pb(C.Structure):
     """struct lsb_pb."""
     _fields_ = [("nrows", C.c_uint), ("ncols_lo", C.c_uint), ("nchunks", C.c_uint), ("nbins", C.c_uint),
-                ("nitems", C.c_uint), ("nnz", C.c_ulonglong), ("nslots", C.c_ulonglong),
+                ("nitems", C.c_uint), ("npieces", C.c_uint), ("cols", C.c_uint), ("rows", C.c_uint),
+                ("nnz", C.c_ulonglong), ("nent", C.c_ulonglong),
                 ("vals", C.POINTER(C.c_double)), ("colw", C.POINTER(C.c_ushort)),
-                ("pos", C.POINTER(C.c_uint)), ("item", C.POINTER(C.c_uint)),
+                ("grp_first", C.POINTER(C.c_uint)), ("grp_mask", C.POINTER(C.c_ulonglong)),
+                ("delta", C.POINTER(C.c_uint)), ("item", C.POINTER(C.c_uint)),
                 ("bin_ptr", C.POINTER(C.c_uint)), ("roww", C.POINTER(C.c_ushort))]
 
 
@@ -148,6 +150,7 @@ SIGNATURES = {
     "lsb_csr_panelize": (C.POINTER(PanelCsr), [_csrp, _u]),
     "lsb_panel_csr_free": (None, [C.POINTER(PanelCsr)]),
     "lsb_csr_pbize": (C.POINTER(Pb), [_csrp]),
+    "lsb_csr_pbize2": (C.POINTER(Pb), [_csrp, _u, _u]),
     "lsb_pb_free": (None, [C.POINTER(Pb)]),
     "lsb_csr_binize": (C.POINTER(Binned), [_csrp, _u]),
     "lsb_binned_free": (None, [C.POINTER(Binned)]),

@@ -4,149 +4,160 @@
 // 8 M rows: 2.7e8 L2 misses, 34 GB of fabric traffic for 3.2 GB of algorithmic
 // bytes); the binned form (k_spmv_binned) keeps the window of x in L2 but still
 // moves a 128-byte L2->L1 line per gather, 33 GB per launch at ~11.7 TB/s = its
-// 2.5-2.8 ms.  Here no gather leaves the compute unit ("propagation blocking"):
-//   phase 1 (k_pb_products)  entries ordered by column chunk (4096 columns: the
-//       window of x is copied into LDS, 32 KB), streamed as value + 16-bit column
-//       offset + 32-bit target slot; each product is stored into its slot of the
-//       row-bin-major product array (the products of one (chunk, bin) pair go to
-//       consecutive slots: contiguous pieces);
-//   phase 2 (k_pb_reduce)    a workgroup owns a row bin (2048 rows) and streams the
-//       bin's slots, wave w the steps w, w+4, ... of 64 slots: product + 16-bit row
-//       offset, added into the wave's own LDS copy of the bin's rows.  The host
-//       laid the slots out so that equal rows of a step are neighbours: a segmented
-//       shuffle scan combines them and one lane per row adds -- 64 lanes, distinct
-//       LDS words, nothing to resolve.  The four copies are summed in a
-//       fixed order and y is written once, coalesced, by one lane per row -- no
-//       y = 0 pass, no atomics, the same bits every run.
-// Traffic per non-zero: 14 B read + 8 B written (phase 1), 10 B read (phase 2).
+// 2.8 ms.  Here no gather leaves the compute unit ("propagation blocking"):
+//   phase 1 (k_pb_products)  entries ordered by column chunk (the chunk's window
+//       of x is copied into LDS: 8192 columns = 64 KB), streamed as value +
+//       16-bit column offset; the product goes to entry index + delta[piece] of
+//       the row-bin-major product array -- a piece = the entries of one (chunk,
+//       bin) pair, contiguous and in the same order on both sides, so the stores
+//       of a piece are one contiguous run; the piece of an entry = grp_first of
+//       its group of 64 + the set bits of grp_mask up to its lane (two scalar
+//       loads per wavefront and trip);
+//   phase 2 (k_pb_reduce)    a WAVEFRONT owns a row bin (2048 rows, 16 KB of LDS)
+//       and streams the bin's slots: product + 16-bit row offset, ds_add_f64
+//       into its own LDS copy of the bin's rows -- nobody else adds there, so the
+//       order of the additions is the wavefront's program order -- then writes
+//       the bin's rows of y once, coalesced.  No y = 0 pass, no global atomics.
+// Traffic per non-zero: 10.2 B read + 8 B written (phase 1), 10 B read (phase 2).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "lsb_impl.h"
 
-#define PB_WG 256
-#define PB_U 8 // entries per lane and trip of phase 1
+#define PB1_U 8   // entries per lane and trip of phase 1
+#define PB2_WG 256
+#define PB2_S 8   // steps of 64 slots a wavefront has in flight in phase 2
 
-__global__ __launch_bounds__(PB_WG) void k_pb_products(
+template <int WG>
+__global__ __launch_bounds__(WG) void k_pb_products(
     const unsigned *__restrict__ item, const double *__restrict__ vals,
-    const unsigned short *__restrict__ colw, const unsigned *__restrict__ pos,
-    const double *__restrict__ x, unsigned xlen, unsigned col_lo, double *__restrict__ prod,
-    const lsb_pcg_state *__restrict__ st) {
-  __shared__ double sx[LSB_PB_COLS];
+    const unsigned short *__restrict__ colw, const unsigned *__restrict__ grp_first,
+    const unsigned long long *__restrict__ grp_mask, const unsigned *__restrict__ delta,
+    const double *__restrict__ x, unsigned xlen, unsigned col_lo, unsigned cols,
+    double *__restrict__ prod, int nt_store, const lsb_pcg_state *__restrict__ st) {
+  extern __shared__ double sx[]; // cols doubles
   if (st && st->status)
     return;
-  const unsigned tid = threadIdx.x;
+  const unsigned tid = threadIdx.x, lane = tid & 63u;
   const unsigned c = item[3 * blockIdx.x], e0 = item[3 * blockIdx.x + 1],
                  e1 = item[3 * blockIdx.x + 2];
-  const unsigned x0 = col_lo + c * LSB_PB_COLS;
-  { // the chunk's window of x: coalesced loads, all in flight, then LDS
-    double t[LSB_PB_COLS / PB_WG];
+  const unsigned x0 = col_lo + c * cols;
+  for (unsigned b = tid; b < cols; b += WG * 8) { // the chunk's window of x: coalesced, 8 loads in flight
+    double t[8];
 #pragma unroll
-    for (int k = 0; k < LSB_PB_COLS / PB_WG; k++) {
-      const unsigned i = x0 + tid + (unsigned)k * PB_WG;
-      t[k] = i < xlen ? x[i] : 0.0;
+    for (int k = 0; k < 8; k++) {
+      const unsigned i = b + (unsigned)k * WG;
+      t[k] = i < cols && x0 + i < xlen ? x[x0 + i] : 0.0;
     }
 #pragma unroll
-    for (int k = 0; k < LSB_PB_COLS / PB_WG; k++)
-      sx[tid + k * PB_WG] = t[k];
+    for (int k = 0; k < 8; k++) {
+      const unsigned i = b + (unsigned)k * WG;
+      if (i < cols)
+        sx[i] = t[k];
+    }
   }
   __syncthreads();
-  for (unsigned e = e0 + tid; e < e1; e += PB_WG * PB_U) {
-    double v[PB_U];
-    unsigned short cw[PB_U];
-    unsigned ps[PB_U];
+  const unsigned long long le = lane == 63 ? ~0ull : (2ull << lane) - 1ull; // lanes <= mine
+  if (e1 <= e0)
+    return;
+  // Loads on CLAMPED indices, no branches around them: all 2 * PB1_U loads of a lane
+  // are in flight before the first product is formed (a trip's wavefronts read the
+  // item's last entry again where they reach past its end; only the stores are
+  // predicated).  e0 and WG are multiples of 64, so a wavefront = a group of 64.
+  for (unsigned e = e0 + tid; e - lane < e1; e += WG * PB1_U) {
+    double v[PB1_U];
+    unsigned short cw[PB1_U];
+    unsigned pc[PB1_U];
 #pragma unroll
-    for (int u = 0; u < PB_U; u++) {
-      const unsigned i = e + (unsigned)u * PB_WG;
-      if (i < e1) {
-        v[u] = __builtin_nontemporal_load(vals + i);
-        cw[u] = __builtin_nontemporal_load(colw + i);
-        ps[u] = __builtin_nontemporal_load(pos + i);
-      }
+    for (int u = 0; u < PB1_U; u++) {
+      const unsigned i = min(e + (unsigned)u * WG, e1 - 1u);
+      v[u] = __builtin_nontemporal_load(vals + i);
+      cw[u] = __builtin_nontemporal_load(colw + i);
     }
 #pragma unroll
-    for (int u = 0; u < PB_U; u++) {
-      const unsigned i = e + (unsigned)u * PB_WG;
-      if (i < e1)
-        prod[ps[u]] = v[u] * sx[cw[u]];
+    for (int u = 0; u < PB1_U; u++) { // wave-uniform: the group's two words by scalar loads
+      const unsigned i = min(e + (unsigned)u * WG, e1 - 1u);
+      const unsigned g = __builtin_amdgcn_readfirstlane(i >> 6);
+      pc[u] = grp_first[g] + (unsigned)__popcll(grp_mask[g] & le);
+    }
+    unsigned d[PB1_U];
+#pragma unroll
+    for (int u = 0; u < PB1_U; u++)
+      d[u] = delta[pc[u]];
+#pragma unroll
+    for (int u = 0; u < PB1_U; u++) {
+      const unsigned i = e + (unsigned)u * WG;
+      if (i < e1) { // (index mod 2^32, like the host's delta)
+        if (nt_store)
+          __builtin_nontemporal_store(v[u] * sx[cw[u]], prod + (unsigned)(i + d[u]));
+        else
+          prod[i + d[u]] = v[u] * sx[cw[u]];
+      }
     }
   }
 }
 
-#define PB_S 8 // steps a wave has in flight
-__global__ __launch_bounds__(PB_WG) void k_pb_reduce(
+__global__ __launch_bounds__(PB2_WG) void k_pb_reduce(
     const unsigned *__restrict__ bin_ptr, const double *__restrict__ prod,
-    const unsigned short *__restrict__ roww, unsigned n, double *__restrict__ y,
-    const double *__restrict__ xdot, double *__restrict__ partials,
+    const unsigned short *__restrict__ roww, unsigned n, unsigned rows, unsigned nbins,
+    double *__restrict__ y, const double *__restrict__ xdot, double *__restrict__ partials,
     const lsb_pcg_state *__restrict__ st) {
-  __shared__ double sy[4][LSB_PB_ROWS]; // 64 KB: everything LDS a workgroup may name statically
+  extern __shared__ double sy[]; // (PB2_WG / 64) * rows doubles: a bin per wavefront
+  __shared__ double sdot[PB2_WG / 64];
   if (st && st->status)
     return;
-  const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, bin = blockIdx.x;
-  double *my = sy[wave];
+  const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const unsigned bin = blockIdx.x * (PB2_WG / 64) + wave;
+  double *my = sy + (size_t)wave * rows;
+  double dot = 0.0;
+  if (bin < nbins) {
+    for (unsigned k = lane; k < rows; k += 64)
+      my[k] = 0.0;
+    const unsigned s0 = bin_ptr[bin], s1 = bin_ptr[bin + 1];
+    for (unsigned sb = s0; sb < s1; sb += 64 * PB2_S) { // (clamped loads: see phase 1)
+      double p[PB2_S];
+      unsigned short r[PB2_S];
 #pragma unroll
-  for (int k = 0; k < LSB_PB_ROWS / 64; k++)
-    my[lane + k * 64] = 0.0;
-  const unsigned s0 = bin_ptr[bin], s1 = bin_ptr[bin + 1]; // multiples of 64
-  // wave w: steps w, w+4, ...; PB_S of them loaded before any is added
-  for (unsigned sb = s0 + wave * 64; sb < s1; sb += 4 * 64 * PB_S) {
-    double p[PB_S];
-    unsigned short r[PB_S];
-#pragma unroll
-    for (int g = 0; g < PB_S; g++) {
-      const unsigned i = sb + (unsigned)g * 256u + lane;
-      p[g] = 0.0, r[g] = 0xFFFFu;
-      if (i < s1) {
+      for (int g = 0; g < PB2_S; g++) {
+        const unsigned i = min(sb + (unsigned)g * 64u + lane, s1 - 1u);
         r[g] = __builtin_nontemporal_load(roww + i);
         p[g] = __builtin_nontemporal_load(prod + i);
       }
-    }
 #pragma unroll
-    for (int g = 0; g < PB_S; g++) {
-      // equal rows of a step are neighbours (host layout): segmented inclusive scan
-      // on the row id, then the LAST lane of a row adds -- one lane per LDS word
-      double pv = p[g];
-      const unsigned rv = r[g];
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const double p2 = __shfl_up(pv, d, 64);
-        const unsigned r2 = __shfl_up(rv, d, 64);
-        if ((int)lane >= d && r2 == rv)
-          pv += p2;
+      for (int g = 0; g < PB2_S; g++) {
+        const unsigned i = sb + (unsigned)g * 64u + lane;
+        if (i < s1)
+          unsafeAtomicAdd(my + r[g], p[g]); // ds_add_f64 on this wavefront's own copy
       }
-      const unsigned rn = __shfl_down(rv, 1, 64);
-      if (rv != 0xFFFFu && (lane == 63 || rn != rv)) // (padding: never written, never used)
-        my[rv] += pv;
     }
-  }
-  __syncthreads();
-  double dot = 0.0;
-  for (unsigned i = tid; i < LSB_PB_ROWS; i += PB_WG) {
-    const unsigned row = bin * LSB_PB_ROWS + i;
-    if (row < n) {
-      const double s = (sy[0][i] + sy[1][i]) + (sy[2][i] + sy[3][i]);
-      y[row] = s;
-      if (xdot)
-        dot += s * xdot[row];
+    // the wavefront's LDS operations complete in order: the sums are final here
+    const unsigned row0 = bin * rows;
+    for (unsigned k = lane; k < rows; k += 64) {
+      const unsigned row = row0 + k;
+      if (row < n) {
+        const double s = my[k];
+        y[row] = s;
+        if (xdot)
+          dot += s * xdot[row];
+      }
     }
   }
   if (partials) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)
       dot += __shfl_xor(dot, off, 64);
-    __syncthreads(); // every read of sy above is done: its first words carry the wave sums
     if (lane == 0)
-      sy[0][wave] = dot;
+      sdot[wave] = dot;
     __syncthreads();
     if (tid == 0)
-      partials[bin] = (sy[0][0] + sy[0][1]) + (sy[0][2] + sy[0][3]);
+      partials[blockIdx.x] = (sdot[0] + sdot[1]) + (sdot[2] + sdot[3]);
   }
 }
 
-// more bins than partial-sum slots: fold the per-bin partial sums
-__global__ __launch_bounds__(PB_WG) void k_pb_fold(const double *__restrict__ in, unsigned nin,
-                                                   double *__restrict__ out, unsigned nout) {
-  const unsigned j = blockIdx.x * PB_WG + threadIdx.x;
+// more workgroups than partial-sum slots: fold the per-workgroup partial sums
+__global__ __launch_bounds__(256) void k_pb_fold(const double *__restrict__ in, unsigned nin,
+                                                 double *__restrict__ out, unsigned nout) {
+  const unsigned j = blockIdx.x * 256 + threadIdx.x;
   if (j >= nout)
     return;
   double s = 0.0;
@@ -157,26 +168,56 @@ __global__ __launch_bounds__(PB_WG) void k_pb_fold(const double *__restrict__ in
 
 extern "C" {
 
-/* y = A x in two launches; prod: nslots doubles of scratch.  partials != NULL:
- * *npartials partial sums of y . xdot are left there (binparts: nbins doubles of
- * scratch when nbins exceeds the partial buffer). */
+/* workgroups of phase 2 = partial sums it leaves (binparts must hold that many) */
+unsigned lsb_k_twophase_groups(unsigned nbins) { return (nbins + PB2_WG / 64 - 1) / (PB2_WG / 64); }
+
+/* y = A x in two launches; prod: nnz doubles of scratch.  partials != NULL:
+ * *npartials partial sums of y . xdot are left there (binparts: scratch for the
+ * per-workgroup sums when there are more of them than the partial buffer holds).
+ * cols <= 16384 (128 KB of LDS for the window of x), rows <= 4096. */
 void lsb_k_spmv_twophase(unsigned nitems, const unsigned *item, const double *vals,
-                         const unsigned short *colw, const unsigned *pos, const unsigned short *roww,
-                         unsigned col_lo, unsigned nbins, const unsigned *bin_ptr, double *prod,
-                         unsigned n, const double *x, unsigned xlen, double *y, const double *xdot,
+                         const unsigned short *colw, const unsigned *grp_first,
+                         const unsigned long long *grp_mask, const unsigned *delta,
+                         const unsigned short *roww, unsigned col_lo, unsigned cols, unsigned rows,
+                         unsigned nbins, const unsigned *bin_ptr, double *prod, unsigned n,
+                         const double *x, unsigned xlen, double *y, const double *xdot,
                          double *partials, unsigned *npartials, double *binparts,
                          const struct lsb_pcg_state *st, void *stream) {
   hipStream_t s = (hipStream_t)stream;
-  if (nitems)
-    k_pb_products<<<nitems, PB_WG, 0, s>>>(item, vals, colw, pos, x, xlen, col_lo, prod, st);
-  const bool fold = partials && nbins > LSB_MAX_PARTIALS;
-  k_pb_reduce<<<nbins, PB_WG, 0, s>>>(bin_ptr, prod, roww, n, y, partials ? xdot : NULL,
-                                      partials ? (fold ? binparts : partials) : NULL, st);
+  static __thread int attr_set = 0; /* a rank = a host thread with its own device */
+  if (!attr_set) { /* more than 64 KB of LDS per workgroup has to be asked for */
+    LSB_CHK_HIP(hipFuncSetAttribute((const void *)k_pb_products<1024>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
+    LSB_CHK_HIP(hipFuncSetAttribute((const void *)k_pb_products<512>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
+    LSB_CHK_HIP(hipFuncSetAttribute((const void *)k_pb_reduce,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (PB2_WG / 64) * 4096 * 8));
+    attr_set = 1;
+  }
+  if (cols > 16384 || rows > 4096)
+    errx(EXIT_FAILURE, "lsb_k_spmv_twophase: tiling %u x %u does not fit the LDS", cols, rows);
+  /* products leave through nontemporal stores: nobody reads them before 2 GB more have
+   * gone by (1.55-1.70 against 1.61-1.71 ms on the 8 M-row power-law operator) */
+  const char *ent = getenv("LSBENCH_HIP_PB_NTSTORE");
+  const int nt = ent ? atoi(ent) : 1;
+  if (nitems) {
+    if (cols > 8192)
+      k_pb_products<1024><<<nitems, 1024, (size_t)cols * 8, s>>>(item, vals, colw, grp_first, grp_mask,
+                                                                 delta, x, xlen, col_lo, cols, prod, nt, st);
+    else
+      k_pb_products<512><<<nitems, 512, (size_t)cols * 8, s>>>(item, vals, colw, grp_first, grp_mask,
+                                                               delta, x, xlen, col_lo, cols, prod, nt, st);
+  }
+  const unsigned g = lsb_k_twophase_groups(nbins);
+  const bool fold = partials && g > LSB_MAX_PARTIALS;
+  k_pb_reduce<<<g, PB2_WG, (size_t)(PB2_WG / 64) * rows * 8, s>>>(
+      bin_ptr, prod, roww, n, rows, nbins, y, partials ? xdot : NULL,
+      partials ? (fold ? binparts : partials) : NULL, st);
   if (npartials)
-    *npartials = fold ? LSB_MAX_PARTIALS : nbins;
+    *npartials = fold ? LSB_MAX_PARTIALS : g;
   if (fold)
-    k_pb_fold<<<(LSB_MAX_PARTIALS + PB_WG - 1) / PB_WG, PB_WG, 0, s>>>(binparts, nbins, partials,
-                                                                       LSB_MAX_PARTIALS);
+    k_pb_fold<<<(LSB_MAX_PARTIALS + 255) / 256, 256, 0, s>>>(binparts, g, partials, LSB_MAX_PARTIALS);
 }
 
 } // extern "C"

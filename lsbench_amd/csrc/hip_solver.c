@@ -122,15 +122,18 @@ static void shard_build_twophase(struct shard *s, const struct csr *view, unsign
   if (!P)
     return;
   s->tp_items = P->nitems, s->tp_bins = P->nbins, s->tp_col_lo = P->ncols_lo, s->tp_xlen = n_glob;
+  s->tp_cols = P->cols, s->tp_rows = P->rows;
   s->tp_item = (unsigned *)dev_upload(P->item, (size_t)P->nitems * 3 * sizeof(unsigned));
   s->tp_binptr = (unsigned *)dev_upload(P->bin_ptr, ((size_t)P->nbins + 1) * sizeof(unsigned));
-  s->tp_pos = (unsigned *)dev_upload(P->pos, (size_t)P->nnz * sizeof(unsigned));
-  s->tp_colw = (unsigned short *)dev_upload(P->colw, (size_t)P->nnz * sizeof(unsigned short));
-  s->tp_roww = (unsigned short *)dev_upload(P->roww, (size_t)P->nslots * sizeof(unsigned short));
-  s->tp_vals = (double *)dev_upload(P->vals, (size_t)P->nnz * sizeof(double));
-  s->tp_prod = (double *)lsb_hip_malloc((size_t)P->nslots * sizeof(double));
-  LSB_CHK_HIP(hipMemsetAsync(s->tp_prod, 0, (size_t)P->nslots * sizeof(double), g_stream));
-  s->tp_binparts = (double *)lsb_hip_malloc((size_t)P->nbins * sizeof(double));
+  s->tp_first = (unsigned *)dev_upload(P->grp_first, (size_t)(P->nent / 64 + 1) * sizeof(unsigned));
+  s->tp_mask = (unsigned long long *)dev_upload(P->grp_mask, (size_t)(P->nent / 64 + 1) * sizeof(unsigned long long));
+  s->tp_delta = (unsigned *)dev_upload(P->delta, ((size_t)P->npieces + 1) * sizeof(unsigned));
+  s->tp_colw = (unsigned short *)dev_upload(P->colw, (size_t)P->nent * sizeof(unsigned short));
+  s->tp_roww = (unsigned short *)dev_upload(P->roww, (size_t)P->nnz * sizeof(unsigned short));
+  s->tp_vals = (double *)dev_upload(P->vals, (size_t)P->nent * sizeof(double));
+  s->tp_prod = (double *)lsb_hip_malloc((size_t)P->nnz * sizeof(double));
+  LSB_CHK_HIP(hipMemsetAsync(s->tp_prod, 0, (size_t)P->nnz * sizeof(double), g_stream));
+  s->tp_binparts = (double *)lsb_hip_malloc((size_t)lsb_k_twophase_groups(P->nbins) * sizeof(double));
   LSB_CHK_HIP(hipStreamSynchronize(g_stream));
   lsb_pb_free(P);
 }
@@ -219,11 +222,10 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
     if (width && (o->spmv_variant == LSB_SPMV_BINNED ||
                   (o->spmv_variant == LSB_SPMV_AUTO && scattered)))
       shard_build_bins(s, &gview, width);
-    /* on request only: measured slower than the binned form on the 8 M-row power-law
-     * operator (4.16 vs 2.78 ms: both phases are latency-bound at the two workgroups
-     * per CU their 64 KB of LDS allow), DESIGN.md section 4 */
+    /* the two-phase form: 1.59 ms against the binned form's 2.79 ms on the 8 M-row
+     * power-law operator; the timing pass decides per shard */
     if (o->spmv_variant == LSB_SPMV_TWOPHASE ||
-        (o->spmv_variant == LSB_SPMV_AUTO && scattered && getenv("LSBENCH_HIP_TRY_TWOPHASE")))
+        (o->spmv_variant == LSB_SPMV_AUTO && scattered && !getenv("LSBENCH_HIP_NO_TWOPHASE")))
       shard_build_twophase(s, &gview, n_glob);
   }
   /* Near-uniform row lengths (stencils, meshes): also keep a sliced-ELL copy;
@@ -367,7 +369,8 @@ void shard_free(struct shard *s) {
   lsb_hip_free(s->bd_chunk), lsb_hip_free(s->bd_rows), lsb_hip_free(s->bd_cols);
   lsb_hip_free(s->bd_vals);
   free(s->h_binchunk);
-  lsb_hip_free(s->tp_item), lsb_hip_free(s->tp_binptr), lsb_hip_free(s->tp_pos);
+  lsb_hip_free(s->tp_item), lsb_hip_free(s->tp_binptr), lsb_hip_free(s->tp_first);
+  lsb_hip_free(s->tp_mask), lsb_hip_free(s->tp_delta);
   lsb_hip_free(s->tp_colw), lsb_hip_free(s->tp_roww), lsb_hip_free(s->tp_vals);
   lsb_hip_free(s->tp_prod), lsb_hip_free(s->tp_binparts);
   precond_free_shard(s);
@@ -667,9 +670,10 @@ void spmv_shard(struct shard *s, const double *xfull, double *y,
     return;
   }
   if (s->variant == LSB_SPMV_TWOPHASE) {
-    lsb_k_spmv_twophase(s->tp_items, s->tp_item, s->tp_vals, s->tp_colw, s->tp_pos, s->tp_roww,
-                        s->tp_col_lo, s->tp_bins, s->tp_binptr, s->tp_prod, s->n, xfull, s->tp_xlen, y,
-                        xdot, partials, np, s->tp_binparts, st, g_stream);
+    lsb_k_spmv_twophase(s->tp_items, s->tp_item, s->tp_vals, s->tp_colw, s->tp_first, s->tp_mask,
+                        s->tp_delta, s->tp_roww, s->tp_col_lo, s->tp_cols, s->tp_rows, s->tp_bins,
+                        s->tp_binptr, s->tp_prod, s->n, xfull, s->tp_xlen, y, xdot, partials, np,
+                        s->tp_binparts, st, g_stream);
     return;
   }
   if (s->variant == LSB_SPMV_BINNED) {
@@ -808,10 +812,12 @@ void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
   s->sp_flags = bf;
   /* the copies that lost are not kept */
   if (any && bv != LSB_SPMV_TWOPHASE && s->tp_bins) {
-    lsb_hip_free(s->tp_item), lsb_hip_free(s->tp_binptr), lsb_hip_free(s->tp_pos);
+    lsb_hip_free(s->tp_item), lsb_hip_free(s->tp_binptr), lsb_hip_free(s->tp_first);
+    lsb_hip_free(s->tp_mask), lsb_hip_free(s->tp_delta);
     lsb_hip_free(s->tp_colw), lsb_hip_free(s->tp_roww), lsb_hip_free(s->tp_vals);
     lsb_hip_free(s->tp_prod), lsb_hip_free(s->tp_binparts);
-    s->tp_item = s->tp_binptr = s->tp_pos = NULL, s->tp_colw = s->tp_roww = NULL;
+    s->tp_item = s->tp_binptr = s->tp_first = s->tp_delta = NULL, s->tp_mask = NULL;
+    s->tp_colw = s->tp_roww = NULL;
     s->tp_vals = s->tp_prod = s->tp_binparts = NULL, s->tp_bins = 0;
   }
   if (any && bv != LSB_SPMV_BINNED && s->bn) {

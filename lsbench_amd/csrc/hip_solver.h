@@ -111,8 +111,9 @@ struct shard {
   unsigned *bd_chunk, *bd_rows, *bd_cols;
   double *bd_vals;
   /* two-phase form (LSB_SPMV_TWOPHASE), built for scattered operators only */
-  unsigned tp_items, tp_bins, tp_col_lo, tp_xlen; /* tp_bins = 0: not built */
-  unsigned *tp_item, *tp_binptr, *tp_pos;
+  unsigned tp_items, tp_bins, tp_col_lo, tp_xlen, tp_cols, tp_rows; /* tp_bins = 0: not built */
+  unsigned *tp_item, *tp_binptr, *tp_first, *tp_delta;
+  unsigned long long *tp_mask;
   unsigned short *tp_colw, *tp_roww;
   double *tp_vals, *tp_prod, *tp_binparts;
   struct lsb_xfer *recv, *send;

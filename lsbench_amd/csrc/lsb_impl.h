@@ -102,11 +102,14 @@ void lsb_k_spmv_binned(unsigned flags, unsigned chunk_cap, const unsigned *chunk
                        unsigned nchunk, const unsigned *rows, const unsigned *cols, const double *vals,
                        const double *x, double *y, const struct lsb_pcg_state *st, void *stream);
 void lsb_k_spmv_twophase(unsigned nitems, const unsigned *item, const double *vals,
-                         const unsigned short *colw, const unsigned *pos, const unsigned short *roww,
-                         unsigned col_lo, unsigned nbins, const unsigned *bin_ptr, double *prod,
-                         unsigned n, const double *x, unsigned xlen, double *y, const double *xdot,
+                         const unsigned short *colw, const unsigned *grp_first,
+                         const unsigned long long *grp_mask, const unsigned *delta,
+                         const unsigned short *roww, unsigned col_lo, unsigned cols, unsigned rows,
+                         unsigned nbins, const unsigned *bin_ptr, double *prod, unsigned n,
+                         const double *x, unsigned xlen, double *y, const double *xdot,
                          double *partials, unsigned *npartials, double *binparts,
                          const struct lsb_pcg_state *st, void *stream);
+unsigned lsb_k_twophase_groups(unsigned nbins);
 void lsb_k_reduce_final(const double *partials, unsigned nparts, unsigned width,
                         double *out, int take_sqrt,
                         const struct lsb_pcg_state *st, void *stream);

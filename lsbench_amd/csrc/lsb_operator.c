@@ -574,166 +574,156 @@ void lsb_binned_free(struct lsb_binned *B) {
 /* ------------------------------------------------------------------------ */
 /* Two-phase form (LSB_SPMV_TWOPHASE): see include/lsbench_hip.h.             */
 /* ------------------------------------------------------------------------ */
-#define PB_ITEM 32768u
-struct lsb_pb *lsb_csr_pbize(const struct csr *A) {
+#define PB_ITEM 131072u /* entries of a phase-1 work item (a multiple of 64) */
+struct lsb_pb *lsb_csr_pbize2(const struct csr *A, unsigned C, unsigned R) {
   if (!A || A->nrows == 0)
     return NULL;
+  C = C ? C : LSB_PB_COLS, R = R ? R : LSB_PB_ROWS;
+  if (C > 16384 || R > 4096 || C % 64 || R % 64)
+    errx(EXIT_FAILURE, "two-phase operator: %u columns x %u rows per piece is not a usable tiling", C, R);
   const unsigned n = A->nrows, base = A->base;
   const unsigned long long nnz = A->offs[n];
   if (nnz == 0 || nnz > 0x7FFFFFF0ull)
     return NULL;
   unsigned lo, hi;
   lsb_csr_col_hull(A, &lo, &hi);
-  lo -= lo % LSB_PB_COLS; /* windows start on a multiple of the chunk width */
-  const unsigned nch = (hi - lo + LSB_PB_COLS - 1) / LSB_PB_COLS;
-  const unsigned nb = (n + LSB_PB_ROWS - 1) / LSB_PB_ROWS;
+  lo -= lo % C; /* windows start on a multiple of the chunk width */
+  const unsigned nch = (hi - lo + C - 1) / C;
+  const unsigned nb = (n + R - 1) / R;
   const unsigned long long nbuck = (unsigned long long)nch * nb;
-  if (nbuck > (1ull << 31))
+  if (nbuck > (1ull << 30))
     return NULL;
   /* counting sort by (chunk, bin); the row-major sweep keeps rows, then columns,
-   * ascending inside a bucket */
+   * ascending inside a bucket.  cnt[k]: first entry of bucket k in UNPADDED
+   * phase-1 order. */
   unsigned *cnt = lsb_calloc(unsigned, (size_t)nbuck + 1);
   if (!cnt)
     errx(EXIT_FAILURE, "out of host memory for the two-phase operator");
   for (unsigned i = 0; i < n; i++) {
-    const unsigned b = i / LSB_PB_ROWS;
+    const unsigned b = i / R;
     for (unsigned j = A->offs[i]; j < A->offs[i + 1]; j++)
-      cnt[(size_t)((A->cols[j] - base - lo) / LSB_PB_COLS) * nb + b + 1]++;
+      cnt[(size_t)((A->cols[j] - base - lo) / C) * nb + b + 1]++;
   }
   for (unsigned long long k = 0; k < nbuck; k++)
     cnt[k + 1] += cnt[k];
+  /* every chunk's entries start on a multiple of 64: pad[c] = what was inserted
+   * in front of chunk c */
+  unsigned *pad = lsb_calloc(unsigned, (size_t)nch + 1);
+  for (unsigned c = 0; c < nch; c++) {
+    const unsigned long long len = cnt[(size_t)(c + 1) * nb] - cnt[(size_t)c * nb];
+    pad[c + 1] = pad[c] + (unsigned)((64 - len % 64) % 64);
+  }
+  const unsigned long long nent = nnz + pad[nch];
+  if (nent > 0xFFFFFFC0ull)
+    return NULL;
   struct lsb_pb *P = lsb_calloc(struct lsb_pb, 1);
-  P->nrows = n, P->ncols_lo = lo, P->nchunks = nch, P->nbins = nb, P->nnz = nnz;
-  P->vals = (double *)malloc((size_t)nnz * sizeof(double));
-  P->colw = (unsigned short *)malloc((size_t)nnz * sizeof(unsigned short));
-  P->pos = (unsigned *)malloc((size_t)nnz * sizeof(unsigned));
+  P->nrows = n, P->ncols_lo = lo, P->nchunks = nch, P->nbins = nb, P->nnz = nnz, P->nent = nent;
+  P->cols = C, P->rows = R;
+  P->vals = (double *)calloc((size_t)nent, sizeof(double));
+  P->colw = (unsigned short *)calloc((size_t)nent, sizeof(unsigned short));
+  P->grp_first = lsb_calloc(unsigned, (size_t)(nent / 64) + 1);
+  P->grp_mask = lsb_calloc(unsigned long long, (size_t)(nent / 64) + 1);
   P->bin_ptr = lsb_calloc(unsigned, (size_t)nb + 1);
-  unsigned short *rw = (unsigned short *)malloc((size_t)nnz * sizeof(unsigned short));
-  if (!P->vals || !P->colw || !P->pos || !rw)
+  P->roww = (unsigned short *)malloc((size_t)nnz * sizeof(unsigned short));
+  unsigned short *rw = (unsigned short *)malloc((size_t)nent * sizeof(unsigned short));
+  if (!P->vals || !P->colw || !P->roww || !rw)
     errx(EXIT_FAILURE, "out of host memory for the two-phase operator");
-  /* phase-1 work items: slices of a chunk */
+  /* phase-1 work items: slices of a chunk, starting on multiples of 64 */
   {
-    size_t cap = (size_t)(nnz / PB_ITEM) + nch + 8, ni = 0;
+    size_t cap = (size_t)(nent / PB_ITEM) + nch + 8, ni = 0;
     P->item = (unsigned *)malloc(cap * 3 * sizeof(unsigned));
     for (unsigned c = 0; c < nch; c++) {
-      const unsigned e0 = cnt[(size_t)c * nb], e1 = cnt[(size_t)(c + 1) * nb];
+      const unsigned e0 = cnt[(size_t)c * nb] + pad[c], e1 = cnt[(size_t)(c + 1) * nb] + pad[c];
       for (unsigned e = e0; e < e1; e += PB_ITEM) {
         P->item[3 * ni] = c, P->item[3 * ni + 1] = e;
-        P->item[3 * ni + 2] = e + PB_ITEM < e1 ? e + PB_ITEM : e1;
+        P->item[3 * ni + 2] = e1 - e > PB_ITEM ? e + PB_ITEM : e1;
         ni++;
       }
     }
     P->nitems = (unsigned)ni;
   }
-  /* scatter into (chunk, bin, row, col) order; afterwards cnt[k] = END of bucket k */
-  for (unsigned i = 0; i < n; i++) {
-    const unsigned b = i / LSB_PB_ROWS;
-    for (unsigned j = A->offs[i]; j < A->offs[i + 1]; j++) {
-      const unsigned c = A->cols[j] - base - lo, ch = c / LSB_PB_COLS;
-      const unsigned e = cnt[(size_t)ch * nb + b]++;
-      P->vals[e] = A->vals[j];
-      P->colw[e] = (unsigned short)(c % LSB_PB_COLS);
-      rw[e] = (unsigned short)(i % LSB_PB_ROWS);
-    }
-  }
-  /* Slots of every bin: pieces in chunk order, steps of 64 slots in which EQUAL
-   * ROWS ARE NEIGHBOURS (a row may repeat only in consecutive slots: phase 2
-   * combines neighbours by a segmented scan, then one lane adds per row).  An
-   * entry whose row is already in the step under construction, but not in the
-   * slot before it, is deferred to the end of the bin, where the deferred ones are
-   * placed sorted by row under the same rule.  pos[e] holds the slot INSIDE the
-   * bin first. */
-  unsigned *blen = lsb_calloc(unsigned, (size_t)nb + 1);
-#pragma omp parallel
+  /* slots: bin-major, chunk-minor.  slot0[k]: first slot of bucket k */
+  unsigned *slot0 = (unsigned *)malloc((size_t)nbuck * sizeof(unsigned));
+  if (!slot0)
+    errx(EXIT_FAILURE, "out of host memory for the two-phase operator");
   {
-    unsigned *stamp = lsb_calloc(unsigned, LSB_PB_ROWS);
-    unsigned *defer = NULL, *dsort = NULL, *dcount = lsb_calloc(unsigned, LSB_PB_ROWS + 1);
-    size_t dcap = 0;
-#pragma omp for schedule(dynamic, 16)
-    for (long long bb = 0; bb < (long long)nb; bb++) {
-      const unsigned b = (unsigned)bb;
-      memset(stamp, 0, LSB_PB_ROWS * sizeof(unsigned));
-      unsigned step = 1, fill = 0, last = 0xFFFFFFFFu; /* stamp[row] == step: row is in the step */
-      size_t nd = 0;
-#define PB_PLACE(e_)                                                           \
-  do {                                                                         \
-    stamp[rw[e_]] = step, last = rw[e_];                                       \
-    P->pos[e_] = (step - 1) * 64 + fill;                                       \
-    if (++fill == 64)                                                          \
-      fill = 0, step++, last = 0xFFFFFFFFu;                                    \
-  } while (0)
+    unsigned long long tot = 0;
+    for (unsigned b = 0; b < nb; b++) {
+      P->bin_ptr[b] = (unsigned)tot;
       for (unsigned c = 0; c < nch; c++) {
         const size_t k = (size_t)c * nb + b;
-        const unsigned e0 = k ? cnt[k - 1] : 0, e1 = cnt[k];
-        for (unsigned e = e0; e < e1; e++) {
-          if (stamp[rw[e]] == step && rw[e] != last) {
-            if (nd == dcap) {
-              dcap = dcap ? 2 * dcap : 1024;
-              defer = (unsigned *)realloc(defer, dcap * sizeof(unsigned));
-              dsort = (unsigned *)realloc(dsort, dcap * sizeof(unsigned));
-              if (!defer || !dsort)
-                errx(EXIT_FAILURE, "out of host memory for the two-phase operator");
-            }
-            defer[nd++] = e;
-            continue;
-          }
-          PB_PLACE(e);
-        }
+        slot0[k] = (unsigned)tot;
+        tot += cnt[k + 1] - cnt[k];
       }
-      if (nd) { /* counting sort of the deferred entries by row: equal rows become neighbours */
-        memset(dcount, 0, (LSB_PB_ROWS + 1) * sizeof(unsigned));
-        for (size_t q = 0; q < nd; q++)
-          dcount[rw[defer[q]] + 1]++;
-        for (unsigned r = 0; r < LSB_PB_ROWS; r++)
-          dcount[r + 1] += dcount[r];
-        for (size_t q = 0; q < nd; q++)
-          dsort[dcount[rw[defer[q]]]++] = defer[q];
-      }
-      size_t q0 = 0;
-      while (q0 < nd) { /* in row order; what collides with the current step closes it */
-        const unsigned e = dsort[q0];
-        if (stamp[rw[e]] == step && rw[e] != last) {
-          fill = 0, step++, last = 0xFFFFFFFFu; /* pad the rest of this step */
+    }
+    P->bin_ptr[nb] = (unsigned)tot;
+  }
+  /* pieces = non-empty buckets in phase-1 order; the group words */
+  {
+    size_t np = 0;
+    for (unsigned long long k = 0; k < nbuck; k++)
+      np += cnt[k + 1] > cnt[k];
+    P->npieces = (unsigned)np;
+    P->delta = lsb_calloc(unsigned, np + 1);
+    np = 0;
+    for (unsigned c = 0; c < nch; c++)
+      for (unsigned b = 0; b < nb; b++) {
+        const size_t k = (size_t)c * nb + b;
+        const unsigned len = cnt[k + 1] - cnt[k];
+        if (!len)
           continue;
-        }
-        PB_PLACE(e);
-        q0++;
+        const unsigned e0 = cnt[k] + pad[c];
+        P->delta[np] = slot0[k] - e0; /* mod 2^32 */
+        if (e0 % 64)
+          P->grp_mask[e0 / 64] |= 1ull << (e0 % 64);
+        for (unsigned g = (e0 + 63) / 64; g <= (e0 + len - 1) / 64; g++)
+          P->grp_first[g] = (unsigned)np;
+        np++;
       }
-#undef PB_PLACE
-      blen[b] = (step - 1) * 64 + (fill ? 64 : 0);
-    }
-    free(stamp), free(defer), free(dsort), free(dcount);
   }
-  unsigned long long tot = 0;
-  for (unsigned b = 0; b < nb; b++) {
-    P->bin_ptr[b] = (unsigned)tot;
-    tot += blen[b];
-  }
-  if (tot > 0xFFFFFFF0ull)
-    errx(EXIT_FAILURE, "two-phase operator too large for 32-bit slots");
-  P->bin_ptr[nb] = (unsigned)tot, P->nslots = tot;
-  P->roww = (unsigned short *)malloc((size_t)(tot ? tot : 1) * sizeof(unsigned short));
-  if (!P->roww)
-    errx(EXIT_FAILURE, "out of host memory for the two-phase operator");
-  memset(P->roww, 0xFF, (size_t)tot * sizeof(unsigned short));
-#pragma omp parallel for schedule(dynamic, 16)
-  for (long long bb = 0; bb < (long long)nb; bb++)
-    for (unsigned c = 0; c < nch; c++) {
-      const size_t k = (size_t)c * nb + (size_t)bb;
-      const unsigned e0 = k ? cnt[k - 1] : 0, e1 = cnt[k];
-      for (unsigned e = e0; e < e1; e++) {
-        P->pos[e] += P->bin_ptr[bb];
-        P->roww[P->pos[e]] = rw[e];
+  /* scatter into (chunk, bin, row, col) order; cur[k] runs through bucket k */
+  {
+    unsigned *cur = (unsigned *)malloc((size_t)nbuck * sizeof(unsigned));
+    if (!cur)
+      errx(EXIT_FAILURE, "out of host memory for the two-phase operator");
+    for (unsigned c = 0; c < nch; c++)
+      for (unsigned b = 0; b < nb; b++)
+        cur[(size_t)c * nb + b] = cnt[(size_t)c * nb + b] + pad[c];
+    for (unsigned i = 0; i < n; i++) {
+      const unsigned b = i / R;
+      for (unsigned j = A->offs[i]; j < A->offs[i + 1]; j++) {
+        const unsigned c = A->cols[j] - base - lo, ch = c / C;
+        const unsigned e = cur[(size_t)ch * nb + b]++;
+        P->vals[e] = A->vals[j];
+        P->colw[e] = (unsigned short)(c % C);
+        rw[e] = (unsigned short)(i % R);
       }
     }
-  free(blen), free(rw), free(cnt);
+    free(cur);
+  }
+  /* the rows in slot order: a piece is contiguous in both orders */
+#pragma omp parallel for schedule(static)
+  for (long long cc = 0; cc < (long long)nch; cc++)
+    for (unsigned b = 0; b < nb; b++) {
+      const size_t k = (size_t)cc * nb + b;
+      const unsigned len = cnt[k + 1] - cnt[k];
+      if (len)
+        memcpy(P->roww + slot0[k], rw + cnt[k] + pad[cc], (size_t)len * sizeof(unsigned short));
+    }
+  free(slot0), free(rw), free(cnt), free(pad);
   return P;
+}
+
+struct lsb_pb *lsb_csr_pbize(const struct csr *A) {
+  const char *ec = getenv("LSBENCH_HIP_PB_COLS"), *er = getenv("LSBENCH_HIP_PB_ROWS");
+  return lsb_csr_pbize2(A, ec ? (unsigned)atoi(ec) : 0, er ? (unsigned)atoi(er) : 0);
 }
 
 void lsb_pb_free(struct lsb_pb *P) {
   if (!P)
     return;
-  free(P->vals), free(P->colw), free(P->pos), free(P->item), free(P->bin_ptr), free(P->roww);
+  free(P->vals), free(P->colw), free(P->grp_first), free(P->grp_mask), free(P->delta);
+  free(P->item), free(P->bin_ptr), free(P->roww);
   free(P);
 }
 

@@ -607,6 +607,8 @@ def test_binned_spmv(hip, width, monkeypatch):
             _check_spmv(A, x, ys[0])
             assert np.array_equal(ys[0], ys[1])
             s.destroy()
+    monkeypatch.delenv("LSBENCH_HIP_PB_COLS", raising=False)
+    monkeypatch.delenv("LSBENCH_HIP_PB_ROWS", raising=False)
     L = hip.lsbench_matrix_synth("lap2d:nx=150,ny=120")
     b = O.rhs(L.nrows)
     xo, ito, _, _ = O.pcg_jacobi(L.offs, L.cols, L.vals, b, 1e-10)
@@ -629,17 +631,30 @@ def test_binned_spmv(hip, width, monkeypatch):
     assert res.status == 1 and np.linalg.norm(bb - M @ x) / np.linalg.norm(bb) <= 2e-10
 
 
-def test_twophase_spmv(hip):
+def test_twophase_spmv(hip, monkeypatch):
     """LSB_SPMV_TWOPHASE (hip_pb.hip): products by column chunk with the window of
-    x in LDS, sums by row bin with the bin's rows in LDS.  Element-wise oracle bound
-    on scattered, ragged, banded and tiny operators, over shards; bit-identical
-    from run to run; fused dot product; PCG and GMRES on top."""
+    x in LDS, sums by row bin with the bin's rows in a wavefront's own LDS (ds_add_f64).
+    Element-wise oracle bound on scattered, ragged, banded and tiny operators, over
+    shards and tilings (columns per chunk x rows per bin: the default, the largest
+    window -- 1024-thread workgroups, 128 KB of LDS -- and a tiny one with many pieces
+    per group of 64 entries); bit-identical from run to run; fused dot product; PCG and
+    GMRES on top."""
     import torch
     import scipy.sparse as sp
     rng = np.random.default_rng(11)
-    for spec in ("powerlaw:n=60000,gamma=%r,max=4096,seed=4" % GAMMA, "powerlaw:n=6500,gamma=1.05,max=4096,seed=9",
-                 "lap2d:nx=300,ny=170", "lap2d:nx=3,ny=2", "powerlaw:n=300000,gamma=2.2,max=64,seed=5"):
+    for spec, tiling in (("powerlaw:n=60000,gamma=%r,max=4096,seed=4" % GAMMA, None),
+                         ("powerlaw:n=60000,gamma=%r,max=4096,seed=4" % GAMMA, ("16384", "1024")),
+                         ("powerlaw:n=60000,gamma=%r,max=4096,seed=4" % GAMMA, ("512", "4096")),
+                         ("powerlaw:n=6500,gamma=1.05,max=4096,seed=9", None),
+                         ("powerlaw:n=6500,gamma=1.05,max=4096,seed=9", ("256", "128")),
+                         ("lap2d:nx=300,ny=170", None), ("lap2d:nx=3,ny=2", None),
+                         ("powerlaw:n=300000,gamma=2.2,max=64,seed=5", None)):
         A = hip.lsbench_matrix_synth(spec)
+        monkeypatch.delenv("LSBENCH_HIP_PB_COLS", raising=False)
+        monkeypatch.delenv("LSBENCH_HIP_PB_ROWS", raising=False)
+        if tiling:
+            monkeypatch.setenv("LSBENCH_HIP_PB_COLS", tiling[0])
+            monkeypatch.setenv("LSBENCH_HIP_PB_ROWS", tiling[1])
         for nvirt in (1, 3):
             if nvirt > 1 and A.nrows < 100:
                 continue
@@ -655,6 +670,8 @@ def test_twophase_spmv(hip):
             _check_spmv(A, x, ys[0])
             assert np.array_equal(ys[0], ys[1])
             s.destroy()
+    monkeypatch.delenv("LSBENCH_HIP_PB_COLS", raising=False)
+    monkeypatch.delenv("LSBENCH_HIP_PB_ROWS", raising=False)
     L = hip.lsbench_matrix_synth("lap2d:nx=150,ny=120")
     b = O.rhs(L.nrows)
     xo, ito, _, _ = O.pcg_jacobi(L.offs, L.cols, L.vals, b, 1e-10)

@@ -524,64 +524,75 @@ def test_powerlaw_spd_variant():
     assert np.array_equal(part.vals, S.vals[S.offs[1000]:S.offs[1800]])
 
 
+@pytest.mark.parametrize("tiling", [(0, 0), (256, 128), (8192, 2048)])
 @pytest.mark.parametrize("spec", ["powerlaw:n=30000,gamma=1.2,max=3000,seed=7",
                                   "powerlaw:n=5000,gamma=1.585350372615855,max=4096,seed=3",
                                   "lap2d:nx=170,ny=150", "powerlaw:n=2500,gamma=0.3,max=2500,seed=5"])
-def test_twophase_form(spec):
-    """lsb_csr_pbize (LSB_SPMV_TWOPHASE): entries ordered by (column chunk, row bin,
-    row, column) with a target slot each; the slots are row-bin major, a bin a whole
-    number of 64-slot steps in which EQUAL ROWS ARE NEIGHBOURS (the property phase 2
-    relies on: segmented scan, then one lane per LDS word), padding marked 0xFFFF; phase-1
-    items tile the entries chunk by chunk; products summed slot by slot give A x."""
+def test_twophase_form(spec, tiling):
+    """lsb_csr_pbize2 (LSB_SPMV_TWOPHASE): entries ordered by (column chunk, row bin,
+    row, column), every chunk starting on a multiple of 64; the product array is row-bin
+    major and a PIECE -- the entries of one (chunk, bin) pair -- is contiguous and in the
+    same order on both sides, so slot = entry + delta[piece]; the piece of an entry is
+    read off grp_first / grp_mask of its group of 64 (what phase 1 does with two scalar
+    loads and a popcount); phase-1 items tile the chunks; products summed slot by slot
+    give A x."""
     import ctypes as C
     L = la._lib
     A = la.lsbench_matrix_synth(spec)
-    P = L.load().lsb_csr_pbize(A.ptr).contents
-    nnz, nb, nch, ni, nsl = int(P.nnz), int(P.nbins), int(P.nchunks), int(P.nitems), int(P.nslots)
-    assert nnz == A.nnz and P.nrows == A.nrows and nb == (A.nrows + L.PB_ROWS - 1) // L.PB_ROWS
-    vals = np.ctypeslib.as_array(P.vals, (nnz,)).copy()
-    colw = np.ctypeslib.as_array(P.colw, (nnz,)).astype(np.int64)
-    pos = np.ctypeslib.as_array(P.pos, (nnz,)).astype(np.int64)
+    P = L.load().lsb_csr_pbize2(A.ptr, tiling[0], tiling[1]).contents
+    Cc, R = int(P.cols), int(P.rows)
+    assert (Cc, R) == (tiling[0] or L.PB_COLS, tiling[1] or L.PB_ROWS)
+    nnz, nent, nb, nch, ni, npc = int(P.nnz), int(P.nent), int(P.nbins), int(P.nchunks), int(P.nitems), int(P.npieces)
+    assert nnz == A.nnz and P.nrows == A.nrows and nb == (A.nrows + R - 1) // R and nent % 64 == 0
+    vals = np.ctypeslib.as_array(P.vals, (nent,)).copy()
+    colw = np.ctypeslib.as_array(P.colw, (nent,)).astype(np.int64)
+    first = np.ctypeslib.as_array(P.grp_first, (nent // 64,)).astype(np.int64)
+    mask = np.ctypeslib.as_array(P.grp_mask, (nent // 64,)).copy()
+    delta = np.ctypeslib.as_array(P.delta, (npc,)).astype(np.int64)
     item = np.ctypeslib.as_array(P.item, (3 * ni,)).reshape(ni, 3).astype(np.int64)
     binptr = np.ctypeslib.as_array(P.bin_ptr, (nb + 1,)).astype(np.int64)
-    roww = np.ctypeslib.as_array(P.roww, (nsl,)).astype(np.int64)
+    roww = np.ctypeslib.as_array(P.roww, (nnz,)).astype(np.int64)
     col_lo = int(P.ncols_lo)
     L.load().lsb_pb_free(C.pointer(P))
-    assert col_lo % L.PB_COLS == 0 and colw.max() < L.PB_COLS
-    assert item[0, 1] == 0 and item[-1, 2] == nnz and np.all(item[1:, 1] == item[:-1, 2])
-    assert np.all(item[:, 2] - item[:, 1] <= 32768) and np.all(np.diff(item[:, 0]) >= 0)
-    chunk_of = np.repeat(item[:, 0], item[:, 2] - item[:, 1])
-    # slots: bins are whole steps, every entry has its own slot, the rest is padding
-    assert binptr[0] == 0 and binptr[-1] == nsl and np.all(binptr % 64 == 0) and np.all(np.diff(binptr) >= 0)
-    assert len(np.unique(pos)) == nnz and pos.max() < nsl
-    used = np.zeros(nsl, bool)
-    used[pos] = True
-    assert np.all(roww[~used] == 0xFFFF) and np.all(roww[used] < L.PB_ROWS)
-    assert nsl - nnz <= 64 * nb + nnz // 20                            # little padding
-    bin_of_slot = np.searchsorted(binptr, np.arange(nsl), side="right") - 1
-    rows = bin_of_slot[pos] * L.PB_ROWS + roww[pos]
-    cols = col_lo + chunk_of * L.PB_COLS + colw
-    # inside a step of 64 slots equal rows are neighbours (one contiguous run per row)
-    steps = roww.reshape(-1, 64)
-    for k in range(steps.shape[0]):
-        live = steps[k][steps[k] != 0xFFFF]
-        runs = 1 + int(np.count_nonzero(np.diff(live))) if len(live) else 0
-        assert runs == len(np.unique(live))
-    # the same multiset of (row, col, value); (chunk, bin)-major entry order
+    assert col_lo % Cc == 0 and colw.max() < Cc
+    # items: slices of a chunk, on multiples of 64, chunk after chunk; the gaps hold zeros
+    assert item[0, 1] == 0 and np.all(item[:, 1] % 64 == 0) and np.all(np.diff(item[:, 0]) >= 0)
+    assert np.all(item[:, 2] - item[:, 1] <= 131072) and np.all(item[1:, 1] - item[:-1, 2] < 64)
+    real = np.zeros(nent, bool)
+    chunk_of = np.zeros(nent, np.int64)
+    for c, e0, e1 in item:
+        real[e0:e1] = True
+        chunk_of[e0:e1] = c
+    assert real.sum() == nnz and np.all(vals[~real] == 0.0) and -(-item[-1, 2] // 64) * 64 == nent
+    # the piece of an entry, the way phase 1 computes it
+    e = np.nonzero(real)[0]
+    lane = e % 64
+    le = np.where(lane == 63, np.uint64(0xFFFFFFFFFFFFFFFF), (np.uint64(2) << lane.astype(np.uint64)) - np.uint64(1))
+    bits = mask[e // 64] & le
+    pop = np.array([bin(int(v)).count("1") for v in bits]) if len(bits) < 400000 else \
+        np.unpackbits(bits.view(np.uint8).reshape(-1, 8), axis=1).sum(axis=1)
+    piece = first[e // 64] + np.asarray(pop, dtype=np.int64)
+    assert piece.max() == npc - 1 and np.all(np.diff(piece) >= 0) and np.all(np.diff(piece) <= 1)
+    slot = (e + delta[piece]) % (1 << 32)
+    assert len(np.unique(slot)) == nnz and slot.max() == nnz - 1       # a permutation of the slots
+    assert binptr[0] == 0 and binptr[-1] == nnz and np.all(np.diff(binptr) >= 0) and roww.max() < R
+    bin_of_slot = np.searchsorted(binptr, np.arange(nnz), side="right") - 1
+    rows = bin_of_slot[slot] * R + roww[slot]
+    cols = col_lo + chunk_of[e] * Cc + colw[e]
+    # one (chunk, bin) pair per piece, contiguous on both sides
+    assert np.all(np.diff(slot)[np.diff(piece) == 0] == 1)
+    pair = chunk_of[e] * nb + rows // R
+    assert np.all(np.diff(pair) >= 0) and np.array_equal(np.diff(pair) > 0, np.diff(piece) == 1)
+    # the same multiset of (row, col, value)
     offs = A.offs.astype(np.int64)
     arow = np.repeat(np.arange(A.nrows), np.diff(offs))
     o1 = np.lexsort((A.cols, arow))
     o2 = np.lexsort((cols, rows))
     assert np.array_equal(arow[o1], rows[o2]) and np.array_equal(A.cols[o1].astype(np.int64), cols[o2])
-    assert np.array_equal(A.vals[o1], vals[o2])
-    assert np.all(np.diff(chunk_of * nb + rows // L.PB_ROWS) >= 0)
-    # products of one (chunk, bin) pair mostly land in consecutive slots
-    same_pair = np.diff(chunk_of * nb + rows // L.PB_ROWS) == 0
-    assert np.mean(np.diff(pos)[same_pair] == 1) > 0.8
+    assert np.array_equal(A.vals[o1], vals[e][o2])
     x = np.sin(np.arange(max(A.nrows, int(cols.max()) + 1), dtype=np.float64))
-    prod = np.zeros(nsl)
-    prod[pos] = vals * x[cols]
+    prod = np.zeros(nnz)
+    prod[slot] = vals[e] * x[cols]
     y = np.zeros(A.nrows)
-    sl = np.nonzero(used)[0]
-    np.add.at(y, bin_of_slot[sl] * L.PB_ROWS + roww[sl], prod[sl])
+    np.add.at(y, bin_of_slot * R + roww, prod)
     assert np.allclose(y, O.spmv(A.offs, A.cols, A.vals, x[:A.nrows]), rtol=1e-12, atol=1e-12)

@@ -20,7 +20,7 @@ step bench_powerlaw 400 python bench.py --workload powerlaw $Q
 step trace_powerlaw 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_powerlaw" -- python3 bench.py --workload powerlaw --steps 1 $Q
 step pmc_fetch_powerlaw 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch_powerlaw" -- python3 bench.py --workload powerlaw --steps 1 $Q
 step pmc_write_powerlaw 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write_powerlaw" -- python3 bench.py --workload powerlaw --steps 1 $Q
-for v in 6 1; do step bench_powerlaw_v$v 400 python bench.py --workload powerlaw --spmv $v $Q; done
+for v in 7 6 1; do step bench_powerlaw_v$v 400 python bench.py --workload powerlaw --spmv $v $Q; done
 step cfg5_spd_cg 600 python bench.py --workload "powerlaw:n=8000000,gamma=1.585350372615855,max=4096,seed=20240607,spd=1" --tol 1e-10 --steps 3 $Q
 step trace_cfg2 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_cfg2" -- python3 bench.py --workload $F --tol 1e-12 --steps 20 --warmup 2 --persistent 0 $Q
 C2="--workload $F --tol 1e-12 --steps 100 --warmup 5 --cfg4 0 --verify 0"
