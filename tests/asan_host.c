@@ -21,12 +21,25 @@ int main(void) {
       if (s != B->nnz) { printf("binize mismatch\n"); return 1; }
       lsb_binned_free(B);
     }
-    struct lsb_pb *P = lsb_csr_pbize(A);
-    unsigned long long s = 0;
-    for (unsigned long long q = 0; q < P->nslots; q++) s += P->roww[q] != 0xFFFFu;
-    for (unsigned long long e = 0; e < P->nnz; e++) if (P->pos[e] >= P->nslots) s = 0;
-    if (s != P->nnz || P->bin_ptr[P->nbins] != P->nslots) { printf("pbize mismatch\n"); return 1; }
-    lsb_pb_free(P);
+    unsigned tilings[][2] = {{0, 0}, {64, 64}, {16384, 4096}};
+    for (int t = 0; t < 3; t++) { /* every slot reached exactly once through grp_first / grp_mask / delta */
+      struct lsb_pb *P = lsb_csr_pbize2(A, tilings[t][0], tilings[t][1]);
+      unsigned char *hit = calloc(P->nnz + 1, 1);
+      unsigned long long s = 0;
+      for (unsigned it = 0; it < P->nitems; it++)
+        for (unsigned e = P->item[3 * it + 1]; e < P->item[3 * it + 2]; e++) {
+          const unsigned lane = e % 64;
+          const unsigned long long le = lane == 63 ? ~0ull : (2ull << lane) - 1ull;
+          const unsigned piece = P->grp_first[e / 64] + (unsigned)__builtin_popcountll(P->grp_mask[e / 64] & le);
+          const unsigned slot = e + P->delta[piece];
+          if (piece >= P->npieces || slot >= P->nnz || hit[slot]++ || P->roww[slot] >= P->rows ||
+              P->colw[e] >= P->cols) { printf("pbize mismatch\n"); return 1; }
+          s++;
+        }
+      if (s != P->nnz || P->bin_ptr[P->nbins] != P->nnz) { printf("pbize mismatch\n"); return 1; }
+      free(hit);
+      lsb_pb_free(P);
+    }
     struct lsb_sell *E = lsb_csr_sellize(A); lsb_sell_free(E);
     E = lsb_csr_sellize16(A, 0); lsb_sell_free(E);
     struct csr *S = lsb_csr_symmetrize_upper(A);
