@@ -574,11 +574,17 @@ void lsb_binned_free(struct lsb_binned *B) {
 /* ------------------------------------------------------------------------ */
 /* Two-phase form (LSB_SPMV_TWOPHASE): see include/lsbench_hip.h.             */
 /* ------------------------------------------------------------------------ */
-#define PB_ITEM 131072u /* entries of a phase-1 work item (a multiple of 64) */
+/* entries of a phase-1 work item (a multiple of 64; LSBENCH_HIP_PB_ITEM).  Measured on the
+ * 8 M-row power-law operator, phase 1: 131072 -> 1322 us, 32768 -> 1247, 8192 -> 1201 (the
+ * window of x is loaded once per item -- 64 KB out of L2 -- but the last workgroups of the
+ * launch finish together) */
+#define PB_ITEM_DEFAULT 8192u
 struct lsb_pb *lsb_csr_pbize2(const struct csr *A, unsigned C, unsigned R) {
   if (!A || A->nrows == 0)
     return NULL;
   C = C ? C : LSB_PB_COLS, R = R ? R : LSB_PB_ROWS;
+  const char *eitem = getenv("LSBENCH_HIP_PB_ITEM");
+  const unsigned PB_ITEM = eitem && atoi(eitem) >= 64 ? ((unsigned)atoi(eitem) + 63u) & ~63u : PB_ITEM_DEFAULT;
   if (C > 16384 || R > 4096 || C % 64 || R % 64)
     errx(EXIT_FAILURE, "two-phase operator: %u columns x %u rows per piece is not a usable tiling", C, R);
   const unsigned n = A->nrows, base = A->base;

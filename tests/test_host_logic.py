@@ -557,7 +557,7 @@ def test_twophase_form(spec, tiling):
     assert col_lo % Cc == 0 and colw.max() < Cc
     # items: slices of a chunk, on multiples of 64, chunk after chunk; the gaps hold zeros
     assert item[0, 1] == 0 and np.all(item[:, 1] % 64 == 0) and np.all(np.diff(item[:, 0]) >= 0)
-    assert np.all(item[:, 2] - item[:, 1] <= 131072) and np.all(item[1:, 1] - item[:-1, 2] < 64)
+    assert np.all(item[:, 2] - item[:, 1] <= 8192) and np.all(item[1:, 1] - item[:-1, 2] < 64)
     real = np.zeros(nent, bool)
     chunk_of = np.zeros(nent, np.int64)
     for c, e0, e1 in item:
