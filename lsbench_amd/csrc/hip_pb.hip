@@ -14,7 +14,7 @@
 //       its group of 64 + the set bits of grp_mask up to its lane (two scalar
 //       loads per wavefront and trip);
 //   phase 2 (k_pb_reduce)    a WAVEFRONT owns a row bin (2048 rows, 16 KB of LDS)
-//       and streams the bin's slots: product + 16-bit row offset, ds_add_f64
+//       and streams the bin's slots in pairs: products + 16-bit row offsets, ds_add_f64
 //       into its own LDS copy of the bin's rows -- nobody else adds there, so the
 //       order of the additions is the wavefront's program order -- then writes
 //       the bin's rows of y once, coalesced.  No y = 0 pass, no global atomics.
@@ -26,7 +26,7 @@
 
 #define PB1_U 8   // entries per lane and trip of phase 1
 #define PB2_WG 256
-#define PB2_S 8   // steps of 64 slots a wavefront has in flight in phase 2
+#define PB2_S 4   // steps of 128 slots a wavefront has in flight in phase 2
 
 template <int WG>
 __global__ __launch_bounds__(WG) void k_pb_products(
@@ -114,20 +114,30 @@ __global__ __launch_bounds__(PB2_WG) void k_pb_reduce(
     for (unsigned k = lane; k < rows; k += 64)
       my[k] = 0.0;
     const unsigned s0 = bin_ptr[bin], s1 = bin_ptr[bin + 1];
-    for (unsigned sb = s0; sb < s1; sb += 64 * PB2_S) { // (clamped loads: see phase 1)
-      double p[PB2_S];
-      unsigned short r[PB2_S];
+    // a lane takes PAIRS of consecutive slots -- one 16-byte and one 4-byte load
+    // (8-byte lane loads stream at 0.54-0.70x the 16-byte rate, MI355X_MICROARCH.md) --
+    // from the even slot at or below s0 on; loads on clamped indices (see phase 1;
+    // prod and roww are allocated two slots longer than they are used)
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    const unsigned a0 = s0 & ~1u, last = (s1 - 1u) & ~1u;
+    for (unsigned sb = a0; sb < s1; sb += 128 * PB2_S) {
+      d2 p[PB2_S];
+      us2 r[PB2_S];
 #pragma unroll
       for (int g = 0; g < PB2_S; g++) {
-        const unsigned i = min(sb + (unsigned)g * 64u + lane, s1 - 1u);
-        r[g] = __builtin_nontemporal_load(roww + i);
-        p[g] = __builtin_nontemporal_load(prod + i);
+        const unsigned i = min(sb + (unsigned)g * 128u + 2u * lane, last);
+        r[g] = __builtin_nontemporal_load((const us2 *)(roww + i));
+        p[g] = __builtin_nontemporal_load((const d2 *)(prod + i));
       }
 #pragma unroll
       for (int g = 0; g < PB2_S; g++) {
-        const unsigned i = sb + (unsigned)g * 64u + lane;
-        if (i < s1)
-          unsafeAtomicAdd(my + r[g], p[g]); // ds_add_f64 on this wavefront's own copy
+        const unsigned i = sb + (unsigned)g * 128u + 2u * lane;
+        if (i >= s0 && i < s1)
+          unsafeAtomicAdd(my + r[g].x, p[g].x); // ds_add_f64 on this wavefront's own copy
+        if (i + 1u < s1) // (i + 1 > a0 >= s0 - 1, and i + 1 == s0 only for i == a0 < s0)
+          if (i + 1u >= s0)
+            unsafeAtomicAdd(my + r[g].y, p[g].y);
       }
     }
     // the wavefront's LDS operations complete in order: the sums are final here

@@ -129,10 +129,12 @@ static void shard_build_twophase(struct shard *s, const struct csr *view, unsign
   s->tp_mask = (unsigned long long *)dev_upload(P->grp_mask, (size_t)(P->nent / 64 + 1) * sizeof(unsigned long long));
   s->tp_delta = (unsigned *)dev_upload(P->delta, ((size_t)P->npieces + 1) * sizeof(unsigned));
   s->tp_colw = (unsigned short *)dev_upload(P->colw, (size_t)P->nent * sizeof(unsigned short));
-  s->tp_roww = (unsigned short *)dev_upload(P->roww, (size_t)P->nnz * sizeof(unsigned short));
+  /* (+2: phase 2 loads slots in pairs, on clamped indices) */
+  s->tp_roww = (unsigned short *)lsb_hip_malloc(((size_t)P->nnz + 2) * sizeof(unsigned short));
+  LSB_CHK_HIP(hipMemcpy(s->tp_roww, P->roww, (size_t)P->nnz * sizeof(unsigned short), hipMemcpyHostToDevice));
   s->tp_vals = (double *)dev_upload(P->vals, (size_t)P->nent * sizeof(double));
-  s->tp_prod = (double *)lsb_hip_malloc((size_t)P->nnz * sizeof(double));
-  LSB_CHK_HIP(hipMemsetAsync(s->tp_prod, 0, (size_t)P->nnz * sizeof(double), g_stream));
+  s->tp_prod = (double *)lsb_hip_malloc(((size_t)P->nnz + 2) * sizeof(double));
+  LSB_CHK_HIP(hipMemsetAsync(s->tp_prod, 0, ((size_t)P->nnz + 2) * sizeof(double), g_stream));
   s->tp_binparts = (double *)lsb_hip_malloc((size_t)lsb_k_twophase_groups(P->nbins) * sizeof(double));
   LSB_CHK_HIP(hipStreamSynchronize(g_stream));
   lsb_pb_free(P);
