@@ -1135,14 +1135,16 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_sell(
 // 146 -> 122 us on the same box (tools/spmv_lab.hip).  A slot holds entries of
 // one diagonal band, so rows can have padding BETWEEN their entries; padding
 // has value 0 and is recognised by that (no gather, contributes an exact 0).
+// CHEB: a Chebyshev step in the epilogue (lsb_cheb_epi, lsb_impl.h) instead of the
+// store of y: the polynomial preconditioner's S z products never travel to memory.
 typedef short s2v __attribute__((ext_vector_type(2)));
-template <int FLAGS, class VT = double>
+template <int FLAGS, class VT = double, bool CHEB = false>
 __global__ __launch_bounds__(WG, 6) void k_spmv_sell16(
     const unsigned *__restrict__ sptr, unsigned s0, unsigned ns, unsigned period, unsigned n,
     unsigned row_begin, const short *__restrict__ codes, const int *__restrict__ sbase,
     const VT *__restrict__ vals, const double *__restrict__ x, double *__restrict__ y,
     const double *__restrict__ xdot, double *__restrict__ partials,
-    const lsb_pcg_state *__restrict__ st, const lsb_ar_tail tail) {
+    const lsb_pcg_state *__restrict__ st, const lsb_ar_tail tail, const lsb_cheb_epi epi) {
   __shared__ double sred[4];
   const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const unsigned gx = gridDim.x / NXCD, xcd = blockIdx.x % NXCD, slot = blockIdx.x / NXCD;
@@ -1191,7 +1193,21 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_sell16(
             a1 += (double)v[u].y * (p1 ? t1 : 0.0);
           }
       }
-      if (row + 1 < n) {
+      if (CHEB) { // d = a d + b D^-1 (r - w); z' = z + d -- k_cheb_step's expression
+        if (row + 1 < n) {
+          const sell_d2v rr = *(const sell_d2v *)(epi.r + row), dd = *(const sell_d2v *)(epi.d + row);
+          const double i0 = epi.dinv ? epi.dinv[row] : epi.dc, i1 = epi.dinv ? epi.dinv[row + 1] : epi.dc;
+          const double v0 = fma(epi.a, dd.x, epi.b * (i0 * (rr.x - a0)));
+          const double v1 = fma(epi.a, dd.y, epi.b * (i1 * (rr.y - a1)));
+          const sell_d2v dn = {v0, v1}, zn = {x[grow] + v0, x[grow + 1] + v1};
+          *(sell_d2v *)(epi.d + row) = dn;
+          *(sell_d2v *)(epi.zout + row) = zn;
+        } else if (row < n) {
+          const double v0 = fma(epi.a, epi.d[row], epi.b * ((epi.dinv ? epi.dinv[row] : epi.dc) * (epi.r[row] - a0)));
+          epi.d[row] = v0;
+          epi.zout[row] = x[grow] + v0;
+        }
+      } else if (row + 1 < n) {
         const sell_d2v o = {a0, a1};
         *(sell_d2v *)(y + row) = o;
         if (xdot) {
@@ -1591,9 +1607,17 @@ void lsb_k_spmv_sell(unsigned flags, unsigned grid_cap, unsigned period, const u
                      unsigned s0, unsigned ns, unsigned n, unsigned row_begin, const void *cols,
                      const int *sbase, const double *vals, const double *x, double *y,
                      const double *xdot, double *partials, unsigned *npartials,
-                     const struct lsb_pcg_state *st, const struct lsb_ar_tail *tail_in, void *stream) {
+                     const struct lsb_pcg_state *st, const struct lsb_ar_tail *tail_in,
+                     const struct lsb_cheb_epi *epi_in, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   const lsb_ar_tail tail = tail_for(tail_in, partials);
+  lsb_cheb_epi epi;
+  memset(&epi, 0, sizeof epi);
+  if (epi_in && epi_in->zout) {
+    if (!(flags & LSB_SP_C16) || (flags & LSB_SP_F32) || partials || ((row_begin | s0) & 1u))
+      errx(EXIT_FAILURE, "lsb_k_spmv_sell: the Chebyshev epilogue rides in the 16-bit fp64 kernel only");
+    epi = *epi_in;
+  }
   const unsigned g = lsb_k_spmv_grid(LSB_SPMV_SELL, n, ns, 0, grid_cap ? grid_cap : 1536);
   if (npartials)
     *npartials = g;
@@ -1603,7 +1627,7 @@ void lsb_k_spmv_sell(unsigned flags, unsigned grid_cap, unsigned period, const u
     period = 0; /* less than a plane: contiguous dealing */
 #define LSB_SELL16(FL, VT, V)                                                                  \
   k_spmv_sell16<FL, VT><<<g, WG, 0, s>>>(sptr, s0, ns, period, n, row_begin, (const short *)cols, \
-                                         sbase, V, x, y, xdot, partials, st, tail)
+                                         sbase, V, x, y, xdot, partials, st, tail, epi)
 #define LSB_SELL32(FL, VT, V)                                                                  \
   k_spmv_sell<FL, VT><<<g, WG, 0, s>>>(sptr, s0, ns, period, n, (const int *)cols, V, x, y, xdot, \
                                        partials, st, tail)
@@ -1617,6 +1641,13 @@ void lsb_k_spmv_sell(unsigned flags, unsigned grid_cap, unsigned period, const u
       LSB_SELL32(SP_NT, float, vals32);
     else
       LSB_SELL32(0, float, vals32);
+  } else if (epi.zout) {
+    if (nt)
+      k_spmv_sell16<SP_NT, double, true><<<g, WG, 0, s>>>(sptr, s0, ns, period, n, row_begin, (const short *)cols,
+                                                          sbase, vals, x, y, xdot, partials, st, tail, epi);
+    else
+      k_spmv_sell16<0, double, true><<<g, WG, 0, s>>>(sptr, s0, ns, period, n, row_begin, (const short *)cols,
+                                                      sbase, vals, x, y, xdot, partials, st, tail, epi);
   } else if (flags & LSB_SP_C16) {
     if (nt)
       LSB_SELL16(SP_NT, double, vals);

@@ -165,6 +165,24 @@ void precond_setup(lsb_hip_solver *sv) {
                     "%d power iterations: %.6g)\n", m, sv->cheb_lmin, sv->cheb_lmax, CHEB_POWER_ITS, lam);
   for (int i = 0; i < sv->nshard; i++)
     LSB_CHK_HIP(hipMemsetAsync(sv->sh[i].d_zfull, 0, (size_t)sv->n_glob * sizeof(double), g_stream));
+  /* One shard in the 16-bit sliced-ELL form: the steps ride in the SpMV's epilogue
+   * (k_spmv_sell16<.., CHEB>): S z is never written, z' goes to a second gather vector.
+   * Step k reads buffer k & 1 and writes the other; the result is in buffer m & 1. */
+  {
+    struct shard *s = &sv->sh[0];
+    const char *e = getenv("LSBENCH_HIP_CHEB_FUSE");
+    sv->cheb_fused = !sv->multi && sv->nshard == 1 && s->variant == LSB_SPMV_SELL &&
+                     (s->sp_flags & LSB_SP_C16) && s->d_scodes && !s->mixed && !(s->row_begin & 1u) &&
+                     !(e && atoi(e) == 0);
+    if (sv->cheb_fused) {
+      s->d_zfull2 = (double *)lsb_hip_malloc((size_t)sv->n_glob * sizeof(double));
+      LSB_CHK_HIP(hipMemsetAsync(s->d_zfull2, 0, (size_t)sv->n_glob * sizeof(double), g_stream));
+      s->d_z = ((m & 1) ? s->d_zfull2 : s->d_zfull) + s->row_begin;
+    }
+    if (sv->o.verbose)
+      fprintf(stderr, "hip_cdna4: Chebyshev steps %s\n",
+              sv->cheb_fused ? "in the SpMV's epilogue" : "as launches of their own");
+  }
   LSB_CHK_HIP(hipStreamSynchronize(g_stream));
 }
 
@@ -177,6 +195,20 @@ void precond_apply(lsb_hip_solver *sv, int after_update) {
       /* after_update: k_pcg_update_xr's r.r partial sums are in d_parts2 (s->np2 records) */
       lsb_k_bj_apply(s->n, s->bj_bs, s->d_binv, s->d_r, s->d_z, s->d_bjpart, s->d_st,
                      after_update && !sv->multi ? s->d_parts2 : NULL, s->np2, g_stream);
+    }
+    return;
+  }
+  if (sv->cheb_fused) {
+    struct shard *s = &sv->sh[0];
+    double *buf[2] = {s->d_zfull, s->d_zfull2};
+    lsb_k_cheb_first(s->n, s->d_r, DINV(s), sv->cheb_c0, s->d_chd, buf[0] + s->row_begin, s->d_st, g_stream);
+    for (int k = 0; k < sv->cheb_m; k++) {
+      s->epi.r = s->d_r, s->epi.dinv = s->dinv_uniform ? NULL : s->d_dinv, s->epi.dc = s->dinv_const;
+      s->epi.a = sv->cheb_a[k], s->epi.b = sv->cheb_b[k], s->epi.d = s->d_chd;
+      s->epi.zout = buf[(k + 1) & 1] + s->row_begin;
+      sell_launch(s, 0, s->nslice, buf[k & 1], NULL, NULL, NULL, NULL, s->d_st);
+      s->epi.zout = NULL;
+      sv->nspmv++;
     }
     return;
   }
@@ -202,4 +234,5 @@ void precond_apply(lsb_hip_solver *sv, int after_update) {
 
 void precond_free_shard(struct shard *s) {
   lsb_hip_free(s->d_binv), lsb_hip_free(s->d_bjpart), lsb_hip_free(s->d_zfull), lsb_hip_free(s->d_chd);
+  lsb_hip_free(s->d_zfull2);
 }

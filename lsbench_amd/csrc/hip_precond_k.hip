@@ -81,7 +81,8 @@ __global__ __launch_bounds__(WG) void k_cheb_step(unsigned n, const double *__re
   if (st && st->status)
     return;
   for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n; i += (size_t)gridDim.x * WG) {
-    const double v = a * d[i] + b * ((dinv ? dinv[i] : dc) * (r[i] - w[i]));
+    // (explicit fma: the same bits as the step fused into the SpMV's epilogue, hip_kernels.hip)
+    const double v = fma(a, d[i], b * ((dinv ? dinv[i] : dc) * (r[i] - w[i])));
     d[i] = v;
     z[i] += v;
   }

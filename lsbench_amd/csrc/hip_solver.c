@@ -643,10 +643,10 @@ void sell_launch(struct shard *s, unsigned s0, unsigned ns, const double *xfull,
   const unsigned f32 = s->mixed ? LSB_SP_F32 : 0u; /* the value arrays hold floats then */
   if ((s->sp_flags & LSB_SP_C16) && s->d_scodes)
     lsb_k_spmv_sell(s->sp_flags | f32, s->sp_grid, s->sp_period, s->d_sptr16, s0, ns, s->n, s->row_begin, s->d_scodes,
-                    s->d_sbase, s->d_svals16, xfull, y, xdot, partials, np, st, &s->tail, g_stream);
+                    s->d_sbase, s->d_svals16, xfull, y, xdot, partials, np, st, &s->tail, &s->epi, g_stream);
   else
     lsb_k_spmv_sell((s->sp_flags & ~LSB_SP_C16) | f32, s->sp_grid, s->sp_period, s->d_sptr, s0, ns, s->n, s->row_begin,
-                    s->d_scols, NULL, s->d_svals, xfull, y, xdot, partials, np, st, &s->tail, g_stream);
+                    s->d_scols, NULL, s->d_svals, xfull, y, xdot, partials, np, st, &s->tail, NULL, g_stream);
 }
 
 void spmv_shard(struct shard *s, const double *xfull, double *y,

@@ -59,6 +59,9 @@ struct shard {
   unsigned npq, np2;   /* partial counts of the SpMV / sweep launches */
   const double *ar2_parts; /* sweep partials the next all-reduce folds in */
   unsigned ar2_n, ar2_width;
+  struct lsb_cheb_epi epi; /* zout != NULL: the next 16-bit sliced-ELL launch of this shard carries a
+                              Chebyshev step in its epilogue (precond_apply arms and clears it) */
+  double *d_zfull2;        /* its second gather vector: z' of step k is step k+1's z */
   struct lsb_ar_tail tail; /* counter != NULL: the next SpMV launch of this shard carries the
                               all-reduce's contribute phase (exchange_and_spmv arms and clears it) */
   /* rows that reference other shards' columns sit in row blocks [0,ov_b1) and
@@ -168,7 +171,7 @@ struct lsb_hip_solver {
   int cg1_implicit;
   int pcur; /* launch-bound fused path: which direction buffer is current */
 #define LSB_CHEB_MAX 16
-  int cheb_m;
+  int cheb_m, cheb_fused; /* fused: the steps ride in the SpMV's epilogue (one shard, 16-bit sliced-ELL) */
   double cheb_lmin, cheb_lmax, cheb_c0, cheb_a[LSB_CHEB_MAX], cheb_b[LSB_CHEB_MAX];
   unsigned nspmv; /* SpMV launches (per shard) of the solve being enqueued */
   /* launch-bound operators: the whole solve as one persistent launch (hip_persist.hip) */

@@ -49,6 +49,15 @@ struct lsb_ar_tail {
   unsigned nparts_before, nparts2, width2;
   int R, me;
 };
+/* A Chebyshev step riding in the epilogue of the 16-bit sliced-ELL SpMV (one shard):
+ * with w = (S z)_row just formed, d = a d + b D^-1 (r - w) and z' = z + d for the lane's
+ * own rows; z' goes to ANOTHER gather vector (other rows are still gathering z).
+ * zout == NULL: off.  The same expression as k_cheb_step, bit for bit. */
+struct lsb_cheb_epi {
+  const double *r, *dinv; /* dinv == NULL: the constant dc */
+  double *d, *zout;       /* local row indices */
+  double dc, a, b;
+};
 struct lsb_ar_collect {
   char *mbox; /* the own mailbox */
   unsigned long long epoch;
@@ -97,7 +106,8 @@ void lsb_k_spmv_sell(unsigned flags, unsigned grid_cap, unsigned period, const u
                      unsigned s0, unsigned ns, unsigned n, unsigned row_begin, const void *cols,
                      const int *sbase, const double *vals, const double *x, double *y,
                      const double *xdot, double *partials, unsigned *npartials,
-                     const struct lsb_pcg_state *st, const struct lsb_ar_tail *tail, void *stream);
+                     const struct lsb_pcg_state *st, const struct lsb_ar_tail *tail,
+                     const struct lsb_cheb_epi *epi, void *stream);
 void lsb_k_spmv_binned(unsigned flags, unsigned chunk_cap, const unsigned *chunk_begin, unsigned c0,
                        unsigned nchunk, const unsigned *rows, const unsigned *cols, const double *vals,
                        const double *x, double *y, const struct lsb_pcg_state *st, void *stream);

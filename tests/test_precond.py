@@ -130,3 +130,36 @@ def test_preconditioners_through_the_driver(hip, matrix_path, golden_x):
         x = np.array([float(l.split("=")[1]) for l in lines if l.startswith("x[")])
         assert int(h[2]) == 1 and int(h[0]) <= itmax
         assert np.linalg.norm(x - xg) / np.linalg.norm(xg) <= 1e-10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("degree", [1, 3, 4])
+def test_chebyshev_steps_in_the_spmv_epilogue(hip, monkeypatch, degree):
+    """One shard in the 16-bit sliced-ELL form: the Chebyshev steps ride in the SpMV's
+    epilogue (k_spmv_sell16<.., CHEB>; S z is never written, z' ping-pongs between two
+    gather vectors) -- the same expression as k_cheb_step, so the solve is bit-identical
+    to the one with the steps as launches of their own (LSBENCH_HIP_CHEB_FUSE=0), odd and
+    even degree, launches and graph replay; and it follows the oracle like that one."""
+    A = hip.lsbench_matrix_synth("lap2d:nx=301,ny=187")      # odd row count: the last lane's single row
+    b = O.rhs(A.nrows)
+    offs, cols, vals = O.lap2d(301, 187)
+    xo, ito, _, sto, _, _ = O.pcg_prec(offs, cols, vals, b, 1e-11, kind="cheb", param=degree)
+    out = {}
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("LSBENCH_HIP_CHEB_FUSE", fuse)
+        for graph in (0, 1):
+            s = hip.Solver(A, hip.default_opts(op_mode=hip.OP_RAW, precond=hip.PRECOND_CHEBYSHEV,
+                                               cheb_degree=degree, tol=1e-11, use_graph=graph,
+                                               spmv_variant=hip.SPMV_SELL))
+            assert s.spmv_variant == hip.SPMV_SELL
+            x, r = s.solve(b)
+            x2, r2 = s.solve(b)
+            s.destroy()
+            assert r.status == 1 and r2.iters == r.iters and np.array_equal(x, x2)
+            assert r.spmvs == r.iters * (degree + 1) + degree
+            out[fuse, graph] = (x, int(r.iters), r.relres)
+    ref = out["0", 0]
+    for k, v in out.items():
+        assert v[1] == ref[1] and v[2] == ref[2] and np.array_equal(v[0], ref[0]), k
+    assert sto == 1 and abs(ref[1] - ito) <= max(2, ito // 25)
+    assert np.linalg.norm(ref[0] - xo) / np.linalg.norm(xo) <= 1e-9
