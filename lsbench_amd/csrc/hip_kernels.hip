@@ -1614,8 +1614,8 @@ void lsb_k_spmv_sell(unsigned flags, unsigned grid_cap, unsigned period, const u
   lsb_cheb_epi epi;
   memset(&epi, 0, sizeof epi);
   if (epi_in && epi_in->zout) {
-    if (!(flags & LSB_SP_C16) || (flags & LSB_SP_F32) || partials || ((row_begin | s0) & 1u))
-      errx(EXIT_FAILURE, "lsb_k_spmv_sell: the Chebyshev epilogue rides in the 16-bit fp64 kernel only");
+    if (!(flags & LSB_SP_C16) || partials || ((row_begin | s0) & 1u))
+      errx(EXIT_FAILURE, "lsb_k_spmv_sell: the Chebyshev epilogue rides in the 16-bit kernel only");
     epi = *epi_in;
   }
   const unsigned g = lsb_k_spmv_grid(LSB_SPMV_SELL, n, ns, 0, grid_cap ? grid_cap : 1536);
@@ -1631,7 +1631,21 @@ void lsb_k_spmv_sell(unsigned flags, unsigned grid_cap, unsigned period, const u
 #define LSB_SELL32(FL, VT, V)                                                                  \
   k_spmv_sell<FL, VT><<<g, WG, 0, s>>>(sptr, s0, ns, period, n, (const int *)cols, V, x, y, xdot, \
                                        partials, st, tail)
-  if (flags & LSB_SP_F32) {
+  if (epi.zout) {
+#define LSB_SELL16C(FL, VT, V)                                                                            \
+  k_spmv_sell16<FL, VT, true><<<g, WG, 0, s>>>(sptr, s0, ns, period, n, row_begin, (const short *)cols, \
+                                               sbase, V, x, y, xdot, partials, st, tail, epi)
+    if (flags & LSB_SP_F32) {
+      if (nt)
+        LSB_SELL16C(SP_NT, float, vals32);
+      else
+        LSB_SELL16C(0, float, vals32);
+    } else if (nt)
+      LSB_SELL16C(SP_NT, double, vals);
+    else
+      LSB_SELL16C(0, double, vals);
+#undef LSB_SELL16C
+  } else if (flags & LSB_SP_F32) {
     if (flags & LSB_SP_C16) {
       if (nt)
         LSB_SELL16(SP_NT, float, vals32);
@@ -1641,13 +1655,6 @@ void lsb_k_spmv_sell(unsigned flags, unsigned grid_cap, unsigned period, const u
       LSB_SELL32(SP_NT, float, vals32);
     else
       LSB_SELL32(0, float, vals32);
-  } else if (epi.zout) {
-    if (nt)
-      k_spmv_sell16<SP_NT, double, true><<<g, WG, 0, s>>>(sptr, s0, ns, period, n, row_begin, (const short *)cols,
-                                                          sbase, vals, x, y, xdot, partials, st, tail, epi);
-    else
-      k_spmv_sell16<0, double, true><<<g, WG, 0, s>>>(sptr, s0, ns, period, n, row_begin, (const short *)cols,
-                                                      sbase, vals, x, y, xdot, partials, st, tail, epi);
   } else if (flags & LSB_SP_C16) {
     if (nt)
       LSB_SELL16(SP_NT, double, vals);

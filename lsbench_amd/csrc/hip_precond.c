@@ -172,7 +172,7 @@ void precond_setup(lsb_hip_solver *sv) {
     struct shard *s = &sv->sh[0];
     const char *e = getenv("LSBENCH_HIP_CHEB_FUSE");
     sv->cheb_fused = !sv->multi && sv->nshard == 1 && s->variant == LSB_SPMV_SELL &&
-                     (s->sp_flags & LSB_SP_C16) && s->d_scodes && !s->mixed && !(s->row_begin & 1u) &&
+                     (s->sp_flags & LSB_SP_C16) && s->d_scodes && !(s->row_begin & 1u) &&
                      !(e && atoi(e) == 0);
     if (sv->cheb_fused) {
       s->d_zfull2 = (double *)lsb_hip_malloc((size_t)sv->n_glob * sizeof(double));
