@@ -165,16 +165,21 @@ void precond_setup(lsb_hip_solver *sv) {
                     "%d power iterations: %.6g)\n", m, sv->cheb_lmin, sv->cheb_lmax, CHEB_POWER_ITS, lam);
   for (int i = 0; i < sv->nshard; i++)
     LSB_CHK_HIP(hipMemsetAsync(sv->sh[i].d_zfull, 0, (size_t)sv->n_glob * sizeof(double), g_stream));
-  /* One shard in the 16-bit sliced-ELL form: the steps ride in the SpMV's epilogue
+  /* Shards in the 16-bit sliced-ELL form: the steps ride in the SpMV's epilogue
    * (k_spmv_sell16<.., CHEB>): S z is never written, z' goes to a second gather vector.
-   * Step k reads buffer k & 1 and writes the other; the result is in buffer m & 1. */
+   * Step k reads buffer k & 1 and writes the other; the result is in buffer m & 1.
+   * (A rank whose shards do not qualify keeps the launches: the same exchanges, the same
+   * bits -- ranks need not agree.) */
   {
-    struct shard *s = &sv->sh[0];
     const char *e = getenv("LSBENCH_HIP_CHEB_FUSE");
-    sv->cheb_fused = !sv->multi && sv->nshard == 1 && s->variant == LSB_SPMV_SELL &&
-                     (s->sp_flags & LSB_SP_C16) && s->d_scodes && !(s->row_begin & 1u) &&
-                     !(e && atoi(e) == 0);
-    if (sv->cheb_fused) {
+    sv->cheb_fused = !(e && atoi(e) == 0);
+    for (int i = 0; i < sv->nshard; i++) {
+      const struct shard *s = &sv->sh[i];
+      sv->cheb_fused &= s->variant == LSB_SPMV_SELL && (s->sp_flags & LSB_SP_C16) && s->d_scodes &&
+                        !(s->row_begin & 1u);
+    }
+    for (int i = 0; i < sv->nshard && sv->cheb_fused; i++) {
+      struct shard *s = &sv->sh[i];
       s->d_zfull2 = (double *)lsb_hip_malloc((size_t)sv->n_glob * sizeof(double));
       LSB_CHK_HIP(hipMemsetAsync(s->d_zfull2, 0, (size_t)sv->n_glob * sizeof(double), g_stream));
       s->d_z = ((m & 1) ? s->d_zfull2 : s->d_zfull) + s->row_begin;
@@ -189,6 +194,8 @@ void precond_setup(lsb_hip_solver *sv) {
 /* z = M^-1 r on every shard (r = shard.d_r, z = shard.d_z); part of a running
  * solve: launches no-op once its state has left RUNNING */
 void precond_apply(lsb_hip_solver *sv, int after_update) {
+  if (sv->nshard > 64)
+    errx(EXIT_FAILURE, "hip_cdna4: more than 64 shards");
   if (sv->o.precond == LSB_PRECOND_BLOCKJACOBI) {
     for (int i = 0; i < sv->nshard; i++) {
       struct shard *s = &sv->sh[i];
@@ -199,15 +206,31 @@ void precond_apply(lsb_hip_solver *sv, int after_update) {
     return;
   }
   if (sv->cheb_fused) {
-    struct shard *s = &sv->sh[0];
-    double *buf[2] = {s->d_zfull, s->d_zfull2};
-    lsb_k_cheb_first(s->n, s->d_r, DINV(s), sv->cheb_c0, s->d_chd, buf[0] + s->row_begin, s->d_st, g_stream);
+    for (int i = 0; i < sv->nshard; i++) {
+      struct shard *s = &sv->sh[i];
+      lsb_k_cheb_first(s->n, s->d_r, DINV(s), sv->cheb_c0, s->d_chd, s->d_zfull + s->row_begin, s->d_st,
+                       g_stream);
+    }
     for (int k = 0; k < sv->cheb_m; k++) {
-      s->epi.r = s->d_r, s->epi.dinv = s->dinv_uniform ? NULL : s->d_dinv, s->epi.dc = s->dinv_const;
-      s->epi.a = sv->cheb_a[k], s->epi.b = sv->cheb_b[k], s->epi.d = s->d_chd;
-      s->epi.zout = buf[(k + 1) & 1] + s->row_begin;
-      sell_launch(s, 0, s->nslice, buf[k & 1], NULL, NULL, NULL, NULL, s->d_st);
-      s->epi.zout = NULL;
+      /* the exchange routines work on shard.d_pfull: lend them this step's z */
+      double *keep[64];
+      for (int i = 0; i < sv->nshard; i++) {
+        struct shard *s = &sv->sh[i];
+        keep[i] = s->d_pfull;
+        s->d_pfull = (k & 1) ? s->d_zfull2 : s->d_zfull;
+      }
+      if (sv->multi)
+        exchange_p(sv, 1);
+      for (int i = 0; i < sv->nshard; i++) {
+        struct shard *s = &sv->sh[i];
+        s->epi.r = s->d_r, s->epi.dinv = s->dinv_uniform ? NULL : s->d_dinv, s->epi.dc = s->dinv_const;
+        s->epi.a = sv->cheb_a[k], s->epi.b = sv->cheb_b[k], s->epi.d = s->d_chd;
+        s->epi.zout = ((k & 1) ? s->d_zfull : s->d_zfull2) + s->row_begin;
+        sell_launch(s, 0, s->nslice, s->d_pfull, NULL, NULL, NULL, NULL, s->d_st);
+        s->epi.zout = NULL;
+      }
+      for (int i = 0; i < sv->nshard; i++)
+        sv->sh[i].d_pfull = keep[i];
       sv->nspmv++;
     }
     return;

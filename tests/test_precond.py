@@ -166,3 +166,30 @@ def test_chebyshev_steps_in_the_spmv_epilogue(hip, monkeypatch, degree, precisio
         assert v[1] == ref[1] and v[2] == ref[2] and np.array_equal(v[0], ref[0]), k
     assert sto == 1 and abs(ref[1] - ito) <= max(2, ito // 25)
     assert np.linalg.norm(ref[0] - xo) / np.linalg.norm(xo) <= 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nvirt,comm", [(3, "COMM_AUTO"), (4, "COMM_P2P")])
+def test_chebyshev_epilogue_over_shards(hip, monkeypatch, nvirt, comm):
+    """The same over shards: the halo of z is exchanged in front of every step (from the
+    gather vector the step reads), the epilogue writes z' of the shard's own rows into the
+    other one -- bit-identical to the steps as launches, whatever carries the exchange."""
+    A = hip.lsbench_matrix_synth("lap3d:nx=40,ny=36,nz=30")
+    b = O.rhs(A.nrows)
+    out = {}
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("LSBENCH_HIP_CHEB_FUSE", fuse)
+        s = hip.Solver(A, hip.default_opts(op_mode=hip.OP_RAW, precond=hip.PRECOND_CHEBYSHEV, cheb_degree=3,
+                                           tol=1e-11, nvirt=nvirt, comm=getattr(hip, comm), verify=0,
+                                           spmv_variant=hip.SPMV_SELL))
+        x, r = s.solve(b)
+        x2, r2 = s.solve(b)
+        s.destroy()
+        assert r.status == 1 and r2.iters == r.iters and np.array_equal(x, x2)
+        out[fuse] = (x, int(r.iters), r.relres)
+    assert out["0"][1] == out["1"][1] and out["0"][2] == out["1"][2]
+    assert np.array_equal(out["0"][0], out["1"][0])
+    offs, cols, vals = O.lap3d(40, 36, 30)
+    xo, ito, _, sto, _, _ = O.pcg_prec(offs, cols, vals, b, 1e-11, kind="cheb", param=3)
+    assert sto == 1 and abs(out["1"][1] - ito) <= max(2, ito // 25)
+    assert np.linalg.norm(out["1"][0] - xo) / np.linalg.norm(xo) <= 1e-9
