@@ -308,6 +308,17 @@ static void p2p_rounds(lsb_hip_solver *sv, int rounds, int check, unsigned *d_ba
                                  d_bad, g_stream);
       lsb_p2p_test_setvals(s->d_scal, sv->dist ? lsb_hip_comm_rank() : i, (unsigned)t, g_stream);
     }
+    if (check && sv->p2p_on && (t & 1)) {
+      /* odd rounds: the split form single-reduction CG uses -- a contribute launch that
+       * waits for nobody, then the collect the way k_cg1_update runs it (64 workgroups, no
+       * fence), each comparing with the known sums */
+      for (int i = 0; i < sv->nshard; i++)
+        lsb_p2p_allreduce(sv->p2p[i], NULL, 0, 0, NULL, 0, 0, sv->sh[i].d_scal, 3, sv->sh[i].d_scal,
+                          sv->sh[i].d_st, 1, g_stream);
+      for (int i = 0; i < sv->nshard; i++)
+        lsb_p2p_test_collect_check(sv->p2p[i], (unsigned)t, d_bad, sv->sh[i].d_st, g_stream);
+      continue;
+    }
     allreduce_scal(sv, 0, 3, 1);
     for (int i = 0; i < sv->nshard && check; i++)
       lsb_p2p_test_checkvals(sv->sh[i].d_scal, sv->dist ? lsb_hip_comm_size() : sv->nshard,

@@ -234,6 +234,30 @@ __global__ void k_p2p_checkvals(const double *v, int R, unsigned round, unsigned
     atomicAdd(bad, 1u);
 }
 
+// The collect phase the way k_cg1_update runs it (hip_ar.h: every workgroup's first
+// wavefront, no acquire fence between the flag and the values), checked against the
+// self-test's known sums by every one of them.
+__global__ __launch_bounds__(P2P_WG) void k_p2p_collect_check(char *mbox, int R, u64 epoch,
+                                                              long long timeout, unsigned round,
+                                                              unsigned *bad,
+                                                              lsb_pcg_state *__restrict__ st) {
+  if (st && st->status)
+    return;
+  if (threadIdx.x >= 64)
+    return;
+  double v[3];
+  if (!ar_collect<false>(mbox, R, epoch, timeout, 3, v)) {
+    if (threadIdx.x == 0 && st)
+      __hip_atomic_store(&st->status, (int)LSB_STATUS_COMM, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  const double t = 0.5 * R * (R + 1);
+  if (threadIdx.x == 0 &&
+      (v[0] != t * (round + 1) || v[1] != t * (round + 7) * 0.5 || v[2] != t))
+    atomicAdd(bad, 1u);
+}
+
 // ---- host side --------------------------------------------------------------
 static unsigned wgs_for(size_t count) {
   size_t w = (count + 4095) / 4096;
@@ -524,6 +548,14 @@ extern "C" void lsb_p2p_fold_contribute(struct lsb_p2p *p, struct lsb_ar_tail *t
 }
 extern "C" void lsb_p2p_fold_collect(const struct lsb_p2p *p, struct lsb_ar_collect *c) {
   c->mbox = p->mbox, c->R = p->R, c->epoch = p->epoch_r, c->timeout = p->timeout_ticks;
+}
+
+/* self-test: collect what the last contribute (phases = 1) sent, the way the sweep does,
+ * in 64 workgroups at once, and compare with the round's known sums */
+extern "C" void lsb_p2p_test_collect_check(struct lsb_p2p *p, unsigned round, unsigned *d_bad,
+                                           struct lsb_pcg_state *st, void *stream) {
+  k_p2p_collect_check<<<64, P2P_WG, 0, (hipStream_t)stream>>>(p->mbox, p->R, p->epoch_r,
+                                                              p->timeout_ticks, round, d_bad, st);
 }
 
 /* self-test pieces (hip_cdna4.c drives them) */

@@ -243,6 +243,8 @@ void lsb_p2p_allreduce(struct lsb_p2p *p, const double *parts, unsigned nparts, 
                        struct lsb_pcg_state *st, int phases, void *stream);
 void lsb_p2p_fold_contribute(struct lsb_p2p *p, struct lsb_ar_tail *t);
 void lsb_p2p_fold_collect(const struct lsb_p2p *p, struct lsb_ar_collect *c);
+void lsb_p2p_test_collect_check(struct lsb_p2p *p, unsigned round, unsigned *d_bad,
+                                struct lsb_pcg_state *st, void *stream);
 void lsb_p2p_test_pattern(double *d_full, size_t goff, size_t n, unsigned round, void *stream);
 void lsb_p2p_test_check_range(const double *d_full, size_t goff, size_t n, unsigned round,
                               unsigned *d_bad, void *stream);
