@@ -364,6 +364,21 @@ struct lsb_sell *lsb_csr_sellize(const struct csr *A);
  * more than 255 slots or the copy does not fit 32-bit offsets. */
 struct lsb_sell *lsb_csr_sellize16(const struct csr *A, unsigned row_begin);
 void lsb_sell_free(struct lsb_sell *S);
+/* Constant slots of the 16-bit form: a slot whose 128 values are one and the same
+ * non-zero number -- a diagonal of a constant-coefficient stencil inside a slice, unit
+ * weights of a graph Laplacian -- needs no value array.  slots[4q .. 4q+3] = {base, code
+ * slot or -1 (as sbase), VALUE slot or -1, 0}; vconst[q] = the slot's value where the
+ * value slot is -1; vals holds the nval_slots remaining slots' 128 values, packed in slot
+ * order.  Lossless: the kernel forms the same products in the same order. */
+struct lsb_sell_vc {
+  unsigned long long nslots; /* = stored / LSB_SELL_ROWS of the copy it was made from */
+  unsigned nval_slots;
+  int *slots;     /* 4 * (nslots + 1) */
+  double *vconst; /* nslots + 1 */
+  double *vals;   /* (nval_slots + 1) * LSB_SELL_ROWS */
+};
+struct lsb_sell_vc *lsb_sell16_value_slots(const struct lsb_sell *S);
+void lsb_sell_vc_free(struct lsb_sell_vc *V);
 /* mean |col - (row + row_begin)| over a sample of the rows */
 double lsb_csr_mean_scatter(const struct csr *A, unsigned row_begin);
 /* [lo,hi) column range referenced by A (0-based). */

@@ -88,6 +88,12 @@ class Sell(C.Structure):
                 ("sbase", C.POINTER(C.c_int)), ("ncode_slots", C.c_uint)]
 
 
+class SellVc(C.Structure):
+    """struct lsb_sell_vc."""
+    _fields_ = [("nslots", C.c_ulonglong), ("nval_slots", C.c_uint), ("slots", C.POINTER(C.c_int)),
+                ("vconst", C.POINTER(C.c_double)), ("vals", C.POINTER(C.c_double))]
+
+
 class Binned(C.Structure):
     """struct lsb_binned."""
     _fields_ = [("nbins", C.c_uint), ("width", C.c_uint), ("nrows", C.c_uint), ("nchunks", C.c_uint),
@@ -158,6 +164,8 @@ SIGNATURES = {
     "lsb_csr_sellize": (C.POINTER(Sell), [_csrp]),
     "lsb_csr_sellize16": (C.POINTER(Sell), [_csrp, _u]),
     "lsb_sell_free": (None, [C.POINTER(Sell)]),
+    "lsb_sell16_value_slots": (C.POINTER(SellVc), [C.POINTER(Sell)]),
+    "lsb_sell_vc_free": (None, [C.POINTER(SellVc)]),
     "lsb_csr_mean_scatter": (_d, [_csrp, _u]),
     "lsb_csr_col_hull": (None, [_csrp, C.POINTER(_u), C.POINTER(_u)]),
     "lsb_plan_exchange": (None, [_i, _i, C.POINTER(_u), C.POINTER(Xfer), C.POINTER(_i),

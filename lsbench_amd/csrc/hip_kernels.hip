@@ -1058,6 +1058,8 @@ __device__ __forceinline__ unsigned sell_deal_slice(const sell_deal &d, unsigned
 }
 
 typedef int i2v __attribute__((ext_vector_type(2)));
+typedef int i4v __attribute__((ext_vector_type(4)));
+typedef double sell_d2u __attribute__((ext_vector_type(2), aligned(8))); // a 16-byte gather at an 8-byte boundary
 typedef double sell_d2v __attribute__((ext_vector_type(2)));
 #define SELL_U 5
 template <class VT> struct vt2;
@@ -1142,9 +1144,14 @@ template <int FLAGS, class VT = double, bool CHEB = false>
 __global__ __launch_bounds__(WG, 6) void k_spmv_sell16(
     const unsigned *__restrict__ sptr, unsigned s0, unsigned ns, unsigned period, unsigned n,
     unsigned row_begin, const short *__restrict__ codes, const int *__restrict__ sbase,
-    const VT *__restrict__ vals, const double *__restrict__ x, double *__restrict__ y,
-    const double *__restrict__ xdot, double *__restrict__ partials,
+    const VT *__restrict__ vals, const double *__restrict__ vconst, unsigned ulen,
+    const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ xdot,
+    double *__restrict__ partials,
     const lsb_pcg_state *__restrict__ st, const lsb_ar_tail tail, const lsb_cheb_epi epi) {
+  // vconst != NULL: the constant-slot layout (lsb_sell16_value_slots) -- sbase holds
+  // {base, code slot, value slot, 0} per slot, and a slot whose value slot is -1 has the
+  // one value vconst[slot] for all its 128 entries (every interior diagonal of a
+  // constant-coefficient stencil): 8 bytes per SLOT instead of per entry.
   __shared__ double sred[4];
   const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const unsigned gx = gridDim.x / NXCD, xcd = blockIdx.x % NXCD, slot = blockIdx.x / NXCD;
@@ -1156,41 +1163,108 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_sell16(
     if (si != 0xFFFFFFFFu) {
       const unsigned s = s0 + si;
       typedef typename vt2<VT>::type v2t;
-      const unsigned base = sptr[s], len = (sptr[s + 1] - base) / LSB_SELL_ROWS;
-      const v2t *vp = (const v2t *)(vals + base) + lane;
-      const i2v *bp = (const i2v *)sbase + base / LSB_SELL_ROWS; // {base, code slot or -1}
+      // ulen != 0: every slice has ulen slots -- no look at sptr, one memory round trip
+      // less in front of the gathers (with the values gone the kernel waits on its chain
+      // of dependent loads, not on bandwidth)
+      const unsigned base = ulen ? s * ulen * LSB_SELL_ROWS : sptr[s];
+      const unsigned len = ulen ? ulen : (sptr[s + 1] - base) / LSB_SELL_ROWS;
+      const unsigned q0 = base / LSB_SELL_ROWS; // first slot of the slice
       const unsigned row = s * LSB_SELL_ROWS + 2 * lane;
       const int grow = (int)(row + row_begin);
       double a0 = 0.0, a1 = 0.0;
+      sell_d2v xd = {0.0, 0.0}; // the dot's operand: asked for up front, not behind the gathers
+      if (!CHEB && xdot) {
+        if (row + 1 < n)
+          xd = *(const sell_d2v *)(xdot + row);
+        else if (row < n)
+          xd.x = xdot[row];
+      }
       for (unsigned j0 = 0; j0 < len; j0 += SELL_U) {
+        if (vconst) {
+          // The common case of a constant-coefficient operator: every slot of this group is
+          // constant (no values, no padding) with one common code.  Straight-line code: all
+          // slot records and constants by scalar loads in one go, then one 16-byte gather per
+          // lane and slot -- rows 2l and 2l + 1 read x at grow + b and grow + b + 1 -- all in
+          // flight together (a branch per slot makes every one of them a round trip of its
+          // own: 61 us instead of the 3x fewer bytes' worth on the 10 M-row operator).
+          const unsigned cnt = len - j0 < SELL_U ? len - j0 : SELL_U;
+          i4v rec[SELL_U];
+          double cst[SELL_U];
+#pragma unroll
+          for (int u = 0; u < SELL_U; u++) { // (past the group's end: its last slot again)
+            const unsigned q = q0 + j0 + ((unsigned)u < cnt ? (unsigned)u : cnt - 1u);
+            rec[u] = ((const i4v *)sbase)[q];
+            cst[u] = vconst[q];
+          }
+          bool fast = true;
+#pragma unroll
+          for (int u = 0; u < SELL_U; u++)
+            fast = fast && (rec[u].y < 0 && rec[u].z < 0);
+          if (fast) {
+            if (stopped)
+              return;
+            sell_d2u t[SELL_U];
+#pragma unroll
+            for (int u = 0; u < SELL_U; u++)
+              t[u] = *(const sell_d2u *)(x + (grow + rec[u].x));
+#pragma unroll
+            for (int u = 0; u < SELL_U; u++)
+              if ((unsigned)u < cnt) { // the same products in the same order as below
+                const VT cv = (VT)cst[u];
+                a0 += (double)cv * t[u].x;
+                a1 += (double)cv * t[u].y;
+              }
+            continue;
+          }
+        }
         s2v c[SELL_U];
         v2t v[SELL_U];
         int b[SELL_U];
+        bool pair[SELL_U]; // wave-uniform: both rows of every lane gather at the same offset
 #pragma unroll
         for (int u = 0; u < SELL_U; u++)
           if (j0 + u < len) {
-            const i2v bk = bp[j0 + u]; // wave-uniform: scalar load
-            b[u] = bk.x;
+            const unsigned q = q0 + j0 + u;
+            int kc, kv; // wave-uniform: scalar loads
+            if (vconst) {
+              const i4v bk = ((const i4v *)sbase)[q];
+              b[u] = bk.x, kc = bk.y, kv = bk.z;
+            } else {
+              const i2v bk = ((const i2v *)sbase)[q]; // {base, code slot or -1}
+              b[u] = bk.x, kc = bk.y, kv = (int)q;
+            }
             c[u] = (s2v){0, 0};
-            if (bk.y >= 0) { // slots with one common code carry none
-              const s2v *cp = (const s2v *)codes + (size_t)bk.y * 64 + lane;
+            if (kc >= 0) { // slots with one common code carry none
+              const s2v *cp = (const s2v *)codes + (size_t)kc * 64 + lane;
               c[u] = (FLAGS & SP_NT) ? __builtin_nontemporal_load(cp) : *cp;
             }
-            if (FLAGS & SP_NT)
-              v[u] = __builtin_nontemporal_load(vp + (size_t)(j0 + u) * 64);
-            else
-              v[u] = vp[(size_t)(j0 + u) * 64];
+            if (kv >= 0) {
+              const v2t *vp = (const v2t *)(vals + (size_t)kv * LSB_SELL_ROWS) + lane;
+              v[u] = (FLAGS & SP_NT) ? __builtin_nontemporal_load(vp) : *vp;
+            } else { // one value for the slot's 128 entries
+              const VT cv = (VT)vconst[q];
+              v[u] = (v2t){cv, cv};
+            }
+            // a constant slot has no padding; with one common code as well, rows 2l and
+            // 2l + 1 read x at grow + b and grow + b + 1: ONE 16-byte gather per lane
+            pair[u] = kv < 0 && kc < 0;
           }
         if (stopped)
           return;
 #pragma unroll
         for (int u = 0; u < SELL_U; u++)
           if (j0 + u < len) {
-            const bool p0 = v[u].x != (VT)0, p1 = v[u].y != (VT)0;
-            const double t0 = x[p0 ? grow + b[u] + (int)c[u].x : 0];
-            const double t1 = x[p1 ? grow + 1 + b[u] + (int)c[u].y : 0];
-            a0 += (double)v[u].x * (p0 ? t0 : 0.0);
-            a1 += (double)v[u].y * (p1 ? t1 : 0.0);
+            if (pair[u]) {
+              const sell_d2u t = *(const sell_d2u *)(x + (grow + b[u]));
+              a0 += (double)v[u].x * t.x;
+              a1 += (double)v[u].y * t.y;
+            } else {
+              const bool p0 = v[u].x != (VT)0, p1 = v[u].y != (VT)0;
+              const double t0 = x[p0 ? grow + b[u] + (int)c[u].x : 0];
+              const double t1 = x[p1 ? grow + 1 + b[u] + (int)c[u].y : 0];
+              a0 += (double)v[u].x * (p0 ? t0 : 0.0);
+              a1 += (double)v[u].y * (p1 ? t1 : 0.0);
+            }
           }
       }
       if (CHEB) { // d = a d + b D^-1 (r - w); z' = z + d -- k_cheb_step's expression
@@ -1211,13 +1285,13 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_sell16(
         const sell_d2v o = {a0, a1};
         *(sell_d2v *)(y + row) = o;
         if (xdot) {
-          dot += a0 * xdot[row];
-          dot += a1 * xdot[row + 1];
+          dot += a0 * xd.x;
+          dot += a1 * xd.y;
         }
       } else if (row < n) {
         y[row] = a0;
         if (xdot)
-          dot += a0 * xdot[row];
+          dot += a0 * xd.x;
       }
     }
   }
@@ -1605,8 +1679,9 @@ void lsb_k_spmv_subwave_p(unsigned n, const int *offs, const int *cols, const do
  * of local row 0); else `cols` holds 32-bit column ids and sbase is unused. */
 void lsb_k_spmv_sell(unsigned flags, unsigned grid_cap, unsigned period, const unsigned *sptr,
                      unsigned s0, unsigned ns, unsigned n, unsigned row_begin, const void *cols,
-                     const int *sbase, const double *vals, const double *x, double *y,
-                     const double *xdot, double *partials, unsigned *npartials,
+                     const int *sbase, const double *vals, const double *vconst, unsigned ulen,
+                     const double *x, double *y, const double *xdot, double *partials,
+                     unsigned *npartials,
                      const struct lsb_pcg_state *st, const struct lsb_ar_tail *tail_in,
                      const struct lsb_cheb_epi *epi_in, void *stream) {
   hipStream_t s = (hipStream_t)stream;
@@ -1627,14 +1702,14 @@ void lsb_k_spmv_sell(unsigned flags, unsigned grid_cap, unsigned period, const u
     period = 0; /* less than a plane: contiguous dealing */
 #define LSB_SELL16(FL, VT, V)                                                                  \
   k_spmv_sell16<FL, VT><<<g, WG, 0, s>>>(sptr, s0, ns, period, n, row_begin, (const short *)cols, \
-                                         sbase, V, x, y, xdot, partials, st, tail, epi)
+                                         sbase, V, vconst, ulen, x, y, xdot, partials, st, tail, epi)
 #define LSB_SELL32(FL, VT, V)                                                                  \
   k_spmv_sell<FL, VT><<<g, WG, 0, s>>>(sptr, s0, ns, period, n, (const int *)cols, V, x, y, xdot, \
                                        partials, st, tail)
   if (epi.zout) {
 #define LSB_SELL16C(FL, VT, V)                                                                            \
   k_spmv_sell16<FL, VT, true><<<g, WG, 0, s>>>(sptr, s0, ns, period, n, row_begin, (const short *)cols, \
-                                               sbase, V, x, y, xdot, partials, st, tail, epi)
+                                               sbase, V, vconst, ulen, x, y, xdot, partials, st, tail, epi)
     if (flags & LSB_SP_F32) {
       if (nt)
         LSB_SELL16C(SP_NT, float, vals32);

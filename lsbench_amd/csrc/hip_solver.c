@@ -290,10 +290,36 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
       if (H) {
         s->d_sptr16 = (unsigned *)dev_upload(H->sptr, ((size_t)H->nslice + 1) * sizeof(unsigned));
         s->d_scodes = (short *)dev_upload(H->codes, ((size_t)H->ncode_slots + 1) * LSB_SELL_ROWS * sizeof(short));
-        s->d_sbase = (int *)dev_upload(H->sbase, 2 * ((size_t)H->stored / LSB_SELL_ROWS + 1) * sizeof(int));
-        s->d_svals16 = s->mixed ? (double *)upload_f32(H->vals, (size_t)H->stored + LSB_SELL_ROWS, NULL)
-                                : (double *)dev_upload(H->vals, ((size_t)H->stored + LSB_SELL_ROWS) * sizeof(double));
+        /* slots whose 128 values are one number keep it once (lsb_sell16_value_slots): on a
+         * constant-coefficient stencil that is every slot away from the grid's faces.  Taken
+         * where it drops at least an eighth of the value slots. */
+        { /* every slice the same number of slots?  then the kernel needs no look at sptr */
+          unsigned ul = H->nslice ? (H->sptr[1] - H->sptr[0]) / LSB_SELL_ROWS : 0;
+          for (unsigned k = 0; k < H->nslice && ul; k++)
+            if ((H->sptr[k + 1] - H->sptr[k]) / LSB_SELL_ROWS != ul)
+              ul = 0;
+          s->sell_ulen = getenv("LSBENCH_HIP_NO_ULEN") ? 0 : ul;
+        }
+        struct lsb_sell_vc *V = getenv("LSBENCH_HIP_NO_VCONST") ? NULL : lsb_sell16_value_slots(H);
+        if (V && (unsigned long long)V->nval_slots * 8 > V->nslots * 7) {
+          lsb_sell_vc_free(V);
+          V = NULL;
+        }
+        if (V) {
+          const size_t nv = ((size_t)V->nval_slots + 1) * LSB_SELL_ROWS;
+          s->d_sbase = (int *)dev_upload(V->slots, 4 * ((size_t)V->nslots + 1) * sizeof(int));
+          s->d_svconst = (double *)dev_upload(V->vconst, ((size_t)V->nslots + 1) * sizeof(double));
+          s->d_svals16 = s->mixed ? (double *)upload_f32(V->vals, nv, NULL)
+                                  : (double *)dev_upload(V->vals, nv * sizeof(double));
+          s->sell_vslots = V->nval_slots, s->sell_slots = (unsigned)V->nslots;
+        } else {
+          s->d_sbase = (int *)dev_upload(H->sbase, 2 * ((size_t)H->stored / LSB_SELL_ROWS + 1) * sizeof(int));
+          s->d_svals16 = s->mixed ? (double *)upload_f32(H->vals, (size_t)H->stored + LSB_SELL_ROWS, NULL)
+                                  : (double *)dev_upload(H->vals, ((size_t)H->stored + LSB_SELL_ROWS) * sizeof(double));
+          s->sell_vslots = s->sell_slots = (unsigned)(H->stored / LSB_SELL_ROWS);
+        }
         LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+        lsb_sell_vc_free(V);
         lsb_sell_free(H);
       }
     }
@@ -366,7 +392,7 @@ void shard_free(struct shard *s) {
   lsb_hip_free(s->pd_rowmap), lsb_hip_free(s->pd_rowblk), lsb_hip_free(s->pd_blklanes);
   lsb_hip_free(s->d_sptr), lsb_hip_free(s->d_scols), lsb_hip_free(s->d_svals);
   lsb_hip_free(s->d_sptr16), lsb_hip_free(s->d_scodes), lsb_hip_free(s->d_sbase);
-  lsb_hip_free(s->d_svals16);
+  lsb_hip_free(s->d_svals16), lsb_hip_free(s->d_svconst);
   free(s->h_pblk);
   lsb_hip_free(s->bd_chunk), lsb_hip_free(s->bd_rows), lsb_hip_free(s->bd_cols);
   lsb_hip_free(s->bd_vals);
@@ -643,10 +669,11 @@ void sell_launch(struct shard *s, unsigned s0, unsigned ns, const double *xfull,
   const unsigned f32 = s->mixed ? LSB_SP_F32 : 0u; /* the value arrays hold floats then */
   if ((s->sp_flags & LSB_SP_C16) && s->d_scodes)
     lsb_k_spmv_sell(s->sp_flags | f32, s->sp_grid, s->sp_period, s->d_sptr16, s0, ns, s->n, s->row_begin, s->d_scodes,
-                    s->d_sbase, s->d_svals16, xfull, y, xdot, partials, np, st, &s->tail, &s->epi, g_stream);
+                    s->d_sbase, s->d_svals16, s->d_svconst, s->sell_ulen, xfull, y, xdot, partials, np, st, &s->tail, &s->epi,
+                    g_stream);
   else
     lsb_k_spmv_sell((s->sp_flags & ~LSB_SP_C16) | f32, s->sp_grid, s->sp_period, s->d_sptr, s0, ns, s->n, s->row_begin,
-                    s->d_scols, NULL, s->d_svals, xfull, y, xdot, partials, np, st, &s->tail, NULL, g_stream);
+                    s->d_scols, NULL, s->d_svals, NULL, 0, xfull, y, xdot, partials, np, st, &s->tail, NULL, g_stream);
 }
 
 void spmv_shard(struct shard *s, const double *xfull, double *y,
@@ -829,8 +856,8 @@ void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
   }
   if (!(bv == LSB_SPMV_SELL && (bf & LSB_SP_C16))) {
     lsb_hip_free(s->d_sptr16), lsb_hip_free(s->d_scodes), lsb_hip_free(s->d_sbase);
-    lsb_hip_free(s->d_svals16);
-    s->d_sptr16 = NULL, s->d_scodes = NULL, s->d_sbase = NULL, s->d_svals16 = NULL;
+    lsb_hip_free(s->d_svals16), lsb_hip_free(s->d_svconst);
+    s->d_sptr16 = NULL, s->d_scodes = NULL, s->d_sbase = NULL, s->d_svals16 = NULL, s->d_svconst = NULL;
   }
   if (any && !(bv == LSB_SPMV_SELL && !(bf & LSB_SP_C16))) {
     lsb_hip_free(s->d_scols), lsb_hip_free(s->d_svals);

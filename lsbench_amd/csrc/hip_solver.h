@@ -82,6 +82,10 @@ struct shard {
   short *d_scodes;
   int *d_sbase;
   double *d_svals16;
+  double *d_svconst;       /* != NULL: the constant-slot layout (lsb_sell16_value_slots): d_sbase holds 4
+                              ints per slot, d_svals16 only the sell_vslots slots that keep their values */
+  unsigned sell_vslots, sell_slots;
+  unsigned sell_ulen;      /* != 0: every slice of the 16-bit copy has this many slots */
   double *d_parts_pq, *d_parts2;
   double *d_scal; /* [0] p.q   [1] r.z'  [2] r.r   (multi-shard path) */
   struct lsb_pcg_state *d_st;

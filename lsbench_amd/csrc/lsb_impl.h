@@ -104,8 +104,9 @@ unsigned lsb_k_spmv_grid(int variant, unsigned n, unsigned nblk,
 #define LSB_SP_F32 32u /* the values pointer holds fp32 (opts.precision = LSB_PREC_MIXED) */
 void lsb_k_spmv_sell(unsigned flags, unsigned grid_cap, unsigned period, const unsigned *sptr,
                      unsigned s0, unsigned ns, unsigned n, unsigned row_begin, const void *cols,
-                     const int *sbase, const double *vals, const double *x, double *y,
-                     const double *xdot, double *partials, unsigned *npartials,
+                     const int *sbase, const double *vals, const double *vconst, unsigned ulen,
+                     const double *x, double *y, const double *xdot, double *partials,
+                     unsigned *npartials,
                      const struct lsb_pcg_state *st, const struct lsb_ar_tail *tail,
                      const struct lsb_cheb_epi *epi, void *stream);
 void lsb_k_spmv_binned(unsigned flags, unsigned chunk_cap, const unsigned *chunk_begin, unsigned c0,

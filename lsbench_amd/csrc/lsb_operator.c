@@ -949,6 +949,41 @@ struct lsb_sell *lsb_csr_sellize16(const struct csr *A, unsigned row_begin) {
   return S;
 }
 
+struct lsb_sell_vc *lsb_sell16_value_slots(const struct lsb_sell *S) {
+  if (!S || !S->codes || !S->sbase)
+    return NULL;
+  const size_t nslots = (size_t)(S->stored / LSB_SELL_ROWS);
+  struct lsb_sell_vc *V = lsb_calloc(struct lsb_sell_vc, 1);
+  V->nslots = nslots;
+  V->slots = lsb_calloc(int, 4 * (nslots + 1));
+  V->vconst = lsb_calloc(double, nslots + 1);
+  size_t nv = 0;
+  for (size_t q = 0; q < nslots; q++) { /* which slots keep their values */
+    const double *v = S->vals + q * LSB_SELL_ROWS;
+    int same = v[0] != 0.0;
+    for (unsigned l = 1; l < LSB_SELL_ROWS && same; l++)
+      same = memcmp(v + l, v, sizeof(double)) == 0; /* the same BITS */
+    V->slots[4 * q] = S->sbase[2 * q], V->slots[4 * q + 1] = S->sbase[2 * q + 1];
+    V->slots[4 * q + 2] = same ? -1 : (int)nv++;
+    V->vconst[q] = same ? v[0] : 0.0;
+  }
+  V->nval_slots = (unsigned)nv;
+  V->vals = (double *)calloc((nv + 1) * LSB_SELL_ROWS, sizeof(double));
+  if (!V->vals)
+    errx(EXIT_FAILURE, "lsb_sell16_value_slots: out of memory");
+  for (size_t q = 0; q < nslots; q++)
+    if (V->slots[4 * q + 2] >= 0)
+      memcpy(V->vals + (size_t)V->slots[4 * q + 2] * LSB_SELL_ROWS, S->vals + q * LSB_SELL_ROWS,
+             LSB_SELL_ROWS * sizeof(double));
+  return V;
+}
+
+void lsb_sell_vc_free(struct lsb_sell_vc *V) {
+  if (!V)
+    return;
+  free(V->slots), free(V->vconst), free(V->vals), free(V);
+}
+
 void lsb_sell_free(struct lsb_sell *S) {
   if (!S)
     return;

@@ -596,3 +596,37 @@ def test_twophase_form(spec, tiling):
     y = np.zeros(A.nrows)
     np.add.at(y, bin_of_slot * R + roww, prod)
     assert np.allclose(y, O.spmv(A.offs, A.cols, A.vals, x[:A.nrows]), rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("spec,frac_kept", [("lap2d:nx=300,ny=170", 0.5), ("lap3d:nx=40,ny=36,nz=30", 0.6),
+                                            ("powerlaw:n=3000,gamma=2.2,max=64,seed=5", 1.0)])
+def test_sell16_value_slots(spec, frac_kept):
+    """lsb_sell16_value_slots: slots of the 16-bit sliced-ELL copy whose 128 values are one
+    non-zero number keep it once; the others keep their values, packed in slot order; base
+    and code slot are carried over.  Lossless: every value is recovered bit for bit."""
+    import ctypes as C
+    lib = la._lib.load()
+    A = la.lsbench_matrix_synth(spec)
+    p = lib.lsb_csr_sellize16(A.ptr, 0)
+    assert p
+    S = p.contents
+    nq = int(S.stored) // la._lib.SELL_ROWS
+    vals = np.ctypeslib.as_array(S.vals, (int(S.stored),)).copy()
+    sbase = np.ctypeslib.as_array(S.sbase, (2 * nq,)).copy().reshape(nq, 2)
+    v = lib.lsb_sell16_value_slots(p)
+    V = v.contents
+    assert int(V.nslots) == nq
+    slots = np.ctypeslib.as_array(V.slots, (4 * nq,)).copy().reshape(nq, 4)
+    vconst = np.ctypeslib.as_array(V.vconst, (nq,)).copy()
+    packed = np.ctypeslib.as_array(V.vals, (max(int(V.nval_slots), 1) * 128,)).copy()
+    nv = int(V.nval_slots)
+    lib.lsb_sell_vc_free(v)
+    lib.lsb_sell_free(p)
+    assert np.array_equal(slots[:, :2], sbase) and np.all(slots[:, 3] == 0)
+    kept = slots[:, 2] >= 0
+    assert kept.sum() == nv and np.array_equal(slots[kept, 2], np.arange(nv))
+    rebuilt = np.where(kept[:, None], packed.reshape(-1, 128)[np.maximum(slots[:, 2], 0)], vconst[:, None])
+    assert np.array_equal(rebuilt.view(np.uint64), vals.reshape(nq, 128).view(np.uint64))
+    const = vals.reshape(nq, 128)
+    assert np.array_equal(~kept, (const[:, :1] == const).all(axis=1) & (const[:, 0] != 0.0))
+    assert nv <= frac_kept * nq         # a stencil: most slots are one number (random values: none)

@@ -210,3 +210,35 @@ def test_plane_periodic_dealing_of_a_3d_stencil(hip, nvirt, overlap, comm, monke
     s.spmv_dev(torch.from_numpy(x).to("cuda:0"), d_y0)
     s.destroy()
     assert np.array_equal(d_y0.cpu().numpy(), y)          # a row's sum does not depend on the dealing
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spec,nvirt,precision", [("lap2d:nx=411,ny=203", 1, "FP64"), ("lap3d:nx=48,ny=40,nz=36", 1, "FP64"),
+                                                  ("lap3d:nx=48,ny=40,nz=36", 3, "FP64"), ("lap2d:nx=411,ny=203", 2, "MIXED")])
+def test_constant_slots_change_no_bit(hip, monkeypatch, spec, nvirt, precision):
+    """The constant-slot layout of the 16-bit sliced-ELL form (lsb_sell16_value_slots: one
+    value per slot whose 128 entries are equal) against the layout with every value stored
+    (LSBENCH_HIP_NO_VCONST=1): the same products in the same order -- SpMV, fused dot and
+    the whole solve bit for bit; over shards and with fp32 matrix values."""
+    import torch
+    A = hip.lsbench_matrix_synth(spec)
+    b = O.rhs(A.nrows)
+    xs = np.sin(np.arange(A.nrows, dtype=np.float64))
+    out = {}
+    for off in ("1", None):
+        if off:
+            monkeypatch.setenv("LSBENCH_HIP_NO_VCONST", off)
+        else:
+            monkeypatch.delenv("LSBENCH_HIP_NO_VCONST", raising=False)
+        s = hip.Solver(A, hip.default_opts(op_mode=hip.OP_RAW, spmv_variant=hip.SPMV_SELL, nvirt=nvirt,
+                                           tol=1e-10, precision=getattr(hip, "PREC_" + precision)))
+        assert s.spmv_variant == hip.SPMV_SELL
+        d_y = torch.empty(A.nrows, dtype=torch.float64, device="cuda:0")
+        s.spmv_dev(torch.from_numpy(xs).to("cuda:0"), d_y)
+        x, r = s.solve(b)
+        s.destroy()
+        out[off] = (d_y.cpu().numpy(), x, int(r.iters), r.relres)
+    assert np.array_equal(out["1"][0], out[None][0]) and np.array_equal(out["1"][1], out[None][1])
+    assert out["1"][2:] == out[None][2:]
+    yo = O.spmv(A.offs, A.cols, A.vals, xs)
+    assert np.allclose(out[None][0], yo, rtol=1e-13, atol=1e-13)
