@@ -422,7 +422,10 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
                      "traffic_source": traffic_src,
                      "note": "achieved/frac are quoted on SURVEY 8(d)'s CSR byte count (12 B per "
                              "non-zero + 20 B per row); the sliced-ELL layout the kernel reads stores "
-                             "8-10 B per entry, so frac exceeds frac_hbm (PMC bytes / time / peak)",
+                             "8-10 B per entry, and ONE value for a slot whose 128 entries are equal "
+                             "(value_slots: kept / all -- a constant-coefficient stencil keeps few), so "
+                             "frac can exceed 1; frac_hbm = PMC bytes / time / peak is what the HBM moved",
+                     "value_slots": dict(zip(("kept", "all"), solver.sell_value_slots)),
                      "kernel": kernel + (" (panels)" if solver.spmv_variant == la.SPMV_PANEL else "") + " (fused p.q)",
                      "launch_ms": spmv_avg_ms, "back_to_back_launch_ms": b2b_ms,
                      "spmv_flags": solver.spmv_flags, "xcd_period_slices": solver.spmv_period,

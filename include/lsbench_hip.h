@@ -456,6 +456,9 @@ unsigned lsb_hip_solver_spmv_grid(const lsb_hip_solver *s);
 /* sliced-ELL: slices per plane the XCD dealing follows (every XCD the same eighth
  * of every plane of a 3-D stencil), 0 = contiguous eighths of the rows. */
 unsigned lsb_hip_solver_spmv_period(const lsb_hip_solver *s);
+/* 16-bit sliced-ELL form in use: slots that keep their 128 values / all slots of the
+ * first shard (lsb_sell16_value_slots); 0 / 0 for every other form */
+void lsb_hip_solver_sell_value_slots(const lsb_hip_solver *s, unsigned *kept, unsigned *total);
 /* 1 when the halo exchange of this solver runs behind its interior rows. */
 int lsb_hip_solver_overlaps(const lsb_hip_solver *s);
 /* 0 one shard; 1 RCCL (device copies between virtual shards); 2 direct xGMI

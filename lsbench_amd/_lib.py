@@ -188,6 +188,7 @@ SIGNATURES = {
     "lsb_hip_solver_spmv_flags": (_u, [_vp]),
     "lsb_hip_solver_spmv_grid": (_u, [_vp]),
     "lsb_hip_solver_spmv_period": (_u, [_vp]),
+    "lsb_hip_solver_sell_value_slots": (None, [_vp, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
     "lsb_hip_solver_overlaps": (_i, [_vp]),
     "lsb_hip_solver_comm": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "lsb_hip_stream": (_vp, []),

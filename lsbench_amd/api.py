@@ -307,6 +307,15 @@ class Solver:
         return L.load().lsb_hip_solver_spmv_period(self._h)
 
     @property
+    def sell_value_slots(self):
+        """(slots that keep their 128 values, all slots) of the 16-bit sliced-ELL form in use,
+        (0, 0) for every other form."""
+        import ctypes as C
+        k, t = C.c_uint(0), C.c_uint(0)
+        L.load().lsb_hip_solver_sell_value_slots(self._h, C.byref(k), C.byref(t))
+        return int(k.value), int(t.value)
+
+    @property
     def comm(self):
         """(mode, p2p_us, rccl_us): mode 0 = one shard, 1 = RCCL / device copies,
         2 = direct xGMI stores for the all-reduces, 3 = and for the halos; the

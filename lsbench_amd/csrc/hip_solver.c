@@ -652,6 +652,14 @@ int lsb_hip_solver_spmv_variant(const lsb_hip_solver *s) { return s->sh[0].varia
 unsigned lsb_hip_solver_spmv_flags(const lsb_hip_solver *s) { return s->sh[0].sp_flags; }
 unsigned lsb_hip_solver_spmv_grid(const lsb_hip_solver *s) { return s->sh[0].sp_grid; }
 unsigned lsb_hip_solver_spmv_period(const lsb_hip_solver *s) { return s->sh[0].sp_period; }
+void lsb_hip_solver_sell_value_slots(const lsb_hip_solver *s, unsigned *kept, unsigned *total) {
+  const struct shard *h = &s->sh[0];
+  const int on = h->variant == LSB_SPMV_SELL && (h->sp_flags & LSB_SP_C16) && h->d_scodes;
+  if (kept)
+    *kept = on ? h->sell_vslots : 0;
+  if (total)
+    *total = on ? h->sell_slots : 0;
+}
 int can_overlap(const lsb_hip_solver *sv);
 int lsb_hip_solver_overlaps(const lsb_hip_solver *s) { return can_overlap(s); }
 int lsb_hip_solver_comm(const lsb_hip_solver *s, double *p2p_us, double *rccl_us) {
