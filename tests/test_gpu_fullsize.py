@@ -160,7 +160,11 @@ def test_bench_line_contract():
     assert abs(d["value"] - d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) <= 1e-9 * d["value"]
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0.5 < rf["frac"] < 1.2
+    # (frac is quoted on SURVEY's CSR byte count; the sliced-ELL form keeps ONE value per slot of
+    # equal values, so on this constant-coefficient operator it moves far fewer bytes: frac > 1,
+    # frac_hbm -- PMC bytes -- is the utilisation)
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0.5 < rf["frac"] < 4.0
+    assert 0 < rf["value_slots"]["kept"] < rf["value_slots"]["all"] // 8
     assert rf["algorithmic_bytes"] == 12 * 49978572 + 20 * 9998244 + 4
     assert rf["traffic"] is None or (0.3 < rf["frac_hbm"] < 1.0 and rf["traffic_source"])
     cb = d["cpu_baseline"]
