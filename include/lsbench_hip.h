@@ -87,9 +87,9 @@ enum { LSB_PRECOND_JACOBI = 0, LSB_PRECOND_NONE = 1,
                                     symmetric S with non-empty rows, no
                                     stored diagonal needed */
        LSB_PRECOND_CHEBYSHEV = 3,   /* z = p_k(D^-1 S) D^-1 r: Chebyshev polynomial
-                                       of degree opts.cheb_degree on the interval
-                                       [lmax/30, 1.1 lmax] of D^-1 S, lmax from a
-                                       power iteration at setup (the smoother the
+                                       of degree m = opts.cheb_degree on the interval
+                                       [l / max(30, 16 m^2), l], l = 1.1 lmax of D^-1 S
+                                       from a power iteration at setup (the smoother the
                                        reference's AMG backends configure,
                                        src/hypre.c:126-158, src/amgx.c:78-85) */
        LSB_PRECOND_BLOCKJACOBI = 4 }; /* M = blockdiag(S) with opts.block_size rows
@@ -166,7 +166,7 @@ struct lsb_hip_opts {
                         residual RECOMPUTED from x; if it does not, CG restarts
                         on the true residual (correction solve) until it does;
                         lsb_hip_result.true_relres carries the number      [0] */
-  int cheb_degree;   /* LSB_PRECOND_CHEBYSHEV: degree of the polynomial, 1..16 [4] */
+  int cheb_degree;   /* LSB_PRECOND_CHEBYSHEV: degree of the polynomial, 1..32 [4] */
   int block_size;    /* LSB_PRECOND_BLOCKJACOBI: rows per diagonal block,
                         2, 4, 8, 16 or 32                                  [8] */
   int precision;     /* LSB_PREC_FP64, or LSB_PREC_MIXED: matrix values stored

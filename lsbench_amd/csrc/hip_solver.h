@@ -174,7 +174,7 @@ struct lsb_hip_solver {
    * rank has the same constant Jacobi diagonal (k_cg1_update<UI>) */
   int cg1_implicit;
   int pcur; /* launch-bound fused path: which direction buffer is current */
-#define LSB_CHEB_MAX 16
+#define LSB_CHEB_MAX 32
   int cheb_m, cheb_fused; /* fused: the steps ride in the SpMV's epilogue (one shard, 16-bit sliced-ELL) */
   double cheb_lmin, cheb_lmax, cheb_c0, cheb_a[LSB_CHEB_MAX], cheb_b[LSB_CHEB_MAX];
   unsigned nspmv; /* SpMV launches (per shard) of the solve being enqueued */

@@ -344,7 +344,7 @@ done:
  * restatement of what lsbench_amd/csrc/hip_precond.c enqueues (no reference
  * source: the nearest statements are the smoother set-ups of src/hypre.c:126-158,
  * src/amgx.c:78-85 and the Jacobi preconditioner of src/ginkgo.cpp:57-58).
- *   kind 3  Chebyshev polynomial of degree `param` in D^-1 A on [lmax/30, lmax],
+ *   kind 3  Chebyshev polynomial of degree m = `param` in D^-1 A on [lmax / max(30, 16 m^2), lmax],
  *           lmax = 1.1 x the estimate of 20 power iterations from the start vector
  *           v_i = 1 + ((7919 i) mod 1024) / 1024:
  *              theta = (lmax+lmin)/2, delta = (lmax-lmin)/2, sigma = theta/delta, rho = 1/sigma
@@ -440,7 +440,9 @@ int orc_pcg_prec(uint64_t n, const uint64_t *offs, const uint32_t *cols, const d
       vv = 1.0;
     }
     lmax = 1.1 * lam;
-    const double lmin = lmax / 30.0;
+    /* the interval grows with the degree: lmax / max(30, 16 m^2) (see hip_precond.c) */
+    const double ratio = 16.0 * param * param > 30.0 ? 16.0 * param * param : 30.0;
+    const double lmin = lmax / ratio;
     theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
   } else if (kind == 4) {
     const uint64_t nb = (n + param - 1) / param;

@@ -30,6 +30,7 @@ step cfg2_dense_inverse 300 python bench.py $C2 --persistent 0 --precond bj --bl
 step cfg2_cheb4 300 python bench.py $C2 --persistent 0 --precond cheb --cheb-degree 4 --cpu-seconds 0
 step cfg3_fp32 400 python bench.py --precision fp32 --steps 2 $Q
 step cfg3_cheb4 400 python bench.py --precond cheb --cheb-degree 4 --steps 2 $Q
+step cfg3_cheb16 400 python bench.py --precond cheb --cheb-degree 16 --steps 2 $Q
 step cfg3_bj8 400 python bench.py --precond bj --block-size 8 --steps 2 $Q
 find "$OUT" -name '*kernel_trace.csv' -size +12M -delete 2>/dev/null
 tail -n 3 $OUT/bench.log
