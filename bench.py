@@ -16,6 +16,14 @@ Laplacian, 3162^2 = 9,998,244 rows, 49,978,572 nnz.  Every line also carries a
 `cfg4` sub-record: configs[3] (7-point 400^3, 64 M rows, the configuration the
 ">= 6x at 8 GPUs" target is stated on) solved on the same N GPUs right after the
 headline -- take the 1 -> 8 ratio of cfg4.value from the N = 1 and N = 8 lines.
+At N = 1 the line also carries `general_values`: the SAME 3162^2 pattern with
+general values (`lap2d:...,coef=1`, one hashed weight per grid edge), i.e. the
+thing the metric names -- an fp64 CSR SpMV whose values must be streamed -- with
+its roofline fraction on SURVEY 8(d)'s CSR byte count.  The constant-coefficient
+headline stores ONE value per constant diagonal of a slice, so its `roofline`
+is quoted on the bytes that layout must move (x once, y once, slot records, the
+kept values), never on bytes it does not move; the CSR-count figure stays in
+the record as `csr_count`.
 Others:
     --workload lap3d     configs[3]: 7-point 400^3, 64 M rows (the 8-GPU config)
     --workload powerlaw  configs[4]: SpMV-only (unsymmetric), reports GB/s
@@ -51,6 +59,7 @@ import lsbench_amd as la  # noqa: E402
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md, chip-level parameters
 WORKLOADS = {
     "lap2d": "lap2d:nx=3162,ny=3162",
+    "lap2d_coef": "lap2d:nx=3162,ny=3162,coef=1",
     "lap3d": "lap3d:nx=400,ny=400,nz=400",
     "powerlaw": "powerlaw:n=8000000,gamma=1.585350372615855,max=4096,seed=20240607",
 }
@@ -86,6 +95,11 @@ def parse():
                         "(7-point 400^3, 64 M rows) solved --cfg4-steps times on the same N GPUs -- the "
                         "workload the 8-vs-1 GPU target is stated on; 0 = skip it")
     p.add_argument("--cfg4-steps", type=int, default=2)
+    p.add_argument("--general-values", type=int, default=1,
+                   help="1 = at N = 1 the line also carries `general_values`: config 3's pattern with "
+                        "general values (lap2d:...,coef=1) -- the SpMV whose values must be streamed, "
+                        "roofline fraction on SURVEY 8(d)'s CSR byte count; 0 = skip it")
+    p.add_argument("--general-values-steps", type=int, default=1)
     p.add_argument("--persistent", type=int, default=0,
                    help="launch-bound operators: 1 = the whole solve as one persistent launch, 0 = "
                         "launch per kernel, -1 = whichever the creation-time timing finds faster")
@@ -238,19 +252,42 @@ def setup_ranks(a):
     return c
 
 
-def pmc_traffic(workload, kernel):
+def kernels_sha16():
+    """sha256 (first 16 hex digits) of the sources the SpMV kernels and their layouts are
+    built from: a committed PMC figure is only quoted for the code it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("hip_kernels.hip", "hip_pb.hip", "lsb_operator.c"):
+        with open(os.path.join(ROOT, "lsbench_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(workload, kernel, value_slots):
     """HBM bytes per launch of `kernel` on `workload` from the committed PMC profile
     (profiles/pmc_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3
-    passes of this same command, tools/gpu_profiles.sh).  The bench process
-    cannot read hardware counters itself; `traffic_source` says where it is from."""
+    passes of this same command, tools/gpu_profiles.sh).  The bench process cannot
+    read hardware counters itself, so the figure is tied to what it was measured
+    on: the entry must name this kernel, the hash of the kernel / layout sources
+    and the layout's kept / all value slots of THIS run -- any mismatch prints
+    traffic null and says why in `traffic_source`."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             t = json.load(f).get(workload)
-        if isinstance(t, dict) and t.get("kernel") == kernel:
-            return t["bytes"], t.get("source", "profiles/pmc_traffic.json")
-    except OSError:
-        pass
-    return None, None
+    except (OSError, ValueError):
+        return None, "no profiles/pmc_traffic.json"
+    if not isinstance(t, dict):
+        return None, "no committed PMC profile of this workload"
+    if t.get("kernel") != kernel:
+        return None, "stale: committed PMC profile is of %s, this run used %s" % (t.get("kernel"), kernel)
+    sha = kernels_sha16()
+    if t.get("kernels_sha16") != sha:
+        return None, ("stale: committed PMC profile was taken on kernel sources %s, these are %s"
+                      % (t.get("kernels_sha16"), sha))
+    if list(t.get("value_slots", [0, 0])) != list(value_slots):
+        return None, ("stale: committed PMC profile kept %s value slots, this run %s"
+                      % (t.get("value_slots"), list(value_slots)))
+    return t["bytes"], t.get("source", "profiles/pmc_traffic.json")
 
 
 def run_workload(a, c, workload, steps, warmup, cpu_leg):
@@ -320,7 +357,15 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
               la.SPMV_SELL: "k_spmv_sell16" if solver.spmv_flags & la.SPMV_FLAG_C16 else "k_spmv_sell"
               }.get(solver.spmv_variant, "?")
     # (the committed PMC profile is of the fp64 forms: no traffic figure for fp32 values)
-    traffic, traffic_src = pmc_traffic(key if world == 1 and a.precision == "fp64" else None, kernel)
+    vslots = solver.sell_value_slots
+    traffic, traffic_src = pmc_traffic(key if world == 1 and a.precision == "fp64" else None, kernel, vslots)
+    # Bytes the roofline figure is quoted on.  SURVEY 8(d)'s CSR count is the figure for a
+    # CSR SpMV whose values are streamed.  A layout that ELIDES values (constant slots: one
+    # value per slot whose 128 entries are equal) does not move them, so for it the count
+    # is what that layout must move in one launch -- its arrays as stored + x once + y once.
+    layout_bytes = solver.spmv_layout_bytes
+    elided = vslots[1] > 0 and vslots[0] < vslots[1]
+    bytes_alg = layout_bytes if (elided and layout_bytes) else bytes_spmv
 
     if spmv_only:
         # config 5: SpMV throughput only (the operator is unsymmetric)
@@ -385,7 +430,8 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
     else:
         spmv_avg_ms = solver.time_spmv(20, 200)  # graph replay: events do not fit inside
         how = "hipEvents around 200 back-to-back launches after the timed solves"
-    gbps = bytes_spmv / spmv_avg_ms / 1e6
+    gbps = bytes_alg / spmv_avg_ms / 1e6
+    gbps_csr = bytes_spmv / spmv_avg_ms / 1e6
     # SURVEY.md section 8(d)'s protocol as well: >= 100 back-to-back launches after >= 10
     # warm-ups (warmer caches than inside the solve; reported, not used for `frac`)
     b2b_ms = solver.time_spmv(10, 100) if spmv_n else spmv_avg_ms
@@ -394,6 +440,9 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
         tt = torch.tensor([float(nnz_loc)], dtype=torch.float64, device=c.cdev)
         dist.all_reduce(tt)
         n_tot_nnz = int(tt.item())
+    comm = dict(zip(("mode", "selftest_direct_us", "selftest_rccl_us"), solver.comm),
+                modes="0 one shard, 1 RCCL, 2 direct xGMI all-reduce, 3 direct xGMI halos too")
+    comm.update(solver.comm_plan)  # rccl_ranks = ncclCommCount; rank 0's halo plan
     rec = {
         "metric": "cg_solves_per_sec", "value": steps / dt, "unit": "solves/s",
         "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -412,24 +461,28 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
                    if (a.verify and a.fixed_iters == 0) else "recurrence residual"},
         "iterations_per_sec": iters / dt,
         "setup_seconds": t_setup,
-        "comm": dict(zip(("mode", "selftest_direct_us", "selftest_rccl_us"), solver.comm),
-                     modes="0 one shard, 1 RCCL, 2 direct xGMI all-reduce, 3 direct xGMI halos too"),
+        "comm": comm,
         "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": gbps / HBM_PEAK_GBPS, "traffic": traffic,
                      # what the HBM actually moved: PMC bytes of the committed profile of this
-                     # command / this run's launch time, as a fraction of peak
+                     # command and these kernel sources / this run's launch time, over peak
                      "frac_hbm": (traffic / spmv_avg_ms / 1e6 / HBM_PEAK_GBPS) if traffic else None,
                      "traffic_source": traffic_src,
-                     "note": "achieved/frac are quoted on SURVEY 8(d)'s CSR byte count (12 B per "
-                             "non-zero + 20 B per row); the sliced-ELL layout the kernel reads stores "
-                             "8-10 B per entry, and ONE value for a slot whose 128 entries are equal "
-                             "(value_slots: kept / all -- a constant-coefficient stencil keeps few), so "
-                             "frac can exceed 1; frac_hbm = PMC bytes / time / peak is what the HBM moved",
-                     "value_slots": dict(zip(("kept", "all"), solver.sell_value_slots)),
+                     "algorithmic_bytes": bytes_alg,
+                     "bytes_basis": ("layout: this operator's values are elided (value_slots kept / all: one value "
+                                     "per slot whose 128 entries are equal), so the figure is quoted on what the "
+                                     "stored layout must move in one launch -- slot records, constants, code "
+                                     "arrays, the kept values, x once, y once; SURVEY 8(d)'s CSR count is under "
+                                     "csr_count and is NOT a roofline fraction for this layout"
+                                     if bytes_alg != bytes_spmv else
+                                     "SURVEY 8(d): 12 B per non-zero + 20 B per row + 4 (values streamed)"),
+                     "csr_count": {"bytes": bytes_spmv, "GBps": gbps_csr, "ratio_to_peak": gbps_csr / HBM_PEAK_GBPS},
+                     "layout_bytes": layout_bytes,
+                     "value_slots": dict(zip(("kept", "all"), vslots)),
                      "kernel": kernel + (" (panels)" if solver.spmv_variant == la.SPMV_PANEL else "") + " (fused p.q)",
                      "launch_ms": spmv_avg_ms, "back_to_back_launch_ms": b2b_ms,
                      "spmv_flags": solver.spmv_flags, "xcd_period_slices": solver.spmv_period,
-                     "algorithmic_bytes": bytes_spmv, "measured": how},
+                     "kernels_sha16": kernels_sha16(), "measured": how},
     }
     if a.fixed_iters > 0:
         rec["metric"] = "EXPERIMENT_fixed_%d_iterations_per_step" % a.fixed_iters
@@ -455,10 +508,26 @@ def main():
                                            "setup_seconds", "comm")}
         line["cfg4"]["config"] = r4["config"]
         line["cfg4"]["spmv"] = {k: r4["roofline"][k] for k in ("kernel", "launch_ms", "achieved", "frac",
-                                                               "algorithmic_bytes", "traffic", "frac_hbm",
-                                                               "xcd_period_slices", "spmv_flags")}
+                                                               "algorithmic_bytes", "bytes_basis", "csr_count",
+                                                               "traffic", "frac_hbm", "traffic_source",
+                                                               "value_slots", "xcd_period_slices", "spmv_flags")}
         line["cfg4"]["note"] = ("BASELINE.json configs[3] on the same %d GPU(s): strong scaling of ONE 64 M-row "
                                 "operator; the >= 6x target is cfg4.value(N=8) / cfg4.value(N=1)" % c.world)
+    if (a.general_values and c.world == 1 and line["metric"] == "cg_solves_per_sec"
+            and spec == WORKLOADS["lap2d"] and a.precision == "fp64" and a.fixed_iters == 0):
+        rg = run_workload(a, c, "lap2d_coef", a.general_values_steps, 1, cpu_leg=False)
+        line["general_values"] = {k: rg[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup",
+                                                     "ms_per_step", "iterations_per_sec", "setup_seconds")}
+        line["general_values"]["config"] = rg["config"]
+        line["general_values"]["spmv"] = {k: rg["roofline"][k] for k in (
+            "kernel", "launch_ms", "back_to_back_launch_ms", "achieved", "peak", "unit", "frac", "algorithmic_bytes",
+            "bytes_basis", "traffic", "frac_hbm", "traffic_source", "layout_bytes", "value_slots", "spmv_flags",
+            "measured")}
+        line["general_values"]["note"] = (
+            "BASELINE.json configs[2]'s pattern (3162^2 5-point, 49,978,572 nnz) with GENERAL values: one hashed "
+            "weight in [1/2, 3/2) per grid edge, Dirichlet, SPD (lsb_synth.c `coef=1`; stated independently in "
+            "oracle/lsb_oracle.c).  Every value is streamed: this is the fp64 CSR SpMV the metric names, and "
+            "spmv.frac is on SURVEY 8(d)'s CSR byte count.")
     if c.rank == 0:
         print(json.dumps(line), flush=True)
     if c.dist_on:

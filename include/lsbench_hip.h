@@ -76,6 +76,18 @@ int hip_cdna4_finalize(void);
 int hip_cdna4_bench(double *x, struct csr *A, const double *r,
                     const struct lsbench *cb);
 
+/* Two optional companions of the trio for a host program's command line and loader
+ * (integration/hip-flags.patch adds the calls to src/lsbench.c:84-133 and
+ * src/lsbench-csr.c:29; with ENABLE_HIP=OFF the stub file answers 1 / NULL):
+ * set one option of hip_cdna4_bench by name -- "tol", "maxit", "ngpus", "krylov",
+ * "operator", "precond", "cheb-degree", "block-size", "precision", "nvirt", "restart",
+ * "reorder", "comm", "overlap", "verify", ... (hip_cdna4.c: OPTS; the same names upper-
+ * cased behind LSBENCH_HIP_ are the environment switches) -- 0 = set, 1 = no such option
+ * or not a value it takes; and the backend's synthetic operators (configs 3-5) as a
+ * `struct csr *` the reference's lsbench_matrix_free can free. */
+int hip_cdna4_set_option(const char *name, const char *value);
+struct csr *hip_cdna4_matrix_synth(const char *spec);
+
 /* ------------------------------------------------------------------------ */
 /* Options / results (additive; the reference has no such knobs)             */
 /* ------------------------------------------------------------------------ */
@@ -92,10 +104,19 @@ enum { LSB_PRECOND_JACOBI = 0, LSB_PRECOND_NONE = 1,
                                        from a power iteration at setup (the smoother the
                                        reference's AMG backends configure,
                                        src/hypre.c:126-158, src/amgx.c:78-85) */
-       LSB_PRECOND_BLOCKJACOBI = 4 }; /* M = blockdiag(S) with opts.block_size rows
+       LSB_PRECOND_BLOCKJACOBI = 4,   /* M = blockdiag(S) with opts.block_size rows
                                        per block, blocks inverted at setup (the
                                        block form of src/ginkgo.cpp:57-58's
                                        Jacobi preconditioner)                 */
+       LSB_PRECOND_FSAI = 5 };        /* factorised sparse approximate inverse,
+                                       M^-1 = G^T G with G on the pattern of tril(S^k),
+                                       k = opts.fsai_power: the expensive part (one small
+                                       dense SPD solve per row, on the device) happens
+                                       once, outside the timed loop -- the reference's
+                                       own protocol for its CPU path, which factorises
+                                       in csr_init (src/cholmod-impl.h:25-26) and times
+                                       only solves (:59-62); an application is two SpMVs,
+                                       no triangular solve, no reduction        */
 enum { LSB_KRYLOV_PCG = 0,    /* preconditioned CG (symmetric operators)    */
        LSB_KRYLOV_GMRES = 1,  /* restarted GMRES(m), right-preconditioned,
                                  for LSB_OP_RAW / unsymmetric operators;
@@ -183,6 +204,9 @@ struct lsb_hip_opts {
   double comm_deadline_s; /* sharded solves: the host gives a poll of the device
                         state at most this long before it reports a hung
                         collective and exits non-zero                    [120] */
+  int fsai_power;    /* LSB_PRECOND_FSAI: G lives on the pattern of tril(S^k),
+                        k = 1..3 (rows of more than 160 pattern entries are cut
+                        to the 160 nearest the diagonal)                    [2] */
 };
 enum { LSB_PREC_FP64 = 0, LSB_PREC_MIXED = 1 };
 
@@ -399,6 +423,10 @@ void lsb_plan_exchange(int me, int nall, const unsigned *hull,
  * 0-based column ids, generated on the host.  spec:
  *   "lap2d:nx=3162,ny=3162"          5-point Laplacian, diag 4, off -1
  *   "lap3d:nx=400,ny=400,nz=400"     7-point Laplacian, diag 6, off -1
+ *   "lap2d:...,coef=K" / "lap3d:...,coef=K" (K != 0)  same pattern, GENERAL values: one
+ *                                    weight in [1/2, 3/2) per grid edge from a counter-
+ *                                    based hash keyed by K, diagonal = sum of the row's
+ *                                    edge weights (Dirichlet) -- SPD, nothing to elide
  *   "powerlaw:n=8000000,avg=32,max=4096,seed=20240607[,spd=1]"
  * r1 = 0 means "to the last row".  *n_global receives the full row count. */
 struct csr *lsbench_matrix_synth(const char *spec, unsigned r0, unsigned r1,
@@ -466,6 +494,17 @@ int lsb_hip_solver_overlaps(const lsb_hip_solver *s);
  * (may be NULL): what one exchange + all-reduce cost each way in the
  * creation-time self-test, 0 if it did not run. */
 int lsb_hip_solver_comm(const lsb_hip_solver *s, double *p2p_us, double *rccl_us);
+/* The exchange plan of this process's first shard, as a scaling line has to show it:
+ * plan[0] ranks RCCL counts in the communicator (ncclCommCount; 0 = no communicator),
+ * plan[1] peers it receives halos from, plan[2] peers it sends to, plan[3] / plan[4] bytes
+ * received / sent per exchange (= per SpMV), plan[5] 1 when the plan is the in-place
+ * all-gather (every shard needs every row), 0 for point-to-point halos, plan[6] shards
+ * in this process, plan[7] 1 when the halo travels behind the interior rows. */
+void lsb_hip_solver_comm_plan(const lsb_hip_solver *s, unsigned long long plan[8]);
+/* Matrix-side bytes ONE launch of the SpMV form in use must stream (its index, code, slot
+ * and value arrays as stored) + x read once + y written once, first shard; 0 for the
+ * multi-pass forms (binned, two-phase).  SURVEY 8(d)'s CSR count is 12 nnz + 20 n + 4. */
+unsigned long long lsb_hip_solver_spmv_layout_bytes(const lsb_hip_solver *s);
 /* hipStream_t of the backend (as void*), for callers that time with events. */
 void *lsb_hip_stream(void);
 
@@ -482,6 +521,8 @@ int lsb_hip_comm_init_rank(const void *id128, int nranks, int rank);
 int lsb_hip_comm_destroy(void);
 int lsb_hip_comm_rank(void);
 int lsb_hip_comm_size(void);
+/* What RCCL itself says (ncclCommCount on this thread's communicator); 0 without one. */
+int lsb_hip_comm_count(void);
 /* In-place sum of `count` doubles over all ranks, device buffer, on the
  * backend stream; and a barrier built from it. */
 int lsb_hip_comm_allreduce_sum_dev(double *d_buf, int count);

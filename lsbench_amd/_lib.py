@@ -20,7 +20,7 @@ UNIQUE_ID_BYTES = 128
 # enums of include/lsbench.h / include/lsbench_hip.h
 SOLVER_HIP = 6
 OP_CHOLMOD_UPPER, OP_RAW = 0, 1
-PRECOND_JACOBI, PRECOND_NONE, PRECOND_L1JACOBI, PRECOND_CHEBYSHEV, PRECOND_BLOCKJACOBI = 0, 1, 2, 3, 4
+PRECOND_JACOBI, PRECOND_NONE, PRECOND_L1JACOBI, PRECOND_CHEBYSHEV, PRECOND_BLOCKJACOBI, PRECOND_FSAI = 0, 1, 2, 3, 4, 5
 KRYLOV_PCG, KRYLOV_GMRES, KRYLOV_PCG1, KRYLOV_AUTO = 0, 1, 2, 3
 SPMV_AUTO, SPMV_ADAPTIVE, SPMV_SUBWAVE, SPMV_SCALAR, SPMV_PANEL, SPMV_SELL, SPMV_BINNED, SPMV_TWOPHASE = 0, 1, 2, 3, 4, 5, 6, 7
 SELL_ROWS = 128
@@ -61,7 +61,7 @@ class Opts(C.Structure):
                 ("restart", C.c_int), ("verbose", C.c_int),
                 ("ngpus", C.c_int), ("verify", C.c_int), ("cheb_degree", C.c_int),
                 ("block_size", C.c_int), ("precision", C.c_int), ("persistent", C.c_int),
-                ("comm_deadline_s", C.c_double)]
+                ("comm_deadline_s", C.c_double), ("fsai_power", C.c_int)]
 
 
 class Result(C.Structure):
@@ -190,6 +190,8 @@ SIGNATURES = {
     "lsb_hip_solver_spmv_period": (_u, [_vp]),
     "lsb_hip_solver_sell_value_slots": (None, [_vp, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
     "lsb_hip_solver_overlaps": (_i, [_vp]),
+    "lsb_hip_solver_comm_plan": (None, [_vp, C.POINTER(C.c_ulonglong)]),
+    "lsb_hip_solver_spmv_layout_bytes": (C.c_ulonglong, [_vp]),
     "lsb_hip_solver_comm": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "lsb_hip_stream": (_vp, []),
     # communicator
@@ -198,6 +200,9 @@ SIGNATURES = {
     "lsb_hip_comm_destroy": (_i, []),
     "lsb_hip_comm_rank": (_i, []),
     "lsb_hip_comm_size": (_i, []),
+    "lsb_hip_comm_count": (_i, []),
+    "hip_cdna4_set_option": (_i, [C.c_char_p, C.c_char_p]),
+    "hip_cdna4_matrix_synth": (_csrp, [C.c_char_p]),
     "lsb_hip_comm_allreduce_sum_dev": (_i, [_vp, _i]),
     "lsb_hip_comm_barrier": (_i, []),
     # kernel-level entry points

@@ -316,6 +316,22 @@ class Solver:
         return int(k.value), int(t.value)
 
     @property
+    def spmv_layout_bytes(self):
+        """Bytes one launch of the SpMV form in use must move: its matrix-side arrays as
+        stored + x once + y once (0 for the multi-pass forms)."""
+        return int(L.load().lsb_hip_solver_spmv_layout_bytes(self._h))
+
+    @property
+    def comm_plan(self):
+        """The exchange plan of this process's first shard (see lsbench_hip.h)."""
+        p = (C.c_ulonglong * 8)()
+        L.load().lsb_hip_solver_comm_plan(self._h, p)
+        return {"rccl_ranks": int(p[0]), "recv_peers": int(p[1]), "send_peers": int(p[2]),
+                "bytes_recv_per_exchange": int(p[3]), "bytes_sent_per_exchange": int(p[4]),
+                "pattern": "all-gather" if p[5] else "halos (point-to-point)",
+                "shards_in_process": int(p[6]), "overlap": bool(p[7])}
+
+    @property
     def comm(self):
         """(mode, p2p_us, rccl_us): mode 0 = one shard, 1 = RCCL / device copies,
         2 = direct xGMI stores for the all-reduces, 3 = and for the halos; the

@@ -31,6 +31,11 @@
  * status word.
  */
 #define _GNU_SOURCE
+#include <ctype.h>
+#include <stdarg.h>
+#include <stddef.h>
+#include <unistd.h>
+
 #include "hip_solver.h"
 
 /* ------------------------------------------------------------------------ */
@@ -42,6 +47,16 @@ static __thread hipStream_t g_comm_stream = 0;
 __thread struct lsb_hip_result g_last;
 static struct lsb_hip_opts g_opts;
 static int g_opts_set = 0;
+
+void lsb_give_up(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vfprintf(stderr, fmt, ap);
+  va_end(ap);
+  fputc('\n', stderr);
+  fflush(stdout), fflush(stderr);
+  _exit(EXIT_FAILURE);
+}
 
 double wall_seconds(void) {
   struct timespec ts;
@@ -75,66 +90,152 @@ void lsb_hip_opts_default(struct lsb_hip_opts *o) {
   o->precision = LSB_PREC_FP64;
   o->persistent = 0; /* measured: 2x slower than the two-launch iteration */
   o->comm_deadline_s = 120.0;
+  o->fsai_power = 2;
+}
+
+/* ONE typed table for everything a caller may set by name: the command line of a host
+ * program (hip_cdna4_set_option -- the reference's lsbench_init after integration/
+ * hip-flags.patch, the stand-in core's lsbench_init) and the environment
+ * (LSBENCH_HIP_<NAME>, '-' -> '_', read once at the first lsb_hip_get_opts). */
+enum { OT_DBL, OT_UINT, OT_INT, OT_ENUM };
+struct optchoice {
+  const char *word;
+  int value;
+};
+static const struct optchoice CH_OPERATOR[] = {{"upper", LSB_OP_CHOLMOD_UPPER}, {"raw", LSB_OP_RAW}, {NULL, 0}};
+static const struct optchoice CH_PRECOND[] = {{"jacobi", LSB_PRECOND_JACOBI},   {"none", LSB_PRECOND_NONE},
+                                              {"l1", LSB_PRECOND_L1JACOBI},     {"cheb", LSB_PRECOND_CHEBYSHEV},
+                                              {"bj", LSB_PRECOND_BLOCKJACOBI},  {"fsai", LSB_PRECOND_FSAI},
+                                              {NULL, 0}};
+static const struct optchoice CH_COMM[] = {{"auto", LSB_COMM_AUTO}, {"rccl", LSB_COMM_RCCL}, {"p2p", LSB_COMM_P2P}, {NULL, 0}};
+static const struct optchoice CH_KRYLOV[] = {{"cg", LSB_KRYLOV_PCG},     {"cg1", LSB_KRYLOV_PCG1},
+                                             {"auto", LSB_KRYLOV_AUTO},  {"gmres", LSB_KRYLOV_GMRES}, {NULL, 0}};
+static const struct optchoice CH_PRECISION[] = {{"fp64", LSB_PREC_FP64}, {"fp32", LSB_PREC_MIXED},
+                                                {"mixed", LSB_PREC_MIXED}, {NULL, 0}};
+#define OPT(n, t, f, c) {n, t, offsetof(struct lsb_hip_opts, f), c}
+static const struct optdef {
+  const char *name;
+  int type;
+  size_t off;
+  const struct optchoice *choices;
+} OPTS[] = {
+    OPT("tol", OT_DBL, tol, NULL),
+    OPT("maxit", OT_UINT, maxit, NULL),
+    OPT("operator", OT_ENUM, op_mode, CH_OPERATOR),
+    OPT("nvirt", OT_INT, nvirt, NULL),
+    OPT("graph", OT_INT, use_graph, NULL),
+    OPT("spmv", OT_INT, spmv_variant, NULL),
+    OPT("precond", OT_ENUM, precond, CH_PRECOND),
+    OPT("comm", OT_ENUM, comm, CH_COMM),
+    OPT("overlap", OT_INT, overlap, NULL),
+    OPT("reorder", OT_INT, reorder, NULL),
+    OPT("krylov", OT_ENUM, krylov, CH_KRYLOV),
+    OPT("restart", OT_INT, restart, NULL),
+    OPT("spmv-tune", OT_INT, spmv_tune, NULL),
+    OPT("spmv-grid", OT_INT, spmv_grid, NULL),
+    OPT("check-every", OT_INT, check_every, NULL),
+    OPT("verbose", OT_INT, verbose, NULL),
+    OPT("ngpus", OT_INT, ngpus, NULL),
+    OPT("verify", OT_INT, verify, NULL),
+    OPT("cheb-degree", OT_INT, cheb_degree, NULL),
+    OPT("block-size", OT_INT, block_size, NULL),
+    OPT("precision", OT_ENUM, precision, CH_PRECISION),
+    OPT("persistent", OT_INT, persistent, NULL),
+    OPT("comm-deadline-s", OT_DBL, comm_deadline_s, NULL),
+    OPT("fsai-power", OT_INT, fsai_power, NULL),
+};
+#undef OPT
+#define NOPTS (sizeof OPTS / sizeof OPTS[0])
+
+static int opt_name_eq(const char *a, const char *b) { /* case-blind, '-' == '_' */
+  for (; *a && *b; a++, b++) {
+    const int ca = *a == '_' ? '-' : tolower((unsigned char)*a), cb = *b == '_' ? '-' : tolower((unsigned char)*b);
+    if (ca != cb)
+      return 0;
+  }
+  return !*a && !*b;
+}
+
+static int opt_assign(struct lsb_hip_opts *o, const struct optdef *d, const char *value) {
+  char *field = (char *)o + d->off, *end = NULL;
+  if (!value || !*value)
+    return 1;
+  switch (d->type) {
+  case OT_DBL: {
+    const double v = strtod(value, &end);
+    if (end == value || *end)
+      return 1;
+    *(double *)field = v;
+    return 0;
+  }
+  case OT_UINT: {
+    const unsigned long v = strtoul(value, &end, 10);
+    if (end == value || *end)
+      return 1;
+    *(unsigned *)field = (unsigned)v;
+    return 0;
+  }
+  case OT_INT: {
+    const long v = strtol(value, &end, 10);
+    if (end == value || *end)
+      return 1;
+    *(int *)field = (int)v;
+    return 0;
+  }
+  default:
+    for (const struct optchoice *c = d->choices; c->word; c++)
+      if (!strcasecmp(c->word, value)) {
+        *(int *)field = c->value;
+        return 0;
+      }
+    return 1;
+  }
 }
 
 static void opts_from_env(struct lsb_hip_opts *o) {
   const char *e;
-  if ((e = getenv("LSBENCH_HIP_TOL")))
-    o->tol = atof(e);
-  if ((e = getenv("LSBENCH_HIP_MAXIT")))
-    o->maxit = (unsigned)strtoul(e, NULL, 10);
-  if ((e = getenv("LSBENCH_HIP_OPERATOR")))
-    o->op_mode = strcasecmp(e, "raw") == 0 ? LSB_OP_RAW : LSB_OP_CHOLMOD_UPPER;
-  if ((e = getenv("LSBENCH_HIP_NVIRT")))
-    o->nvirt = atoi(e);
-  if ((e = getenv("LSBENCH_HIP_GRAPH")))
-    o->use_graph = atoi(e);
-  if ((e = getenv("LSBENCH_HIP_SPMV")))
-    o->spmv_variant = atoi(e);
-  if ((e = getenv("LSBENCH_HIP_PRECOND")))
-    o->precond = !strcasecmp(e, "none")   ? LSB_PRECOND_NONE
-                 : !strcasecmp(e, "l1")   ? LSB_PRECOND_L1JACOBI
-                 : !strcasecmp(e, "cheb") ? LSB_PRECOND_CHEBYSHEV
-                 : !strcasecmp(e, "bj")   ? LSB_PRECOND_BLOCKJACOBI
-                                          : LSB_PRECOND_JACOBI;
-  if ((e = getenv("LSBENCH_HIP_COMM")))
-    o->comm = !strcmp(e, "rccl") ? LSB_COMM_RCCL : !strcmp(e, "p2p") ? LSB_COMM_P2P : LSB_COMM_AUTO;
-  if ((e = getenv("LSBENCH_HIP_OVERLAP")))
-    o->overlap = atoi(e);
-  if ((e = getenv("LSBENCH_HIP_REORDER")))
-    o->reorder = atoi(e);
-  if ((e = getenv("LSBENCH_HIP_KRYLOV")))
-    o->krylov = strcasecmp(e, "gmres") == 0  ? LSB_KRYLOV_GMRES
-                : strcasecmp(e, "cg1") == 0  ? LSB_KRYLOV_PCG1
-                : strcasecmp(e, "auto") == 0 ? LSB_KRYLOV_AUTO
-                                             : LSB_KRYLOV_PCG;
-  if ((e = getenv("LSBENCH_HIP_RESTART")))
-    o->restart = atoi(e);
-  if ((e = getenv("LSBENCH_HIP_SPMV_TUNE")))
-    o->spmv_tune = atoi(e);
-  if ((e = getenv("LSBENCH_HIP_SPMV_GRID")))
-    o->spmv_grid = atoi(e);
+  for (size_t k = 0; k < NOPTS; k++) {
+    char var[64] = "LSBENCH_HIP_";
+    size_t z = strlen(var);
+    for (const char *p = OPTS[k].name; *p && z + 1 < sizeof var; p++)
+      var[z++] = *p == '-' ? '_' : (char)toupper((unsigned char)*p);
+    var[z] = 0;
+    if ((e = getenv(var)) && opt_assign(o, &OPTS[k], e))
+      warnx("hip_cdna4: %s=%s is not a value of option `%s'; ignored", var, e, OPTS[k].name);
+  }
   if ((e = getenv("LSBENCH_HIP_BLAS1_NT")))
     lsb_k_set_blas1_nt(atoi(e));
-  if ((e = getenv("LSBENCH_HIP_CHECK_EVERY")))
-    o->check_every = atoi(e);
-  if ((e = getenv("LSBENCH_HIP_VERBOSE")))
-    o->verbose = atoi(e);
-  if ((e = getenv("LSBENCH_HIP_NGPUS")))
-    o->ngpus = atoi(e);
-  if ((e = getenv("LSBENCH_HIP_VERIFY")))
-    o->verify = atoi(e);
-  if ((e = getenv("LSBENCH_HIP_CHEB_DEGREE")))
-    o->cheb_degree = atoi(e);
-  if ((e = getenv("LSBENCH_HIP_BLOCK_SIZE")))
-    o->block_size = atoi(e);
-  if ((e = getenv("LSBENCH_HIP_PRECISION")))
-    o->precision = (!strcasecmp(e, "fp32") || !strcasecmp(e, "mixed")) ? LSB_PREC_MIXED : LSB_PREC_FP64;
-  if ((e = getenv("LSBENCH_HIP_PERSISTENT")))
-    o->persistent = atoi(e);
-  if ((e = getenv("LSBENCH_HIP_COMM_DEADLINE_S")))
-    o->comm_deadline_s = atof(e);
 }
+
+/* Set one option of hip_cdna4_bench by name ("tol", "maxit", "ngpus", "krylov", "operator",
+ * "precond", ...: the table above).  What a host program's command line calls: the reference's
+ * lsbench_init after integration/hip-flags.patch (src/lsbench.c:84-92 gains --tol, --maxit,
+ * --ngpus, ... and hands name + optarg over), the stand-in core's.  0 = set, 1 = unknown name
+ * or a value the option does not take (a warning says which). */
+int hip_cdna4_set_option(const char *name, const char *value) {
+  struct lsb_hip_opts o;
+  if (!name)
+    return 1;
+  lsb_hip_get_opts(&o);
+  for (size_t k = 0; k < NOPTS; k++)
+    if (opt_name_eq(name, OPTS[k].name)) {
+      if (opt_assign(&o, &OPTS[k], value)) {
+        warnx("hip_cdna4: `%s' is not a value of option `%s'", value ? value : "(null)", OPTS[k].name);
+        return 1;
+      }
+      lsb_hip_set_opts(&o);
+      return 0;
+    }
+  warnx("hip_cdna4: no option `%s'", name);
+  return 1;
+}
+
+/* The backend's synthetic operators (BASELINE.json configs 3-5; lsb_synth.c) for a host
+ * program whose loader only reads files: the reference's lsbench_matrix_read after
+ * integration/hip-flags.patch returns this for a `synth:SPEC' matrix name
+ * (src/lsbench-csr.c:29).  The arrays are malloc'ed: lsbench_matrix_free frees them
+ * (src/lsbench-csr.c:101-108).  NULL for a spec the generator does not know. */
+struct csr *hip_cdna4_matrix_synth(const char *spec) { return lsbench_matrix_synth(spec, 0, 0, NULL); }
 
 void lsb_hip_set_opts(const struct lsb_hip_opts *o) {
   g_opts = *o;

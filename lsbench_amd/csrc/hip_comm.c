@@ -64,6 +64,16 @@ int lsb_hip_comm_destroy(void) {
   return 0;
 }
 
+/* ranks RCCL itself counts in this thread's communicator (ncclCommCount), 0 without one --
+ * what a scaling line quotes as proof that the collectives ran over N ranks */
+int lsb_hip_comm_count(void) {
+  int n = 0;
+  if (!g_have_comm)
+    return 0;
+  LSB_CHK_NCCL(ncclCommCount(g_comm, &n));
+  return n;
+}
+
 int lsb_hip_comm_rank(void) { return g_rank; }
 int lsb_hip_comm_size(void) { return g_nranks; }
 

@@ -66,8 +66,9 @@ void check_aux_status(lsb_hip_solver *sv, const char *where) {
     struct lsb_pcg_state h;
     LSB_CHK_HIP(hipMemcpy(&h, sv->sh[i].d_st_aux, sizeof h, hipMemcpyDeviceToHost));
     if (h.status == LSB_STATUS_COMM)
-      errx(EXIT_FAILURE, "hip_cdna4: %s: a peer did not arrive within the time-out of the direct "
-                         "xGMI path (LSBENCH_HIP_P2P_TIMEOUT_MS)", where);
+      lsb_give_up("hip_cdna4: %s: a peer did not arrive within the time-out of the direct "
+                  "xGMI path (LSBENCH_HIP_P2P_TIMEOUT_MS) (rank %d of %d)", where, lsb_hip_comm_rank(),
+                  lsb_hip_comm_size());
   }
 }
 
@@ -334,7 +335,7 @@ static float timed_rounds(lsb_hip_solver *sv) {
   LSB_CHK_HIP(hipEventRecord(sv->ev_t0, g_stream));
   p2p_rounds(sv, P2P_TIMED, 0, NULL);
   LSB_CHK_HIP(hipEventRecord(sv->ev_t1, g_stream));
-  LSB_CHK_HIP(hipEventSynchronize(sv->ev_t1));
+  wait_event(sv, sv->ev_t1, "self-test of the communication paths (timed rounds)");
   LSB_CHK_HIP(hipEventElapsedTime(&ms, sv->ev_t0, sv->ev_t1));
   return ms * 1e3f / P2P_TIMED;
 }
@@ -373,7 +374,7 @@ void p2p_setup(lsb_hip_solver *sv) {
     if (sv->dist)
       lsb_hip_comm_barrier();
     p2p_rounds(sv, P2P_ROUNDS, 1, d_bad);
-    LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+    drain_stream(sv, "self-test of the direct xGMI path");
     lsb_hip_memcpy_d2h(&bad, d_bad, sizeof(unsigned));
     for (int i = 0; i < sv->nshard; i++) {
       struct lsb_pcg_state hst;

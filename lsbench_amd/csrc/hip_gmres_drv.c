@@ -126,7 +126,7 @@ int gmres_solve_dev(lsb_hip_solver *sv, const double *d_b, double *d_x,
                             w->st, g_stream);
     LSB_CHK_HIP(hipMemcpyAsync(sv->gm_hst, sv->gm[0].st, sizeof *sv->gm_hst,
                                hipMemcpyDeviceToHost, g_stream));
-    LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+    drain_stream(sv, "GMRES restart cycle");
     if (sv->gm_hst->status != LSB_STATUS_RUNNING)
       break;
     if ((unsigned)cycle > sv->o.maxit + 2u)

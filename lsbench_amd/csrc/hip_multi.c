@@ -44,6 +44,7 @@ struct mg_shared {
   double t0, t1;
   struct lsb_hip_result res0;
   int comm_mode;
+  unsigned long long plan[8]; /* rank 0's exchange plan (lsb_hip_solver_comm_plan) */
 };
 
 struct mg_arg {
@@ -87,6 +88,7 @@ static void *mg_rank(void *argp) {
     g->t1 = wall_seconds();
     g->res0 = res;
     g->comm_mode = lsb_hip_solver_comm(sv, NULL, NULL);
+    lsb_hip_solver_comm_plan(sv, g->plan);
   }
   LSB_CHK_HIP(hipMemcpy(g->x + r0, d_x, bytes, hipMemcpyDeviceToHost)); /* :199 */
 
@@ -164,10 +166,16 @@ int bench_multi(double *x, struct csr *A, const double *r, const struct lsbench 
   printf("===hip_cdna4:iterations,relres,status,tol,solves_per_sec,nshards===\n");
   printf("%u,%.6e,%d,%.3e,%.6f,%d\n", g->res0.iters, g->res0.relres, g->res0.status, o_in->tol,
          elapsed > 0 ? cb->trials / elapsed : 0.0, ngpus);
-  printf("===hip_cdna4:ngpus,comm===\n%d,%s\n", ngpus,
+  /* third record: what ran between the GPUs -- the ranks RCCL itself counts
+   * (ncclCommCount) and rank 0's exchange plan, so that a line can be checked for
+   * "N ranks, neighbour halos (not an all-gather)" */
+  printf("===hip_cdna4:ngpus,comm,rccl_ranks,pattern,recv_peers,send_peers,bytes_recv_per_exchange,"
+         "bytes_sent_per_exchange,overlap===\n%d,%s,%llu,%s,%llu,%llu,%llu,%llu,%llu\n", ngpus,
          g->comm_mode == 3   ? "direct-xgmi(halos+allreduce)"
          : g->comm_mode == 2 ? "direct-xgmi(allreduce)+rccl(halos)"
-                             : "rccl");
+                             : "rccl",
+         g->plan[0], g->plan[5] ? "all-gather" : "halos", g->plan[1], g->plan[2], g->plan[3], g->plan[4],
+         g->plan[7]);
   fflush(stdout);
   lsb_csr_free(S);
   free(g);

@@ -348,7 +348,7 @@ static int auto_chunk(const lsb_hip_solver *sv) {
  * node until somebody's job limit (opts.comm_deadline_s,
  * LSBENCH_HIP_COMM_DEADLINE_S).  One shard alone simply blocks. */
 #include <sched.h>
-static void wait_event(lsb_hip_solver *sv, hipEvent_t ev, const char *what) {
+void wait_event(lsb_hip_solver *sv, hipEvent_t ev, const char *what) {
   if (!sv->multi || !(sv->o.comm_deadline_s > 0.0)) {
     LSB_CHK_HIP(hipEventSynchronize(ev));
     return;
@@ -361,13 +361,13 @@ static void wait_event(lsb_hip_solver *sv, hipEvent_t ev, const char *what) {
     if (e != hipErrorNotReady)
       LSB_CHK_HIP(e);
     if (wall_seconds() - t0 > sv->o.comm_deadline_s)
-      errx(EXIT_FAILURE, "hip_cdna4: %s: the device did not get there within %.0f s -- a collective "
-                         "of the sharded solve is hung (rank %d of %d); giving up",
-           what, sv->o.comm_deadline_s, lsb_hip_comm_rank(), lsb_hip_comm_size());
+      lsb_give_up("hip_cdna4: %s: the device did not get there within %.0f s -- a collective "
+                  "of the sharded solve is hung (rank %d of %d); giving up",
+                  what, sv->o.comm_deadline_s, lsb_hip_comm_rank(), lsb_hip_comm_size());
     sched_yield();
   }
 }
-static void drain_stream(lsb_hip_solver *sv, const char *what) {
+void drain_stream(lsb_hip_solver *sv, const char *what) {
   if (!sv->multi) {
     LSB_CHK_HIP(hipStreamSynchronize(g_stream));
     return;
@@ -465,7 +465,7 @@ int lsb_hip_solver_solve_dev(lsb_hip_solver *sv, const double *d_b, double *d_x,
   lsb_k_perm_gather(sv->n_here, sv->d_perm, d_b, sv->d_bp, g_stream);
   const int rc = solve_core(sv, sv->d_bp, sv->d_xp, res);
   lsb_k_perm_scatter(sv->n_here, sv->d_perm, sv->d_xp, d_x, g_stream);
-  LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+  drain_stream(sv, "un-permuting x");
   return rc;
 }
 
@@ -678,8 +678,9 @@ static int pcg_run(lsb_hip_solver *sv, const double *d_b, double *d_x, struct ls
   if (fin != 0)
     hst[0] = hst[fin];
   if (hst[0].status == LSB_STATUS_COMM)
-    errx(EXIT_FAILURE, "hip_cdna4: a peer did not arrive within the time-out of the direct "
-                       "xGMI path (LSBENCH_HIP_P2P_TIMEOUT_MS); iteration %d", hst[0].iters);
+    lsb_give_up("hip_cdna4: a peer did not arrive within the time-out of the direct "
+                "xGMI path (LSBENCH_HIP_P2P_TIMEOUT_MS); iteration %d (rank %d of %d)", hst[0].iters,
+                lsb_hip_comm_rank(), lsb_hip_comm_size());
   *hint = (unsigned)hst[0].iters;
   /* (single-reduction form: r.r of the maxit-th update and the final status --
    * MAXIT, or CONVERGED exactly at maxit -- are settled on the device by the

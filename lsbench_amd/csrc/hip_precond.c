@@ -71,7 +71,7 @@ static double global_dot(lsb_hip_solver *sv, double *const *a, double *const *b)
   sv->p2p_on = on, sv->p2p_halo = halo;
   double v = 0.0;
   LSB_CHK_HIP(hipMemcpyAsync(&v, sv->sh[0].d_scal + 4, sizeof v, hipMemcpyDeviceToHost, g_stream));
-  LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+  drain_stream(sv, "preconditioner set-up (all-reduced dot product)");
   return v;
 }
 

@@ -257,6 +257,7 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
           s->sell_period = bw / LSB_SELL_ROWS;
       }
       s->nslice = E->nslice;
+      s->sell32_bytes = (unsigned long long)E->stored * (s->mixed ? 8 : 12) + ((unsigned long long)E->nslice + 1) * 4;
       s->d_sptr = (unsigned *)dev_upload(E->sptr, ((size_t)E->nslice + 1) * sizeof(unsigned));
       s->d_scols = (int *)dev_upload(E->cols, ((size_t)E->stored + LSB_SELL_ROWS) * sizeof(int));
       s->d_svals = s->mixed ? (double *)upload_f32(E->vals, (size_t)E->stored + LSB_SELL_ROWS, NULL)
@@ -312,12 +313,19 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
           s->d_svals16 = s->mixed ? (double *)upload_f32(V->vals, nv, NULL)
                                   : (double *)dev_upload(V->vals, nv * sizeof(double));
           s->sell_vslots = V->nval_slots, s->sell_slots = (unsigned)V->nslots;
+          s->sell16_bytes = (unsigned long long)V->nslots * 24; /* slot record + the slot's constant */
         } else {
           s->d_sbase = (int *)dev_upload(H->sbase, 2 * ((size_t)H->stored / LSB_SELL_ROWS + 1) * sizeof(int));
           s->d_svals16 = s->mixed ? (double *)upload_f32(H->vals, (size_t)H->stored + LSB_SELL_ROWS, NULL)
                                   : (double *)dev_upload(H->vals, ((size_t)H->stored + LSB_SELL_ROWS) * sizeof(double));
           s->sell_vslots = s->sell_slots = (unsigned)(H->stored / LSB_SELL_ROWS);
+          s->sell16_bytes = (unsigned long long)s->sell_slots * 8;
         }
+        /* what one launch of the 16-bit form streams besides x and y: slot records (and
+         * constants), the code arrays, the kept values, the slice offsets where it looks */
+        s->sell16_bytes += (unsigned long long)H->ncode_slots * LSB_SELL_ROWS * sizeof(short) +
+                           (unsigned long long)s->sell_vslots * LSB_SELL_ROWS * (s->mixed ? 4 : 8) +
+                           (s->sell_ulen ? 0ull : ((unsigned long long)H->nslice + 1) * 4);
         LSB_CHK_HIP(hipStreamSynchronize(g_stream));
         lsb_sell_vc_free(V);
         lsb_sell_free(H);
@@ -660,7 +668,36 @@ void lsb_hip_solver_sell_value_slots(const lsb_hip_solver *s, unsigned *kept, un
   if (total)
     *total = on ? h->sell_slots : 0;
 }
-int can_overlap(const lsb_hip_solver *sv);
+void lsb_hip_solver_comm_plan(const lsb_hip_solver *s, unsigned long long plan[8]) {
+  const struct shard *h = &s->sh[0];
+  memset(plan, 0, 8 * sizeof plan[0]);
+  plan[0] = (unsigned long long)lsb_hip_comm_count();
+  plan[6] = (unsigned long long)s->nshard;
+  if (!s->multi)
+    return;
+  plan[5] = h->nsend == 1 && h->send[0].peer == -1;
+  if (plan[5]) { /* in-place all-gather: count doubles per rank */
+    const unsigned long long P = s->dist ? (unsigned long long)lsb_hip_comm_size() : (unsigned long long)s->nshard;
+    plan[1] = plan[2] = P - 1;
+    plan[3] = (P - 1) * h->send[0].count * 8ull, plan[4] = h->send[0].count * 8ull;
+  } else {
+    plan[1] = (unsigned long long)h->nrecv, plan[2] = (unsigned long long)h->nsend;
+    for (int k = 0; k < h->nrecv; k++)
+      plan[3] += h->recv[k].count * 8ull;
+    for (int k = 0; k < h->nsend; k++)
+      plan[4] += h->send[k].count * 8ull;
+  }
+  plan[7] = (unsigned long long)can_overlap(s);
+}
+unsigned long long lsb_hip_solver_spmv_layout_bytes(const lsb_hip_solver *s) {
+  const struct shard *h = &s->sh[0];
+  unsigned long long m = 12ull * h->nnz + 4ull * ((unsigned long long)h->n + 1); /* the CSR arrays */
+  if (h->variant == LSB_SPMV_SELL)
+    m = (h->sp_flags & LSB_SP_C16) && h->d_scodes ? h->sell16_bytes : h->sell32_bytes;
+  else if (h->variant == LSB_SPMV_TWOPHASE || h->variant == LSB_SPMV_BINNED)
+    return 0; /* more than one pass over intermediate data: no single-pass figure */
+  return m + 16ull * h->n; /* + x read once, y written once */
+}
 int lsb_hip_solver_overlaps(const lsb_hip_solver *s) { return can_overlap(s); }
 int lsb_hip_solver_comm(const lsb_hip_solver *s, double *p2p_us, double *rccl_us) {
   if (p2p_us)
@@ -900,7 +937,7 @@ int lsb_hip_solver_spmv_dev(lsb_hip_solver *sv, const double *d_x, double *d_y) 
   }
   if (d_yout)
     lsb_k_perm_scatter(sv->n_here, sv->d_perm, d_y, d_yout, g_stream);
-  LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+  drain_stream(sv, "lsb_hip_solver_spmv_dev");
   check_aux_status(sv, "lsb_hip_solver_spmv_dev");
   return 0;
 }

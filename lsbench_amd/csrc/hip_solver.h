@@ -85,6 +85,7 @@ struct shard {
   double *d_svconst;       /* != NULL: the constant-slot layout (lsb_sell16_value_slots): d_sbase holds 4
                               ints per slot, d_svals16 only the sell_vslots slots that keep their values */
   unsigned sell_vslots, sell_slots;
+  unsigned long long sell16_bytes, sell32_bytes; /* matrix-side bytes one launch of the form streams */
   unsigned sell_ulen;      /* != 0: every slice of the 16-bit copy has this many slots */
   double *d_parts_pq, *d_parts2;
   double *d_scal; /* [0] p.q   [1] r.z'  [2] r.r   (multi-shard path) */
@@ -199,6 +200,13 @@ struct lsb_hip_solver {
 
 /* hip_cdna4.c */
 LSB_INTERNAL double wall_seconds(void);
+/* Leave the process from a state in which a stream of this process may never drain (a hung
+ * collective, a peer that never arrived): message, flush, _exit(EXIT_FAILURE).  Never exit():
+ * exit() runs the HIP runtime's teardown, which waits for exactly that stream. */
+LSB_INTERNAL void lsb_give_up(const char *fmt, ...) __attribute__((noreturn, format(printf, 1, 2)));
+/* hipStreamSynchronize(g_stream) that gives up after opts.comm_deadline_s on a sharded solver */
+LSB_INTERNAL void drain_stream(lsb_hip_solver *sv, const char *what);
+LSB_INTERNAL void wait_event(lsb_hip_solver *sv, hipEvent_t ev, const char *what);
 LSB_INTERNAL void *dev_upload(const void *h, size_t bytes);
 /* hip_solver.c */
 LSB_INTERNAL unsigned pow2_ceil(unsigned v);

@@ -80,10 +80,12 @@ static void usage(const char *prog) {
   printf("  --nvirt <P>          (hip) P row-range shards on one device (test)\n");
   printf("  --krylov <cg|cg1|auto|gmres> (hip) cg1 = single-reduction CG, gmres for --operator raw\n");
   printf("  --restart <M>        (hip) GMRES restart length, 1..32, default 30\n");
-  printf("  --precond <jacobi|l1|none|cheb|bj> (hip) diag(S); diag(sum_j |S_ij|); none; Chebyshev\n");
+  printf("  --precond <jacobi|l1|none|cheb|bj|fsai> (hip) diag(S); diag(sum_j |S_ij|); none; Chebyshev\n");
   printf("                       polynomial in D^-1 S (--cheb-degree M, default 4); block-Jacobi with\n");
   printf("                       dense inverted blocks of --block-size B rows (default 8; B >= n = a\n");
-  printf("                       cached dense inverse, for operators of a few thousand rows)\n");
+  printf("                       cached dense inverse, for operators of a few thousand rows); fsai =\n");
+  printf("                       factorised sparse approximate inverse G^T G on the pattern of\n");
+  printf("                       tril(S^k), k = --fsai-power (default 2), set up once on the device\n");
   printf("  --ngpus <N>          (hip) row-partition the operator over N GPUs of this node\n");
   printf("                       (0 = all visible), driven from this one process\n");
   printf("  --reorder            (hip) solve the RCM-permuted operator (any --ordering\n");
@@ -98,23 +100,24 @@ struct lsbench *lsbench_init(int argc, char *argv[]) {
       {"ordering", required_argument, 0, 30}, {"precision", required_argument, 0, 40},
       {"verbose", required_argument, 0, 50},  {"trials", required_argument, 0, 60},
       {"help", no_argument, 0, 70},           {"tol", required_argument, 0, 80},
-      {"maxit", required_argument, 0, 81},    {"operator", required_argument, 0, 82},
-      {"nvirt", required_argument, 0, 83},    {"krylov", required_argument, 0, 84},
-      {"restart", required_argument, 0, 85},  {"reorder", no_argument, 0, 86},
-      {"precond", required_argument, 0, 87},  {"ngpus", required_argument, 0, 88},
-      {"cheb-degree", required_argument, 0, 89}, {"block-size", required_argument, 0, 90},
+      {"maxit", required_argument, 0, 80},    {"operator", required_argument, 0, 80},
+      {"nvirt", required_argument, 0, 80},    {"krylov", required_argument, 0, 80},
+      {"restart", required_argument, 0, 80},  {"reorder", no_argument, 0, 86},
+      {"precond", required_argument, 0, 80},  {"ngpus", required_argument, 0, 80},
+      {"cheb-degree", required_argument, 0, 80}, {"block-size", required_argument, 0, 80},
+      {"fsai-power", required_argument, 0, 80}, {"comm", required_argument, 0, 80},
+      {"verify", required_argument, 0, 80},
       {0, 0, 0, 0}};
 
   /* zero-filled => solver 0 (CUSOLVER), ordering 0 (RCM), FP64: the
    * reference's de-facto defaults (src/lsbench.c:95-96) */
   struct lsbench *cb = lsb_calloc(struct lsbench, 1);
   cb->trials = 100;
-  struct lsb_hip_opts o;
-  lsb_hip_get_opts(&o);
+  int li = 0;
 
   optind = 1;
   for (;;) {
-    int c = getopt_long(argc, argv, "", longopts, NULL);
+    int c = getopt_long(argc, argv, "", longopts, &li);
     if (c == -1)
       break;
     switch (c) {
@@ -140,45 +143,15 @@ struct lsbench *lsbench_init(int argc, char *argv[]) {
     case 70:
       usage(argv[0]);
       exit(EXIT_SUCCESS);
-    case 80:
-      o.tol = atof(optarg);
+    case 86: /* --reorder takes no argument */
+      if (hip_cdna4_set_option("reorder", "1"))
+        exit(EXIT_FAILURE);
       break;
-    case 81:
-      o.maxit = (unsigned)strtoul(optarg, NULL, 10);
-      break;
-    case 82:
-      o.op_mode = strcasecmp(optarg, "raw") == 0 ? LSB_OP_RAW : LSB_OP_CHOLMOD_UPPER;
-      break;
-    case 83:
-      o.nvirt = atoi(optarg);
-      break;
-    case 84:
-      o.krylov = strcasecmp(optarg, "gmres") == 0  ? LSB_KRYLOV_GMRES
-                 : strcasecmp(optarg, "cg1") == 0  ? LSB_KRYLOV_PCG1
-                 : strcasecmp(optarg, "auto") == 0 ? LSB_KRYLOV_AUTO
-                                                   : LSB_KRYLOV_PCG;
-      break;
-    case 85:
-      o.restart = atoi(optarg);
-      break;
-    case 86:
-      o.reorder = 1;
-      break;
-    case 87:
-      o.precond = strcasecmp(optarg, "none") == 0   ? LSB_PRECOND_NONE
-                  : strcasecmp(optarg, "l1") == 0   ? LSB_PRECOND_L1JACOBI
-                  : strcasecmp(optarg, "cheb") == 0 ? LSB_PRECOND_CHEBYSHEV
-                  : strcasecmp(optarg, "bj") == 0   ? LSB_PRECOND_BLOCKJACOBI
-                                                    : LSB_PRECOND_JACOBI;
-      break;
-    case 89:
-      o.cheb_degree = atoi(optarg);
-      break;
-    case 90:
-      o.block_size = atoi(optarg);
-      break;
-    case 88:
-      o.ngpus = atoi(optarg);
+    case 80: /* every other (hip) flag: name and value go to the backend's typed option table */
+      if (hip_cdna4_set_option(longopts[li].name, optarg)) {
+        usage(argv[0]);
+        exit(EXIT_FAILURE);
+      }
       break;
     default:
       usage(argv[0]);
@@ -191,12 +164,15 @@ struct lsbench *lsbench_init(int argc, char *argv[]) {
    * FP32 as "fp32 matrix values, fp64 vectors and refinement" (SURVEY.md 8(f)-4:
    * the reference's AMG paths already run fp32, src/amgx.c:91) */
   if (cb->precision == LSBENCH_PRECISION_FP32 && cb->solver == LSBENCH_SOLVER_HIP)
-    o.precision = LSB_PREC_MIXED;
+    hip_cdna4_set_option("precision", "fp32");
   else if (cb->precision != LSBENCH_PRECISION_FP64)
     errx(EXIT_FAILURE, "Precisions other than FP64 are not implemented yet%s.",
          cb->solver == LSBENCH_SOLVER_HIP ? " (hip: FP64, FP32)" : "");
-  o.verbose = (int)cb->verbose;
-  lsb_hip_set_opts(&o);
+  {
+    char v[16];
+    snprintf(v, sizeof v, "%u", cb->verbose);
+    hip_cdna4_set_option("verbose", v);
+  }
 
   /* every built backend is initialised whatever --solver says (:143-147);
    * here that is the hip backend alone.  Return value ignored like there. */

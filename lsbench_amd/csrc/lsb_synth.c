@@ -10,6 +10,16 @@
  *           neighbours -1, Dirichlet boundary (missing neighbours dropped)
  *   lap3d   7-point Laplacian on nx x ny x nz, row = (k*ny + j)*nx + i,
  *           diagonal 6, neighbours -1
+ *   lap2d / lap3d with ",coef=K" (K != 0): the same pattern with GENERAL values --
+ *           the stencil of -div(w grad u) with one weight per grid edge,
+ *           w(a,b) = 1/2 + (mix(K, a, b) >> 11) * 2^-53 in [1/2, 3/2) for the
+ *           edge between rows a < b, and w = 1/2 + (mix(K ^ GHOST, row, d) >> 11)
+ *           * 2^-53 for the edge that leaves the grid in direction d (0..5 =
+ *           k-, j-, i-, i+, j+, k+; Dirichlet).  Off-diagonal = -w, diagonal =
+ *           the weights of the row's 4 (6) edges added in direction order from
+ *           0.0.  Exactly symmetric, weakly diagonally dominant with strict rows
+ *           at the boundary, irreducible => SPD.  The operator the roofline line
+ *           "fp64 CSR SpMV with values that must be streamed" is measured on.
  *   powerlaw  n x n, row degree d_i from a truncated discrete power law
  *           P(d) ~ d^-gamma on [1,max] by inverse CDF on a 2^53-scaled integer
  *           table; the k-th entry of row i sits in column
@@ -64,9 +74,30 @@ static void alloc_entries(struct csr *A, const unsigned long long *cnt) {
     errx(EXIT_FAILURE, "out of host memory for %llu synthetic non-zeros", acc);
 }
 
+static unsigned long long mix64(unsigned long long seed, unsigned long long a,
+                                unsigned long long b) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (a + 1) +
+                         0xC2B2AE3D27D4EB4Full * (b + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+#define TWO53 9007199254740992.0
+#define COEF_GHOST 0x5851F42D4C957F2Dull
+
+/* weight of the grid edge between rows a < b / of the edge leaving the grid */
+static double edge_w(unsigned long long cseed, unsigned long long a, unsigned long long b) {
+  return 0.5 + (double)(mix64(cseed, a, b) >> 11) * (1.0 / TWO53);
+}
+static double ghost_w(unsigned long long cseed, unsigned long long row, unsigned dir) {
+  return 0.5 + (double)(mix64(cseed ^ COEF_GHOST, row, dir) >> 11) * (1.0 / TWO53);
+}
+
 static struct csr *gen_lap(unsigned long long nx, unsigned long long ny,
                            unsigned long long nz, int three,
-                           unsigned long long r0, unsigned long long r1) {
+                           unsigned long long r0, unsigned long long r1,
+                           unsigned long long cseed) {
   const unsigned long long nxy = nx * ny;
   const double diag = three ? 6.0 : 4.0;
   struct csr *A = alloc_rows((unsigned)(r1 - r0));
@@ -84,34 +115,59 @@ static struct csr *gen_lap(unsigned long long nx, unsigned long long ny,
   for (long long rr = (long long)r0; rr < (long long)r1; rr++) {
     const unsigned long long row = (unsigned long long)rr;
     const unsigned long long i = row % nx, j = (row / nx) % ny, k = row / nxy;
-    unsigned z = A->offs[row - r0];
-    if (three && k > 0)
-      A->cols[z] = (unsigned)(row - nxy), A->vals[z++] = -1.0;
+    unsigned z = A->offs[row - r0], zd;
+    if (!cseed) {
+      if (three && k > 0)
+        A->cols[z] = (unsigned)(row - nxy), A->vals[z++] = -1.0;
+      if (j > 0)
+        A->cols[z] = (unsigned)(row - nx), A->vals[z++] = -1.0;
+      if (i > 0)
+        A->cols[z] = (unsigned)(row - 1), A->vals[z++] = -1.0;
+      A->cols[z] = (unsigned)row, A->vals[z++] = diag;
+      if (i + 1 < nx)
+        A->cols[z] = (unsigned)(row + 1), A->vals[z++] = -1.0;
+      if (j + 1 < ny)
+        A->cols[z] = (unsigned)(row + nx), A->vals[z++] = -1.0;
+      if (three && k + 1 < nz)
+        A->cols[z] = (unsigned)(row + nxy), A->vals[z++] = -1.0;
+      continue;
+    }
+    /* general values: one weight per edge, the diagonal = their sum in direction order */
+    double w, d = 0.0;
+    if (three) {
+      w = k > 0 ? edge_w(cseed, row - nxy, row) : ghost_w(cseed, row, 0);
+      d += w;
+      if (k > 0)
+        A->cols[z] = (unsigned)(row - nxy), A->vals[z++] = -w;
+    }
+    w = j > 0 ? edge_w(cseed, row - nx, row) : ghost_w(cseed, row, 1);
+    d += w;
     if (j > 0)
-      A->cols[z] = (unsigned)(row - nx), A->vals[z++] = -1.0;
+      A->cols[z] = (unsigned)(row - nx), A->vals[z++] = -w;
+    w = i > 0 ? edge_w(cseed, row - 1, row) : ghost_w(cseed, row, 2);
+    d += w;
     if (i > 0)
-      A->cols[z] = (unsigned)(row - 1), A->vals[z++] = -1.0;
-    A->cols[z] = (unsigned)row, A->vals[z++] = diag;
+      A->cols[z] = (unsigned)(row - 1), A->vals[z++] = -w;
+    zd = z++;
+    A->cols[zd] = (unsigned)row;
+    w = i + 1 < nx ? edge_w(cseed, row, row + 1) : ghost_w(cseed, row, 3);
+    d += w;
     if (i + 1 < nx)
-      A->cols[z] = (unsigned)(row + 1), A->vals[z++] = -1.0;
+      A->cols[z] = (unsigned)(row + 1), A->vals[z++] = -w;
+    w = j + 1 < ny ? edge_w(cseed, row, row + nx) : ghost_w(cseed, row, 4);
+    d += w;
     if (j + 1 < ny)
-      A->cols[z] = (unsigned)(row + nx), A->vals[z++] = -1.0;
-    if (three && k + 1 < nz)
-      A->cols[z] = (unsigned)(row + nxy), A->vals[z++] = -1.0;
+      A->cols[z] = (unsigned)(row + nx), A->vals[z++] = -w;
+    if (three) {
+      w = k + 1 < nz ? edge_w(cseed, row, row + nxy) : ghost_w(cseed, row, 5);
+      d += w;
+      if (k + 1 < nz)
+        A->cols[z] = (unsigned)(row + nxy), A->vals[z++] = -w;
+    }
+    A->vals[zd] = d;
   }
   return A;
 }
-
-static unsigned long long mix64(unsigned long long seed, unsigned long long a,
-                                unsigned long long b) {
-  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (a + 1) +
-                         0xC2B2AE3D27D4EB4Full * (b + 1);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
-}
-
-#define TWO53 9007199254740992.0
 
 /* thr[d-1] = floor(2^53 * CDF(d)) of P(d) ~ d^-gamma on [1,dmax] */
 static double pl_table(double gamma, unsigned dmax, unsigned long long *thr) {
@@ -313,5 +369,8 @@ struct csr *lsbench_matrix_synth(const char *spec, unsigned r0, unsigned r1,
     return gen_powerlaw_spd(n, gamma, dmax, seed, r0, r1);
   if (kind == 3)
     return gen_powerlaw(n, gamma, dmax, seed, r0, r1);
-  return gen_lap(nx, ny, kind == 2 ? nz : 1, kind == 2, r0, r1);
+  unsigned long long cseed = 0;
+  if (spec_get(spec, "coef", &v) && v != 0.0)
+    cseed = (unsigned long long)v;
+  return gen_lap(nx, ny, kind == 2 ? nz : 1, kind == 2, r0, r1, cseed);
 }

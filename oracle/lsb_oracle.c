@@ -778,6 +778,59 @@ static uint64_t orc_mix(uint64_t seed, uint64_t a, uint64_t b) {
   return z ^ (z >> 31);
 }
 
+/* Variable-coefficient 5-/7-point operator on the lap2d / lap3d pattern
+ * ("...,coef=K" of the product's generator; DESIGN.md "Synthetic operators"):
+ * the stencil of -div(w grad u) with one weight per grid edge.  Directions
+ * d = 0..5 are k-, j-, i-, i+, j+, k+ (2-D: d = 1..4 only).  An edge joining
+ * rows a < b weighs 1/2 + (mix(K, a, b) >> 11) / 2^53; an edge leaving the
+ * grid from `row` in direction d weighs 1/2 + (mix(K ^ 0x5851F42D4C957F2D,
+ * row, d) >> 11) / 2^53 (Dirichlet: it only feeds the diagonal).  Entry
+ * (row, neighbour) = -w, diagonal = sum of the row's weights in direction
+ * order, starting from 0.  Stated from the definition with a direction table,
+ * not from the product's unrolled code. */
+uint64_t orc_lap_coef(uint64_t nx, uint64_t ny, uint64_t nz, int three, uint64_t K,
+                      uint64_t r0, uint64_t r1, uint64_t *offs, uint32_t *cols,
+                      double *vals) {
+  const int64_t stride[6] = {-(int64_t)(nx * ny), -(int64_t)nx, -1, 1, (int64_t)nx,
+                             (int64_t)(nx * ny)};
+  uint64_t z = 0;
+  for (uint64_t row = r0; row < r1; row++) {
+    const uint64_t c[3] = {row % nx, (row / nx) % ny, row / (nx * ny)}; /* i, j, k */
+    const uint64_t ext[3] = {nx, ny, three ? nz : 1};
+    double w[6], diag = 0.0;
+    int inside[6];
+    for (int d = 0; d < 6; d++) {
+      const int axis = d < 3 ? 2 - d : d - 3; /* k j i | i j k */
+      inside[d] = d < 3 ? c[axis] > 0 : c[axis] + 1 < ext[axis];
+      if (!three && axis == 2) {
+        w[d] = 0.0, inside[d] = -1; /* no such direction in 2-D */
+        continue;
+      }
+      if (inside[d]) {
+        const uint64_t nb = (uint64_t)((int64_t)row + stride[d]);
+        const uint64_t a = nb < row ? nb : row, b = nb < row ? row : nb;
+        w[d] = 0.5 + (double)(orc_mix(K, a, b) >> 11) / 9007199254740992.0;
+      } else {
+        w[d] = 0.5 + (double)(orc_mix(K ^ 0x5851F42D4C957F2Dull, row, (uint64_t)d) >> 11) /
+                         9007199254740992.0;
+      }
+      diag += w[d];
+    }
+    if (offs)
+      offs[row - r0] = z;
+    for (int d = 0; d < 3; d++)
+      if (inside[d] == 1)
+        ORC_PUT((uint64_t)((int64_t)row + stride[d]), -w[d]);
+    ORC_PUT(row, diag);
+    for (int d = 3; d < 6; d++)
+      if (inside[d] == 1)
+        ORC_PUT((uint64_t)((int64_t)row + stride[d]), -w[d]);
+  }
+  if (offs)
+    offs[r1 - r0] = z;
+  return z;
+}
+
 /* Row degree: inverse-CDF of a discrete power law P(d) ~ d^-gamma on
  * [1, dmax], through an integer threshold table thr[d-1] = floor(2^53 *
  * CDF(d)) that the caller passes in (it is part of the operator's

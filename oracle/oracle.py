@@ -49,10 +49,11 @@ def lib():
     L.orc_pcg_jacobi.argtypes = [C.c_uint64, _u64p, _u32p, _f64p, _f64p, _f64p,
                                  C.c_double, C.c_uint32, C.c_int,
                                  C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
-    for name in ("orc_lap2d", "orc_lap3d", "orc_powerlaw"):
+    for name in ("orc_lap2d", "orc_lap3d", "orc_powerlaw", "orc_lap_coef"):
         getattr(L, name).restype = C.c_uint64
     L.orc_lap2d.argtypes = [C.c_uint64] * 4 + [C.c_void_p] * 3
     L.orc_lap3d.argtypes = [C.c_uint64] * 5 + [C.c_void_p] * 3
+    L.orc_lap_coef.argtypes = [C.c_uint64] * 3 + [C.c_int] + [C.c_uint64] * 3 + [C.c_void_p] * 3
     L.orc_powerlaw_table.restype = C.c_double
     L.orc_powerlaw_table.argtypes = [C.c_double, C.c_uint32, _u64p]
     L.orc_powerlaw.argtypes = [C.c_uint64, C.c_uint32, _u64p, C.c_uint64,
@@ -245,6 +246,15 @@ def lap3d(nx, ny, nz, r0=0, r1=None):
     """7-point Laplacian, lexicographic, diag 6 / off-diag -1."""
     r1 = nx * ny * nz if r1 is None else r1
     return _gen(lib().orc_lap3d, (nx, ny, nz), r0, r1)
+
+
+def lap_coef(nx, ny, nz=None, coef=1, r0=0, r1=None):
+    """Variable-coefficient 5-point (nz None) / 7-point operator, `...,coef=K`."""
+    three = nz is not None
+    n = nx * ny * (nz if three else 1)
+    r1 = n if r1 is None else r1
+    L = lib()
+    return _gen(lambda *a: L.orc_lap_coef(nx, ny, nz if three else 1, int(three), coef, *a), (), r0, r1)
 
 
 def powerlaw_gamma(avg, dmax):

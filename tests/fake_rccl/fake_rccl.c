@@ -176,6 +176,11 @@ ncclResult_t ncclCommInitRank(ncclComm_t *out, int nranks, ncclUniqueId id, int 
   return ncclSuccess;
 }
 
+ncclResult_t ncclCommCount(const ncclComm_t comm, int *count) {
+  *count = ((const struct fake_comm *)comm)->nranks;
+  return ncclSuccess;
+}
+
 ncclResult_t ncclCommDestroy(ncclComm_t comm) {
   struct fake_comm *c = (struct fake_comm *)comm;
   barrier(c);
@@ -190,14 +195,14 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm) {
  * k-th behave like a collective whose peers never arrive -- the call returns at
  * once (RCCL calls are asynchronous) and the STREAM stops making progress; so do
  * all of that rank's later collectives (a real hung stream never gets to them).
- * The product's host-side deadline has to notice.  The sleeping host functions
- * end as soon as the process starts exiting, so that the runtime's teardown
- * does not wait for them. */
-static volatile int g_exiting = 0;
-static void note_exit(void) { g_exiting = 1; }
+ * The product's host-side deadline has to notice -- and has to leave the process
+ * although this stream will not drain for another 45 s (a real hung collective
+ * never drains): the host function keeps sleeping whatever the process does, so
+ * an exit() that runs the HIP runtime's teardown would sit here; the product's
+ * give-up path is _exit() (lsb_give_up), and the test checks the elapsed time. */
 static void stall_fn(void *arg) {
   (void)arg;
-  for (int i = 0; i < 450 && !g_exiting; i++)
+  for (int i = 0; i < 450; i++)
     usleep(100000);
 }
 static __thread int g_allreduces = 0, g_stalled = 0;
@@ -207,9 +212,6 @@ ncclResult_t ncclAllReduce(const void *send, void *recv, size_t count, ncclDataT
   struct fake_comm *c = (struct fake_comm *)comm;
   const char *sr = getenv("FAKE_RCCL_STALL_RANK"), *sa = getenv("FAKE_RCCL_STALL_AFTER");
   if (sr && atoi(sr) == c->rank && ++g_allreduces > (sa ? atoi(sa) : 0)) {
-    static int registered = 0;
-    if (!__atomic_exchange_n(&registered, 1, __ATOMIC_ACQ_REL))
-      atexit(note_exit);
     if (!g_stalled && hipLaunchHostFunc(stream, stall_fn, NULL) != hipSuccess)
       die("hipLaunchHostFunc");
     g_stalled = 1;

@@ -9,6 +9,7 @@ node in the 8-GPU bench."""
 import json
 import os
 import subprocess
+import time
 import sys
 
 import numpy as np
@@ -145,9 +146,15 @@ def test_driver_ngpus_from_one_process(ngpus, comm, matrix, matrix_path, golden_
         assert int(f[-4]) == 2 and int(f[-3]) == 6 and len(x) == int(f[-6])  # (a synth: name has commas)
         assert int(h[2]) == 1 and int(h[5]) == n                   # converged; N shards
         if n > 1:
-            k = lines.index("===hip_cdna4:ngpus,comm===")
+            k = [i for i, l in enumerate(lines) if l.startswith("===hip_cdna4:ngpus,comm,rccl_ranks,")][0]
             got = lines[k + 1].split(",")
             assert int(got[0]) == n
+            # the ranks the communicator itself counts (ncclCommCount), and rank 0's plan: a
+            # banded operator exchanges halos with its one neighbour, not an all-gather
+            assert int(got[2]) == n
+            if synth:
+                assert got[3] == "halos" and int(got[4]) == 1 and int(got[5]) == 1
+                assert int(got[6]) == int(got[7]) == 40 * 36 * 8       # one plane of the 40 x 36 x 30 grid
             if comm == "rccl":
                 assert got[1] == "rccl"
             if comm == "p2p":
@@ -175,8 +182,13 @@ def test_hung_collective_ends_with_a_message():
     env = _env()
     env.update(LSBENCH_HIP_SHARE_DEVICE="1", LSBENCH_HIP_COMM="rccl", FAKE_RCCL_STALL_RANK="1",
                FAKE_RCCL_STALL_AFTER="40", LSBENCH_HIP_COMM_DEADLINE_S="5")
+    t0 = time.time()
     r = subprocess.run([drv, "--solver", "hip", "--matrix", "synth:lap2d:nx=300,ny=200", "--operator", "raw",
                         "--tol", "1e-10", "--trials=1", "--ngpus", "2"], capture_output=True, text=True,
                        env=env, timeout=300)
+    dt = time.time() - t0
     assert r.returncode != 0
     assert "a collective of the sharded solve is hung" in r.stderr     # the product's deadline, not the double's
+    # the stalled stream keeps "running" for 45 s (the double's host function sleeps whatever the
+    # process does): the product has to leave without waiting for it -- _exit(), not exit()
+    assert dt < 35, "the give-up path waited for a stream that cannot drain (%.0f s)" % dt

@@ -216,6 +216,46 @@ def test_synth_equals_oracle():
         la.lsbench_matrix_synth("hilbert:n=4")
 
 
+@pytest.mark.parametrize("spec,dims,rng_rows", [
+    ("lap2d:nx=61,ny=47,coef=1", (61, 47, None), (0, None)),
+    ("lap2d:nx=33,ny=20,coef=77", (33, 20, None), (101, 500)),
+    ("lap3d:nx=13,ny=11,nz=9,coef=1", (13, 11, 9), (0, None)),
+    ("lap3d:nx=7,ny=6,nz=5,coef=3", (7, 6, 5), (40, 171)),
+    ("lap2d:nx=128,ny=1,coef=1", (128, 1, None), (0, None))])
+def test_variable_coefficient_operator(spec, dims, rng_rows):
+    """`coef=K`: the lap2d / lap3d pattern with general values (one weight per grid
+    edge, Dirichlet).  Product generator == oracle's independent statement bit for
+    bit, any row range; same pattern as the constant operator; exactly symmetric;
+    weights in [1/2, 3/2); row sums = the weights of the edges leaving the grid."""
+    import scipy.sparse as sp
+    nx, ny, nz = dims
+    r0, r1 = rng_rows
+    n = nx * ny * (nz or 1)
+    L = la.lsbench_matrix_synth(spec, r0, r1 or 0)
+    o, c, v = O.lap_coef(nx, ny, nz, int(spec.rsplit("=", 1)[1]), r0, r1)
+    assert L.n_global == n and np.array_equal(L.offs, o)
+    assert np.array_equal(L.cols, c) and np.array_equal(L.vals, v)
+    plain = la.lsbench_matrix_synth(spec.rsplit(",", 1)[0], r0, r1 or 0)
+    assert np.array_equal(plain.offs, L.offs) and np.array_equal(plain.cols, L.cols)
+    full = la.lsbench_matrix_synth(spec)
+    S = sp.csr_matrix((full.vals, full.cols.astype(np.int64), full.offs.astype(np.int64)), shape=(n, n))
+    assert (S != S.T).nnz == 0                           # exactly symmetric
+    off = S - sp.diags(S.diagonal())
+    assert off.data.max() <= -0.5 and off.data.min() > -1.5
+    rs = np.asarray(S.sum(axis=1)).ravel()               # = sum of the ghost-edge weights
+    assert rs.min() >= -16 * np.finfo(float).eps         # round-off of a row sum of ~9
+    i = np.arange(n) % nx
+    j = (np.arange(n) // nx) % ny
+    k = np.arange(n) // (nx * ny)
+    interior = (i > 0) & (i < nx - 1) & (j > 0) & (j < ny - 1)
+    if nz:
+        interior &= (k > 0) & (k < nz - 1)
+    assert np.all(np.abs(rs[interior]) <= 16 * np.finfo(float).eps) and np.all(rs[~interior] >= 0.5 - 1e-15)
+    assert len(np.unique(full.vals)) > 0.9 * full.nnz / 2  # general values: nothing to elide
+    if n <= 4000:                                        # SPD (dense check on the small ones)
+        assert np.linalg.eigvalsh(S.toarray()).min() > 0
+
+
 def test_synth_through_matrix_read_prefix():
     A = la.lsbench_matrix_read("synth:lap2d:nx=9,ny=4")
     assert A.nrows == 36 and A.nnz == 5 * 36 - 2 * 9 - 2 * 4

@@ -7,12 +7,17 @@ OUT=gpurun_out/${1:-profiles}; mkdir -p $OUT; export TMPDIR=/tmp
 step() { local name=$1 secs=$2; shift 2
   echo "=== $name"; timeout -k 10 "$secs" "$@" > "$OUT/$name.log" 2>&1; local rc=$?
   echo "rc=$rc"; if [ $rc -ge 124 ]; then echo "step $name killed: stopping"; exit $rc; fi; }
-Q="--cpu-seconds 0 --cfg4 0"
+Q="--cpu-seconds 0 --cfg4 0 --general-values 0"
 F=file:tests/golden/matrices/xn3b_A_18.txt.gz
-step bench 500 python bench.py
+step bench 600 python bench.py
 step trace 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --steps 1 --warmup 0 $Q
 step pmc_fetch 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py --fixed-iters 60 --steps 1 --warmup 0 $Q
 step pmc_write 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -- python3 bench.py --fixed-iters 60 --steps 1 --warmup 0 $Q
+G="--workload lap2d_coef --general-values 0"
+step bench_coef 400 python bench.py $G --steps 2 $Q
+step trace_coef 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_coef" -- python3 bench.py $G --fixed-iters 200 --steps 1 --warmup 0 $Q
+step pmc_fetch_coef 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch_coef" -- python3 bench.py $G --fixed-iters 60 --steps 1 --warmup 0 $Q
+step pmc_write_coef 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write_coef" -- python3 bench.py $G --fixed-iters 60 --steps 1 --warmup 0 $Q
 step trace_lap3d 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_lap3d" -- python3 bench.py --workload lap3d --fixed-iters 100 --steps 1 --warmup 0 $Q
 step pmc_fetch_lap3d 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch_lap3d" -- python3 bench.py --workload lap3d --fixed-iters 40 --steps 1 --warmup 0 $Q
 step pmc_write_lap3d 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write_lap3d" -- python3 bench.py --workload lap3d --fixed-iters 40 --steps 1 --warmup 0 $Q

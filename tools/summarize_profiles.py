@@ -17,13 +17,24 @@ def one(pattern):
     return g[-1] if g else None  # newest run wins
 
 
-for tag in ("trace", "trace_lap3d", "trace_cfg2", "trace_powerlaw"):
+for tag in ("trace", "trace_coef", "trace_lap3d", "trace_cfg2", "trace_powerlaw"):
     f = one(tag + "/*/*kernel_stats.csv")
     if f:
         shutil.copyfile(f, os.path.join(out, "%s_%s_kernel_stats.csv" % (rnd, tag)))
 
 traffic = {}
-for wl, suffix in (("lap2d", ""), ("lap3d", "_lap3d"), ("powerlaw", "_powerlaw")):
+def bench_line_of(tag):
+    """The JSON line the profiled command itself printed (its roofline record names the
+    kernel sources' hash and the layout's kept / all value slots the counters belong to)."""
+    f = os.path.join(src, tag + ".log")
+    if os.path.exists(f):
+        for l in open(f):
+            if l.startswith("{"):
+                return json.loads(l)
+    return None
+
+
+for wl, suffix in (("lap2d", ""), ("lap2d_coef", "_coef"), ("lap3d", "_lap3d"), ("powerlaw", "_powerlaw")):
     pmc = {}
     for cname, tag in (("FETCH_SIZE", "pmc_fetch" + suffix), ("WRITE_SIZE", "pmc_write" + suffix)):
         f = one(tag + "/*/*counter_collection.csv")
@@ -83,7 +94,12 @@ for wl, suffix in (("lap2d", ""), ("lap3d", "_lap3d"), ("powerlaw", "_powerlaw")
                              "pass, %d in the WRITE pass): %.0f bytes" % (nbins, nf, nw, tot))
     open(os.path.join(out, "%s_pmc_traffic_%s.csv" % (rnd, wl)), "w").write("\n".join(lines) + "\n")
     if best:
+        d = bench_line_of("pmc_fetch" + suffix) or {}
+        roof = d.get("roofline", {})
+        vs = roof.get("value_slots", {})
         traffic[wl] = {"bytes": best[2], "kernel": best[0], "launches": best[1],
+                       "kernels_sha16": roof.get("kernels_sha16"),
+                       "value_slots": [vs.get("kept", 0), vs.get("all", 0)],
                        "source": "profiles/%s_pmc_traffic_%s.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                  "separate passes of this command; FETCH_SIZE x 2)" % (rnd, wl)}
     print(wl)
@@ -91,7 +107,7 @@ for wl, suffix in (("lap2d", ""), ("lap3d", "_lap3d"), ("powerlaw", "_powerlaw")
 if traffic:
     json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 # bench lines
-names = ["bench", "bench_powerlaw", "bench_powerlaw_v7", "bench_powerlaw_v6", "bench_powerlaw_v1", "cfg5_spd_cg", "cfg2_launches", "cfg2_persistent",
+names = ["bench", "bench_coef", "bench_powerlaw", "bench_powerlaw_v7", "bench_powerlaw_v6", "bench_powerlaw_v1", "cfg5_spd_cg", "cfg2_launches", "cfg2_persistent",
          "cfg2_dense_inverse", "cfg2_cheb4", "cfg3_fp32", "cfg3_cheb4", "cfg3_cheb16", "cfg3_bj8"]
 with open(os.path.join(out, "%s_bench.jsonl" % rnd), "w") as fo:
     for tag in names:
