@@ -353,6 +353,12 @@ struct lsb_pb {
 struct lsb_pb *lsb_csr_pbize2(const struct csr *A, unsigned cols, unsigned rows);
 struct lsb_pb *lsb_csr_pbize(const struct csr *A);
 void lsb_pb_free(struct lsb_pb *P);
+/* Host-side assertions of the bounds the two kernels rely on: every index they form against
+ * arrays of prod_len / roww_len slots as the caller allocated them (the backend allocates
+ * nnz + 2).  0 = all hold; else a code, and the violated rule in why[whylen].  deep: also
+ * every entry's 16-bit offsets.  Run at every upload (shallow) and under ASan (deep). */
+int lsb_pb_check(const struct lsb_pb *P, unsigned long long prod_len, unsigned long long roww_len, int deep,
+                 char *why, size_t whylen);
 /* Sliced-ELL copy of a CSR for LSB_SPMV_SELL: rows in slices of LSB_SELL_ROWS,
  * every slice padded to its longest row and stored column-major (entry j of
  * row 128s+i at sptr[s] + 128j + i), so that a wavefront's lane l reads the

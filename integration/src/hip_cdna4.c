@@ -18,4 +18,6 @@ int hip_cdna4_bench(double *x, struct csr *A, const double *r,
                     const struct lsbench *cb) {
   return 1;
 }
+int hip_cdna4_set_option(const char *name, const char *value) { return 1; }
+struct csr *hip_cdna4_matrix_synth(const char *spec) { return 0; }
 #endif

@@ -121,6 +121,11 @@ static void shard_build_twophase(struct shard *s, const struct csr *view, unsign
   struct lsb_pb *P = lsb_csr_pbize(view);
   if (!P)
     return;
+  { /* the bounds k_pb_products / k_pb_reduce rely on, against the allocations made below */
+    char why[256];
+    if (lsb_pb_check(P, P->nnz + 2, P->nnz + 2, 0, why, sizeof why))
+      errx(EXIT_FAILURE, "hip_cdna4: two-phase layout breaks a bound its kernels rely on: %s", why);
+  }
   s->tp_items = P->nitems, s->tp_bins = P->nbins, s->tp_col_lo = P->ncols_lo, s->tp_xlen = n_glob;
   s->tp_cols = P->cols, s->tp_rows = P->rows;
   s->tp_item = (unsigned *)dev_upload(P->item, (size_t)P->nitems * 3 * sizeof(unsigned));

@@ -720,6 +720,100 @@ struct lsb_pb *lsb_csr_pbize2(const struct csr *A, unsigned C, unsigned R) {
   return P;
 }
 
+/* Every index the two kernels of the two-phase SpMV form (hip_pb.hip), checked on the host
+ * against the arrays as they are ALLOCATED -- the bounds those kernels rely on, as assertions:
+ *   phase 1: work items start on a multiple of 64 inside [0, nent), name a chunk < nchunks
+ *            and end inside nent (its clamped loads reach e1 - 1); the piece of every group
+ *            of 64 entries, grp_first[g] + popcount(grp_mask[g]), stays below npieces; the
+ *            stores of a piece, entry index + delta[piece] (mod 2^32), land in [0, nnz);
+ *   phase 2: bin_ptr is non-decreasing, ends at nnz, and the PAIR loads of a bin -- from the
+ *            even slot at or below its first to the even slot at or below its last, two slots
+ *            each -- stay inside prod_len / roww_len slots (the device arrays are allocated two
+ *            slots longer than they are used for exactly this).
+ * deep != 0 also walks all entries: colw < cols, roww < rows.
+ * Returns 0 when everything holds, else a non-zero code and the violated rule in `why`.
+ * Round 2's two GPU-side failures were experiments that broke exactly
+ * these rules: stores at the PADDED entry index, pair loads past the last slot. */
+int lsb_pb_check(const struct lsb_pb *P, unsigned long long prod_len, unsigned long long roww_len, int deep,
+                 char *why, size_t whylen) {
+#define PB_FAIL(code, ...)                                                                     \
+  do {                                                                                         \
+    if (why && whylen)                                                                         \
+      snprintf(why, whylen, __VA_ARGS__);                                                      \
+    return code;                                                                               \
+  } while (0)
+  if (!P)
+    PB_FAIL(1, "no layout");
+  if (P->nent % 64 || P->nent < P->nnz || P->nent > 0xFFFFFFC0ull)
+    PB_FAIL(2, "nent = %llu is not a multiple of 64 in [nnz, 2^32)", P->nent);
+  if (prod_len < P->nnz + 1 || roww_len < P->nnz + 1)
+    PB_FAIL(3, "product / row arrays of %llu / %llu slots: phase 2's pair loads need nnz + 1 = %llu", prod_len,
+            roww_len, P->nnz + 1);
+  unsigned long long covered = 0;
+  for (unsigned it = 0; it < P->nitems; it++) {
+    const unsigned c = P->item[3 * it], e0 = P->item[3 * it + 1], e1 = P->item[3 * it + 2];
+    if (c >= P->nchunks || e0 % 64 || e1 <= e0 || e1 > P->nent)
+      PB_FAIL(4, "work item %u = {chunk %u, [%u, %u)} outside %u chunks / %llu entries or not 64-aligned", it, c,
+              e0, e1, P->nchunks, P->nent);
+    covered += e1 - e0;
+  }
+  if (covered != P->nnz)
+    PB_FAIL(5, "work items cover %llu entries, the operator has %llu", covered, P->nnz);
+  const unsigned long long ngrp = P->nent / 64;
+  for (unsigned long long g = 0; g < ngrp; g++)
+    if ((unsigned long long)P->grp_first[g] + (unsigned)__builtin_popcountll(P->grp_mask[g]) >= P->npieces + (P->npieces == 0))
+      PB_FAIL(6, "group %llu names piece %u + %d of %u", g, P->grp_first[g], __builtin_popcountll(P->grp_mask[g]),
+              P->npieces);
+  /* stores: walk the pieces in phase-1 order through the group words, the way the kernel does */
+  for (unsigned it = 0; it < P->nitems; it++) {
+    const unsigned e0 = P->item[3 * it + 1], e1 = P->item[3 * it + 2];
+    for (unsigned e = e0; e < e1;) { /* e = first entry of a piece (or of the item inside one) */
+      const unsigned lane = e % 64;
+      const unsigned long long le = lane == 63 ? ~0ull : (2ull << lane) - 1ull;
+      const unsigned piece = P->grp_first[e / 64] + (unsigned)__builtin_popcountll(P->grp_mask[e / 64] & le);
+      /* the piece runs to the next set bit / next group whose first piece differs / the item's end */
+      unsigned f = e + 1;
+      while (f < e1) {
+        const unsigned fl = f % 64;
+        const unsigned long long fle = fl == 63 ? ~0ull : (2ull << fl) - 1ull;
+        if (P->grp_first[f / 64] + (unsigned)__builtin_popcountll(P->grp_mask[f / 64] & fle) != piece)
+          break;
+        f = deep ? f + 1 : (fl == 63 || !(P->grp_mask[f / 64] >> (fl + 1)) ? (f | 63u) + 1 : f + 1);
+      }
+      if (f > e1)
+        f = e1;
+      const unsigned first = e + P->delta[piece], last = (f - 1) + P->delta[piece]; /* mod 2^32, like the kernel */
+      if (first >= P->nnz || last >= P->nnz || last < first)
+        PB_FAIL(7, "piece %u: entries [%u, %u) store to slots [%u, %u] of %llu", piece, e, f, first, last, P->nnz);
+      e = f;
+    }
+  }
+  if (P->bin_ptr[P->nbins] != P->nnz)
+    PB_FAIL(8, "bin_ptr ends at %u, not at nnz = %llu", P->bin_ptr[P->nbins], P->nnz);
+  for (unsigned b = 0; b < P->nbins; b++) {
+    const unsigned s0 = P->bin_ptr[b], s1 = P->bin_ptr[b + 1];
+    if (s1 < s0)
+      PB_FAIL(9, "bin %u: slots [%u, %u)", b, s0, s1);
+    if (s1 > s0) { /* pair loads at even indices a0 .. last, two slots each */
+      const unsigned long long last = (s1 - 1u) & ~1u;
+      if (last + 1 >= prod_len || last + 1 >= roww_len)
+        PB_FAIL(10, "bin %u: the pair load at slot %llu reaches past %llu / %llu allocated slots", b, last,
+                prod_len, roww_len);
+    }
+  }
+  if (deep) {
+    for (unsigned it = 0; it < P->nitems; it++)
+      for (unsigned e = P->item[3 * it + 1]; e < P->item[3 * it + 2]; e++)
+        if (P->colw[e] >= P->cols)
+          PB_FAIL(11, "entry %u: column offset %u in a chunk of %u", e, P->colw[e], P->cols);
+    for (unsigned long long k = 0; k < P->nnz; k++)
+      if (P->roww[k] >= P->rows)
+        PB_FAIL(12, "slot %llu: row offset %u in a bin of %u", k, P->roww[k], P->rows);
+  }
+  return 0;
+#undef PB_FAIL
+}
+
 struct lsb_pb *lsb_csr_pbize(const struct csr *A) {
   const char *ec = getenv("LSBENCH_HIP_PB_COLS"), *er = getenv("LSBENCH_HIP_PB_ROWS");
   return lsb_csr_pbize2(A, ec ? (unsigned)atoi(ec) : 0, er ? (unsigned)atoi(er) : 0);

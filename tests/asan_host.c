@@ -38,6 +38,24 @@ int main(void) {
         }
       if (s != P->nnz || P->bin_ptr[P->nbins] != P->nnz) { printf("pbize mismatch\n"); return 1; }
       free(hit);
+      /* the bounds the kernels rely on, as the backend asserts them at upload (deep here); and the
+       * two rules round 2's experiments broke must be caught: a product array without the two spare
+       * slots of the pair loads, stores at the padded entry index (delta = 0) */
+      char why[256];
+      if (lsb_pb_check(P, P->nnz + 2, P->nnz + 2, 1, why, sizeof why)) { printf("pb_check: %s\n", why); return 1; }
+      if (lsb_pb_check(P, P->nnz + 2, P->nnz + 2, 0, why, sizeof why)) { printf("pb_check shallow: %s\n", why); return 1; }
+      if (!(P->bin_ptr[P->nbins] - 1u) % 2 == 0 && lsb_pb_check(P, P->nnz, P->nnz + 2, 0, why, sizeof why) != 3) {
+        printf("pb_check accepted a product array without spare slots\n"); return 1; }
+      if (P->nent > P->nnz) { /* padded chunks: storing at the entry index itself leaves [0, nnz) */
+        unsigned keep = P->delta[P->npieces - 1];
+        P->delta[P->npieces - 1] = 0;
+        const int rc = lsb_pb_check(P, P->nnz + 2, P->nnz + 2, 0, why, sizeof why);
+        P->delta[P->npieces - 1] = keep;
+        /* (the last piece's entries sit at padded indices >= its slots; index + 0 reaches past nnz
+         * unless nothing was padded in front of it) */
+        unsigned last_e1 = P->item[3 * (P->nitems - 1) + 2];
+        if (last_e1 > P->nnz && rc != 7) { printf("pb_check accepted stores at the padded entry index\n"); return 1; }
+      }
       lsb_pb_free(P);
     }
     struct lsb_sell *E = lsb_csr_sellize(A); lsb_sell_free(E);

@@ -6,7 +6,15 @@ the reference is copied into this repository), the tree is compiled with plain
 gcc/g++ with every other backend off -- the recipe of oracle/Makefile `ref`,
 not the reference's CMake -- once with -DLSBENCH_HIP linked against this
 repository's liblsbench_hip.so and once without (the disabled-backend stubs),
-and `driver --solver hip` is run on a reference matrix.
+and `driver --solver hip` is run on a reference matrix.  The CMake leg is run as
+well: the reference's own CMakeLists.txt (as patched) + integration/libs/hip.cmake are
+configured with -DENABLE_HIP=ON / OFF (every downloaded backend off;
+--compile-no-warning-as-error because the reference's -Werror trips on its own
+src/lsbench.c:70 with this gcc), built, and the built driver is
+run -- with integration/hip-flags.patch on top, which gives the reference's own
+lsbench_init the backend's flags (--tol, --maxit, --ngpus, ...) and its
+lsbench_matrix_read the `synth:` prefix, so that BASELINE configs 3-5 are reachable
+through the real driver.
 Reference wiring points: CMakeLists.txt:5-10,22-25,32-55; src/lsbench.c:15-35,
 73-74,143-147,162-184,190-194; stub convention src/cholmod.c:74-81."""
 import os
@@ -27,12 +35,13 @@ C_FILES = ["lsbench.c", "lsbench-csr.c", "cusparse.c", "hypre.c", "amgx.c", "cho
 CXX_FILES = ["paralmond.cpp", "ginkgo.cpp"]
 
 
-def _patched_tree(tmp_path):
+def _patched_tree(tmp_path, flags=False):
     tree = tmp_path / "lsbench"
     shutil.copytree(REF, tree, ignore=shutil.ignore_patterns("tests"))
-    r = subprocess.run(["patch", "-p1", "--no-backup-if-mismatch", "-i", os.path.join(INTEG, "hip.patch")],
-                       cwd=tree, capture_output=True, text=True)
-    assert r.returncode == 0, r.stdout + r.stderr
+    for name in ["hip.patch"] + (["hip-flags.patch"] if flags else []):
+        r = subprocess.run(["patch", "-p1", "--no-backup-if-mismatch", "-i", os.path.join(INTEG, name)],
+                           cwd=tree, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
     shutil.copy(os.path.join(INTEG, "src", "hip_cdna4.c"), tree / "src" / "hip_cdna4.c")
     shutil.copy(os.path.join(INTEG, "libs", "hip.cmake"), tree / "libs" / "hip.cmake")
     return tree
@@ -110,3 +119,67 @@ def test_patched_reference_builds_links_and_runs(tmp_path):
     r = subprocess.run([str(drv1), "--solver", "cholmod", "--matrix", matrix], capture_output=True, text=True,
                        env=env)
     assert r.returncode == 0
+
+
+def _cmake(tree, bdir, hip):
+    """The reference's own build: CMakeLists.txt:5-10,22-25,32-55 as patched + libs/hip.cmake."""
+    cfg = subprocess.run(["cmake", "-S", str(tree), "-B", str(bdir), "-DENABLE_CHOLMOD=OFF",
+                          "-DENABLE_HIP=" + ("ON" if hip else "OFF"), "-DLSBENCH_HIP_ROOT=" + ROOT,
+                          "--compile-no-warning-as-error"], capture_output=True, text=True)
+    assert cfg.returncode == 0, cfg.stdout[-2000:] + cfg.stderr[-2000:]
+    bld = subprocess.run(["cmake", "--build", str(bdir)], capture_output=True, text=True)
+    assert bld.returncode == 0, bld.stdout[-2000:] + bld.stderr[-3000:]
+    return bdir / "liblsbench.so", bdir / "driver"
+
+
+@pytest.mark.skipif(shutil.which("cmake") is None, reason="no cmake")
+@pytest.mark.parametrize("flags", [False, True])
+def test_cmake_leg_configures_builds_and_runs(tmp_path, flags):
+    """cmake -DENABLE_HIP=ON -DLSBENCH_HIP_ROOT=<this repository> on the patched reference:
+    libs/hip.cmake finds and links liblsbench_hip.so, the built driver runs `--solver hip`;
+    -DENABLE_HIP=OFF builds the stubs.  With hip-flags.patch the reference's CLI takes the
+    backend's flags and `--matrix synth:SPEC`."""
+    tree = _patched_tree(tmp_path, flags=flags)
+    matrix = os.path.join(REF, "tests", "I1_05x05.txt")
+    env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    lib1, drv1 = _cmake(tree, tmp_path / "build_on", hip=True)
+    ldd = subprocess.run(["ldd", str(lib1)], capture_output=True, text=True, env=env).stdout
+    assert os.path.join(CSRC, "liblsbench_hip.so") in ldd           # found through LSBENCH_HIP_ROOT, rpath set
+    nm = subprocess.run(["nm", "-D", str(lib1)], capture_output=True, text=True).stdout
+    assert " U hip_cdna4_bench" in nm and " T lsbench_bench" in nm and " T hip_cdna4_init" not in nm
+    import lsbench_amd as la
+    gpu = la._lib.load().lsb_hip_device_count() > 0
+    r = subprocess.run([str(drv1), "--solver", "hip", "--matrix", matrix, "--trials=2"],
+                       capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert ("===matrix,n,nnz,trials,solver,ordering,elapsed===" in r.stdout) == gpu
+    if flags:
+        assert " U hip_cdna4_set_option" in nm and " U hip_cdna4_matrix_synth" in nm
+        # BASELINE config 3's generator through the REAL driver, the backend's flags on its command line
+        r = subprocess.run([str(drv1), "--solver", "hip", "--matrix", "synth:lap2d:nx=40,ny=30",
+                            "--operator", "raw", "--tol", "1e-9", "--maxit", "500", "--ngpus", "1",
+                            "--krylov", "cg", "--trials=1"], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+        if gpu:
+            rec = r.stdout.splitlines()
+            k = rec.index("===hip_cdna4:iterations,relres,status,tol,solves_per_sec,nshards===")
+            f = rec[k + 1].split(",")
+            assert int(f[2]) == 1 and float(f[3]) == 1e-9 and "synth:lap2d:nx=40,ny=30,1200,5860,1,6," in r.stdout
+        # a value the option does not take, a spec the generator does not know: exit 1 with a message
+        r = subprocess.run([str(drv1), "--solver", "hip", "--matrix", matrix, "--krylov", "qmr"],
+                           capture_output=True, text=True, env=env)
+        assert r.returncode == 1 and "not a value of option `krylov'" in r.stderr
+        r = subprocess.run([str(drv1), "--solver", "hip", "--matrix", "synth:hilbert:n=4"],
+                           capture_output=True, text=True, env=env)
+        assert r.returncode == 1 and "Unable to generate" in r.stderr
+    # ENABLE_HIP=OFF: the stub file is what defines the symbols; `--solver hip` is the silent no-op
+    lib0, drv0 = _cmake(tree, tmp_path / "build_off", hip=False)
+    nm0 = subprocess.run(["nm", "-D", str(lib0)], capture_output=True, text=True).stdout
+    assert " T hip_cdna4_bench" in nm0 and "lsbench_hip" not in subprocess.run(
+        ["ldd", str(lib0)], capture_output=True, text=True).stdout
+    r = subprocess.run([str(drv0), "--solver", "hip", "--matrix", matrix], capture_output=True, text=True)
+    assert r.returncode == 0 and "===matrix" not in r.stdout
+    if flags:
+        r = subprocess.run([str(drv0), "--solver", "hip", "--matrix", "synth:lap2d:nx=9,ny=4"],
+                           capture_output=True, text=True)
+        assert r.returncode == 1 and "ENABLE_HIP off" in r.stderr

@@ -46,12 +46,11 @@ typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
 typedef double d2v __attribute__((ext_vector_type(2)));
 
 #define TMAX 8
-struct tmpl { // a pure slice: nslots constant, code-free slots
+struct tmpl { // a pure slice: nslots constant, code-free slots, bases ascending
   int nslots;
+  int centre;     // slot c with neighbours derived from it by lane shifts, -1 = none (all gathered)
   int base[TMAX];
-  int kind[TMAX]; // 0 gather; 1 = the slot at src shifted by -1 element; 2 = by +1
-  int src[TMAX];
-  int centre;     // slot whose base is 0 (the dot's operand), -1 if none
+  int kind[TMAX]; // 0 gather; 1 = base[centre] - 1 (the centre pair shifted up); 2 = base[centre] + 1
   double cst[TMAX];
 };
 
@@ -83,12 +82,12 @@ __device__ __forceinline__ deal deal_init(unsigned ns, unsigned xcd) {
 
 // generic slice (a slot keeps its values, e.g. where a grid line ends): the product's
 // per-slot path without codes (structured grids have none)
-__device__ __forceinline__ void slice_generic(unsigned s, unsigned ulen, const i4v *__restrict__ rec,
+__device__ __forceinline__ void slice_generic(unsigned s, const unsigned *__restrict__ sptr, const i4v *__restrict__ rec,
                                               const double *__restrict__ vconst,
                                               const double *__restrict__ vals,
                                               const double *__restrict__ x, int grow, unsigned lane,
                                               double &a0, double &a1) {
-  const unsigned q0 = s * ulen;
+  const unsigned q0 = sptr[s] / ROWS, ulen = (sptr[s + 1] - sptr[s]) / ROWS;
   for (unsigned j = 0; j < ulen; j++) {
     const i4v r = rec[q0 + j];
     if (r.z < 0) {
@@ -104,9 +103,9 @@ __device__ __forceinline__ void slice_generic(unsigned s, unsigned ulen, const i
   }
 }
 
-// ---- T5: templates, five gathers ------------------------------------------------------------
-template <int MINW>
-__global__ __launch_bounds__(WG, MINW) void k_t5(unsigned ns, unsigned n, unsigned ulen,
+// ---- T5: templates, every slot gathered ------------------------------------------------------
+template <int MINW, int TM>
+__global__ __launch_bounds__(WG, MINW) void k_t5(unsigned ns, unsigned n, const unsigned *__restrict__ sptr,
                                                 const unsigned char *__restrict__ tid8,
                                                 const tmpl *__restrict__ td,
                                                 const i4v *__restrict__ rec,
@@ -123,7 +122,7 @@ __global__ __launch_bounds__(WG, MINW) void k_t5(unsigned ns, unsigned n, unsign
     const unsigned s = __builtin_amdgcn_readfirstlane(d.base + g * 4 + wave);
     if (s >= ns)
       continue;
-    const unsigned t = tid8[s];
+    const unsigned t = __builtin_amdgcn_readfirstlane((unsigned)tid8[s]);
     const unsigned row = s * ROWS + 2 * lane;
     const int grow = (int)row;
     double a0 = 0.0, a1 = 0.0;
@@ -134,17 +133,20 @@ __global__ __launch_bounds__(WG, MINW) void k_t5(unsigned ns, unsigned n, unsign
       xd.x = x[row];
     if (t != 255u) {
       const tmpl *T = td + t;
-      d2u v[5];
+      const int cnt = T->nslots;
+      d2u v[TM];
 #pragma unroll
-      for (int u = 0; u < 5; u++)
-        v[u] = *(const d2u *)(x + (grow + T->base[u]));
+      for (int u = 0; u < TM; u++)
+        if (u < cnt)
+          v[u] = *(const d2u *)(x + (grow + T->base[u]));
 #pragma unroll
-      for (int u = 0; u < 5; u++) {
-        const double c = T->cst[u];
-        a0 += c * v[u].x, a1 += c * v[u].y;
-      }
+      for (int u = 0; u < TM; u++)
+        if (u < cnt) {
+          const double c = T->cst[u];
+          a0 += c * v[u].x, a1 += c * v[u].y;
+        }
     } else {
-      slice_generic(s, ulen, rec, vconst, vals, x, grow, lane, a0, a1);
+      slice_generic(s, sptr, rec, vconst, vals, x, grow, lane, a0, a1);
     }
     if (row + 1 < n) {
       const d2v o = {a0, a1};
@@ -184,45 +186,66 @@ __device__ __forceinline__ double lane_down(double v) { // value of lane + 1
   return __shfl_down(v, 1, 64);
 }
 
+template <int TM>
 struct pure_loads {
-  d2u v[5];
+  d2u v[TM];
   double edge;
 };
-// issue the loads of a pure 5-slot slice whose slots 1..3 are (c-1, c, c+1)
+// issue the loads of a pure slice: one 16-byte gather per kind-0 slot; where slots are derived from
+// the centre pair, the two elements beyond the wave's 128 come by one two-lane load
+template <int TM>
 __device__ __forceinline__ void pure_issue(const tmpl *T, const double *__restrict__ x, int grow,
-                                           unsigned lane, int wave_row0, unsigned n_cols, pure_loads &L) {
-  L.v[0] = *(const d2u *)(x + (grow + T->base[0]));
-  L.v[2] = *(const d2u *)(x + (grow + T->base[2]));
-  L.v[4] = *(const d2u *)(x + (grow + T->base[4]));
-  // lane 0: x[first row + c - 1]; lane 63: x[first row + c + 128] (clamped: a pure slice never
-  // uses an element outside the operator, the clamp only keeps the address legal)
+                                           unsigned lane, int wave_row0, unsigned n_cols, pure_loads<TM> &L) {
+  const int cnt = T->nslots;
+#pragma unroll
+  for (int u = 0; u < TM; u++)
+    if (u < cnt && T->kind[u] == 0)
+      L.v[u] = *(const d2u *)(x + (grow + T->base[u]));
   L.edge = 0.0;
-  if (lane == 0 || lane == 63) {
-    long long e = (long long)wave_row0 + T->base[2] + (lane == 0 ? -1 : ROWS);
+  const int c = T->centre;
+  if (c >= 0 && (lane == 0 || lane == 63)) {
+    // lane 0: x[first row + b - 1]; lane 63: x[first row + b + 128], b = base[centre] (clamped: a
+    // pure slice never USES an element outside the operator, the clamp keeps the address legal)
+    long long e = (long long)wave_row0 + T->base[c] + (lane == 0 ? -1 : ROWS);
     e = e < 0 ? 0 : (e >= (long long)n_cols ? (long long)n_cols - 1 : e);
     L.edge = x[e];
   }
 }
-template <bool DPP>
-__device__ __forceinline__ void pure_fma(const tmpl *T, pure_loads &L, unsigned lane, double &a0, double &a1) {
-  const d2u c = L.v[2];
-  double up = lane_up<DPP>(c.y), dn = lane_down<DPP>(c.x);
-  if (lane == 0)
-    up = L.edge;
-  if (lane == 63)
-    dn = L.edge;
-  L.v[1].x = up, L.v[1].y = c.x;   // base c-1: rows 2l, 2l+1 read x[2l-1], x[2l]
-  L.v[3].x = c.y, L.v[3].y = dn;   // base c+1: x[2l+1], x[2l+2]
+template <int TM, bool DPP>
+__device__ __forceinline__ void pure_fma(const tmpl *T, pure_loads<TM> &L, unsigned lane, double &a0, double &a1,
+                                         d2v &centre_pair) {
+  const int cnt = T->nslots, ci = T->centre;
+  d2u c = {0.0, 0.0};
 #pragma unroll
-  for (int u = 0; u < 5; u++) {
-    const double k = T->cst[u];
-    a0 += k * L.v[u].x, a1 += k * L.v[u].y;
+  for (int u = 0; u < TM; u++)
+    if (u == ci)
+      c = L.v[u];
+  double up = 0.0, dn = 0.0;
+  if (ci >= 0) {
+    up = lane_up<DPP>(c.y), dn = lane_down<DPP>(c.x);
+    if (lane == 0)
+      up = L.edge;
+    if (lane == 63)
+      dn = L.edge;
   }
+  centre_pair.x = c.x, centre_pair.y = c.y;
+#pragma unroll
+  for (int u = 0; u < TM; u++)
+    if (u < cnt) {
+      const int kd = T->kind[u];
+      d2u v = L.v[u];
+      if (kd == 1) // base - 1: rows 2l, 2l + 1 read x[2l - 1], x[2l]
+        v.x = up, v.y = c.x;
+      else if (kd == 2) // base + 1: x[2l + 1], x[2l + 2]
+        v.x = c.y, v.y = dn;
+      const double k = T->cst[u];
+      a0 += k * v.x, a1 += k * v.y; // slot order: the order of the shipped kernel
+    }
 }
 
 // ---- T3: templates + lane shifts; PER slices per wave and turn --------------------------------
-template <int MINW, int PER, bool DPP>
-__global__ __launch_bounds__(WG, MINW) void k_t3(unsigned ns, unsigned n, unsigned ulen,
+template <int MINW, int PER, bool DPP, int TM>
+__global__ __launch_bounds__(WG, MINW) void k_t3(unsigned ns, unsigned n, const unsigned *__restrict__ sptr,
                                                 const unsigned char *__restrict__ tid8,
                                                 const tmpl *__restrict__ td,
                                                 const i4v *__restrict__ rec,
@@ -238,16 +261,14 @@ __global__ __launch_bounds__(WG, MINW) void k_t3(unsigned ns, unsigned n, unsign
   for (unsigned g = slot; g < d.turns; g += gx) {
     const unsigned s0 = __builtin_amdgcn_readfirstlane(d.base + (g * 4 + wave) * PER);
     unsigned t[PER];
-    pure_loads L[PER];
+    pure_loads<TM> L[PER];
+#pragma unroll
+    for (int k = 0; k < PER; k++) // 254: no such slice
+      t[k] = s0 + k < ns ? __builtin_amdgcn_readfirstlane((unsigned)tid8[s0 + k]) : 254u;
 #pragma unroll
     for (int k = 0; k < PER; k++)
-      t[k] = s0 + k < ns ? (unsigned)tid8[s0 + k] : 254u; // 254: no such slice
-#pragma unroll
-    for (int k = 0; k < PER; k++) {
-      const unsigned row = (s0 + k) * ROWS + 2 * lane;
-      if (t[k] < 254u && td[t[k]].src[1] == 2)
-        pure_issue(td + t[k], x, (int)row, lane, (int)((s0 + k) * ROWS), n, L[k]);
-    }
+      if (t[k] < 254u)
+        pure_issue<TM>(td + t[k], x, (int)((s0 + k) * ROWS + 2 * lane), lane, (int)((s0 + k) * ROWS), n, L[k]);
 #pragma unroll
     for (int k = 0; k < PER; k++) {
       if (t[k] == 254u)
@@ -255,23 +276,18 @@ __global__ __launch_bounds__(WG, MINW) void k_t3(unsigned ns, unsigned n, unsign
       const unsigned s = s0 + k, row = s * ROWS + 2 * lane;
       double a0 = 0.0, a1 = 0.0;
       d2v xd = {0.0, 0.0};
-      if (t[k] != 255u && td[t[k]].src[1] == 2) {
-        pure_fma<DPP>(td + t[k], L[k], lane, a0, a1);
-        xd.x = L[k].v[2].x, xd.y = L[k].v[2].y; // the centre pair IS the dot's operand
+      bool have_xd = false;
+      if (t[k] != 255u) {
+        pure_fma<TM, DPP>(td + t[k], L[k], lane, a0, a1, xd);
+        have_xd = td[t[k]].centre >= 0 && td[t[k]].base[td[t[k]].centre] == 0; // the centre pair IS the dot's operand
       } else {
+        slice_generic(s, sptr, rec, vconst, vals, x, (int)row, lane, a0, a1);
+      }
+      if (!have_xd) {
         if (row + 1 < n)
           xd = *(const d2v *)(x + row);
         else if (row < n)
           xd.x = x[row];
-        if (t[k] != 255u) { // pure, but not of the (c-1, c, c+1) shape: five gathers
-          const tmpl *T = td + t[k];
-          for (int u = 0; u < T->nslots; u++) {
-            const d2u v = *(const d2u *)(x + ((int)row + T->base[u]));
-            a0 += T->cst[u] * v.x, a1 += T->cst[u] * v.y;
-          }
-        } else {
-          slice_generic(s, ulen, rec, vconst, vals, x, (int)row, lane, a0, a1);
-        }
       }
       if (row + 1 < n) {
         const d2v o = {a0, a1};
@@ -391,38 +407,47 @@ int main(int argc, char **argv) {
   }
   struct lsb_sell_vc *V = lsb_sell16_value_slots(H);
   const unsigned ns = H->nslice;
-  unsigned ulen = (H->sptr[1] - H->sptr[0]) / ROWS;
-  for (unsigned k = 0; k < ns; k++)
-    if ((H->sptr[k + 1] - H->sptr[k]) / ROWS != ulen)
-      ulen = 0;
-  printf("%s: n=%u nnz=%u slices=%u ulen=%u slots=%llu kept=%u code_slots=%u\n", spec, n, A->offs[n], ns, ulen,
+  printf("%s: n=%u nnz=%u slices=%u slots=%llu kept=%u code_slots=%u\n", spec, n, A->offs[n], ns,
          V->nslots, V->nval_slots, H->ncode_slots);
-  if (!ulen || ulen > TMAX || H->ncode_slots) {
-    fprintf(stderr, "lab handles uniform code-free slices only\n");
+  if (H->ncode_slots) {
+    fprintf(stderr, "lab handles code-free slices only\n");
     return 1;
   }
-  // templates: pure slices with identical records share one
+  // templates: pure slices (every slot constant and code-free, at most TMAX of them) with identical
+  // records share one; a slot c whose neighbours c-1 / c+1 hold base[c] -+ 1 becomes the centre
   std::map<std::string, int> seen;
   std::vector<tmpl> T;
   std::vector<unsigned char> tid(ns + 8, 255);
-  unsigned pure = 0, shaped = 0;
+  unsigned pure = 0, shaped = 0, maxslots = 0;
   for (unsigned s = 0; s < ns; s++) {
+    const unsigned q0 = H->sptr[s] / ROWS, len = (H->sptr[s + 1] - H->sptr[s]) / ROWS;
+    if (len > TMAX || len == 0)
+      continue;
     bool ok = true;
     tmpl t;
     memset(&t, 0, sizeof t);
-    t.nslots = (int)ulen, t.centre = -1;
-    for (unsigned j = 0; j < ulen && ok; j++) {
-      const int *r = V->slots + 4 * ((size_t)s * ulen + j);
+    t.nslots = (int)len, t.centre = -1;
+    for (unsigned j = 0; j < len && ok; j++) {
+      const int *r = V->slots + 4 * ((size_t)q0 + j);
       ok = r[1] < 0 && r[2] < 0;
-      t.base[j] = r[0], t.cst[j] = V->vconst[(size_t)s * ulen + j];
-      if (r[0] == 0)
-        t.centre = (int)j;
+      t.base[j] = r[0], t.cst[j] = V->vconst[(size_t)q0 + j];
     }
     if (!ok)
       continue;
-    // the shape the shift path handles: 5 slots, slots 1..3 = (c-1, c, c+1) with c = 0
-    if (ulen == 5 && t.base[2] == 0 && t.base[1] == -1 && t.base[3] == 1) {
-      t.kind[1] = 1, t.src[1] = 2, t.kind[3] = 2, t.src[3] = 2;
+    // centre: prefer an even base (16-byte aligned gather) with both neighbours, then with one
+    int best = -1, bestscore = 0;
+    for (int j = 0; j < (int)len; j++) {
+      const int lo = j > 0 && t.base[j - 1] == t.base[j] - 1, hi = j + 1 < (int)len && t.base[j + 1] == t.base[j] + 1;
+      const int score = (lo + hi) * 2 + ((lo + hi) && !(t.base[j] & 1));
+      if (score > bestscore)
+        best = j, bestscore = score;
+    }
+    if (best >= 0 && !getenv("LAB_NO_SHIFT")) {
+      t.centre = best;
+      if (best > 0 && t.base[best - 1] == t.base[best] - 1)
+        t.kind[best - 1] = 1;
+      if (best + 1 < (int)len && t.base[best + 1] == t.base[best] + 1)
+        t.kind[best + 1] = 2;
     }
     std::string key((const char *)&t, sizeof t);
     auto it = seen.find(key);
@@ -434,9 +459,18 @@ int main(int argc, char **argv) {
     } else
       id = it->second;
     tid[s] = (unsigned char)id, pure++;
-    shaped += t.src[1] == 2;
+    shaped += t.centre >= 0;
+    if (len > maxslots)
+      maxslots = len;
   }
-  printf("templates: %zu; pure slices %u of %u (%u of the shift shape)\n", T.size(), pure, ns, shaped);
+  printf("templates: %zu; pure slices %u of %u (%u with a centre), at most %u slots\n", T.size(), pure, ns, shaped,
+         maxslots);
+  for (size_t k = 0; k < T.size() && k < 6; k++) {
+    printf("  T%zu:", k);
+    for (int j = 0; j < T[k].nslots; j++)
+      printf(" (%d,%g,k%d)", T[k].base[j], T[k].cst[j], T[k].kind[j]);
+    printf(" centre %d\n", T[k].centre);
+  }
 
   // device data
   std::vector<double> hx(n), yref(n);
@@ -508,35 +542,36 @@ int main(int argc, char **argv) {
       char nm[64];
       snprintf(nm, sizeof nm, "prod flags=%u cap=%u", fl, cap);
       run(nm, g, [&] {
-        lsb_k_spmv_sell(fl, cap, 0, d_sptr, 0, ns, n, 0, d_codes, d_rec, d_vals, d_vc, ulen, dx, dy, dx, dparts, &np,
+        lsb_k_spmv_sell(fl, cap, 0, d_sptr, 0, ns, n, 0, d_codes, d_rec, d_vals, d_vc, 0, dx, dy, dx, dparts, &np,
                         NULL, &notail, NULL, st);
       }, true);
     }
   }
-#define ARGS ns, n, ulen, d_tid, d_T, (const i4v *)d_rec, d_vc, d_vals, dx, dy, dparts
+#define TMK 5
+#define ARGS ns, n, d_sptr, d_tid, d_T, (const i4v *)d_rec, d_vc, d_vals, dx, dy, dparts
   for (unsigned cap : {1024u, 1536u, 2048u}) {
     char nm[64];
     unsigned g = grid_for(ns, 4, cap);
     snprintf(nm, sizeof nm, "T5 minw6 cap=%u", cap);
-    run(nm, g, [&] { k_t5<6><<<g, WG, 0, st>>>(ARGS); }, true);
+    run(nm, g, [&] { k_t5<6, TMK><<<g, WG, 0, st>>>(ARGS); }, true);
     snprintf(nm, sizeof nm, "T5 minw8 cap=%u", cap);
-    run(nm, g, [&] { k_t5<8><<<g, WG, 0, st>>>(ARGS); }, true);
+    run(nm, g, [&] { k_t5<8, TMK><<<g, WG, 0, st>>>(ARGS); }, true);
     snprintf(nm, sizeof nm, "T3 shfl minw6 cap=%u", cap);
-    run(nm, g, [&] { k_t3<6, 1, false><<<g, WG, 0, st>>>(ARGS); }, true);
+    run(nm, g, [&] { k_t3<6, 1, false, TMK><<<g, WG, 0, st>>>(ARGS); }, true);
     snprintf(nm, sizeof nm, "T3 shfl minw8 cap=%u", cap);
-    run(nm, g, [&] { k_t3<8, 1, false><<<g, WG, 0, st>>>(ARGS); }, true);
+    run(nm, g, [&] { k_t3<8, 1, false, TMK><<<g, WG, 0, st>>>(ARGS); }, true);
     snprintf(nm, sizeof nm, "T3 dpp minw8 cap=%u", cap);
-    run(nm, g, [&] { k_t3<8, 1, true><<<g, WG, 0, st>>>(ARGS); }, true);
+    run(nm, g, [&] { k_t3<8, 1, true, TMK><<<g, WG, 0, st>>>(ARGS); }, true);
     g = grid_for(ns, 8, cap);
     snprintf(nm, sizeof nm, "T3x2 shfl minw6 cap=%u", cap);
-    run(nm, g, [&] { k_t3<6, 2, false><<<g, WG, 0, st>>>(ARGS); }, true);
+    run(nm, g, [&] { k_t3<6, 2, false, TMK><<<g, WG, 0, st>>>(ARGS); }, true);
     snprintf(nm, sizeof nm, "T3x2 dpp minw6 cap=%u", cap);
-    run(nm, g, [&] { k_t3<6, 2, true><<<g, WG, 0, st>>>(ARGS); }, true);
+    run(nm, g, [&] { k_t3<6, 2, true, TMK><<<g, WG, 0, st>>>(ARGS); }, true);
     snprintf(nm, sizeof nm, "T3x2 dpp minw8 cap=%u", cap);
-    run(nm, g, [&] { k_t3<8, 2, true><<<g, WG, 0, st>>>(ARGS); }, true);
+    run(nm, g, [&] { k_t3<8, 2, true, TMK><<<g, WG, 0, st>>>(ARGS); }, true);
     g = grid_for(ns, 16, cap);
     snprintf(nm, sizeof nm, "T3x4 dpp minw4 cap=%u", cap);
-    run(nm, g, [&] { k_t3<4, 4, true><<<g, WG, 0, st>>>(ARGS); }, true);
+    run(nm, g, [&] { k_t3<4, 4, true, TMK><<<g, WG, 0, st>>>(ARGS); }, true);
     g = grid_for(ns, 4, cap);
     snprintf(nm, sizeof nm, "hard x1 minw8 cap=%u", cap);
     run(nm, g, [&] { k_hard<8, 1><<<g, WG, 0, st>>>(ns, n, nx, dx, dy, dparts); }, false);
