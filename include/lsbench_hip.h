@@ -409,6 +409,40 @@ struct lsb_sell_vc {
 };
 struct lsb_sell_vc *lsb_sell16_value_slots(const struct lsb_sell *S);
 void lsb_sell_vc_free(struct lsb_sell_vc *V);
+/* Slice TEMPLATES of the constant-slot layout.  A code-free slice is described by its slots'
+ * {base, constant or "keeps its values"} records, and on a structured grid a handful of such
+ * descriptions cover everything: slices with identical records share ONE template, tid[slice]
+ * says which (255 = none: the slice goes the per-slot way) and vbase[slice] where the slice's
+ * kept value slots start (they are consecutive: the k-th kept slot of the slice is value slot
+ * vbase + k).  The kernel then reads five bytes per slice and the template out of the scalar
+ * cache instead of 24 bytes of cold records per slot.  Where a template holds a slot c with
+ * base[c-1] = base[c]-1 and base[c+1] = base[c]+1 (the three inner diagonals of a stencil) it
+ * is SHAPED: [nfar far slots][c-1, c, c+1][nfar far slots] with the set's one nfar -- lanes
+ * take the operands of c-1 and c+1 from the centre's 16-byte pair by a lane shift: three
+ * gathers instead of five on a 5-point row, none misaligned.  In a shaped template the far
+ * slots and the centre are constant; c-1 and c+1 may keep their values (a grid line that
+ * ends inside the slice: padding zeros there).  Every other template is all-constant.
+ * Lossless: the same products in the same order. */
+#define LSB_TMPL_SLOTS 8
+struct lsb_sell_tmpl { /* 144 bytes, read by scalar loads */
+  int nslots;
+  int shaped; /* 1: [nfar][c-1, c, c+1][nfar], nfar = the set's */
+  int base[LSB_TMPL_SLOTS];
+  int kidx[LSB_TMPL_SLOTS]; /* -1: constant cst[j]; k >= 0: the slice's k-th kept value slot */
+  int pad_[2];
+  double cst[LSB_TMPL_SLOTS];
+};
+struct lsb_sell_tmpls {
+  unsigned nslice, ntmpl, nfar;
+  unsigned long long covered, shaped; /* slices that have a template / a shaped one */
+  unsigned char *tid;                 /* nslice + 8 */
+  unsigned *vbase;                    /* nslice + 8: first kept value slot of the slice */
+  struct lsb_sell_tmpl *t;            /* ntmpl <= 254 */
+};
+/* NULL when fewer than 7/8 of the slices get a template, shaped ones cover less than 3/4,
+ * or the copy has code slots (not a structured grid). */
+struct lsb_sell_tmpls *lsb_sell16_templates(const struct lsb_sell *S, const struct lsb_sell_vc *V);
+void lsb_sell_tmpls_free(struct lsb_sell_tmpls *T);
 /* mean |col - (row + row_begin)| over a sample of the rows */
 double lsb_csr_mean_scatter(const struct csr *A, unsigned row_begin);
 /* [lo,hi) column range referenced by A (0-based). */

@@ -26,7 +26,7 @@ SPMV_AUTO, SPMV_ADAPTIVE, SPMV_SUBWAVE, SPMV_SCALAR, SPMV_PANEL, SPMV_SELL, SPMV
 SELL_ROWS = 128
 BIN_CHUNK = 2048
 PB_COLS, PB_ROWS = 8192, 2048
-SPMV_FLAG_PREFETCH, SPMV_FLAG_NT, SPMV_FLAG_C16 = 1, 2, 4
+SPMV_FLAG_PREFETCH, SPMV_FLAG_NT, SPMV_FLAG_C16, SPMV_FLAG_TMPL = 1, 2, 4, 64
 STATUS_RUNNING, STATUS_CONVERGED, STATUS_BREAKDOWN, STATUS_MAXIT = 0, 1, 2, 3
 STATUS_COMM = 4
 COMM_AUTO, COMM_RCCL, COMM_P2P = 0, 1, 2
@@ -92,6 +92,19 @@ class SellVc(C.Structure):
     """struct lsb_sell_vc."""
     _fields_ = [("nslots", C.c_ulonglong), ("nval_slots", C.c_uint), ("slots", C.POINTER(C.c_int)),
                 ("vconst", C.POINTER(C.c_double)), ("vals", C.POINTER(C.c_double))]
+
+
+class SellTmpl(C.Structure):
+    """struct lsb_sell_tmpl (144 bytes)."""
+    _fields_ = [("nslots", C.c_int), ("shaped", C.c_int), ("base", C.c_int * 8), ("kidx", C.c_int * 8),
+                ("pad_", C.c_int * 2), ("cst", C.c_double * 8)]
+
+
+class SellTmpls(C.Structure):
+    """struct lsb_sell_tmpls."""
+    _fields_ = [("nslice", C.c_uint), ("ntmpl", C.c_uint), ("nfar", C.c_uint), ("covered", C.c_ulonglong),
+                ("shaped", C.c_ulonglong), ("tid", C.POINTER(C.c_ubyte)), ("vbase", C.POINTER(C.c_uint)),
+                ("t", C.POINTER(SellTmpl))]
 
 
 class Binned(C.Structure):
@@ -166,6 +179,8 @@ SIGNATURES = {
     "lsb_sell_free": (None, [C.POINTER(Sell)]),
     "lsb_sell16_value_slots": (C.POINTER(SellVc), [C.POINTER(Sell)]),
     "lsb_sell_vc_free": (None, [C.POINTER(SellVc)]),
+    "lsb_sell16_templates": (C.POINTER(SellTmpls), [C.POINTER(Sell), C.POINTER(SellVc)]),
+    "lsb_sell_tmpls_free": (None, [C.POINTER(SellTmpls)]),
     "lsb_csr_mean_scatter": (_d, [_csrp, _u]),
     "lsb_csr_col_hull": (None, [_csrp, C.POINTER(_u), C.POINTER(_u)]),
     "lsb_plan_exchange": (None, [_i, _i, C.POINTER(_u), C.POINTER(Xfer), C.POINTER(_i),

@@ -741,7 +741,12 @@ __global__ __launch_bounds__(WG) void k_pcg_update_xr(
 }
 
 // (rz', rr) = sum partials ; stop test ; beta = rz'/rz ; p = dinv.*r + beta p
-template <bool V2, bool NT>
+// X2: a lane keeps TWO 16-byte pairs per operand in flight (rows i and i + grid).  With one
+// pair a lane has 32 bytes on their way (r and p; the constant diagonal is a register) --
+// 2048 workgroups x 256 lanes x 32 B = 16.8 MB, about what 8 TB/s x 2 us of latency needs, and
+// the sweep ran at 0.73 of peak where its five-operand sibling k_pcg_update_xr (64-80 B per
+// lane) reaches 0.84 (profiles/r02_trace_kernel_stats.csv).
+template <bool V2, bool NT, bool X2>
 __global__ __launch_bounds__(WG) void k_pcg_update_p(
     unsigned n, const double *__restrict__ r, const double *__restrict__ dinv, double dc,
     const double *pin, double *p, lsb_pcg_state *__restrict__ st, int parity,
@@ -758,10 +763,13 @@ __global__ __launch_bounds__(WG) void k_pcg_update_p(
   // as in k_pcg_update_xr: one round trip for status, scalars and operands
   const int stopped = st->status;
   const double rz_old = st->rz[parity], thresh2 = st->thresh2;
-  d2v rv = {0.0, 0.0}, dv = rv, pv = rv;
+  d2v rv = {0.0, 0.0}, dv = rv, pv = rv, rw = rv, dw = rv, pw = rv;
   const bool first = V2 && gtid < n2;
+  bool second = X2 && V2 && gtid + gsz < n2;
   if (first)
     rv = ld2<NT>(r2 + gtid), dv = ldd<NT>(d2, gtid, dc), pv = ld2<NT>(pi2 + gtid);
+  if (second)
+    rw = ld2<NT>(r2 + gtid + gsz), dw = ldd<NT>(d2, gtid + gsz, dc), pw = ld2<NT>(pi2 + gtid + gsz);
   double v[2];
   wg_sum_partials<2>(parts2, nparts2, v, sred);
   if (stopped)
@@ -785,14 +793,25 @@ __global__ __launch_bounds__(WG) void k_pcg_update_p(
   if (V2) {
     if (first) {
       size_t i = gtid;
+      const size_t step = X2 ? 2 * gsz : gsz;
       for (;;) {
         pv.x = dv.x * rv.x + beta * pv.x;
         pv.y = dv.y * rv.y + beta * pv.y;
         p2[i] = pv;
-        i += gsz;
+        if (X2 && second) {
+          pw.x = dw.x * rw.x + beta * pw.x;
+          pw.y = dw.y * rw.y + beta * pw.y;
+          p2[i + gsz] = pw;
+        }
+        i += step;
         if (i >= n2)
           break;
         rv = ld2<NT>(r2 + i), dv = ldd<NT>(d2, i, dc), pv = ld2<NT>(pi2 + i);
+        if (X2) {
+          second = i + gsz < n2;
+          if (second)
+            rw = ld2<NT>(r2 + i + gsz), dw = ldd<NT>(d2, i + gsz, dc), pw = ld2<NT>(pi2 + i + gsz);
+        }
       }
     }
     if ((n & 1) && gtid == gsz - 1)
@@ -1001,6 +1020,14 @@ static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 static int g_blas1_nt = 1;
 
 // --------------------------------------------------------------------------
+// ONE ROUNDING RULE for the sliced-ELL kernels (k_spmv_sell, k_spmv_sell16, k_spmv_tmpl): a
+// row's sum is the chain a = fma(value_j, x_j, a) over its slots in slot order, written with
+// explicit fma() -- not left to the compiler's contraction, which fused some products of one
+// source expression and not others (slot 0 of a group in k_spmv_sell16's per-slot path came
+// out as v_mul + v_add, the rest as v_fma: found when the template kernel disagreed with it in
+// the last bit).  With the rule in the source every layout of one operator -- 32-bit columns,
+// 16-bit codes, constant slots, templates -- produces the same bits by construction.
+// --------------------------------------------------------------------------
 // a2-1, sliced-ELL form (LSB_SPMV_SELL, host side lsb_csr_sellize): slices of
 // 128 rows stored column-major; lane l of the slice's wavefront owns rows 2l
 // and 2l+1 and reads their j-th entries as ONE int2 + ONE double2, so every
@@ -1105,8 +1132,8 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_sell(
 #pragma unroll
         for (int u = 0; u < SELL_U; u++)
           if (j0 + u < len) {
-            a0 += (double)v[u].x * x[c[u].x];
-            a1 += (double)v[u].y * x[c[u].y];
+            a0 = fma((double)v[u].x, x[c[u].x], a0); // explicit: see "one rounding rule" below
+            a1 = fma((double)v[u].y, x[c[u].y], a1);
           }
       }
       const unsigned row = s * LSB_SELL_ROWS + 2 * lane;
@@ -1114,13 +1141,13 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_sell(
         const sell_d2v o = {a0, a1};
         *(sell_d2v *)(y + row) = o;
         if (xdot) {
-          dot += a0 * xdot[row];
-          dot += a1 * xdot[row + 1];
+          dot = fma(a0, xdot[row], dot);
+          dot = fma(a1, xdot[row + 1], dot);
         }
       } else if (row < n) {
         y[row] = a0;
         if (xdot)
-          dot += a0 * xdot[row];
+          dot = fma(a0, xdot[row], dot);
       }
     }
   }
@@ -1211,8 +1238,8 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_sell16(
             for (int u = 0; u < SELL_U; u++)
               if ((unsigned)u < cnt) { // the same products in the same order as below
                 const VT cv = (VT)cst[u];
-                a0 += (double)cv * t[u].x;
-                a1 += (double)cv * t[u].y;
+                a0 = fma((double)cv, t[u].x, a0);
+                a1 = fma((double)cv, t[u].y, a1);
               }
             continue;
           }
@@ -1256,14 +1283,14 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_sell16(
           if (j0 + u < len) {
             if (pair[u]) {
               const sell_d2u t = *(const sell_d2u *)(x + (grow + b[u]));
-              a0 += (double)v[u].x * t.x;
-              a1 += (double)v[u].y * t.y;
+              a0 = fma((double)v[u].x, t.x, a0);
+              a1 = fma((double)v[u].y, t.y, a1);
             } else {
               const bool p0 = v[u].x != (VT)0, p1 = v[u].y != (VT)0;
               const double t0 = x[p0 ? grow + b[u] + (int)c[u].x : 0];
               const double t1 = x[p1 ? grow + 1 + b[u] + (int)c[u].y : 0];
-              a0 += (double)v[u].x * (p0 ? t0 : 0.0);
-              a1 += (double)v[u].y * (p1 ? t1 : 0.0);
+              a0 = fma((double)v[u].x, p0 ? t0 : 0.0, a0);
+              a1 = fma((double)v[u].y, p1 ? t1 : 0.0, a1);
             }
           }
       }
@@ -1285,14 +1312,235 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_sell16(
         const sell_d2v o = {a0, a1};
         *(sell_d2v *)(y + row) = o;
         if (xdot) {
-          dot += a0 * xd.x;
-          dot += a1 * xd.y;
+          dot = fma(a0, xd.x, dot);
+          dot = fma(a1, xd.y, dot);
         }
       } else if (row < n) {
         y[row] = a0;
         if (xdot)
-          dot += a0 * xd.x;
+          dot = fma(a0, xd.x, dot);
       }
+    }
+  }
+  if (stopped)
+    return;
+  spmv_publish(partials, dot, sred, tail);
+}
+
+// --------------------------------------------------------------------------
+// a2-1, sliced-ELL with slice TEMPLATES (LSB_SP_TMPL; host side lsb_sell16_templates) -- the
+// constant-slot layout of a structured grid, where the shipped kernel above is bound by its
+// chain of dependent loads per slice (cold slot records -> gathers), not by bytes: 176 MB in
+// 41-48 us.  Measured on the 10 M-row 5-point operator (tools/stencil_lab.hip, back to back):
+//   slot records by scalar loads per slice, five gathers (k_spmv_sell16)        40.8-48.0 us
+//   one byte per slice + the template out of the scalar cache, five gathers     32.5 us
+//   + the +-1 diagonals from the centre's pair by a lane shift (three aligned
+//     gathers, the dot's operand = the centre pair), straight-line              24.6-26.9 us
+//   y = 4 x with the fused dot (the HBM floor of these bytes)                   23.2-24.6 us
+// A wave takes a slice per turn as above.  tid8[slice] names its template (255: none --
+// the slice keeps values somewhere, e.g. where a grid line ends, and goes the per-slot way);
+// a SHAPED template is [NF far slots][c-1, c, c+1][NF far slots]: lanes gather the far slots
+// and the centre c, and form the operands of c-1 / c+1 from the centre pair of the
+// neighbouring lane (DPP wave shift; lane 0 and lane 63 fetch the one element beyond the
+// wave's 128 by a two-lane load).  Products are formed in slot order, i.e. in the order of
+// k_spmv_sell16: bit-identical results (tests/test_sell.py).
+// --------------------------------------------------------------------------
+__device__ __forceinline__ double lane_above(double v) { // the value lane - 1 holds (lane 0: 0)
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, false); // wave_shr:1
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_below(double v) { // the value lane + 1 holds (lane 63: 0)
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, false); // wave_shl:1
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+template <int NF, bool CHEB>
+__global__ __launch_bounds__(WG, 6) void k_spmv_tmpl(
+    const unsigned *__restrict__ sptr, unsigned s0, unsigned ns, unsigned period, unsigned n,
+    unsigned row_begin, unsigned xlen, const unsigned char *__restrict__ tid8,
+    const unsigned *__restrict__ vbase, const lsb_sell_tmpl *__restrict__ td,
+    const int *__restrict__ sbase, const void *__restrict__ vals, int f32,
+    const double *__restrict__ vconst, const double *__restrict__ x, double *__restrict__ y,
+    const double *__restrict__ xdot, int dot_is_x, double *__restrict__ partials,
+    const lsb_pcg_state *__restrict__ st, const lsb_ar_tail tail, const lsb_cheb_epi epi) {
+  __shared__ double sred[4];
+  const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const unsigned gx = gridDim.x / NXCD, xcd = blockIdx.x % NXCD, slot = blockIdx.x / NXCD;
+  const sell_deal deal = sell_deal_init(ns, period, xcd);
+  const int stopped = st ? st->status : 0; // tested behind the first loads
+  double dot = 0.0;
+  for (unsigned g = slot; g < deal.turns; g += gx) {
+    const unsigned si = __builtin_amdgcn_readfirstlane(sell_deal_slice(deal, g, wave, ns));
+    if (si == 0xFFFFFFFFu)
+      continue;
+    const unsigned s = s0 + si;
+    const unsigned t = __builtin_amdgcn_readfirstlane((unsigned)tid8[s]);
+    const unsigned row = s * LSB_SELL_ROWS + 2 * lane;
+    const int grow = (int)(row + row_begin);
+    double a0 = 0.0, a1 = 0.0;
+    sell_d2v xd = {0.0, 0.0};
+    bool have_xd = CHEB || !xdot;
+    if (t != 255u && td[t].shaped) {
+      const lsb_sell_tmpl *T = td + t;
+      const int bc = T->base[NF + 1];
+      sell_d2u lo[NF > 0 ? NF : 1], hi[NF > 0 ? NF : 1];
+#pragma unroll
+      for (int k = 0; k < NF; k++)
+        lo[k] = *(const sell_d2u *)(x + (grow + T->base[k]));
+      const sell_d2u c = *(const sell_d2u *)(x + (grow + bc));
+#pragma unroll
+      for (int k = 0; k < NF; k++)
+        hi[k] = *(const sell_d2u *)(x + (grow + T->base[NF + 3 + k]));
+      // slots c-1 / c+1 may keep their values (a grid line ends inside the slice: zeros there)
+      const int km = T->kidx[NF], kp = T->kidx[NF + 2];
+      double vm0 = T->cst[NF], vm1 = vm0, vp0 = T->cst[NF + 2], vp1 = vp0;
+      if (km >= 0 || kp >= 0) {
+        const unsigned vb = __builtin_amdgcn_readfirstlane(vbase[s]);
+        if (f32) {
+          typedef vt2<float>::type f2;
+          if (km >= 0) {
+            const f2 v = *((const f2 *)((const float *)vals + (size_t)(vb + (unsigned)km) * LSB_SELL_ROWS) + lane);
+            vm0 = (double)v.x, vm1 = (double)v.y;
+          }
+          if (kp >= 0) {
+            const f2 v = *((const f2 *)((const float *)vals + (size_t)(vb + (unsigned)kp) * LSB_SELL_ROWS) + lane);
+            vp0 = (double)v.x, vp1 = (double)v.y;
+          }
+        } else {
+          if (km >= 0) {
+            const sell_d2v v = *((const sell_d2v *)((const double *)vals + (size_t)(vb + (unsigned)km) * LSB_SELL_ROWS) + lane);
+            vm0 = v.x, vm1 = v.y;
+          }
+          if (kp >= 0) {
+            const sell_d2v v = *((const sell_d2v *)((const double *)vals + (size_t)(vb + (unsigned)kp) * LSB_SELL_ROWS) + lane);
+            vp0 = v.x, vp1 = v.y;
+          }
+        }
+      }
+      // the element in front of the wave's first operand of slot c-1 / behind its last of slot
+      // c+1.  Where the slot is constant it exists; where it keeps values the entry it belongs to
+      // may be padding at the operator's first / last row: the index is clamped (the product is
+      // an exact 0 there whatever is read)
+      double edge = 0.0;
+      if (lane == 0 || lane == 63) {
+        long long e = (long long)grow + bc + (lane == 0 ? -1 : 2);
+        e = e < 0 ? 0 : (e >= (long long)xlen ? (long long)xlen - 1 : e);
+        edge = x[e];
+      }
+      if (!have_xd && !(dot_is_x && bc == 0)) {
+        if (row + 1 < n)
+          xd = *(const sell_d2v *)(xdot + row);
+        else if (row < n)
+          xd.x = xdot[row];
+        have_xd = true;
+      }
+      if (stopped)
+        return;
+      double up = lane_above(c.y), dn = lane_below(c.x);
+      if (lane == 0)
+        up = edge;
+      if (lane == 63)
+        dn = edge;
+      if (!have_xd)
+        xd.x = c.x, xd.y = c.y, have_xd = true; // the centre pair IS the dot's operand
+#pragma unroll
+      for (int k = 0; k < NF; k++) {
+        const double v = T->cst[k];
+        a0 = fma(v, lo[k].x, a0), a1 = fma(v, lo[k].y, a1);
+      }
+      {
+        // value 0 = padding: no operand, an exact 0 (the rule of k_spmv_sell16)
+        const double vc = T->cst[NF + 1];
+        a0 = fma(vm0, vm0 != 0.0 ? up : 0.0, a0), a1 = fma(vm1, vm1 != 0.0 ? c.x : 0.0, a1); // slot c-1: x[. - 1], x[.]
+        a0 = fma(vc, c.x, a0), a1 = fma(vc, c.y, a1);                                         // slot c
+        a0 = fma(vp0, vp0 != 0.0 ? c.y : 0.0, a0), a1 = fma(vp1, vp1 != 0.0 ? dn : 0.0, a1); // slot c+1
+      }
+#pragma unroll
+      for (int k = 0; k < NF; k++) {
+        const double v = T->cst[NF + 3 + k];
+        a0 = fma(v, hi[k].x, a0), a1 = fma(v, hi[k].y, a1);
+      }
+    } else {
+      if (!have_xd) {
+        if (row + 1 < n)
+          xd = *(const sell_d2v *)(xdot + row);
+        else if (row < n)
+          xd.x = xdot[row];
+        have_xd = true;
+      }
+      if (t != 255u) { // a pure slice of another shape (first / last grid line): every slot gathered
+        const lsb_sell_tmpl *T = td + t;
+        const int cnt = T->nslots;
+        if (stopped)
+          return;
+        for (int u0 = 0; u0 < LSB_TMPL_SLOTS; u0 += 4) { // (rare slices: four gathers in flight will do)
+          sell_d2u v[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            if (u0 + u < cnt)
+              v[u] = *(const sell_d2u *)(x + (grow + T->base[u0 + u]));
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            if (u0 + u < cnt) {
+              const double k = T->cst[u0 + u];
+              a0 = fma(k, v[u].x, a0), a1 = fma(k, v[u].y, a1);
+            }
+        }
+      } else { // a slot keeps its values (or the slice has > 8 slots): slot by slot
+        const unsigned q0 = sptr[s] / LSB_SELL_ROWS, len = (sptr[s + 1] - sptr[s]) / LSB_SELL_ROWS;
+        if (stopped)
+          return;
+        for (unsigned j = 0; j < len; j++) {
+          const i4v r = ((const i4v *)sbase)[q0 + j]; // {base, -1 (no codes here), value slot or -1, 0}
+          if (r.z < 0) {
+            const double k = vconst[q0 + j];
+            const sell_d2u v = *(const sell_d2u *)(x + (grow + r.x));
+            a0 = fma(k, v.x, a0), a1 = fma(k, v.y, a1);
+          } else {
+            double v0, v1;
+            if (f32) {
+              const vt2<float>::type v = *((const vt2<float>::type *)((const float *)vals + (size_t)r.z * LSB_SELL_ROWS) + lane);
+              v0 = (double)v.x, v1 = (double)v.y;
+            } else {
+              const sell_d2v v = *((const sell_d2v *)((const double *)vals + (size_t)r.z * LSB_SELL_ROWS) + lane);
+              v0 = v.x, v1 = v.y;
+            }
+            const bool p0 = v0 != 0.0, p1 = v1 != 0.0; // padding: no gather, an exact 0
+            const double t0 = x[p0 ? grow + r.x : 0], t1 = x[p1 ? grow + 1 + r.x : 0];
+            a0 = fma(v0, p0 ? t0 : 0.0, a0), a1 = fma(v1, p1 ? t1 : 0.0, a1);
+          }
+        }
+      }
+    }
+    if (CHEB) { // d = a d + b D^-1 (r - w); z' = z + d -- k_cheb_step's expression
+      if (row + 1 < n) {
+        const sell_d2v rr = *(const sell_d2v *)(epi.r + row), dd = *(const sell_d2v *)(epi.d + row);
+        const double i0 = epi.dinv ? epi.dinv[row] : epi.dc, i1 = epi.dinv ? epi.dinv[row + 1] : epi.dc;
+        const double v0 = fma(epi.a, dd.x, epi.b * (i0 * (rr.x - a0)));
+        const double v1 = fma(epi.a, dd.y, epi.b * (i1 * (rr.y - a1)));
+        const sell_d2v dn2 = {v0, v1}, zn = {x[grow] + v0, x[grow + 1] + v1};
+        *(sell_d2v *)(epi.d + row) = dn2;
+        *(sell_d2v *)(epi.zout + row) = zn;
+      } else if (row < n) {
+        const double v0 = fma(epi.a, epi.d[row], epi.b * ((epi.dinv ? epi.dinv[row] : epi.dc) * (epi.r[row] - a0)));
+        epi.d[row] = v0;
+        epi.zout[row] = x[grow] + v0;
+      }
+    } else if (row + 1 < n) {
+      const sell_d2v o = {a0, a1};
+      *(sell_d2v *)(y + row) = o;
+      if (xdot) {
+        dot = fma(a0, xd.x, dot);
+        dot = fma(a1, xd.y, dot);
+      }
+    } else if (row < n) {
+      y[row] = a0;
+      if (xdot)
+        dot = fma(a0, xd.x, dot);
     }
   }
   if (stopped)
@@ -1743,6 +1991,48 @@ void lsb_k_spmv_sell(unsigned flags, unsigned grid_cap, unsigned period, const u
 #undef LSB_SELL32
 }
 
+/* The constant-slot layout through slice templates (k_spmv_tmpl).  vals: the kept value slots
+ * (fp32 when flags & LSB_SP_F32; the templates' constants are then fp32-rounded by the caller). */
+void lsb_k_spmv_tmpl(unsigned flags, unsigned grid_cap, unsigned period, const unsigned *sptr, unsigned s0,
+                     unsigned ns, unsigned n, unsigned row_begin, unsigned xlen, const unsigned char *tid8,
+                     const unsigned *vbase, const struct lsb_sell_tmpl *td, unsigned nfar, const int *sbase,
+                     const void *vals,
+                     const double *vconst, const double *x, double *y, const double *xdot,
+                     double *partials, unsigned *npartials, const struct lsb_pcg_state *st,
+                     const struct lsb_ar_tail *tail_in, const struct lsb_cheb_epi *epi_in, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const lsb_ar_tail tail = tail_for(tail_in, partials);
+  lsb_cheb_epi epi;
+  memset(&epi, 0, sizeof epi);
+  if (epi_in && epi_in->zout) {
+    if (partials || ((row_begin | s0) & 1u))
+      errx(EXIT_FAILURE, "lsb_k_spmv_tmpl: the Chebyshev epilogue takes no dot and even row offsets");
+    epi = *epi_in;
+  }
+  const unsigned g = lsb_k_spmv_grid(LSB_SPMV_SELL, n, ns, 0, grid_cap ? grid_cap : 1536);
+  if (npartials)
+    *npartials = g;
+  if (period && (period < NXCD || ns < period))
+    period = 0;
+  const int f32 = (flags & LSB_SP_F32) != 0, dot_is_x = xdot && xdot == x + row_begin;
+#define LSB_TMPL(NF)                                                                                 \
+  do {                                                                                               \
+    if (epi.zout)                                                                                    \
+      k_spmv_tmpl<NF, true><<<g, WG, 0, s>>>(sptr, s0, ns, period, n, row_begin, xlen, tid8, vbase, td, sbase, vals, f32, \
+                                             vconst, x, y, xdot, dot_is_x, partials, st, tail, epi);   \
+    else                                                                                             \
+      k_spmv_tmpl<NF, false><<<g, WG, 0, s>>>(sptr, s0, ns, period, n, row_begin, xlen, tid8, vbase, td, sbase, vals, f32, \
+                                              vconst, x, y, xdot, dot_is_x, partials, st, tail, epi);  \
+  } while (0)
+  switch (nfar) {
+  case 0: LSB_TMPL(0); break;
+  case 1: LSB_TMPL(1); break;
+  case 2: LSB_TMPL(2); break;
+  default: errx(EXIT_FAILURE, "lsb_k_spmv_tmpl: %u far slots per side", nfar);
+  }
+#undef LSB_TMPL
+}
+
 void lsb_k_reduce_final(const double *partials, unsigned nparts, unsigned width,
                         double *out, int take_sqrt,
                         const struct lsb_pcg_state *st, void *stream) {
@@ -1899,17 +2189,28 @@ void lsb_k_pcg_update_p(unsigned n, const double *r, const double *dinv, double 
                         const double *pin, double *p, struct lsb_pcg_state *st, int parity,
                         const double *parts2, unsigned nparts2, void *stream) {
   const unsigned g = lsb_k_blas1_grid(n);
-  if (aligned16(r) && aligned16(dinv) && aligned16(p) && aligned16(pin)) {
-    if (g_blas1_nt)
-      k_pcg_update_p<true, true><<<g, WG, 0, (hipStream_t)stream>>>(n, r, dinv, dc, pin, p, st, parity,
-                                                                    parts2, nparts2);
-    else
-      k_pcg_update_p<true, false><<<g, WG, 0, (hipStream_t)stream>>>(n, r, dinv, dc, pin, p, st, parity,
-                                                                     parts2, nparts2);
-  } else {
-    k_pcg_update_p<false, false><<<g, WG, 0, (hipStream_t)stream>>>(n, r, dinv, dc, pin, p, st, parity,
-                                                                    parts2, nparts2);
+  static int x2 = -1; /* A/B switch: LSBENCH_HIP_UPD_P_X2=0 keeps one pair per lane in flight */
+  if (x2 < 0) {
+    const char *e = getenv("LSBENCH_HIP_UPD_P_X2");
+    x2 = e ? atoi(e) != 0 : 1;
   }
+  hipStream_t s = (hipStream_t)stream;
+#define LSB_UPD_P(V2, NT, X2) k_pcg_update_p<V2, NT, X2><<<g, WG, 0, s>>>(n, r, dinv, dc, pin, p, st, parity, parts2, nparts2)
+  if (aligned16(r) && aligned16(dinv) && aligned16(p) && aligned16(pin)) {
+    const bool big = x2 && (size_t)n / 2 > (size_t)g * WG; /* a second pair exists at all */
+    if (g_blas1_nt) {
+      if (big)
+        LSB_UPD_P(true, true, true);
+      else
+        LSB_UPD_P(true, true, false);
+    } else if (big)
+      LSB_UPD_P(true, false, true);
+    else
+      LSB_UPD_P(true, false, false);
+  } else {
+    LSB_UPD_P(false, false, false);
+  }
+#undef LSB_UPD_P
 }
 
 } // extern "C"

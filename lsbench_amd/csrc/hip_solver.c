@@ -153,7 +153,7 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
   const unsigned a = local ? 0 : r0, b = local ? S->nrows : r1;
   const unsigned n = b - a, j0 = S->offs[a], j1 = S->offs[b];
   const unsigned base = S->base;
-  s->row_begin = row_begin, s->n = n, s->nnz = j1 - j0;
+  s->row_begin = row_begin, s->n = n, s->nnz = j1 - j0, s->n_glob = n_glob;
   int *offs = (int *)malloc(((size_t)n + 1) * sizeof(int));
   int *cols = (int *)malloc(((size_t)s->nnz + 1) * sizeof(int));
   unsigned lo = 0xFFFFFFFFu, hi = 0;
@@ -319,6 +319,29 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
                                   : (double *)dev_upload(V->vals, nv * sizeof(double));
           s->sell_vslots = V->nval_slots, s->sell_slots = (unsigned)V->nslots;
           s->sell16_bytes = (unsigned long long)V->nslots * 24; /* slot record + the slot's constant */
+          /* slices with identical constant records share a template (a structured grid has a
+           * handful): a byte per slice instead of 24 per slot, and the three inner diagonals
+           * from one gather (k_spmv_tmpl) */
+          struct lsb_sell_tmpls *TT = getenv("LSBENCH_HIP_NO_TMPL") ? NULL : lsb_sell16_templates(H, V);
+          if (TT) {
+            if (s->mixed) /* fp32 matrix values: the constants as the fp32 kernels see them */
+              for (unsigned t = 0; t < TT->ntmpl; t++)
+                for (int j = 0; j < TT->t[t].nslots; j++)
+                  TT->t[t].cst[j] = (double)(float)TT->t[t].cst[j];
+            s->d_tid8 = (unsigned char *)dev_upload(TT->tid, (size_t)TT->nslice + 8);
+            s->d_vbase = (unsigned *)dev_upload(TT->vbase, ((size_t)TT->nslice + 8) * sizeof(unsigned));
+            s->d_tmpl = (struct lsb_sell_tmpl *)dev_upload(TT->t, (size_t)TT->ntmpl * sizeof(struct lsb_sell_tmpl));
+            s->tmpl_nfar = TT->nfar, s->tmpl_count = TT->ntmpl;
+            s->tmpl_pure = TT->covered, s->tmpl_shaped = TT->shaped;
+            /* what a launch streams with templates: a byte per slice, the templates, and for the
+             * slices without one their slot records, constants and two offsets */
+            s->tmpl_bytes = 5ull * TT->nslice + (unsigned long long)TT->ntmpl * sizeof(struct lsb_sell_tmpl);
+            for (unsigned k = 0; k < H->nslice; k++)
+              if (TT->tid[k] == 255)
+                s->tmpl_bytes += (unsigned long long)(H->sptr[k + 1] - H->sptr[k]) / LSB_SELL_ROWS * 24 + 8;
+            LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+            lsb_sell_tmpls_free(TT);
+          }
         } else {
           s->d_sbase = (int *)dev_upload(H->sbase, 2 * ((size_t)H->stored / LSB_SELL_ROWS + 1) * sizeof(int));
           s->d_svals16 = s->mixed ? (double *)upload_f32(H->vals, (size_t)H->stored + LSB_SELL_ROWS, NULL)
@@ -331,6 +354,8 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
         s->sell16_bytes += (unsigned long long)H->ncode_slots * LSB_SELL_ROWS * sizeof(short) +
                            (unsigned long long)s->sell_vslots * LSB_SELL_ROWS * (s->mixed ? 4 : 8) +
                            (s->sell_ulen ? 0ull : ((unsigned long long)H->nslice + 1) * 4);
+        if (s->d_tid8)
+          s->tmpl_bytes += (unsigned long long)s->sell_vslots * LSB_SELL_ROWS * (s->mixed ? 4 : 8);
         LSB_CHK_HIP(hipStreamSynchronize(g_stream));
         lsb_sell_vc_free(V);
         lsb_sell_free(H);
@@ -406,6 +431,7 @@ void shard_free(struct shard *s) {
   lsb_hip_free(s->d_sptr), lsb_hip_free(s->d_scols), lsb_hip_free(s->d_svals);
   lsb_hip_free(s->d_sptr16), lsb_hip_free(s->d_scodes), lsb_hip_free(s->d_sbase);
   lsb_hip_free(s->d_svals16), lsb_hip_free(s->d_svconst);
+  lsb_hip_free(s->d_tid8), lsb_hip_free(s->d_tmpl), lsb_hip_free(s->d_vbase);
   free(s->h_pblk);
   lsb_hip_free(s->bd_chunk), lsb_hip_free(s->bd_rows), lsb_hip_free(s->bd_cols);
   lsb_hip_free(s->bd_vals);
@@ -698,7 +724,9 @@ unsigned long long lsb_hip_solver_spmv_layout_bytes(const lsb_hip_solver *s) {
   const struct shard *h = &s->sh[0];
   unsigned long long m = 12ull * h->nnz + 4ull * ((unsigned long long)h->n + 1); /* the CSR arrays */
   if (h->variant == LSB_SPMV_SELL)
-    m = (h->sp_flags & LSB_SP_C16) && h->d_scodes ? h->sell16_bytes : h->sell32_bytes;
+    m = (h->sp_flags & LSB_SP_C16) && h->d_scodes
+            ? ((h->sp_flags & LSB_SP_TMPL) && h->d_tid8 ? h->tmpl_bytes : h->sell16_bytes)
+            : h->sell32_bytes;
   else if (h->variant == LSB_SPMV_TWOPHASE || h->variant == LSB_SPMV_BINNED)
     return 0; /* more than one pass over intermediate data: no single-pass figure */
   return m + 16ull * h->n; /* + x read once, y written once */
@@ -717,7 +745,11 @@ void sell_launch(struct shard *s, unsigned s0, unsigned ns, const double *xfull,
                         const double *xdot, double *partials, unsigned *np,
                         const struct lsb_pcg_state *st) {
   const unsigned f32 = s->mixed ? LSB_SP_F32 : 0u; /* the value arrays hold floats then */
-  if ((s->sp_flags & LSB_SP_C16) && s->d_scodes)
+  if ((s->sp_flags & LSB_SP_C16) && (s->sp_flags & LSB_SP_TMPL) && s->d_tid8 && s->d_scodes)
+    lsb_k_spmv_tmpl(s->sp_flags | f32, s->sp_grid, s->sp_period, s->d_sptr16, s0, ns, s->n, s->row_begin, s->n_glob,
+                    s->d_tid8, s->d_vbase, s->d_tmpl, s->tmpl_nfar, s->d_sbase, s->d_svals16, s->d_svconst, xfull, y, xdot, partials, np, st,
+                    &s->tail, &s->epi, g_stream);
+  else if ((s->sp_flags & LSB_SP_C16) && s->d_scodes)
     lsb_k_spmv_sell(s->sp_flags | f32, s->sp_grid, s->sp_period, s->d_sptr16, s0, ns, s->n, s->row_begin, s->d_scodes,
                     s->d_sbase, s->d_svals16, s->d_svconst, s->sell_ulen, xfull, y, xdot, partials, np, st, &s->tail, &s->epi,
                     g_stream);
@@ -805,8 +837,9 @@ void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
   if (getenv("LSBENCH_HIP_FORCE_PERIOD")) /* tests: the plane-periodic dealing on small operators */
     s->sp_period = s->sell_period;
   if (o->spmv_tune >= 0) {
-    s->sp_flags = (unsigned)o->spmv_tune & 31u; /* bit 2: 16-bit codes, where that copy exists;
-                                                   bits 3, 4: binned form's gather flavour */
+    s->sp_flags = (unsigned)o->spmv_tune & (31u | LSB_SP_TMPL); /* bit 2: 16-bit codes, where that copy exists;
+                                                   bits 3, 4: binned form's gather flavour; bit 6: slice
+                                                   templates, where the constant-slot layout has them */
     return;
   }
   if (s->variant == LSB_SPMV_SELL && !s->d_sptr)
@@ -859,6 +892,18 @@ void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
         cand[ncand].v = LSB_SPMV_SELL, cand[ncand].f = c16, cand[ncand].p = s->sell_period,
         cand[ncand++].g = grid0;
       }
+      if (c16 && s->d_tid8) { /* slice templates (no stream to load nontemporally: NT only marks the
+                                 flavour as "solve-like" for the 3 % rule below) */
+        const unsigned f = c16 | LSB_SP_NT | LSB_SP_TMPL;
+        cand[ncand].v = LSB_SPMV_SELL, cand[ncand].f = f, cand[ncand++].g = grid0;
+        if (o->spmv_grid <= 0)
+          cand[ncand].v = LSB_SPMV_SELL, cand[ncand].f = f, cand[ncand++].g = 1536;
+        if (s->sell_period && !getenv("LSBENCH_HIP_NO_PERIOD")) {
+          cand[ncand].v = LSB_SPMV_SELL, cand[ncand].f = f, cand[ncand].p = s->sell_period, cand[ncand++].g = grid0;
+          if (o->spmv_grid <= 0)
+            cand[ncand].v = LSB_SPMV_SELL, cand[ncand].f = f, cand[ncand].p = s->sell_period, cand[ncand++].g = 1536;
+        }
+      }
     }
   for (int ci = 0; ci < ncand; ci++) {
     s->variant = cand[ci].v, s->sp_flags = cand[ci].f, s->sp_grid = cand[ci].g, s->sp_period = cand[ci].p;
@@ -908,6 +953,10 @@ void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
     lsb_hip_free(s->d_sptr16), lsb_hip_free(s->d_scodes), lsb_hip_free(s->d_sbase);
     lsb_hip_free(s->d_svals16), lsb_hip_free(s->d_svconst);
     s->d_sptr16 = NULL, s->d_scodes = NULL, s->d_sbase = NULL, s->d_svals16 = NULL, s->d_svconst = NULL;
+  }
+  if (!(bv == LSB_SPMV_SELL && (bf & LSB_SP_TMPL))) {
+    lsb_hip_free(s->d_tid8), lsb_hip_free(s->d_tmpl), lsb_hip_free(s->d_vbase);
+    s->d_tid8 = NULL, s->d_tmpl = NULL, s->d_vbase = NULL;
   }
   if (any && !(bv == LSB_SPMV_SELL && !(bf & LSB_SP_C16))) {
     lsb_hip_free(s->d_scols), lsb_hip_free(s->d_svals);

@@ -86,6 +86,13 @@ struct shard {
                               ints per slot, d_svals16 only the sell_vslots slots that keep their values */
   unsigned sell_vslots, sell_slots;
   unsigned long long sell16_bytes, sell32_bytes; /* matrix-side bytes one launch of the form streams */
+  /* slice templates of the constant-slot layout (lsb_sell16_templates; LSB_SP_TMPL in sp_flags) */
+  unsigned char *d_tid8;
+  unsigned *d_vbase;
+  unsigned n_glob; /* columns of the operator = length of the gather vector */
+  struct lsb_sell_tmpl *d_tmpl;
+  unsigned tmpl_nfar, tmpl_count;
+  unsigned long long tmpl_pure, tmpl_shaped, tmpl_bytes;
   unsigned sell_ulen;      /* != 0: every slice of the 16-bit copy has this many slots */
   double *d_parts_pq, *d_parts2;
   double *d_scal; /* [0] p.q   [1] r.z'  [2] r.r   (multi-shard path) */

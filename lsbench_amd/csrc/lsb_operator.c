@@ -1072,6 +1072,115 @@ struct lsb_sell_vc *lsb_sell16_value_slots(const struct lsb_sell *S) {
   return V;
 }
 
+/* centre of a pure slice's records: slot c with both neighbours one element away; prefers
+ * base 0 (the dot's operand comes for free), then an even base (aligned 16-byte gather) */
+static int tmpl_centre(const int *base, int n) {
+  int best = -1, score = -1;
+  for (int c = 1; c + 1 < n; c++)
+    if (base[c - 1] == base[c] - 1 && base[c + 1] == base[c] + 1) {
+      const int sc = (base[c] == 0) * 2 + !(base[c] & 1);
+      if (sc > score)
+        best = c, score = sc;
+    }
+  return best;
+}
+
+struct lsb_sell_tmpls *lsb_sell16_templates(const struct lsb_sell *S, const struct lsb_sell_vc *V) {
+  if (!S || !V || !S->sptr || S->ncode_slots || !S->nslice)
+    return NULL;
+  const unsigned ns = S->nslice;
+  struct lsb_sell_tmpls *T = lsb_calloc(struct lsb_sell_tmpls, 1);
+  T->nslice = ns;
+  T->tid = (unsigned char *)malloc((size_t)ns + 8);
+  T->vbase = lsb_calloc(unsigned, (size_t)ns + 8);
+  T->t = lsb_calloc(struct lsb_sell_tmpl, 254);
+  memset(T->tid, 255, (size_t)ns + 8);
+  unsigned long long *count = lsb_calloc(unsigned long long, 254);
+  for (unsigned s = 0; s < ns; s++) {
+    const unsigned q0 = S->sptr[s] / LSB_SELL_ROWS, len = (S->sptr[s + 1] - S->sptr[s]) / LSB_SELL_ROWS;
+    if (len == 0 || len > LSB_TMPL_SLOTS)
+      continue;
+    struct lsb_sell_tmpl t;
+    memset(&t, 0, sizeof t);
+    t.nslots = (int)len;
+    int ok = 1, nkept = 0, vb = -1;
+    for (unsigned j = 0; j < len && ok; j++) {
+      const int *r = V->slots + 4 * ((size_t)q0 + j);
+      ok = r[1] < 0 && (j == 0 || r[0] > t.base[j - 1]); /* code-free, ascending */
+      t.base[j] = r[0];
+      if (r[2] < 0) {
+        t.kidx[j] = -1, t.cst[j] = V->vconst[(size_t)q0 + j];
+      } else {
+        if (vb < 0)
+          vb = r[2];
+        ok = ok && r[2] == vb + nkept; /* the slice's kept slots are consecutive value slots */
+        t.kidx[j] = nkept++;
+      }
+    }
+    if (!ok)
+      continue;
+    /* kept slots only as the neighbours c-1 / c+1 of a constant centre, far slots constant */
+    const int c = tmpl_centre(t.base, (int)len);
+    for (int j = 0; j < (int)len && ok; j++)
+      if (t.kidx[j] >= 0 && !(c >= 1 && (j == c - 1 || j == c + 1)))
+        ok = 0;
+    if (!ok)
+      continue;
+    unsigned id = 0;
+    while (id < T->ntmpl && memcmp(&T->t[id], &t, sizeof t))
+      id++;
+    if (id == T->ntmpl) {
+      if (T->ntmpl == 254)
+        continue; /* table full: the slice goes the per-slot way */
+      T->t[T->ntmpl++] = t;
+    }
+    T->tid[s] = (unsigned char)id, T->vbase[s] = vb < 0 ? 0u : (unsigned)vb, count[id]++, T->covered++;
+  }
+  /* the set's shape: the nfar (<= 2, the same on both sides) most slices have */
+  unsigned long long by_nfar[3] = {0, 0, 0};
+  for (unsigned id = 0; id < T->ntmpl; id++) {
+    const int n = T->t[id].nslots, c = tmpl_centre(T->t[id].base, n);
+    if (c >= 1 && c - 1 == n - c - 2 && c - 1 <= 2)
+      by_nfar[c - 1] += count[id];
+  }
+  unsigned nf = 0;
+  for (unsigned k = 1; k < 3; k++)
+    if (by_nfar[k] > by_nfar[nf])
+      nf = k;
+  T->nfar = nf;
+  for (unsigned id = 0; id < T->ntmpl; id++) {
+    const int n = T->t[id].nslots, c = tmpl_centre(T->t[id].base, n);
+    if (c >= 1 && (unsigned)(c - 1) == nf && (unsigned)(n - c - 2) == nf)
+      T->t[id].shaped = 1, T->shaped += count[id];
+  }
+  /* a template that keeps values has to be shaped (only that path loads them): the others'
+   * slices go back to the per-slot way */
+  for (unsigned s = 0; s < ns; s++)
+    if (T->tid[s] != 255) {
+      const struct lsb_sell_tmpl *t = &T->t[T->tid[s]];
+      int kept = 0;
+      for (int j = 0; j < t->nslots; j++)
+        kept |= t->kidx[j] >= 0;
+      if (kept && !t->shaped)
+        T->tid[s] = 255, T->covered--;
+    }
+  free(count);
+  if (getenv("LSBENCH_HIP_TMPL_DEBUG"))
+    fprintf(stderr, "lsb_sell16_templates: %u slices, %u templates, %llu covered, %llu shaped (nfar %u)\n", ns,
+            T->ntmpl, T->covered, T->shaped, T->nfar);
+  if (T->covered * 8 < (unsigned long long)ns * 7 || T->shaped * 4 < (unsigned long long)ns * 3) {
+    lsb_sell_tmpls_free(T);
+    return NULL;
+  }
+  return T;
+}
+
+void lsb_sell_tmpls_free(struct lsb_sell_tmpls *T) {
+  if (!T)
+    return;
+  free(T->tid), free(T->vbase), free(T->t), free(T);
+}
+
 void lsb_sell_vc_free(struct lsb_sell_vc *V) {
   if (!V)
     return;

@@ -670,3 +670,51 @@ def test_sell16_value_slots(spec, frac_kept):
     const = vals.reshape(nq, 128)
     assert np.array_equal(~kept, (const[:, :1] == const).all(axis=1) & (const[:, 0] != 0.0))
     assert nv <= frac_kept * nq         # a stencil: most slots are one number (random values: none)
+
+
+def test_templates_cover_a_structured_grid():
+    hip = la
+    """lsb_sell16_templates on the host: the 5-point operator has a handful of templates, all
+    interior slices share the shaped one [far][c-1, c, c+1][far]; general values have none."""
+    import ctypes as C
+    lib = hip._lib.load()
+    for spec, nfar in (("lap2d:nx=411,ny=203", 1), ("lap3d:nx=64,ny=64,nz=40", 2), ("lap2d:nx=9000,ny=1", 0)):
+        A = hip.lsbench_matrix_synth(spec)
+        H = lib.lsb_csr_sellize16(A.ptr, 0)
+        V = lib.lsb_sell16_value_slots(H)
+        T = lib.lsb_sell16_templates(H, V)
+        assert T, spec
+        t = T.contents
+        assert t.nfar == nfar and t.ntmpl <= 32 and t.nslice == H.contents.nslice
+        assert t.shaped * 4 >= t.nslice * 3 and t.covered >= t.shaped
+        tid = np.ctypeslib.as_array(t.tid, (t.nslice,))
+        assert tid.max() == 255 or t.covered == t.nslice
+        assert int((tid != 255).sum()) == t.covered
+        shaped = [t.t[k] for k in range(t.ntmpl) if t.t[k].shaped]
+        for q in shaped:
+            c = nfar + 1
+            assert q.nslots == 2 * nfar + 3 and q.base[c - 1] + 1 == q.base[c] == q.base[c + 1] - 1
+            kept = [j for j in range(q.nslots) if q.kidx[j] >= 0]
+            assert set(kept) <= {c - 1, c + 1} and [q.kidx[j] for j in kept] == list(range(len(kept)))
+        for k in set(int(v) for v in np.unique(tid) if v != 255):  # all-gathered templates IN USE keep nothing
+            if not t.t[k].shaped:
+                assert all(t.t[k].kidx[j] < 0 for j in range(t.t[k].nslots))
+        vb = np.ctypeslib.as_array(t.vbase, (t.nslice,))
+        sp = np.ctypeslib.as_array(H.contents.sptr, (t.nslice + 1,)) // 128
+        rec = np.ctypeslib.as_array(V.contents.slots, (V.contents.nslots * 4,)).reshape(-1, 4)
+        for sl in np.nonzero(tid != 255)[0][::7]:                  # the records a template stands for
+            q = t.t[int(tid[sl])]
+            r = rec[sp[sl]:sp[sl + 1]]
+            assert q.nslots == len(r) and list(q.base)[:len(r)] == r[:, 0].tolist() and np.all(r[:, 1] < 0)
+            for j in range(len(r)):
+                assert (q.kidx[j] < 0) == (r[j, 2] < 0)
+                if q.kidx[j] >= 0:
+                    assert vb[sl] + q.kidx[j] == r[j, 2]
+                else:
+                    assert q.cst[j] == V.contents.vconst[sp[sl] + j]
+        lib.lsb_sell_tmpls_free(T), lib.lsb_sell_vc_free(V), lib.lsb_sell_free(H)
+    A = hip.lsbench_matrix_synth("lap2d:nx=411,ny=203,coef=1")
+    H = lib.lsb_csr_sellize16(A.ptr, 0)
+    V = lib.lsb_sell16_value_slots(H)
+    assert not lib.lsb_sell16_templates(H, V)
+    lib.lsb_sell_vc_free(V), lib.lsb_sell_free(H)

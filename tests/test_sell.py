@@ -212,33 +212,67 @@ def test_plane_periodic_dealing_of_a_3d_stencil(hip, nvirt, overlap, comm, monke
     assert np.array_equal(d_y0.cpu().numpy(), y)          # a row's sum does not depend on the dealing
 
 
+def _penta(n):
+    """1-D pentadiagonal SPD operator (bases -2 .. 2): a far slot on each side of the (c-1, c, c+1) group."""
+    import scipy.sparse as sp
+    M = sp.diags([-0.5, -1.0, 4.0, -1.0, -0.5], [-2, -1, 0, 1, 2], shape=(n, n), format="csr")
+    M.sort_indices()
+    return M.indptr, M.indices, M.data
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("spec,nvirt,precision", [("lap2d:nx=411,ny=203", 1, "FP64"), ("lap3d:nx=48,ny=40,nz=36", 1, "FP64"),
-                                                  ("lap3d:nx=48,ny=40,nz=36", 3, "FP64"), ("lap2d:nx=411,ny=203", 2, "MIXED")])
+@pytest.mark.parametrize("spec,nvirt,precision", [
+    ("lap2d:nx=411,ny=203", 1, "FP64"), ("lap3d:nx=64,ny=64,nz=40", 1, "FP64"),
+    ("lap3d:nx=64,ny=64,nz=40", 3, "FP64"), ("lap2d:nx=411,ny=203", 2, "MIXED"),
+    ("lap2d:nx=70001,ny=1", 1, "FP64"), ("penta:n=50000", 1, "FP64"), ("lap2d:nx=411,ny=203,coef=1", 1, "FP64"),
+    ("lap2d:nx=640,ny=100", 4, "FP64")])
 def test_constant_slots_change_no_bit(hip, monkeypatch, spec, nvirt, precision):
-    """The constant-slot layout of the 16-bit sliced-ELL form (lsb_sell16_value_slots: one
-    value per slot whose 128 entries are equal) against the layout with every value stored
-    (LSBENCH_HIP_NO_VCONST=1): the same products in the same order -- SpMV, fused dot and
-    the whole solve bit for bit; over shards and with fp32 matrix values."""
+    """Three layouts of the 16-bit sliced-ELL form, forced (spmv_tune): every value stored
+    (LSBENCH_HIP_NO_VCONST=1); constant slots (lsb_sell16_value_slots: one value per slot
+    whose 128 entries are equal); constant slots through slice TEMPLATES (k_spmv_tmpl: a
+    byte per slice, the three inner diagonals from one gather by lane shifts).  The same
+    products in the same order -- SpMV, fused dot and the whole solve bit for bit; over
+    shards (split interior / boundary launches included) and with fp32 matrix values; 5-point
+    (one far slot per side), 7-point (two), tridiagonal (none), pentadiagonal; with general
+    values nothing is constant, no template exists and the template flag changes nothing."""
     import torch
-    A = hip.lsbench_matrix_synth(spec)
+    if spec.startswith("penta"):
+        A = hip.Matrix.from_arrays(*_penta(50000))
+    else:
+        A = hip.lsbench_matrix_synth(spec)
     b = O.rhs(A.nrows)
     xs = np.sin(np.arange(A.nrows, dtype=np.float64))
     out = {}
-    for off in ("1", None):
+    for name, off, tune in (("full", "1", 6), ("const", None, 6), ("tmpl", None, 6 | 64)):
         if off:
             monkeypatch.setenv("LSBENCH_HIP_NO_VCONST", off)
         else:
             monkeypatch.delenv("LSBENCH_HIP_NO_VCONST", raising=False)
         s = hip.Solver(A, hip.default_opts(op_mode=hip.OP_RAW, spmv_variant=hip.SPMV_SELL, nvirt=nvirt,
-                                           tol=1e-10, precision=getattr(hip, "PREC_" + precision)))
-        assert s.spmv_variant == hip.SPMV_SELL
+                                           tol=1e-10, precision=getattr(hip, "PREC_" + precision),
+                                           spmv_tune=tune, use_graph=0,
+                                           overlap=1 if nvirt == 4 else -1))
+        assert s.spmv_variant == hip.SPMV_SELL and s.spmv_flags == tune
+        kept, total = s.sell_value_slots
+        if name == "full" or "coef" in spec:
+            assert kept == total > 0
+        else:
+            assert 0 <= kept < total // 2
         d_y = torch.empty(A.nrows, dtype=torch.float64, device="cuda:0")
         s.spmv_dev(torch.from_numpy(xs).to("cuda:0"), d_y)
         x, r = s.solve(b)
+        lb = s.spmv_layout_bytes
         s.destroy()
-        out[off] = (d_y.cpu().numpy(), x, int(r.iters), r.relres)
-    assert np.array_equal(out["1"][0], out[None][0]) and np.array_equal(out["1"][1], out[None][1])
-    assert out["1"][2:] == out[None][2:]
+        out[name] = (d_y.cpu().numpy(), x, int(r.iters), r.relres, lb)
+    for name in ("const", "tmpl"):
+        assert np.array_equal(out["full"][0], out[name][0]) and np.array_equal(out["full"][1], out[name][1])
+        assert out["full"][2:4] == out[name][2:4]
+    if "coef" not in spec:
+        # bytes a launch has to move (a small shard may not qualify for templates: then equal)
+        assert out["tmpl"][4] <= out["const"][4] < out["full"][4]
+        if nvirt == 1:
+            assert out["tmpl"][4] < out["const"][4]
     yo = O.spmv(A.offs, A.cols, A.vals, xs)
-    assert np.allclose(out[None][0], yo, rtol=1e-13, atol=1e-13)
+    assert np.allclose(out["tmpl"][0], yo, rtol=1e-13, atol=1e-13)
+
+
