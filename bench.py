@@ -364,8 +364,21 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
     # value per slot whose 128 entries are equal) does not move them, so for it the count
     # is what that layout must move in one launch -- its arrays as stored + x once + y once.
     layout_bytes = solver.spmv_layout_bytes
-    elided = vslots[1] > 0 and vslots[0] < vslots[1]
-    bytes_alg = layout_bytes if (elided and layout_bytes) else bytes_spmv
+    # the template form with a constant Jacobi diagonal folds the direction update into the SpMV
+    # launch (k_spmv_tmpl_p): that launch also reads r and writes p -- 16 bytes per row on top
+    fused_p = solver.fused_p == 2
+    if fused_p:
+        kernel = "k_spmv_tmpl_p"
+        layout_bytes += 16 * nl
+        bytes_spmv += 16 * nl
+    elif solver.spmv_flags & la.SPMV_FLAG_TMPL and kernel == "k_spmv_sell16":
+        kernel = "k_spmv_tmpl"
+    # A roofline fraction is quoted on bytes the kernel must MOVE: the layout's arrays as stored +
+    # x once + y once (lsb_hip_solver_spmv_layout_bytes).  SURVEY 8(d)'s CSR count (12 B per non-zero
+    # + 20 B per row) is what a CSR kernel moves; the sliced-ELL layouts move less (8 B per entry
+    # where a slot is one diagonal, ONE value per constant slot), so on the CSR count their ratio to
+    # peak can exceed 1 -- it is kept under csr_count, and is NOT the fraction.
+    bytes_alg = layout_bytes if layout_bytes else bytes_spmv
 
     if spmv_only:
         # config 5: SpMV throughput only (the operator is unsymmetric)
@@ -469,18 +482,23 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
                      "frac_hbm": (traffic / spmv_avg_ms / 1e6 / HBM_PEAK_GBPS) if traffic else None,
                      "traffic_source": traffic_src,
                      "algorithmic_bytes": bytes_alg,
-                     "bytes_basis": ("layout: this operator's values are elided (value_slots kept / all: one value "
-                                     "per slot whose 128 entries are equal), so the figure is quoted on what the "
-                                     "stored layout must move in one launch -- slot records, constants, code "
-                                     "arrays, the kept values, x once, y once; SURVEY 8(d)'s CSR count is under "
-                                     "csr_count and is NOT a roofline fraction for this layout"
+                     "bytes_basis": ("layout: what the stored layout must move in one launch -- its index / code / "
+                                     "slot / template arrays and the values it keeps (value_slots kept / all: one "
+                                     "value per slot whose 128 entries are equal), x once, y once"
+                                     + (", r once and p written once (the direction update rides in this launch)"
+                                        if fused_p else "")
+                                     + "; SURVEY 8(d)'s CSR count is under csr_count (a CSR kernel's bytes: this "
+                                     "layout moves fewer, so that ratio is not a fraction of anything)"
                                      if bytes_alg != bytes_spmv else
                                      "SURVEY 8(d): 12 B per non-zero + 20 B per row + 4 (values streamed)"),
+                     "direction_update_in_this_launch": fused_p,
                      "csr_count": {"bytes": bytes_spmv, "GBps": gbps_csr, "ratio_to_peak": gbps_csr / HBM_PEAK_GBPS},
                      "layout_bytes": layout_bytes,
                      "value_slots": dict(zip(("kept", "all"), vslots)),
                      "kernel": kernel + (" (panels)" if solver.spmv_variant == la.SPMV_PANEL else "") + " (fused p.q)",
                      "launch_ms": spmv_avg_ms, "back_to_back_launch_ms": b2b_ms,
+                     "back_to_back_kernel": ("k_spmv_tmpl (y = S x alone, %d B)" % (layout_bytes - 16 * nl))
+                     if fused_p else kernel,
                      "spmv_flags": solver.spmv_flags, "xcd_period_slices": solver.spmv_period,
                      "kernels_sha16": kernels_sha16(), "measured": how},
     }
@@ -521,13 +539,15 @@ def main():
         line["general_values"]["config"] = rg["config"]
         line["general_values"]["spmv"] = {k: rg["roofline"][k] for k in (
             "kernel", "launch_ms", "back_to_back_launch_ms", "achieved", "peak", "unit", "frac", "algorithmic_bytes",
-            "bytes_basis", "traffic", "frac_hbm", "traffic_source", "layout_bytes", "value_slots", "spmv_flags",
-            "measured")}
+            "bytes_basis", "csr_count", "traffic", "frac_hbm", "traffic_source", "layout_bytes", "value_slots",
+            "spmv_flags", "measured")}
         line["general_values"]["note"] = (
             "BASELINE.json configs[2]'s pattern (3162^2 5-point, 49,978,572 nnz) with GENERAL values: one hashed "
             "weight in [1/2, 3/2) per grid edge, Dirichlet, SPD (lsb_synth.c `coef=1`; stated independently in "
-            "oracle/lsb_oracle.c).  Every value is streamed: this is the fp64 CSR SpMV the metric names, and "
-            "spmv.frac is on SURVEY 8(d)'s CSR byte count.")
+            "oracle/lsb_oracle.c).  Every value is streamed: this is the fp64 SpMV the metric names.  spmv.frac "
+            "is on the bytes the kernel's layout moves (8 B of value per entry, no column index where a slot is "
+            "one diagonal); spmv.csr_count is the same launch on SURVEY 8(d)'s CSR byte count (12 B per entry), "
+            "the figure a CSR kernel would have to reach.")
     if c.rank == 0:
         print(json.dumps(line), flush=True)
     if c.dist_on:

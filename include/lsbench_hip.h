@@ -545,6 +545,11 @@ void lsb_hip_solver_comm_plan(const lsb_hip_solver *s, unsigned long long plan[8
  * and value arrays as stored) + x read once + y written once, first shard; 0 for the
  * multi-pass forms (binned, two-phase).  SURVEY 8(d)'s CSR count is 12 nnz + 20 n + 4. */
 unsigned long long lsb_hip_solver_spmv_layout_bytes(const lsb_hip_solver *s);
+/* 0: an iteration's direction update p = D^-1 r + beta p is a launch of its own; 1 / 2: it rides
+ * in the NEXT iteration's SpMV launch, formed for every gathered operand (1 = sub-wavefront form
+ * of launch-bound operators, 2 = slice-template form of a structured grid with a constant
+ * Jacobi diagonal: that launch then also reads r and writes p, 16 bytes per row more). */
+int lsb_hip_solver_fused_p(const lsb_hip_solver *s);
 /* hipStream_t of the backend (as void*), for callers that time with events. */
 void *lsb_hip_stream(void);
 

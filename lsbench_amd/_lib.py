@@ -171,6 +171,7 @@ SIGNATURES = {
     "lsb_csr_pbize": (C.POINTER(Pb), [_csrp]),
     "lsb_csr_pbize2": (C.POINTER(Pb), [_csrp, _u, _u]),
     "lsb_pb_free": (None, [C.POINTER(Pb)]),
+    "lsb_pb_check": (_i, [C.POINTER(Pb), C.c_ulonglong, C.c_ulonglong, _i, C.c_char_p, C.c_size_t]),
     "lsb_csr_binize": (C.POINTER(Binned), [_csrp, _u]),
     "lsb_binned_free": (None, [C.POINTER(Binned)]),
     "lsb_csr_sell_stored": (C.c_ulonglong, [_csrp]),
@@ -207,6 +208,7 @@ SIGNATURES = {
     "lsb_hip_solver_overlaps": (_i, [_vp]),
     "lsb_hip_solver_comm_plan": (None, [_vp, C.POINTER(C.c_ulonglong)]),
     "lsb_hip_solver_spmv_layout_bytes": (C.c_ulonglong, [_vp]),
+    "lsb_hip_solver_fused_p": (_i, [_vp]),
     "lsb_hip_solver_comm": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "lsb_hip_stream": (_vp, []),
     # communicator

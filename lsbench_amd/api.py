@@ -322,6 +322,11 @@ class Solver:
         return int(L.load().lsb_hip_solver_spmv_layout_bytes(self._h))
 
     @property
+    def fused_p(self):
+        """0 / 1 / 2: the direction update rides in the next SpMV launch (see lsbench_hip.h)."""
+        return int(L.load().lsb_hip_solver_fused_p(self._h))
+
+    @property
     def comm_plan(self):
         """The exchange plan of this process's first shard (see lsbench_hip.h)."""
         p = (C.c_ulonglong * 8)()

@@ -720,6 +720,7 @@ void lsb_hip_solver_comm_plan(const lsb_hip_solver *s, unsigned long long plan[8
   }
   plan[7] = (unsigned long long)can_overlap(s);
 }
+int lsb_hip_solver_fused_p(const lsb_hip_solver *s) { return lsb_fuse_p_kind(s); }
 unsigned long long lsb_hip_solver_spmv_layout_bytes(const lsb_hip_solver *s) {
   const struct shard *h = &s->sh[0];
   unsigned long long m = 12ull * h->nnz + 4ull * ((unsigned long long)h->n + 1); /* the CSR arrays */

@@ -239,6 +239,7 @@ LSB_INTERNAL void allreduce_pq_contribute(lsb_hip_solver *sv);
 LSB_INTERNAL void exchange_and_spmv(lsb_hip_solver *sv, int sample);
 LSB_INTERNAL double true_resid2(lsb_hip_solver *sv, const double *d_b, const double *d_x);
 /* hip_pcg.c */
+LSB_INTERNAL int lsb_fuse_p_kind(const lsb_hip_solver *sv);
 LSB_INTERNAL void drop_graphs(lsb_hip_solver *sv);
 LSB_INTERNAL void persist_setup(lsb_hip_solver *sv);
 LSB_INTERNAL int solve_core(lsb_hip_solver *sv, const double *d_b, double *d_x,
