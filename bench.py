@@ -103,9 +103,11 @@ def parse():
     p.add_argument("--persistent", type=int, default=0,
                    help="launch-bound operators: 1 = the whole solve as one persistent launch, 0 = "
                         "launch per kernel, -1 = whichever the creation-time timing finds faster")
-    p.add_argument("--precond", default="jacobi", choices=["jacobi", "l1", "none", "cheb", "bj"],
+    p.add_argument("--precond", default="jacobi", choices=["jacobi", "l1", "none", "cheb", "bj", "fsai"],
                    help="preconditioner: Jacobi (headline), l1-Jacobi, none, Chebyshev polynomial "
-                        "(--cheb-degree), block-Jacobi (--block-size)")
+                        "(--cheb-degree), block-Jacobi (--block-size), factorised sparse approximate "
+                        "inverse on the pattern of tril(S^k) (--fsai-power k; one GPU)")
+    p.add_argument("--fsai-power", type=int, default=3)
     p.add_argument("--cheb-degree", type=int, default=4)
     p.add_argument("--block-size", type=int, default=8)
     p.add_argument("--precision", default="fp64", choices=["fp64", "fp32"],
@@ -329,8 +331,8 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
                            precond=la.PRECOND_NONE if spmv_only else {
                                "jacobi": la.PRECOND_JACOBI, "l1": la.PRECOND_L1JACOBI,
                                "none": la.PRECOND_NONE, "cheb": la.PRECOND_CHEBYSHEV,
-                               "bj": la.PRECOND_BLOCKJACOBI}[a.precond],
-                           cheb_degree=a.cheb_degree, block_size=a.block_size,
+                               "bj": la.PRECOND_BLOCKJACOBI, "fsai": la.PRECOND_FSAI}[a.precond],
+                           cheb_degree=a.cheb_degree, block_size=a.block_size, fsai_power=a.fsai_power,
                            precision=la.PREC_MIXED if a.precision == "fp32" else la.PREC_FP64,
                            persistent=a.persistent, verbose=a.verbose,
                            verify=1 if (a.verify and a.fixed_iters == 0) else 0)
@@ -463,7 +465,9 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
         "vs_baseline": None, "dtype": "f64",
         "data": "synthetic" if not workload.startswith("file:") else "reference tests/ matrix",
         "config": {"workload": name, "rows": n, "nnz": n_tot_nnz,
-                   "solver": "PCG+Jacobi" + (" (single-reduction form)" if (
+                   "solver": {"jacobi": "PCG+Jacobi", "l1": "PCG+l1-Jacobi", "none": "CG", "bj": "PCG+block-Jacobi(%d)"
+                              % a.block_size, "cheb": "PCG+Chebyshev(%d)" % a.cheb_degree,
+                              "fsai": "PCG+FSAI(tril(S^%d))" % a.fsai_power}[a.precond] + (" (single-reduction form)" if (
                        a.krylov == "cg1" or (a.krylov == "auto" and world > 1)) else ""),
                    "tol": tol, "rhs": "b_i=i", "partition": "row-range x%d" % world,
                    "iterations_per_solve": its, "relres": res.relres,

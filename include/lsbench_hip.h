@@ -205,8 +205,8 @@ struct lsb_hip_opts {
                         state at most this long before it reports a hung
                         collective and exits non-zero                    [120] */
   int fsai_power;    /* LSB_PRECOND_FSAI: G lives on the pattern of tril(S^k),
-                        k = 1..3 (rows of more than 160 pattern entries are cut
-                        to the 160 nearest the diagonal)                    [2] */
+                        k = 1..3 (rows of more than 128 pattern entries are cut
+                        to the 128 nearest the diagonal)                    [3] */
 };
 enum { LSB_PREC_FP64 = 0, LSB_PREC_MIXED = 1 };
 
@@ -359,6 +359,18 @@ void lsb_pb_free(struct lsb_pb *P);
  * every entry's 16-bit offsets.  Run at every upload (shallow) and under ASan (deep). */
 int lsb_pb_check(const struct lsb_pb *P, unsigned long long prod_len, unsigned long long roww_len, int deep,
                  char *why, size_t whylen);
+/* Pattern of the factorised sparse approximate inverse (LSB_PRECOND_FSAI): row i holds the
+ * columns j <= i that row i of S^power reaches (S taken as a graph: its stored pattern, both
+ * triangles, diagonal included), cut to the `cap` largest (nearest the diagonal) where there
+ * are more; sorted, the diagonal last.  offs[n+1], cols[offs[n]]; pure host logic. */
+struct lsb_fsai_pattern {
+  unsigned n, cap;
+  unsigned long long nnz;
+  unsigned *offs, *cols;
+};
+#define LSB_FSAI_CAP 128
+struct lsb_fsai_pattern *lsb_csr_fsai_pattern(const struct csr *S, int power, unsigned cap);
+void lsb_fsai_pattern_free(struct lsb_fsai_pattern *P);
 /* Sliced-ELL copy of a CSR for LSB_SPMV_SELL: rows in slices of LSB_SELL_ROWS,
  * every slice padded to its longest row and stored column-major (entry j of
  * row 128s+i at sptr[s] + 128j + i), so that a wavefront's lane l reads the

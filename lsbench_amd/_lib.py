@@ -94,6 +94,12 @@ class SellVc(C.Structure):
                 ("vconst", C.POINTER(C.c_double)), ("vals", C.POINTER(C.c_double))]
 
 
+class FsaiPattern(C.Structure):
+    """struct lsb_fsai_pattern."""
+    _fields_ = [("n", C.c_uint), ("cap", C.c_uint), ("nnz", C.c_ulonglong), ("offs", C.POINTER(C.c_uint)),
+                ("cols", C.POINTER(C.c_uint))]
+
+
 class SellTmpl(C.Structure):
     """struct lsb_sell_tmpl (144 bytes)."""
     _fields_ = [("nslots", C.c_int), ("shaped", C.c_int), ("base", C.c_int * 8), ("kidx", C.c_int * 8),
@@ -180,6 +186,8 @@ SIGNATURES = {
     "lsb_sell_free": (None, [C.POINTER(Sell)]),
     "lsb_sell16_value_slots": (C.POINTER(SellVc), [C.POINTER(Sell)]),
     "lsb_sell_vc_free": (None, [C.POINTER(SellVc)]),
+    "lsb_csr_fsai_pattern": (C.POINTER(FsaiPattern), [_csrp, _i, _u]),
+    "lsb_fsai_pattern_free": (None, [C.POINTER(FsaiPattern)]),
     "lsb_sell16_templates": (C.POINTER(SellTmpls), [C.POINTER(Sell), C.POINTER(SellVc)]),
     "lsb_sell_tmpls_free": (None, [C.POINTER(SellTmpls)]),
     "lsb_csr_mean_scatter": (_d, [_csrp, _u]),

@@ -90,7 +90,7 @@ void lsb_hip_opts_default(struct lsb_hip_opts *o) {
   o->precision = LSB_PREC_FP64;
   o->persistent = 0; /* measured: 2x slower than the two-launch iteration */
   o->comm_deadline_s = 120.0;
-  o->fsai_power = 2;
+  o->fsai_power = 3;
 }
 
 /* ONE typed table for everything a caller may set by name: the command line of a host

@@ -23,51 +23,8 @@
 #include "hip_ar.h"
 #include "lsb_impl.h"
 
-#define WG 256      // threads per workgroup = 4 wavefronts of 64
+#include "hip_wg.h"
 static_assert(WG == AR_WG, "the folded all-reduce phases assume this workgroup size");
-#define NXCD 8      // XCDs per MI355X; blocks are dealt round-robin over them
-
-// --------------------------------------------------------------------------
-// Reductions: wavefront butterfly -> LDS across the 4 waves, fixed order.
-// Every thread of the workgroup returns with the same bits.
-// --------------------------------------------------------------------------
-template <int W>
-__device__ __forceinline__ void wg_sum(double (&v)[W], double *sred /*4*W*/) {
-#pragma unroll
-  for (int k = 0; k < W; k++) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-      v[k] += __shfl_xor(v[k], off, 64);
-  }
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  __syncthreads(); // sred may still be read from a previous call
-  if (lane == 0) {
-#pragma unroll
-    for (int k = 0; k < W; k++)
-      sred[wave * W + k] = v[k];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < W; k++)
-    v[k] = (sred[0 * W + k] + sred[1 * W + k]) + (sred[2 * W + k] + sred[3 * W + k]);
-}
-
-// Sum `nparts` partial records of width W (written by an earlier launch, one
-// record per workgroup) in an order that depends only on nparts.
-template <int W>
-__device__ __forceinline__ void wg_sum_partials(const double *__restrict__ parts,
-                                                unsigned nparts, double (&v)[W],
-                                                double *sred) {
-#pragma unroll
-  for (int k = 0; k < W; k++)
-    v[k] = 0.0;
-  for (unsigned i = threadIdx.x; i < nparts; i += WG) {
-#pragma unroll
-    for (int k = 0; k < W; k++)
-      v[k] += parts[(size_t)i * W + k];
-  }
-  wg_sum<W>(v, sred);
-}
 
 // End of an SpMV launch with the fused dot: the workgroup's partial sum goes to
 // partials[blockIdx.x]; with a tail (sharded solve over the direct xGMI path)
@@ -82,13 +39,6 @@ __device__ __forceinline__ void spmv_publish(double *__restrict__ partials, doub
     ar_tail(partials, d[0], tail);
   else if (threadIdx.x == 0)
     partials[blockIdx.x] = d[0];
-}
-
-// Logical workgroup id such that each XCD owns a contiguous range of logical
-// ids (gridDim.x is a multiple of NXCD).  Placement is a speed matter only.
-__device__ __forceinline__ unsigned xcd_contiguous_wg() {
-  const unsigned b = blockIdx.x, per = gridDim.x / NXCD;
-  return (b % NXCD) * per + b / NXCD;
 }
 
 // --------------------------------------------------------------------------

@@ -95,6 +95,39 @@ static void gen_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int sa
   }
 }
 
+/* FSAI-PCG of a launch-bound operator in three launches per iteration (hip_fsai.hip):
+ *   A  beta, stop test, p = z + beta p in the gather of S's rows, q = S p, p.q   (k_spmv_subwave_p)
+ *   B  alpha, x += alpha p, r' = r - alpha q in the gather of G's rows, t = G r'  (k_fsai_xr_gr)
+ *   C  z = G^T t, partial sums of (r'.z, r'.r')                                   (k_fsai_gt_dots)
+ * p and r alternate between two buffers each; the last iteration of an enqueued run closes
+ * with the stand-alone direction sweep and leaves r in the shard's own residual vector. */
+static void fsai_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int pos) {
+  struct shard *s = &sv->sh[0];
+  double *pb[2] = {s->d_pfull, s->d_p1}, *rb[2] = {s->d_r, s->d_r1};
+  if (pos & 1) { /* first of the run: p is in the gather vector, r in d_r, (r.z, r.r) in the state */
+    sv->pcur = 0, sv->rcur = 0;
+    spmv_shard(s, pb[0], s->d_q, pb[0], s->d_parts_pq, &s->npq, s->d_st);
+  } else {
+    lsb_k_spmv_subwave_p(s->n, s->d_offs, s->d_cols, s->d_vals, s->lanes, s->d_z, NULL, 1.0, pb[sv->pcur],
+                         pb[sv->pcur ^ 1], s->d_q, s->d_parts_pq, &s->npq, s->d_st, parity ^ 1, s->d_parts2,
+                         s->np2, g_stream);
+    sv->pcur ^= 1;
+  }
+  sv->nspmv++;
+  lsb_k_fsai_xr_gr(s->n, s->fs_g.offs, s->fs_g.cols, s->fs_g.vals, s->fs_g.lanes, pb[sv->pcur], s->d_q, d_x,
+                   rb[sv->rcur], rb[sv->rcur ^ 1], s->d_fst, s->d_st, parity, s->d_parts_pq, s->npq, g_stream);
+  sv->rcur ^= 1;
+  lsb_k_fsai_gt_dots(s->n, s->fs_gt.offs, s->fs_gt.cols, s->fs_gt.vals, s->fs_gt.lanes, s->d_fst, s->d_z,
+                     rb[sv->rcur], s->d_parts2, &s->np2, s->d_st, g_stream);
+  if (pos & 2) { /* last of the run */
+    lsb_k_pcg_update_p(s->n, s->d_z, NULL, 1.0, pb[sv->pcur], pb[0], s->d_st, parity, s->d_parts2, s->np2,
+                       g_stream);
+    if (sv->rcur)
+      LSB_CHK_HIP(hipMemcpyAsync(s->d_r, s->d_r1, (size_t)s->n * sizeof(double), hipMemcpyDeviceToDevice,
+                                 g_stream));
+  }
+}
+
 static void pcg_enqueue_init(lsb_hip_solver *sv, const double *d_b, double *d_x) {
   if (generic_precond(sv)) {
     gen_enqueue_init(sv, d_b, d_x);
@@ -196,6 +229,10 @@ static void fused_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int 
  * events 4*sample .. 4*sample+3.  pos: bit 0 = first, bit 1 = last iteration of
  * the run being enqueued. */
 static void pcg_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int sample, int pos) {
+  if (fsai_three_launches(sv)) {
+    fsai_enqueue_iter(sv, d_x, parity, pos);
+    return;
+  }
   if (generic_precond(sv)) {
     gen_enqueue_iter(sv, d_x, parity, sample);
     return;

@@ -10,7 +10,117 @@
 #define DINV(s) ((s)->dinv_uniform ? NULL : (s)->d_dinv), (s)->dinv_const
 
 int generic_precond(const lsb_hip_solver *sv) {
-  return sv->o.precond == LSB_PRECOND_CHEBYSHEV || sv->o.precond == LSB_PRECOND_BLOCKJACOBI;
+  return sv->o.precond == LSB_PRECOND_CHEBYSHEV || sv->o.precond == LSB_PRECOND_BLOCKJACOBI ||
+         sv->o.precond == LSB_PRECOND_FSAI;
+}
+
+/* ---- FSAI: G on the pattern of tril(S^k), rows by batched dense solves on the device ------- */
+static void fsai_upload_csr(struct fsai_csr *c, unsigned n, const unsigned *offs, const unsigned *cols,
+                            const double *vals) {
+  const unsigned long long nnz = offs[n];
+  int *o32 = (int *)malloc(((size_t)n + 1) * sizeof(int));
+  for (unsigned i = 0; i <= n; i++)
+    o32[i] = (int)offs[i];
+  c->nnz = nnz;
+  c->offs = (int *)dev_upload(o32, ((size_t)n + 1) * sizeof(int));
+  c->cols = (int *)dev_upload(cols, (size_t)(nnz ? nnz : 1) * sizeof(int)); /* < 2^31: same bits */
+  c->vals = (double *)dev_upload(vals, (size_t)(nnz ? nnz : 1) * sizeof(double));
+  /* launch-bound sizes: the sub-wavefront kernel; else the row-blocked one */
+  struct csr view = {n, 0, (unsigned *)offs, NULL, NULL};
+  const unsigned mean = n ? (unsigned)((nnz + n - 1) / n) : 1;
+  unsigned L = pow2_ceil(mean ? mean : 1);
+  c->lanes = L < 2 ? 2 : (L > 64 ? 64 : L);
+  c->variant = nnz <= 2000000ull ? LSB_SPMV_SUBWAVE : LSB_SPMV_ADAPTIVE;
+  unsigned *rb = NULL;
+  c->nblk = lsb_csr_row_blocks(&view, LSB_BLOCK_NNZ, &rb);
+  c->rowblk = (int *)dev_upload(rb, ((size_t)c->nblk + 1) * sizeof(int));
+  unsigned char *lanes = (unsigned char *)malloc((size_t)c->nblk + 1);
+  lsb_csr_block_lanes(&view, rb, c->nblk, lanes);
+  c->blklanes = (unsigned char *)dev_upload(lanes, (size_t)c->nblk);
+  LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+  free(o32), free(rb), free(lanes);
+}
+
+static void fsai_free_csr(struct fsai_csr *c) {
+  lsb_hip_free(c->offs), lsb_hip_free(c->cols), lsb_hip_free(c->vals);
+  lsb_hip_free(c->rowblk), lsb_hip_free(c->blklanes);
+  memset(c, 0, sizeof *c);
+}
+
+static void fsai_spmv(const struct shard *s, const struct fsai_csr *c, const double *x, double *y,
+                      const struct lsb_pcg_state *st) {
+  lsb_k_spmv(c->variant, s->n, c->offs, c->cols, c->vals, c->rowblk, c->blklanes, c->nblk, c->lanes,
+             LSB_SP_PREFETCH | LSB_SP_NT, 0, x, y, NULL, NULL, NULL, st, NULL, NULL, g_stream);
+}
+
+static void precond_shard_fsai(struct shard *s, const int *offs, const int *cols, const double *vals,
+                               const struct lsb_hip_opts *o) {
+  if (s->row_begin != 0 || s->n != s->n_glob)
+    errx(EXIT_FAILURE, "hip_cdna4: --precond fsai runs on one shard (rows of G reach into other shards' "
+                       "columns); use it without --ngpus / --nvirt");
+  const unsigned n = s->n;
+  struct csr view = {n, 0, (unsigned *)offs, (unsigned *)cols, (double *)vals};
+  const int power = o->fsai_power < 1 ? 1 : (o->fsai_power > 3 ? 3 : o->fsai_power);
+  struct lsb_fsai_pattern *P = lsb_csr_fsai_pattern(&view, power, LSB_FSAI_CAP);
+  if (!P)
+    errx(EXIT_FAILURE, "hip_cdna4: cannot build the FSAI pattern");
+  /* rows by size class: a wavefront per row up to 32 entries, a workgroup beyond */
+  unsigned *small = (unsigned *)malloc((size_t)n * sizeof(unsigned)), *big = (unsigned *)malloc((size_t)n * sizeof(unsigned));
+  unsigned nsmall = 0, nbig = 0, maxrow = 0;
+  for (unsigned i = 0; i < n; i++) {
+    const unsigned m = P->offs[i + 1] - P->offs[i];
+    if (m == 0 || P->cols[P->offs[i + 1] - 1] != i)
+      errx(EXIT_FAILURE, "hip_cdna4: FSAI pattern row %u does not end in its diagonal", i);
+    if (m <= 32)
+      small[nsmall++] = i;
+    else
+      big[nbig++] = i;
+    if (m > maxrow)
+      maxrow = m;
+  }
+  s->fs_maxrow = maxrow;
+  unsigned *d_poffs = (unsigned *)dev_upload(P->offs, ((size_t)n + 1) * sizeof(unsigned));
+  unsigned *d_pcols = (unsigned *)dev_upload(P->cols, (size_t)(P->nnz ? P->nnz : 1) * sizeof(unsigned));
+  unsigned *d_small = (unsigned *)dev_upload(small, (size_t)(nsmall ? nsmall : 1) * sizeof(unsigned));
+  unsigned *d_big = (unsigned *)dev_upload(big, (size_t)(nbig ? nbig : 1) * sizeof(unsigned));
+  double *d_g = (double *)lsb_hip_malloc((size_t)(P->nnz ? P->nnz : 1) * sizeof(double));
+  int *d_bad = (int *)lsb_hip_malloc(sizeof(int)), bad = 0;
+  LSB_CHK_HIP(hipMemsetAsync(d_bad, 0, sizeof(int), g_stream));
+  lsb_k_fsai_rows(d_small, nsmall, 32, s->d_offs, s->d_cols, s->d_vals, s->row_begin, d_poffs, d_pcols, d_g, d_bad,
+                  g_stream);
+  lsb_k_fsai_rows(d_big, nbig, LSB_FSAI_CAP, s->d_offs, s->d_cols, s->d_vals, s->row_begin, d_poffs, d_pcols, d_g,
+                  d_bad, g_stream);
+  double *g = (double *)malloc((size_t)(P->nnz ? P->nnz : 1) * sizeof(double));
+  LSB_CHK_HIP(hipMemcpyAsync(g, d_g, (size_t)P->nnz * sizeof(double), hipMemcpyDeviceToHost, g_stream));
+  LSB_CHK_HIP(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, g_stream));
+  LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+  if (bad)
+    errx(EXIT_FAILURE, "hip_cdna4: --precond fsai needs a symmetric positive definite operator (a local "
+                       "system S[J, J] had a pivot <= 0)");
+  /* G as it stands; G^T by a counting sort (rows of G^T come out with ascending columns) */
+  fsai_upload_csr(&s->fs_g, n, P->offs, P->cols, g);
+  unsigned *toffs = lsb_calloc(unsigned, (size_t)n + 2);
+  for (unsigned long long e = 0; e < P->nnz; e++)
+    toffs[P->cols[e] + 2]++;
+  for (unsigned i = 0; i < n; i++)
+    toffs[i + 2] += toffs[i + 1];
+  unsigned *tcols = (unsigned *)malloc((size_t)(P->nnz ? P->nnz : 1) * sizeof(unsigned));
+  double *tvals = (double *)malloc((size_t)(P->nnz ? P->nnz : 1) * sizeof(double));
+  for (unsigned i = 0; i < n; i++)
+    for (unsigned e = P->offs[i]; e < P->offs[i + 1]; e++) {
+      const unsigned at = toffs[P->cols[e] + 1]++;
+      tcols[at] = i, tvals[at] = g[e];
+    }
+  fsai_upload_csr(&s->fs_gt, n, toffs, tcols, tvals);
+  s->d_fst = (double *)lsb_hip_malloc((size_t)n * sizeof(double));
+  if (o->verbose)
+    fprintf(stderr, "hip_cdna4: FSAI on the pattern of tril(S^%d): %llu entries (%.1f per row, longest %u%s), "
+                    "%u rows by wavefronts, %u by workgroups\n", power, P->nnz, (double)P->nnz / n, maxrow,
+            maxrow == LSB_FSAI_CAP ? " = the cap" : "", nsmall, nbig);
+  lsb_hip_free(d_poffs), lsb_hip_free(d_pcols), lsb_hip_free(d_small), lsb_hip_free(d_big);
+  lsb_hip_free(d_g), lsb_hip_free(d_bad);
+  free(small), free(big), free(g), free(toffs), free(tcols), free(tvals);
+  lsb_fsai_pattern_free(P);
 }
 
 /* ---- block-Jacobi: dense diagonal blocks out of the shard's rows ------------ */
@@ -18,6 +128,8 @@ int generic_precond(const lsb_hip_solver *sv) {
  * consecutive rows of the shard (a block never reaches into another shard). */
 void precond_shard_blocks(struct shard *s, const int *offs, const int *cols, const double *vals,
                           const struct lsb_hip_opts *o) {
+  if (o->precond == LSB_PRECOND_FSAI)
+    precond_shard_fsai(s, offs, cols, vals, o);
   if (o->precond != LSB_PRECOND_BLOCKJACOBI)
     return;
   unsigned bs = o->block_size < 1 ? 1u : (unsigned)o->block_size;
@@ -104,9 +216,24 @@ static void op_apply(lsb_hip_solver *sv, int which_z, double *const *y, int gate
 #define CHEB_SAFETY 1.1
 #define CHEB_RATIO 30.0
 
+/* FSAI on a launch-bound operator (everything sub-wavefront kernels, one shard): the iteration
+ * runs in three launches (hip_fsai.hip, hip_pcg.c) */
+int fsai_three_launches(const lsb_hip_solver *sv) {
+  const struct shard *s = &sv->sh[0];
+  return sv->o.precond == LSB_PRECOND_FSAI && !sv->multi && !s->mixed && s->variant == LSB_SPMV_SUBWAVE &&
+         s->fs_g.variant == LSB_SPMV_SUBWAVE && s->fs_gt.variant == LSB_SPMV_SUBWAVE && sv->o.sample_spmv <= 0 &&
+         sv->o.krylov != LSB_KRYLOV_PCG1 && !getenv("LSBENCH_HIP_NO_FSAI_FUSE");
+}
+
 void precond_setup(lsb_hip_solver *sv) {
   if (!generic_precond(sv))
     return;
+  if (sv->o.precond == LSB_PRECOND_FSAI) { /* buffers of the three-launch iteration */
+    struct shard *s = &sv->sh[0];
+    if (!s->d_p1)
+      s->d_p1 = (double *)lsb_hip_malloc((size_t)s->n * sizeof(double));
+    s->d_r1 = (double *)lsb_hip_malloc((size_t)s->n * sizeof(double));
+  }
   for (int i = 0; i < sv->nshard; i++) {
     struct shard *s = &sv->sh[i];
     /* z lives in a gather vector of its own: Chebyshev multiplies it by S */
@@ -206,6 +333,12 @@ void precond_setup(lsb_hip_solver *sv) {
 void precond_apply(lsb_hip_solver *sv, int after_update) {
   if (sv->nshard > 64)
     errx(EXIT_FAILURE, "hip_cdna4: more than 64 shards");
+  if (sv->o.precond == LSB_PRECOND_FSAI) { /* z = G^T (G r): two SpMVs, nothing else */
+    struct shard *s = &sv->sh[0];
+    fsai_spmv(s, &s->fs_g, s->d_r, s->d_fst, s->d_st);
+    fsai_spmv(s, &s->fs_gt, s->d_fst, s->d_z, s->d_st);
+    return;
+  }
   if (sv->o.precond == LSB_PRECOND_BLOCKJACOBI) {
     for (int i = 0; i < sv->nshard; i++) {
       struct shard *s = &sv->sh[i];
@@ -268,4 +401,5 @@ void precond_apply(lsb_hip_solver *sv, int after_update) {
 void precond_free_shard(struct shard *s) {
   lsb_hip_free(s->d_binv), lsb_hip_free(s->d_bjpart), lsb_hip_free(s->d_zfull), lsb_hip_free(s->d_chd);
   lsb_hip_free(s->d_zfull2);
+  fsai_free_csr(&s->fs_g), fsai_free_csr(&s->fs_gt), lsb_hip_free(s->d_fst), lsb_hip_free(s->d_r1);
 }

@@ -120,6 +120,18 @@ struct shard {
   double *d_chd;         /* Chebyshev: the recurrence's direction vector */
   double *d_binv, *d_bjpart; /* block-Jacobi: inverted diagonal blocks; chunk partial sums */
   unsigned bj_bs;
+  /* FSAI (LSB_PRECOND_FSAI): G and G^T as CSR of their own, z = G^T (G r) through the row kernels */
+  struct fsai_csr {
+    int *offs, *cols, *rowblk;
+    unsigned char *blklanes;
+    double *vals;
+    unsigned nblk, lanes;
+    int variant;
+    unsigned long long nnz;
+  } fs_g, fs_gt;
+  double *d_fst;     /* t = G r */
+  double *d_r1;      /* the three-launch iteration's second residual buffer */
+  unsigned fs_maxrow; /* longest row of the pattern */
   /* binned form (LSB_SPMV_BINNED), built for scattered operators only */
   unsigned bn, bcap;   /* bins (0 = not built), entries per chunk */
   unsigned *h_binchunk; /* bn+1: first chunk of each bin (host) */
@@ -181,7 +193,7 @@ struct lsb_hip_solver {
   /* single-reduction PCG without the vector u = D^-1 r: every shard of every
    * rank has the same constant Jacobi diagonal (k_cg1_update<UI>) */
   int cg1_implicit;
-  int pcur; /* launch-bound fused path: which direction buffer is current */
+  int pcur, rcur; /* launch-bound fused paths: which direction / residual buffer is current */
 #define LSB_CHEB_MAX 32
   int cheb_m, cheb_fused; /* fused: the steps ride in the SpMV's epilogue (one shard, 16-bit sliced-ELL) */
   double cheb_lmin, cheb_lmax, cheb_c0, cheb_a[LSB_CHEB_MAX], cheb_b[LSB_CHEB_MAX];
@@ -205,6 +217,17 @@ struct lsb_hip_solver {
   double p2p_us, rccl_us; /* self-test: one exchange + all-reduce, each way */
 };
 
+/* hip_fsai.hip */
+void lsb_k_fsai_rows(const unsigned *rows, unsigned nrows, unsigned mcap, const int *offs, const int *cols,
+                     const double *vals, unsigned row_begin, const unsigned *poffs, const unsigned *pcols,
+                     double *gvals, int *bad, void *stream);
+void lsb_k_fsai_xr_gr(unsigned n, const int *goffs, const int *gcols, const double *gvals, unsigned lanes,
+                      const double *p, const double *q, double *x, const double *rold, double *rnew, double *t,
+                      struct lsb_pcg_state *st, int parity, const double *pq_parts, unsigned npq, void *stream);
+void lsb_k_fsai_gt_dots(unsigned n, const int *offs, const int *cols, const double *vals, unsigned lanes,
+                        const double *t, double *z, const double *r, double *partials2, unsigned *npartials,
+                        const struct lsb_pcg_state *st, void *stream);
+LSB_INTERNAL int fsai_three_launches(const lsb_hip_solver *sv);
 /* hip_cdna4.c */
 LSB_INTERNAL double wall_seconds(void);
 /* Leave the process from a state in which a stream of this process may never drain (a hung

@@ -85,7 +85,7 @@ static void usage(const char *prog) {
   printf("                       dense inverted blocks of --block-size B rows (default 8; B >= n = a\n");
   printf("                       cached dense inverse, for operators of a few thousand rows); fsai =\n");
   printf("                       factorised sparse approximate inverse G^T G on the pattern of\n");
-  printf("                       tril(S^k), k = --fsai-power (default 2), set up once on the device\n");
+  printf("                       tril(S^k), k = --fsai-power (default 3), set up once on the device\n");
   printf("  --ngpus <N>          (hip) row-partition the operator over N GPUs of this node\n");
   printf("                       (0 = all visible), driven from this one process\n");
   printf("  --reorder            (hip) solve the RCM-permuted operator (any --ordering\n");

@@ -843,6 +843,89 @@ double lsb_csr_mean_scatter(const struct csr *A, unsigned row_begin) {
 }
 
 /* ------------------------------------------------------------------------ */
+/* FSAI pattern (LSB_PRECOND_FSAI; hip_precond.c, hip_fsai.hip).  No reference */
+/* counterpart: the reference's own "expensive set-up once" is CHOLMOD's       */
+/* factorisation in csr_init (src/cholmod-impl.h:25-26).                       */
+/* ------------------------------------------------------------------------ */
+struct lsb_fsai_pattern *lsb_csr_fsai_pattern(const struct csr *S, int power, unsigned cap) {
+  if (!S || S->nrows == 0 || power < 1 || power > 3 || cap == 0)
+    return NULL;
+  const unsigned n = S->nrows, base = S->base;
+  struct lsb_fsai_pattern *P = lsb_calloc(struct lsb_fsai_pattern, 1);
+  P->n = n, P->cap = cap;
+  P->offs = lsb_calloc(unsigned, (size_t)n + 1);
+  /* two passes (count, fill) of the same row routine; per thread: a stamp array to make
+   * the union, a list of what was reached */
+  unsigned *len = lsb_calloc(unsigned, (size_t)n);
+  for (int pass = 0; pass < 2; pass++) {
+    if (pass == 1) {
+      unsigned long long acc = 0;
+      for (unsigned i = 0; i < n; i++)
+        P->offs[i] = (unsigned)acc, acc += len[i];
+      if (acc > 0xFFFFFFF0ull)
+        errx(EXIT_FAILURE, "FSAI pattern with %llu entries exceeds 32-bit offsets", acc);
+      P->offs[n] = (unsigned)acc, P->nnz = acc;
+      P->cols = (unsigned *)malloc((size_t)(acc ? acc : 1) * sizeof(unsigned));
+      if (!P->cols)
+        errx(EXIT_FAILURE, "out of host memory for the FSAI pattern");
+    }
+#pragma omp parallel
+    {
+      unsigned *stamp = lsb_calloc(unsigned, (size_t)n); /* stamp[j] == i + 1: j reached from row i */
+      unsigned *list = (unsigned *)malloc((size_t)n * sizeof(unsigned));
+#pragma omp for schedule(dynamic, 256)
+      for (long long ii = 0; ii < (long long)n; ii++) {
+        const unsigned i = (unsigned)ii;
+        unsigned cnt = 0, lo = 0;
+        stamp[i] = i + 1, list[cnt++] = i;
+        for (int step = 0; step < power; step++) { /* one more hop from everything reached so far */
+          const unsigned hi = cnt;
+          for (unsigned a = lo; a < hi; a++) {
+            const unsigned j = list[a];
+            for (unsigned e = S->offs[j]; e < S->offs[j + 1]; e++) {
+              const unsigned c = S->cols[e] - base;
+              if (c < n && stamp[c] != i + 1)
+                stamp[c] = i + 1, list[cnt++] = c;
+            }
+          }
+          lo = hi;
+        }
+        /* keep j <= i, the `cap` largest of them */
+        unsigned m = 0;
+        for (unsigned a = 0; a < cnt; a++)
+          if (list[a] <= i)
+            list[m++] = list[a];
+        /* (insertion sort would be quadratic on long rows: qsort-free selection by a counting
+         * pass over the small index window is overkill too -- sort ascending with a simple
+         * shell sort, rows are at most a few thousand long) */
+        for (unsigned gap = m / 2; gap > 0; gap /= 2)
+          for (unsigned a = gap; a < m; a++) {
+            const unsigned v = list[a];
+            unsigned b = a;
+            for (; b >= gap && list[b - gap] > v; b -= gap)
+              list[b] = list[b - gap];
+            list[b] = v;
+          }
+        const unsigned keep = m > cap ? cap : m;
+        if (pass == 0)
+          len[i] = keep;
+        else
+          memcpy(P->cols + P->offs[i], list + (m - keep), (size_t)keep * sizeof(unsigned));
+      }
+      free(stamp), free(list);
+    }
+  }
+  free(len);
+  return P;
+}
+
+void lsb_fsai_pattern_free(struct lsb_fsai_pattern *P) {
+  if (!P)
+    return;
+  free(P->offs), free(P->cols), free(P);
+}
+
+/* ------------------------------------------------------------------------ */
 /* Sliced-ELL copy (LSB_SPMV_SELL).  No reference counterpart: a device      */
 /* layout of the same operator.                        */
 /* ------------------------------------------------------------------------ */

@@ -401,13 +401,111 @@ static void orc_chol_solve(uint64_t n, uint32_t bs, const double *L, const doubl
   }
 }
 
+/* FSAI (kind 5 of orc_pcg_prec; the product: lsb_csr_fsai_pattern + hip_fsai.hip), restated
+ * from the definition: row i of G lives on J = {j <= i reached from i in `power` hops of S's
+ * graph (stored pattern, both triangles)}, the 128 largest where there are more, and is
+ * y / sqrt(y_last) with S[J, J] y = e_last.  The local systems are solved by Gaussian
+ * elimination with partial pivoting on a dense copy (the product uses a Cholesky
+ * factorisation in LDS); the pattern is found by a breadth-first sweep with a visited array
+ * per row (the product: stamps + a shell sort).  goffs[n+1], gcols/gvals: caller frees. */
+static int orc_cmp_u32(const void *a, const void *b) {
+  const uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b;
+  return x < y ? -1 : x > y;
+}
+static void orc_fsai_build(uint64_t n, const uint64_t *offs, const uint32_t *cols, const double *vals,
+                           uint32_t power, uint64_t **goffs_out, uint32_t **gcols_out, double **gvals_out) {
+  const uint32_t cap = 128;
+  uint64_t *goffs = (uint64_t *)calloc(n + 1, sizeof(uint64_t));
+  uint64_t capn = 16 * n + 16, used = 0;
+  uint32_t *gcols = (uint32_t *)malloc(capn * sizeof(uint32_t));
+  double *gvals = (double *)malloc(capn * sizeof(double));
+  unsigned char *seen = (unsigned char *)calloc(n, 1);
+  uint32_t *front = (uint32_t *)malloc(n * sizeof(uint32_t)), *J = (uint32_t *)malloc(n * sizeof(uint32_t));
+  double *A = (double *)malloc((size_t)cap * cap * sizeof(double)), *y = (double *)malloc(cap * sizeof(double));
+  for (uint64_t i = 0; i < n; i++) {
+    /* breadth first, `power` levels */
+    uint64_t nf = 0, lo = 0;
+    front[nf++] = (uint32_t)i, seen[i] = 1;
+    for (uint32_t lev = 0; lev < power; lev++) {
+      const uint64_t hi = nf;
+      for (uint64_t a = lo; a < hi; a++)
+        for (uint64_t e = offs[front[a]]; e < offs[front[a] + 1]; e++)
+          if (cols[e] < n && !seen[cols[e]])
+            seen[cols[e]] = 1, front[nf++] = cols[e];
+      lo = hi;
+    }
+    uint64_t m = 0;
+    for (uint64_t a = 0; a < nf; a++) {
+      seen[front[a]] = 0;
+      if (front[a] <= i)
+        J[m++] = front[a];
+    }
+    qsort(J, m, sizeof(uint32_t), orc_cmp_u32);
+    const uint32_t *Jk = J + (m > cap ? m - cap : 0);
+    const uint32_t mk = (uint32_t)(m > cap ? cap : m);
+    /* dense S[J, J] (both triangles), right-hand side e_last */
+    for (uint32_t a = 0; a < mk; a++) {
+      for (uint32_t b = 0; b < mk; b++)
+        A[(size_t)a * mk + b] = 0.0;
+      for (uint64_t e = offs[Jk[a]]; e < offs[Jk[a] + 1]; e++) {
+        const uint32_t *hit = (const uint32_t *)bsearch(&cols[e], Jk, mk, sizeof(uint32_t), orc_cmp_u32);
+        if (hit)
+          A[(size_t)a * mk + (size_t)(hit - Jk)] = vals[e];
+      }
+      y[a] = a + 1 == mk ? 1.0 : 0.0;
+    }
+    for (uint32_t k = 0; k < mk; k++) { /* elimination with partial pivoting */
+      uint32_t piv = k;
+      for (uint32_t a = k + 1; a < mk; a++)
+        if (fabs(A[(size_t)a * mk + k]) > fabs(A[(size_t)piv * mk + k]))
+          piv = a;
+      if (piv != k) {
+        for (uint32_t b = 0; b < mk; b++) {
+          const double t = A[(size_t)k * mk + b];
+          A[(size_t)k * mk + b] = A[(size_t)piv * mk + b], A[(size_t)piv * mk + b] = t;
+        }
+        const double t = y[k];
+        y[k] = y[piv], y[piv] = t;
+      }
+      for (uint32_t a = k + 1; a < mk; a++) {
+        const double f = A[(size_t)a * mk + k] / A[(size_t)k * mk + k];
+        if (f != 0.0) {
+          for (uint32_t b = k; b < mk; b++)
+            A[(size_t)a * mk + b] -= f * A[(size_t)k * mk + b];
+          y[a] -= f * y[k];
+        }
+      }
+    }
+    for (uint32_t k = mk; k-- > 0;) {
+      double t = y[k];
+      for (uint32_t b = k + 1; b < mk; b++)
+        t -= A[(size_t)k * mk + b] * y[b];
+      y[k] = t / A[(size_t)k * mk + k];
+    }
+    const double sc = 1.0 / sqrt(y[mk - 1]);
+    if (used + mk > capn) {
+      capn = 2 * capn + mk;
+      gcols = (uint32_t *)realloc(gcols, capn * sizeof(uint32_t));
+      gvals = (double *)realloc(gvals, capn * sizeof(double));
+    }
+    goffs[i] = used;
+    for (uint32_t a = 0; a < mk; a++)
+      gcols[used] = Jk[a], gvals[used++] = y[a] * sc;
+  }
+  goffs[n] = used;
+  free(seen), free(front), free(J), free(A), free(y);
+  *goffs_out = goffs, *gcols_out = gcols, *gvals_out = gvals;
+}
+
 int orc_pcg_prec(uint64_t n, const uint64_t *offs, const uint32_t *cols, const double *vals,
                  const double *b, double *x, double tol, uint32_t maxit, int kind, uint32_t param,
                  uint32_t *iters_out, double *relres_out, uint32_t *spmv_out, double *lmax_out) {
   double *r = (double *)malloc(n * sizeof(double)), *p = (double *)malloc(n * sizeof(double));
   double *q = (double *)malloc(n * sizeof(double)), *z = (double *)malloc(n * sizeof(double));
   double *d = (double *)calloc(n, sizeof(double)), *dinv = (double *)malloc(n * sizeof(double));
-  double *L = NULL;
+  double *L = NULL, *gvals = NULL;
+  uint64_t *goffs = NULL;
+  uint32_t *gcols = NULL;
   uint32_t it = 0, nspmv = 0;
   int status = 3;
   double lmax = 0.0, theta = 0.0, delta = 0.0, sigma = 0.0;
@@ -448,10 +546,22 @@ int orc_pcg_prec(uint64_t n, const uint64_t *offs, const uint32_t *cols, const d
     const uint64_t nb = (n + param - 1) / param;
     L = (double *)calloc(nb * (uint64_t)param * param, sizeof(double));
     orc_chol_blocks(n, param, offs, cols, vals, L);
+  } else if (kind == 5) {
+    orc_fsai_build(n, offs, cols, vals, param, &goffs, &gcols, &gvals);
   }
 #define ORC_PREC()                                                                       \
   do {                                                                                   \
-    if (kind == 4) {                                                                     \
+    if (kind == 5) { /* z = G^T (G r): t by rows, z by scattering rows of G */          \
+      for (uint64_t i = 0; i < n; i++) {                                                 \
+        double t = 0.0;                                                                  \
+        for (uint64_t e = goffs[i]; e < goffs[i + 1]; e++)                               \
+          t += gvals[e] * r[gcols[e]];                                                   \
+        d[i] = t, z[i] = 0.0;                                                            \
+      }                                                                                  \
+      for (uint64_t i = 0; i < n; i++)                                                   \
+        for (uint64_t e = goffs[i]; e < goffs[i + 1]; e++)                               \
+          z[gcols[e]] += gvals[e] * d[i];                                                \
+    } else if (kind == 4) {                                                              \
       orc_chol_solve(n, param, L, r, z);                                                 \
     } else {                                                                             \
       double rho = 1.0 / sigma;                                                          \
@@ -517,6 +627,7 @@ done:
   if (lmax_out)
     *lmax_out = lmax;
   free(r), free(p), free(q), free(z), free(d), free(dinv), free(L);
+  free(goffs), free(gcols), free(gvals);
   return status;
 }
 

@@ -187,7 +187,8 @@ def pcg1_jacobi(offs, cols, vals, b, tol=1e-12, maxit=20000):
 def pcg_prec(offs, cols, vals, b, tol=1e-12, maxit=20000, kind="cheb", param=4):
     """PCG with z = M^-1 r as a vector operation: kind "cheb" = Chebyshev polynomial
     of degree `param` in D^-1 A, "bj" = block-Jacobi with `param`-row blocks (dense
-    Cholesky per block).  Returns (x, iters, relres, status, spmvs, lmax)."""
+    Cholesky per block), "fsai" = factorised sparse approximate inverse G^T G on the pattern of
+    tril(A^param) (rows by dense Gaussian elimination).  Returns (x, iters, relres, status, spmvs, lmax)."""
     L = lib()
     L.orc_set_threads(1)
     n = len(offs) - 1
@@ -199,7 +200,7 @@ def pcg_prec(offs, cols, vals, b, tol=1e-12, maxit=20000, kind="cheb", param=4):
                                C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
     st = L.orc_pcg_prec(n, _as64(offs), np.ascontiguousarray(cols, np.uint32),
                         np.ascontiguousarray(vals, np.float64), np.ascontiguousarray(b, np.float64),
-                        x, tol, maxit, {"cheb": 3, "bj": 4}[kind], int(param), C.byref(it),
+                        x, tol, maxit, {"cheb": 3, "bj": 4, "fsai": 5}[kind], int(param), C.byref(it),
                         C.byref(rel), C.byref(nsp), C.byref(lmax))
     return x, it.value, rel.value, st, nsp.value, lmax.value
 

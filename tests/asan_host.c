@@ -58,6 +58,24 @@ int main(void) {
       }
       lsb_pb_free(P);
     }
+    for (int pw = 1; pw <= 3; pw++) { /* FSAI pattern: rows end in their diagonal, ascending, within the cap */
+      struct lsb_fsai_pattern *F = lsb_csr_fsai_pattern(A, pw, pw == 3 ? 7 : LSB_FSAI_CAP);
+      for (unsigned i = 0; i < F->n; i++) {
+        const unsigned a = F->offs[i], b = F->offs[i + 1];
+        if (b <= a || b - a > F->cap || F->cols[b - 1] != i) { printf("fsai pattern row %u\n", i); return 1; }
+        for (unsigned e = a + 1; e < b; e++)
+          if (F->cols[e] <= F->cols[e - 1]) { printf("fsai pattern order\n"); return 1; }
+      }
+      lsb_fsai_pattern_free(F);
+    }
+    {
+      struct lsb_sell *H16 = lsb_csr_sellize16(A, 0);
+      if (H16) {
+        struct lsb_sell_vc *Vc = lsb_sell16_value_slots(H16);
+        struct lsb_sell_tmpls *Tm = lsb_sell16_templates(H16, Vc);
+        lsb_sell_tmpls_free(Tm), lsb_sell_vc_free(Vc), lsb_sell_free(H16);
+      }
+    }
     struct lsb_sell *E = lsb_csr_sellize(A); lsb_sell_free(E);
     E = lsb_csr_sellize16(A, 0); lsb_sell_free(E);
     struct csr *S = lsb_csr_symmetrize_upper(A);

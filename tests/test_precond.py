@@ -34,6 +34,132 @@ def test_oracle_preconditioners_reach_golden(name, matrix_path, golden_x):
         assert st == 1 and it <= 2 and np.linalg.norm(x - xg) / np.linalg.norm(xg) <= 1e-10
 
 
+@pytest.mark.parametrize("name", SPD)
+def test_oracle_fsai_reaches_golden(name, matrix_path, golden_x):
+    """FSAI G^T G on the pattern of tril(S^k) (oracle: breadth-first pattern, dense Gaussian
+    elimination per row): golden x to 1e-10, and the iterations the set-up buys -- less than
+    half of Jacobi's at k = 1, about a quarter at k = 2 (xn3b_A_18: 267 -> 115 -> 69)."""
+    S = O.operator_upper(O.matrix_read(matrix_path(name)))
+    b = O.rhs(len(S.offs) - 1)
+    xg = golden_x(name)
+    _, itj, _, _ = O.pcg_jacobi(S.offs, S.cols, S.vals, b, 1e-12)
+    its = {}
+    for k in (1, 2):
+        x, it, rel, st, nsp, _ = O.pcg_prec(S.offs, S.cols, S.vals, b, 1e-12, kind="fsai", param=k)
+        assert st == 1 and nsp == it and np.linalg.norm(x - xg) / np.linalg.norm(xg) <= 1e-10
+        its[k] = it
+    assert its[1] <= 0.55 * itj and its[2] <= 0.36 * itj and its[2] < its[1]
+    if name == "xn3b_A_18":
+        assert (itj, its[1], its[2]) == (267, 115, 69)
+
+
+@pytest.mark.parametrize("spec,power", [("lap2d:nx=23,ny=17", 1), ("lap2d:nx=23,ny=17", 2), ("lap3d:nx=7,ny=6,nz=5", 2),
+                                        ("lap3d:nx=9,ny=8,nz=7", 3), ("powerlaw:n=900,avg=9,max=300,seed=3,spd=1", 2)])
+def test_fsai_pattern_is_tril_of_the_power(spec, power):
+    """lsb_csr_fsai_pattern (host): row i = the columns j <= i of row i of (pattern of S)^power,
+    cut to the `cap` nearest the diagonal; against a scipy construction."""
+    import ctypes as C
+    import scipy.sparse as sp
+    import lsbench_amd as la
+    lib = la._lib.load()
+    A = la.lsbench_matrix_synth(spec)
+    n = A.nrows
+    P1 = sp.csr_matrix((np.ones(A.nnz), A.cols.astype(np.int64), A.offs.astype(np.int64)), shape=(n, n))
+    P1 = ((P1 + P1.T + sp.identity(n)) > 0).astype(np.float64) if "powerlaw" not in spec else P1
+    Q = sp.identity(n, format="csr")
+    for _ in range(power):
+        Q = ((Q @ P1) > 0).astype(np.float64)
+    Q = sp.tril(Q + sp.identity(n)).tocsr()
+    Q.sort_indices()
+    for cap in (128, 5):
+        T = lib.lsb_csr_fsai_pattern(A.ptr, power, cap)
+        t = T.contents
+        offs = np.ctypeslib.as_array(t.offs, (n + 1,))
+        cols = np.ctypeslib.as_array(t.cols, (max(int(t.nnz), 1),))
+        assert t.n == n and offs[-1] == t.nnz
+        for i in range(n):
+            want = Q.indices[Q.indptr[i]:Q.indptr[i + 1]][-cap:]
+            assert np.array_equal(cols[offs[i]:offs[i + 1]], want) and want[-1] == i
+        lib.lsb_fsai_pattern_free(T)
+    assert not lib.lsb_csr_fsai_pattern(A.ptr, 0, 128) and not lib.lsb_csr_fsai_pattern(A.ptr, 4, 128)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SPD)
+def test_hip_fsai_follows_the_oracle(hip, monkeypatch, name, matrix_path, golden_x):
+    """LSB_PRECOND_FSAI: pattern on the host, rows of G by batched dense Cholesky solves on the
+    device (hip_fsai.hip), z = G^T (G r) as two SpMVs.  Iteration counts of the oracle's
+    restatement (Gaussian elimination on the CPU), golden x to 1e-10, repeatable, with and
+    without graph replay; the iteration as three launches (the sweeps ride in the gathers of
+    S, G and G^T: the default on these launch-bound operators) and as the generic six."""
+    A = hip.lsbench_matrix_read(matrix_path(name))
+    S = O.operator_upper(O.matrix_read(matrix_path(name)))
+    b = O.rhs(A.nrows)
+    xg = golden_x(name)
+    for power in (1, 2):
+        xo, ito, relo, sto, nspo, _ = O.pcg_prec(S.offs, S.cols, S.vals, b, 1e-12, kind="fsai", param=power)
+        its = {}
+        for six in ("1", None):
+            if six:
+                monkeypatch.setenv("LSBENCH_HIP_NO_FSAI_FUSE", six)
+            else:
+                monkeypatch.delenv("LSBENCH_HIP_NO_FSAI_FUSE", raising=False)
+            for graph in (0, 1):
+                s = hip.Solver(A, hip.default_opts(precond=hip.PRECOND_FSAI, fsai_power=power, use_graph=graph))
+                x, r = s.solve(b)
+                x2, r2 = s.solve(b)
+                s.destroy()
+                assert r.status == hip.STATUS_CONVERGED and sto == 1
+                assert abs(int(r.iters) - ito) <= max(2, ito // 25)
+                assert r2.iters == r.iters and np.array_equal(x, x2)
+                assert np.linalg.norm(x - xg) / np.linalg.norm(xg) <= 1e-10
+                assert r.spmvs == r.iters                      # one multiplication by S per iteration
+                its[six, graph] = int(r.iters)
+        assert max(its.values()) - min(its.values()) <= 2
+    # a run cut by maxit: both forms stop at the same iterate count with MAXIT
+    for six in ("1", None):
+        if six:
+            monkeypatch.setenv("LSBENCH_HIP_NO_FSAI_FUSE", six)
+        else:
+            monkeypatch.delenv("LSBENCH_HIP_NO_FSAI_FUSE", raising=False)
+        s = hip.Solver(A, hip.default_opts(precond=hip.PRECOND_FSAI, fsai_power=2, maxit=7, use_graph=0))
+        x, r = s.solve(b)
+        s.destroy()
+        xo7, it7, _, st7, _, _ = O.pcg_prec(S.offs, S.cols, S.vals, b, 1e-12, maxit=7, kind="fsai", param=2)
+        assert r.status == hip.STATUS_MAXIT and r.iters == 7 == it7
+        assert np.linalg.norm(x - xo7) / np.linalg.norm(xo7) <= 1e-9
+
+
+@pytest.mark.gpu
+def test_hip_fsai_on_a_grid_and_its_refusals(hip, matrix_path):
+    """A 3-D stencil (rows of G by wavefronts: <= 32 entries at k = 2); an indefinite operator and a
+    sharded solve are refused with a message (the driver process exits non-zero)."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    A = hip.lsbench_matrix_synth("lap3d:nx=24,ny=20,nz=18")
+    b = O.rhs(A.nrows)
+    xo, ito, _, sto, _, _ = O.pcg_prec(A.offs, A.cols, A.vals, b, 1e-10, kind="fsai", param=2)
+    s = hip.Solver(A, hip.default_opts(op_mode=hip.OP_RAW, precond=hip.PRECOND_FSAI, fsai_power=2, tol=1e-10))
+    x, r = s.solve(b)
+    s.destroy()
+    assert r.status == 1 and sto == 1 and abs(int(r.iters) - ito) <= 2
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-8
+    drv = os.path.join(ROOT, "lsbench_amd", "csrc", "driver")
+    r = subprocess.run([drv, "--solver", "hip", "--matrix", matrix_path("A0_02x02"), "--precond", "fsai", "--trials=1"],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "positive definite" in r.stderr
+    r = subprocess.run([drv, "--solver", "hip", "--matrix", "synth:lap2d:nx=40,ny=30", "--operator", "raw",
+                        "--precond", "fsai", "--nvirt", "2", "--trials=1"], capture_output=True, text=True)
+    assert r.returncode != 0 and "one shard" in r.stderr
+    r = subprocess.run([drv, "--solver", "hip", "--matrix", matrix_path("xn3b_A_18"), "--precond", "fsai",
+                        "--fsai-power", "2", "--trials=3"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rec = r.stdout.splitlines()
+    f = rec[rec.index("===hip_cdna4:iterations,relres,status,tol,solves_per_sec,nshards===") + 1].split(",")
+    assert abs(int(f[0]) - 69) <= 3 and int(f[2]) == 1
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", SPD)
 def test_hip_preconditioners_follow_the_oracle(hip, name, matrix_path, golden_x):
