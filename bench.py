@@ -366,14 +366,8 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
     # value per slot whose 128 entries are equal) does not move them, so for it the count
     # is what that layout must move in one launch -- its arrays as stored + x once + y once.
     layout_bytes = solver.spmv_layout_bytes
-    # the template form with a constant Jacobi diagonal folds the direction update into the SpMV
-    # launch (k_spmv_tmpl_p): that launch also reads r and writes p -- 16 bytes per row on top
-    fused_p = solver.fused_p == 2
-    if fused_p:
-        kernel = "k_spmv_tmpl_p"
-        layout_bytes += 16 * nl
-        bytes_spmv += 16 * nl
-    elif solver.spmv_flags & la.SPMV_FLAG_TMPL and kernel == "k_spmv_sell16":
+    fused_p = False
+    if solver.spmv_flags & la.SPMV_FLAG_TMPL and kernel == "k_spmv_sell16":
         kernel = "k_spmv_tmpl"
     # A roofline fraction is quoted on bytes the kernel must MOVE: the layout's arrays as stored +
     # x once + y once (lsb_hip_solver_spmv_layout_bytes).  SURVEY 8(d)'s CSR count (12 B per non-zero

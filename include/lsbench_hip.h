@@ -433,22 +433,30 @@ void lsb_sell_vc_free(struct lsb_sell_vc *V);
  * take the operands of c-1 and c+1 from the centre's 16-byte pair by a lane shift: three
  * gathers instead of five on a 5-point row, none misaligned.  In a shaped template the far
  * slots and the centre are constant; c-1 and c+1 may keep their values (a grid line that
- * ends inside the slice: padding zeros there).  Every other template is all-constant.
- * Lossless: the same products in the same order. */
+ * ends inside the slice: padding zeros there) -- and where those values are ONE number or
+ * zero (every such slot of a constant-coefficient stencil), the slot is MASKED: the number
+ * in the template, a 128-bit mask per slice and slot instead of 1 KB of values.  Every other
+ * template is all-constant.  Lossless: the same products in the same order. */
 #define LSB_TMPL_SLOTS 8
-struct lsb_sell_tmpl { /* 144 bytes, read by scalar loads */
+struct lsb_sell_tmpl { /* 176 bytes, read by scalar loads */
   int nslots;
   int shaped; /* 1: [nfar][c-1, c, c+1][nfar], nfar = the set's */
   int base[LSB_TMPL_SLOTS];
-  int kidx[LSB_TMPL_SLOTS]; /* -1: constant cst[j]; k >= 0: the slice's k-th kept value slot */
+  int kidx[LSB_TMPL_SLOTS]; /* -1: constant cst[j]; k >= 0: the slice's k-th kept value slot
+                               (kind 1) or k-th mask (kind 2) */
+  int kind[LSB_TMPL_SLOTS]; /* 0 constant, 1 keeps its 128 values, 2 masked constant cst[j] */
   int pad_[2];
   double cst[LSB_TMPL_SLOTS];
 };
 struct lsb_sell_tmpls {
   unsigned nslice, ntmpl, nfar;
   unsigned long long covered, shaped; /* slices that have a template / a shaped one */
+  unsigned long long nmask;           /* masks (two 64-bit words each: bit r = row r of the slice) */
+  unsigned long long kept_read;       /* value slots the template kernel still reads (kind 1 slots
+                                         of templated slices + the slices without a template) */
   unsigned char *tid;                 /* nslice + 8 */
-  unsigned *vbase;                    /* nslice + 8: first kept value slot of the slice */
+  unsigned *vbase;                    /* 2 * (nslice + 8): {first kept value slot, first mask} */
+  unsigned long long *mask;           /* 2 * (nmask + 1) */
   struct lsb_sell_tmpl *t;            /* ntmpl <= 254 */
 };
 /* NULL when fewer than 7/8 of the slices get a template, shaped ones cover less than 3/4,
@@ -557,10 +565,9 @@ void lsb_hip_solver_comm_plan(const lsb_hip_solver *s, unsigned long long plan[8
  * and value arrays as stored) + x read once + y written once, first shard; 0 for the
  * multi-pass forms (binned, two-phase).  SURVEY 8(d)'s CSR count is 12 nnz + 20 n + 4. */
 unsigned long long lsb_hip_solver_spmv_layout_bytes(const lsb_hip_solver *s);
-/* 0: an iteration's direction update p = D^-1 r + beta p is a launch of its own; 1 / 2: it rides
- * in the NEXT iteration's SpMV launch, formed for every gathered operand (1 = sub-wavefront form
- * of launch-bound operators, 2 = slice-template form of a structured grid with a constant
- * Jacobi diagonal: that launch then also reads r and writes p, 16 bytes per row more). */
+/* 0: an iteration's direction update p = D^-1 r + beta p is a launch of its own; 1: it rides in the
+ * NEXT iteration's SpMV launch, formed for every gathered operand (the sub-wavefront form of
+ * launch-bound operators). */
 int lsb_hip_solver_fused_p(const lsb_hip_solver *s);
 /* hipStream_t of the backend (as void*), for callers that time with events. */
 void *lsb_hip_stream(void);

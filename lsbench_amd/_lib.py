@@ -101,16 +101,17 @@ class FsaiPattern(C.Structure):
 
 
 class SellTmpl(C.Structure):
-    """struct lsb_sell_tmpl (144 bytes)."""
+    """struct lsb_sell_tmpl (176 bytes)."""
     _fields_ = [("nslots", C.c_int), ("shaped", C.c_int), ("base", C.c_int * 8), ("kidx", C.c_int * 8),
-                ("pad_", C.c_int * 2), ("cst", C.c_double * 8)]
+                ("kind", C.c_int * 8), ("pad_", C.c_int * 2), ("cst", C.c_double * 8)]
 
 
 class SellTmpls(C.Structure):
     """struct lsb_sell_tmpls."""
     _fields_ = [("nslice", C.c_uint), ("ntmpl", C.c_uint), ("nfar", C.c_uint), ("covered", C.c_ulonglong),
-                ("shaped", C.c_ulonglong), ("tid", C.POINTER(C.c_ubyte)), ("vbase", C.POINTER(C.c_uint)),
-                ("t", C.POINTER(SellTmpl))]
+                ("shaped", C.c_ulonglong), ("nmask", C.c_ulonglong), ("kept_read", C.c_ulonglong),
+                ("tid", C.POINTER(C.c_ubyte)), ("vbase", C.POINTER(C.c_uint)),
+                ("mask", C.POINTER(C.c_ulonglong)), ("t", C.POINTER(SellTmpl))]
 
 
 class Binned(C.Structure):

@@ -1001,6 +1001,12 @@ static int g_blas1_nt = 1;
 struct sell_deal {
   unsigned turns, base, L, period, full, total;
 };
+// (Tried in round 3 and taken out: MARCHING along z -- inside its eighth of every plane a wave keeps
+// ONE position and walks plane after plane, so that the +-plane operands of a step are what the
+// same positions touched one and two steps ago and come out of the L2 by time rather than by the
+// concurrency of the workgroups that hold the neighbouring planes.  Bit-identical, and 622-685 us
+// per launch of the 64 M-row 7-point operator against 322-327 us: gpurun_out/r3_march,
+// profiles/r03_cfg4_dealing.txt.)
 __device__ __forceinline__ sell_deal sell_deal_init(unsigned ns, unsigned period, unsigned xcd) {
   sell_deal d;
   d.period = period, d.full = 0, d.total = 0;
@@ -1308,11 +1314,46 @@ __device__ __forceinline__ double lane_below(double v) { // the value lane + 1 h
   return __hiloint2double(hi, lo);
 }
 
+// values of the slots c-1 / c+1 of a shaped template where they are not plain constants
+__device__ __forceinline__ void tmpl_side_values(const lsb_sell_tmpl *T, int NF, unsigned s, unsigned lane,
+                                                 const unsigned *__restrict__ vbase,
+                                                 const unsigned long long *__restrict__ mask,
+                                                 const void *__restrict__ vals, int f32, double &vm0, double &vm1,
+                                                 double &vp0, double &vp1) {
+  const unsigned vb = __builtin_amdgcn_readfirstlane(vbase[2 * s]);
+  const unsigned mb = __builtin_amdgcn_readfirstlane(vbase[2 * s + 1]);
+#pragma unroll
+  for (int side = 0; side < 2; side++) {
+    const int j = NF + 2 * side, k = T->kidx[j], kd = T->kind[j];
+    if (k < 0)
+      continue;
+    double v0, v1;
+    if (kd == 2) { // bit r of the slice's mask: row r holds the template's number
+      const unsigned long long w = mask[2 * ((size_t)mb + (unsigned)k) + (lane >> 5)];
+      const unsigned sh = (2u * lane) & 63u;
+      v0 = (w >> sh) & 1ull ? T->cst[j] : 0.0;
+      v1 = (w >> (sh + 1u)) & 1ull ? T->cst[j] : 0.0;
+    } else if (f32) {
+      typedef vt2<float>::type f2;
+      const f2 v = *((const f2 *)((const float *)vals + (size_t)(vb + (unsigned)k) * LSB_SELL_ROWS) + lane);
+      v0 = (double)v.x, v1 = (double)v.y;
+    } else {
+      const sell_d2v v = *((const sell_d2v *)((const double *)vals + (size_t)(vb + (unsigned)k) * LSB_SELL_ROWS) + lane);
+      v0 = v.x, v1 = v.y;
+    }
+    if (side == 0)
+      vm0 = v0, vm1 = v1;
+    else
+      vp0 = v0, vp1 = v1;
+  }
+}
+
 template <int NF, bool CHEB>
 __global__ __launch_bounds__(WG, 6) void k_spmv_tmpl(
     const unsigned *__restrict__ sptr, unsigned s0, unsigned ns, unsigned period, unsigned n,
     unsigned row_begin, unsigned xlen, const unsigned char *__restrict__ tid8,
-    const unsigned *__restrict__ vbase, const lsb_sell_tmpl *__restrict__ td,
+    const unsigned *__restrict__ vbase, const unsigned long long *__restrict__ mask,
+    const lsb_sell_tmpl *__restrict__ td,
     const int *__restrict__ sbase, const void *__restrict__ vals, int f32,
     const double *__restrict__ vconst, const double *__restrict__ x, double *__restrict__ y,
     const double *__restrict__ xdot, int dot_is_x, double *__restrict__ partials,
@@ -1345,32 +1386,6 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_tmpl(
 #pragma unroll
       for (int k = 0; k < NF; k++)
         hi[k] = *(const sell_d2u *)(x + (grow + T->base[NF + 3 + k]));
-      // slots c-1 / c+1 may keep their values (a grid line ends inside the slice: zeros there)
-      const int km = T->kidx[NF], kp = T->kidx[NF + 2];
-      double vm0 = T->cst[NF], vm1 = vm0, vp0 = T->cst[NF + 2], vp1 = vp0;
-      if (km >= 0 || kp >= 0) {
-        const unsigned vb = __builtin_amdgcn_readfirstlane(vbase[s]);
-        if (f32) {
-          typedef vt2<float>::type f2;
-          if (km >= 0) {
-            const f2 v = *((const f2 *)((const float *)vals + (size_t)(vb + (unsigned)km) * LSB_SELL_ROWS) + lane);
-            vm0 = (double)v.x, vm1 = (double)v.y;
-          }
-          if (kp >= 0) {
-            const f2 v = *((const f2 *)((const float *)vals + (size_t)(vb + (unsigned)kp) * LSB_SELL_ROWS) + lane);
-            vp0 = (double)v.x, vp1 = (double)v.y;
-          }
-        } else {
-          if (km >= 0) {
-            const sell_d2v v = *((const sell_d2v *)((const double *)vals + (size_t)(vb + (unsigned)km) * LSB_SELL_ROWS) + lane);
-            vm0 = v.x, vm1 = v.y;
-          }
-          if (kp >= 0) {
-            const sell_d2v v = *((const sell_d2v *)((const double *)vals + (size_t)(vb + (unsigned)kp) * LSB_SELL_ROWS) + lane);
-            vp0 = v.x, vp1 = v.y;
-          }
-        }
-      }
       // the element in front of the wave's first operand of slot c-1 / behind its last of slot
       // c+1.  Where the slot is constant it exists; where it keeps values the entry it belongs to
       // may be padding at the operator's first / last row: the index is clamped (the product is
@@ -1403,6 +1418,12 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_tmpl(
         a0 = fma(v, lo[k].x, a0), a1 = fma(v, lo[k].y, a1);
       }
       {
+        // slots c-1 / c+1 may keep their values (a grid line ends inside the slice: zeros there) or
+        // be MASKED: the template's number where the slice's 128-bit mask says so, else zero
+        // (looked up here, behind the far slots' products: their registers are free by now)
+        double vm0 = T->cst[NF], vm1 = vm0, vp0 = T->cst[NF + 2], vp1 = vp0;
+        if (T->kidx[NF] >= 0 || T->kidx[NF + 2] >= 0)
+          tmpl_side_values(T, NF, s, lane, vbase, mask, vals, f32, vm0, vm1, vp0, vp1);
         // value 0 = padding: no operand, an exact 0 (the rule of k_spmv_sell16)
         const double vc = T->cst[NF + 1];
         a0 = fma(vm0, vm0 != 0.0 ? up : 0.0, a0), a1 = fma(vm1, vm1 != 0.0 ? c.x : 0.0, a1); // slot c-1: x[. - 1], x[.]
@@ -1496,161 +1517,6 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_tmpl(
   if (stopped)
     return;
   spmv_publish(partials, dot, sred, tail);
-}
-
-// The same with the direction update of the PREVIOUS iteration folded in (one shard, constant
-// Jacobi diagonal dc): p' = dc r + beta p is formed for every gathered operand -- the far slots'
-// pairs, the centre's pair, the two edge elements -- and stored, for the slice's own rows, into
-// the OTHER direction buffer; y = S p' and p'.y come out of the same launch.  An iteration is
-// then two launches, and the direction update's own pass over r and p (24 B per row read, 8
-// written) shrinks to what this launch reads on top of a plain SpMV (r: 8 B per row): 880 ->
-// 800 MB per iteration on the 10 M-row 5-point operator.  The head is k_pcg_update_p's
-// (beta, stop test, bookkeeping), the row sums are k_spmv_tmpl's in the same order, p' is
-// pnew_of() as everywhere: the iterates keep their bits.
-template <int NF>
-__global__ __launch_bounds__(WG, 6) void k_spmv_tmpl_p(
-    const unsigned *__restrict__ sptr, unsigned ns, unsigned n, unsigned xlen,
-    const unsigned char *__restrict__ tid8, const unsigned *__restrict__ vbase,
-    const lsb_sell_tmpl *__restrict__ td, const int *__restrict__ sbase, const double *__restrict__ vals,
-    const double *__restrict__ vconst, const double *__restrict__ r, double dc,
-    const double *__restrict__ pold, double *__restrict__ pnew, double *__restrict__ y,
-    double *__restrict__ partials, lsb_pcg_state *__restrict__ st, int parity,
-    const double *__restrict__ parts2, unsigned nparts2) {
-  __shared__ double sred[8];
-  const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const unsigned gx = gridDim.x / NXCD, xcd = blockIdx.x % NXCD, slot = blockIdx.x / NXCD;
-  const sell_deal deal = sell_deal_init(ns, 0, xcd);
-  const int stopped = st->status;
-  const double rz_old = st->rz[parity], thresh2 = st->thresh2;
-  double v2[2];
-  wg_sum_partials<2>(parts2, nparts2, v2, sred);
-  if (stopped)
-    return;
-  const double rz_new = v2[0], rr = v2[1];
-  const bool conv = rr <= thresh2;
-  if (blockIdx.x == 0 && threadIdx.x == 0) { // exactly k_pcg_update_p's bookkeeping
-    const int it = st->iters + 1;
-    st->iters = it;
-    st->rr = rr;
-    st->rz[parity ^ 1] = rz_new;
-    if (conv)
-      st->status = LSB_STATUS_CONVERGED;
-    else if (it >= st->maxit)
-      st->status = LSB_STATUS_MAXIT;
-  }
-  if (conv)
-    return;
-  const double beta = rz_new / rz_old;
-#define PNEW2(R, P) sell_d2u{pnew_of(dc, (R).x, beta, (P).x), pnew_of(dc, (R).y, beta, (P).y)}
-  double dot = 0.0;
-  for (unsigned g = slot; g < deal.turns; g += gx) {
-    const unsigned s = __builtin_amdgcn_readfirstlane(sell_deal_slice(deal, g, wave, ns));
-    if (s == 0xFFFFFFFFu)
-      continue;
-    const unsigned t = __builtin_amdgcn_readfirstlane((unsigned)tid8[s]);
-    const unsigned row = s * LSB_SELL_ROWS + 2 * lane;
-    const int grow = (int)row;
-    double a0 = 0.0, a1 = 0.0;
-    sell_d2u c = {0.0, 0.0}; // p' of the lane's own two rows
-    if (t != 255u && td[t].shaped && td[t].base[NF + 1] == 0) {
-      const lsb_sell_tmpl *T = td + t;
-      sell_d2u rl[NF > 0 ? NF : 1], pl[NF > 0 ? NF : 1], rh[NF > 0 ? NF : 1], ph[NF > 0 ? NF : 1];
-#pragma unroll
-      for (int k = 0; k < NF; k++) {
-        rl[k] = *(const sell_d2u *)(r + (grow + T->base[k]));
-        pl[k] = *(const sell_d2u *)(pold + (grow + T->base[k]));
-      }
-      const sell_d2u rc = *(const sell_d2u *)(r + grow), pc = *(const sell_d2u *)(pold + grow);
-#pragma unroll
-      for (int k = 0; k < NF; k++) {
-        rh[k] = *(const sell_d2u *)(r + (grow + T->base[NF + 3 + k]));
-        ph[k] = *(const sell_d2u *)(pold + (grow + T->base[NF + 3 + k]));
-      }
-      const int km = T->kidx[NF], kp = T->kidx[NF + 2];
-      double vm0 = T->cst[NF], vm1 = vm0, vp0 = T->cst[NF + 2], vp1 = vp0;
-      if (km >= 0 || kp >= 0) {
-        const unsigned vb = __builtin_amdgcn_readfirstlane(vbase[s]);
-        if (km >= 0) {
-          const sell_d2v v = *((const sell_d2v *)(vals + (size_t)(vb + (unsigned)km) * LSB_SELL_ROWS) + lane);
-          vm0 = v.x, vm1 = v.y;
-        }
-        if (kp >= 0) {
-          const sell_d2v v = *((const sell_d2v *)(vals + (size_t)(vb + (unsigned)kp) * LSB_SELL_ROWS) + lane);
-          vp0 = v.x, vp1 = v.y;
-        }
-      }
-      double er = 0.0, ep = 0.0;
-      if (lane == 0 || lane == 63) {
-        long long e = (long long)grow + (lane == 0 ? -1 : 2);
-        e = e < 0 ? 0 : (e >= (long long)xlen ? (long long)xlen - 1 : e);
-        er = r[e], ep = pold[e];
-      }
-      c = PNEW2(rc, pc);
-      const double edge = pnew_of(dc, er, beta, ep);
-      double up = lane_above(c.y), dn = lane_below(c.x);
-      if (lane == 0)
-        up = edge;
-      if (lane == 63)
-        dn = edge;
-#pragma unroll
-      for (int k = 0; k < NF; k++) {
-        const double v = T->cst[k];
-        const sell_d2u q = PNEW2(rl[k], pl[k]);
-        a0 = fma(v, q.x, a0), a1 = fma(v, q.y, a1);
-      }
-      {
-        const double vc = T->cst[NF + 1];
-        a0 = fma(vm0, vm0 != 0.0 ? up : 0.0, a0), a1 = fma(vm1, vm1 != 0.0 ? c.x : 0.0, a1);
-        a0 = fma(vc, c.x, a0), a1 = fma(vc, c.y, a1);
-        a0 = fma(vp0, vp0 != 0.0 ? c.y : 0.0, a0), a1 = fma(vp1, vp1 != 0.0 ? dn : 0.0, a1);
-      }
-#pragma unroll
-      for (int k = 0; k < NF; k++) {
-        const double v = T->cst[NF + 3 + k];
-        const sell_d2u q = PNEW2(rh[k], ph[k]);
-        a0 = fma(v, q.x, a0), a1 = fma(v, q.y, a1);
-      }
-    } else {
-      // every other slice: slot by slot, p' formed per gathered element
-      if (row + 1 < n) {
-        const sell_d2u rc = *(const sell_d2u *)(r + grow), pc = *(const sell_d2u *)(pold + grow);
-        c = PNEW2(rc, pc);
-      } else if (row < n) {
-        c.x = pnew_of(dc, r[grow], beta, pold[grow]);
-      }
-      const unsigned q0 = sptr[s] / LSB_SELL_ROWS, len = (sptr[s + 1] - sptr[s]) / LSB_SELL_ROWS;
-      for (unsigned j = 0; j < len; j++) {
-        const i4v rec = ((const i4v *)sbase)[q0 + j];
-        double v0, v1;
-        if (rec.z < 0) {
-          v0 = v1 = vconst[q0 + j];
-        } else {
-          const sell_d2v v = *((const sell_d2v *)(vals + (size_t)rec.z * LSB_SELL_ROWS) + lane);
-          v0 = v.x, v1 = v.y;
-        }
-        const bool p0 = v0 != 0.0, p1 = v1 != 0.0; // padding: no gather, an exact 0
-        const int i0 = p0 ? grow + rec.x : 0, i1 = p1 ? grow + 1 + rec.x : 0;
-        const double t0 = pnew_of(dc, r[i0], beta, pold[i0]), t1 = pnew_of(dc, r[i1], beta, pold[i1]);
-        a0 = fma(v0, p0 ? t0 : 0.0, a0), a1 = fma(v1, p1 ? t1 : 0.0, a1);
-      }
-    }
-    if (row + 1 < n) {
-      const sell_d2v o = {a0, a1}, pn = {c.x, c.y};
-      *(sell_d2v *)(pnew + row) = pn;
-      *(sell_d2v *)(y + row) = o;
-      dot = fma(a0, c.x, dot);
-      dot = fma(a1, c.y, dot);
-    } else if (row < n) {
-      pnew[row] = c.x;
-      y[row] = a0;
-      dot = fma(a0, c.x, dot);
-    }
-  }
-#undef PNEW2
-  double d[1] = {dot};
-  wg_sum<1>(d, sred);
-  if (tid == 0)
-    partials[blockIdx.x] = d[0];
 }
 
 // --------------------------------------------------------------------------
@@ -2100,8 +1966,8 @@ void lsb_k_spmv_sell(unsigned flags, unsigned grid_cap, unsigned period, const u
  * (fp32 when flags & LSB_SP_F32; the templates' constants are then fp32-rounded by the caller). */
 void lsb_k_spmv_tmpl(unsigned flags, unsigned grid_cap, unsigned period, const unsigned *sptr, unsigned s0,
                      unsigned ns, unsigned n, unsigned row_begin, unsigned xlen, const unsigned char *tid8,
-                     const unsigned *vbase, const struct lsb_sell_tmpl *td, unsigned nfar, const int *sbase,
-                     const void *vals,
+                     const unsigned *vbase, const unsigned long long *mask, const struct lsb_sell_tmpl *td,
+                     unsigned nfar, const int *sbase, const void *vals,
                      const double *vconst, const double *x, double *y, const double *xdot,
                      double *partials, unsigned *npartials, const struct lsb_pcg_state *st,
                      const struct lsb_ar_tail *tail_in, const struct lsb_cheb_epi *epi_in, void *stream) {
@@ -2123,10 +1989,10 @@ void lsb_k_spmv_tmpl(unsigned flags, unsigned grid_cap, unsigned period, const u
 #define LSB_TMPL(NF)                                                                                 \
   do {                                                                                               \
     if (epi.zout)                                                                                    \
-      k_spmv_tmpl<NF, true><<<g, WG, 0, s>>>(sptr, s0, ns, period, n, row_begin, xlen, tid8, vbase, td, sbase, vals, f32, \
+      k_spmv_tmpl<NF, true><<<g, WG, 0, s>>>(sptr, s0, ns, period, n, row_begin, xlen, tid8, vbase, mask, td, sbase, vals, f32, \
                                              vconst, x, y, xdot, dot_is_x, partials, st, tail, epi);   \
     else                                                                                             \
-      k_spmv_tmpl<NF, false><<<g, WG, 0, s>>>(sptr, s0, ns, period, n, row_begin, xlen, tid8, vbase, td, sbase, vals, f32, \
+      k_spmv_tmpl<NF, false><<<g, WG, 0, s>>>(sptr, s0, ns, period, n, row_begin, xlen, tid8, vbase, mask, td, sbase, vals, f32, \
                                               vconst, x, y, xdot, dot_is_x, partials, st, tail, epi);  \
   } while (0)
   switch (nfar) {
@@ -2136,29 +2002,6 @@ void lsb_k_spmv_tmpl(unsigned flags, unsigned grid_cap, unsigned period, const u
   default: errx(EXIT_FAILURE, "lsb_k_spmv_tmpl: %u far slots per side", nfar);
   }
 #undef LSB_TMPL
-}
-
-/* k_spmv_tmpl with the previous iteration's direction update folded in (one shard, code-free
- * layout, constant Jacobi diagonal dc, fp64 values): pnew = dc r + beta pold, y = S pnew. */
-void lsb_k_spmv_tmpl_p(unsigned grid_cap, const unsigned *sptr, unsigned ns, unsigned n, unsigned xlen,
-                       const unsigned char *tid8, const unsigned *vbase, const struct lsb_sell_tmpl *td,
-                       unsigned nfar, const int *sbase, const double *vals, const double *vconst,
-                       const double *r, double dc, const double *pold, double *pnew, double *y,
-                       double *partials, unsigned *npartials, struct lsb_pcg_state *st, int parity,
-                       const double *parts2, unsigned nparts2, void *stream) {
-  hipStream_t s = (hipStream_t)stream;
-  const unsigned g = lsb_k_spmv_grid(LSB_SPMV_SELL, n, ns, 0, grid_cap ? grid_cap : 1536);
-  *npartials = g;
-#define LSB_TMPL_P(NF)                                                                                        \
-  k_spmv_tmpl_p<NF><<<g, WG, 0, s>>>(sptr, ns, n, xlen, tid8, vbase, td, sbase, vals, vconst, r, dc, pold, pnew, y, \
-                                     partials, st, parity, parts2, nparts2)
-  switch (nfar) {
-  case 0: LSB_TMPL_P(0); break;
-  case 1: LSB_TMPL_P(1); break;
-  case 2: LSB_TMPL_P(2); break;
-  default: errx(EXIT_FAILURE, "lsb_k_spmv_tmpl_p: %u far slots per side", nfar);
-  }
-#undef LSB_TMPL_P
 }
 
 void lsb_k_reduce_final(const double *partials, unsigned nparts, unsigned width,

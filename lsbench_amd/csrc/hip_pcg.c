@@ -165,58 +165,36 @@ static void pcg_enqueue_init(lsb_hip_solver *sv, const double *d_b, double *d_x)
  * launches per iteration; the two direction buffers alternate.  Only the last
  * iteration of an enqueued run closes with the stand-alone update, which also
  * brings the direction back into the gather vector. */
-/* 1 = the sub-wavefront form of launch-bound operators; 2 = the template form of a structured
- * grid (k_spmv_tmpl_p: one shard, slice templates in use, constant Jacobi diagonal, fp64): there
- * the fold is a matter of BYTES, not of launches -- the direction update's own pass over r and p
- * disappears (880 -> 800 MB per iteration on the 10 M-row 5-point operator).  MEASURED, NOT
- * ADOPTED: the folded launch takes 81.4 us where k_spmv_tmpl + k_pcg_update_p take 40.4 + 40.4
- * (rocprofv3 means inside the solve, gpurun_out/r3_fuse3): both SpMV-shaped launches run at
- * 4.0 TB/s inside the solve, the sweep it replaces at 5.9.  On request only
- * (LSBENCH_HIP_FUSE_P_TMPL=1); tests/test_sell.py keeps it bit-identical to the three launches. */
+/* 1 = the direction update rides in the next SpMV launch (the sub-wavefront form of launch-bound
+ * operators).  The same fold was built for the slice-template form of a structured grid
+ * (k_spmv_tmpl_p, round 3: the direction update's own pass over r and p disappears, 880 -> 800 MB
+ * per iteration on the 10 M-row 5-point operator), measured -- 81.4 us where k_spmv_tmpl +
+ * k_pcg_update_p take 40.4 + 40.4 (rocprofv3 means inside the solve, gpurun_out/r3_fuse3): no
+ * gain, both SpMV-shaped launches run at 4.0 TB/s inside the solve -- and taken out again when
+ * its 7-point instantiation turned out not to be repeatable run to run once the masked slots
+ * came in (gpurun_out/r3_mask, tools/gpu_tmpl_diag3.py): DESIGN.md section 4. */
 int lsb_fuse_p_kind(const lsb_hip_solver *sv) {
   if (sv->multi || use_cg1(sv) || generic_precond(sv) || sv->sh[0].mixed || getenv("LSBENCH_HIP_NO_FUSE_P"))
     return 0;
   const struct shard *s = &sv->sh[0];
-  /* (the sub-wavefront form not while SpMV launches are being event-timed: the fused launch
-   * has no SpMV of its own to bracket, and solve_core reads the sample events) */
-  if (s->variant == LSB_SPMV_SUBWAVE && sv->o.sample_spmv <= 0)
-    return 1;
-  if (s->variant == LSB_SPMV_SELL && (s->sp_flags & LSB_SP_C16) && (s->sp_flags & LSB_SP_TMPL) && s->d_tid8 &&
-      s->d_scodes && s->dinv_uniform && s->row_begin == 0 && s->n == sv->n_glob && !s->sp_period) {
-    const char *e = getenv("LSBENCH_HIP_FUSE_P_TMPL");
-    if (e && atoi(e) > 0)
-      return 2;
-  }
-  return 0;
+  /* (not while SpMV launches are being event-timed: the fused launch has no SpMV of its own to
+   * bracket, and solve_core reads the sample events) */
+  return s->variant == LSB_SPMV_SUBWAVE && sv->o.sample_spmv <= 0;
 }
 static int fuse_p(const lsb_hip_solver *sv) { return lsb_fuse_p_kind(sv) != 0; }
 
-static void fused_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int pos, int sample) {
+static void fused_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int pos) {
   struct shard *s = &sv->sh[0];
   double *buf[2] = {s->d_pfull, s->d_p1};
   unsigned np2 = s->np2;
-  const int kind = lsb_fuse_p_kind(sv);
-  if (sample >= 0) /* (template form only: the launch that holds the SpMV is bracketed) */
-    LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample], g_stream));
   if (pos & 1) { /* first of the run: the direction is in the gather vector */
     sv->pcur = 0;
     spmv_shard(s, buf[0], s->d_q, buf[0], s->d_parts_pq, &s->npq, s->d_st);
-  } else if (kind == 2) { /* beta, stop test, p = dc r + beta p formed in the gather, then S p */
-    lsb_k_spmv_tmpl_p(s->sp_grid, s->d_sptr16, s->nslice, s->n, s->n_glob, s->d_tid8, s->d_vbase, s->d_tmpl,
-                      s->tmpl_nfar, s->d_sbase, s->d_svals16, s->d_svconst, s->d_r, s->dinv_const, buf[sv->pcur],
-                      buf[sv->pcur ^ 1], s->d_q, s->d_parts_pq, &s->npq, s->d_st, parity ^ 1, s->d_parts2, np2,
-                      g_stream);
-    sv->pcur ^= 1;
   } else { /* beta, stop test and p = D^-1 r + beta p of the previous iteration, then S p */
     lsb_k_spmv_subwave_p(s->n, s->d_offs, s->d_cols, s->d_vals, s->lanes, s->d_r, DINV(s),
                          buf[sv->pcur], buf[sv->pcur ^ 1], s->d_q, s->d_parts_pq, &s->npq, s->d_st,
                          parity ^ 1, s->d_parts2, np2, g_stream);
     sv->pcur ^= 1;
-  }
-  if (sample >= 0) { /* e2, e3 bracket nothing: what an event marker costs here (see below) */
-    LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 1], g_stream));
-    LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 2], g_stream));
-    LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 3], g_stream));
   }
   lsb_k_pcg_update_xr(s->n, buf[sv->pcur], s->d_q, DINV(s), d_x, s->d_r, s->d_st, parity,
                       s->d_parts_pq, s->npq, s->d_parts2, &s->np2, g_stream);
@@ -242,7 +220,7 @@ static void pcg_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int sa
     return;
   }
   if (fuse_p(sv)) {
-    fused_enqueue_iter(sv, d_x, parity, pos, sample);
+    fused_enqueue_iter(sv, d_x, parity, pos);
     return;
   }
   unsigned npq = 0, np2 = 0;

@@ -329,13 +329,16 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
                 for (int j = 0; j < TT->t[t].nslots; j++)
                   TT->t[t].cst[j] = (double)(float)TT->t[t].cst[j];
             s->d_tid8 = (unsigned char *)dev_upload(TT->tid, (size_t)TT->nslice + 8);
-            s->d_vbase = (unsigned *)dev_upload(TT->vbase, ((size_t)TT->nslice + 8) * sizeof(unsigned));
+            s->d_vbase = (unsigned *)dev_upload(TT->vbase, 2 * ((size_t)TT->nslice + 8) * sizeof(unsigned));
+            s->d_tmask = (unsigned long long *)dev_upload(TT->mask, 2 * ((size_t)TT->nmask + 1) * sizeof(unsigned long long));
             s->d_tmpl = (struct lsb_sell_tmpl *)dev_upload(TT->t, (size_t)TT->ntmpl * sizeof(struct lsb_sell_tmpl));
             s->tmpl_nfar = TT->nfar, s->tmpl_count = TT->ntmpl;
             s->tmpl_pure = TT->covered, s->tmpl_shaped = TT->shaped;
             /* what a launch streams with templates: a byte per slice, the templates, and for the
              * slices without one their slot records, constants and two offsets */
-            s->tmpl_bytes = 5ull * TT->nslice + (unsigned long long)TT->ntmpl * sizeof(struct lsb_sell_tmpl);
+            s->tmpl_bytes = 9ull * TT->nslice + (unsigned long long)TT->ntmpl * sizeof(struct lsb_sell_tmpl) +
+                            16ull * TT->nmask +
+                            TT->kept_read * LSB_SELL_ROWS * (s->mixed ? 4ull : 8ull); /* the values it still reads */
             for (unsigned k = 0; k < H->nslice; k++)
               if (TT->tid[k] == 255)
                 s->tmpl_bytes += (unsigned long long)(H->sptr[k + 1] - H->sptr[k]) / LSB_SELL_ROWS * 24 + 8;
@@ -354,8 +357,7 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
         s->sell16_bytes += (unsigned long long)H->ncode_slots * LSB_SELL_ROWS * sizeof(short) +
                            (unsigned long long)s->sell_vslots * LSB_SELL_ROWS * (s->mixed ? 4 : 8) +
                            (s->sell_ulen ? 0ull : ((unsigned long long)H->nslice + 1) * 4);
-        if (s->d_tid8)
-          s->tmpl_bytes += (unsigned long long)s->sell_vslots * LSB_SELL_ROWS * (s->mixed ? 4 : 8);
+
         LSB_CHK_HIP(hipStreamSynchronize(g_stream));
         lsb_sell_vc_free(V);
         lsb_sell_free(H);
@@ -431,7 +433,7 @@ void shard_free(struct shard *s) {
   lsb_hip_free(s->d_sptr), lsb_hip_free(s->d_scols), lsb_hip_free(s->d_svals);
   lsb_hip_free(s->d_sptr16), lsb_hip_free(s->d_scodes), lsb_hip_free(s->d_sbase);
   lsb_hip_free(s->d_svals16), lsb_hip_free(s->d_svconst);
-  lsb_hip_free(s->d_tid8), lsb_hip_free(s->d_tmpl), lsb_hip_free(s->d_vbase);
+  lsb_hip_free(s->d_tid8), lsb_hip_free(s->d_tmpl), lsb_hip_free(s->d_vbase), lsb_hip_free(s->d_tmask);
   free(s->h_pblk);
   lsb_hip_free(s->bd_chunk), lsb_hip_free(s->bd_rows), lsb_hip_free(s->bd_cols);
   lsb_hip_free(s->bd_vals);
@@ -748,7 +750,7 @@ void sell_launch(struct shard *s, unsigned s0, unsigned ns, const double *xfull,
   const unsigned f32 = s->mixed ? LSB_SP_F32 : 0u; /* the value arrays hold floats then */
   if ((s->sp_flags & LSB_SP_C16) && (s->sp_flags & LSB_SP_TMPL) && s->d_tid8 && s->d_scodes)
     lsb_k_spmv_tmpl(s->sp_flags | f32, s->sp_grid, s->sp_period, s->d_sptr16, s0, ns, s->n, s->row_begin, s->n_glob,
-                    s->d_tid8, s->d_vbase, s->d_tmpl, s->tmpl_nfar, s->d_sbase, s->d_svals16, s->d_svconst, xfull, y, xdot, partials, np, st,
+                    s->d_tid8, s->d_vbase, s->d_tmask, s->d_tmpl, s->tmpl_nfar, s->d_sbase, s->d_svals16, s->d_svconst, xfull, y, xdot, partials, np, st,
                     &s->tail, &s->epi, g_stream);
   else if ((s->sp_flags & LSB_SP_C16) && s->d_scodes)
     lsb_k_spmv_sell(s->sp_flags | f32, s->sp_grid, s->sp_period, s->d_sptr16, s0, ns, s->n, s->row_begin, s->d_scodes,
@@ -956,8 +958,8 @@ void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
     s->d_sptr16 = NULL, s->d_scodes = NULL, s->d_sbase = NULL, s->d_svals16 = NULL, s->d_svconst = NULL;
   }
   if (!(bv == LSB_SPMV_SELL && (bf & LSB_SP_TMPL))) {
-    lsb_hip_free(s->d_tid8), lsb_hip_free(s->d_tmpl), lsb_hip_free(s->d_vbase);
-    s->d_tid8 = NULL, s->d_tmpl = NULL, s->d_vbase = NULL;
+    lsb_hip_free(s->d_tid8), lsb_hip_free(s->d_tmpl), lsb_hip_free(s->d_vbase), lsb_hip_free(s->d_tmask);
+    s->d_tid8 = NULL, s->d_tmpl = NULL, s->d_vbase = NULL, s->d_tmask = NULL;
   }
   if (any && !(bv == LSB_SPMV_SELL && !(bf & LSB_SP_C16))) {
     lsb_hip_free(s->d_scols), lsb_hip_free(s->d_svals);

@@ -89,6 +89,7 @@ struct shard {
   /* slice templates of the constant-slot layout (lsb_sell16_templates; LSB_SP_TMPL in sp_flags) */
   unsigned char *d_tid8;
   unsigned *d_vbase;
+  unsigned long long *d_tmask;
   unsigned n_glob; /* columns of the operator = length of the gather vector */
   struct lsb_sell_tmpl *d_tmpl;
   unsigned tmpl_nfar, tmpl_count;

@@ -112,17 +112,11 @@ void lsb_k_spmv_sell(unsigned flags, unsigned grid_cap, unsigned period, const u
 #define LSB_SP_TMPL 64u /* 16-bit sliced-ELL with constant slots: slice templates (k_spmv_tmpl) */
 void lsb_k_spmv_tmpl(unsigned flags, unsigned grid_cap, unsigned period, const unsigned *sptr, unsigned s0,
                      unsigned ns, unsigned n, unsigned row_begin, unsigned xlen, const unsigned char *tid8,
-                     const unsigned *vbase, const struct lsb_sell_tmpl *td, unsigned nfar, const int *sbase,
-                     const void *vals,
+                     const unsigned *vbase, const unsigned long long *mask, const struct lsb_sell_tmpl *td,
+                     unsigned nfar, const int *sbase, const void *vals,
                      const double *vconst, const double *x, double *y, const double *xdot,
                      double *partials, unsigned *npartials, const struct lsb_pcg_state *st,
                      const struct lsb_ar_tail *tail, const struct lsb_cheb_epi *epi, void *stream);
-void lsb_k_spmv_tmpl_p(unsigned grid_cap, const unsigned *sptr, unsigned ns, unsigned n, unsigned xlen,
-                       const unsigned char *tid8, const unsigned *vbase, const struct lsb_sell_tmpl *td,
-                       unsigned nfar, const int *sbase, const double *vals, const double *vconst,
-                       const double *r, double dc, const double *pold, double *pnew, double *y,
-                       double *partials, unsigned *npartials, struct lsb_pcg_state *st, int parity,
-                       const double *parts2, unsigned nparts2, void *stream);
 void lsb_k_spmv_binned(unsigned flags, unsigned chunk_cap, const unsigned *chunk_begin, unsigned c0,
                        unsigned nchunk, const unsigned *rows, const unsigned *cols, const double *vals,
                        const double *x, double *y, const struct lsb_pcg_state *st, void *stream);

@@ -1175,10 +1175,12 @@ struct lsb_sell_tmpls *lsb_sell16_templates(const struct lsb_sell *S, const stru
   struct lsb_sell_tmpls *T = lsb_calloc(struct lsb_sell_tmpls, 1);
   T->nslice = ns;
   T->tid = (unsigned char *)malloc((size_t)ns + 8);
-  T->vbase = lsb_calloc(unsigned, (size_t)ns + 8);
+  T->vbase = lsb_calloc(unsigned, 2 * ((size_t)ns + 8));
   T->t = lsb_calloc(struct lsb_sell_tmpl, 254);
   memset(T->tid, 255, (size_t)ns + 8);
   unsigned long long *count = lsb_calloc(unsigned long long, 254);
+  size_t mcap = 1024, nmask = 0;
+  unsigned long long *mask = (unsigned long long *)malloc(2 * mcap * sizeof *mask);
   for (unsigned s = 0; s < ns; s++) {
     const unsigned q0 = S->sptr[s] / LSB_SELL_ROWS, len = (S->sptr[s + 1] - S->sptr[s]) / LSB_SELL_ROWS;
     if (len == 0 || len > LSB_TMPL_SLOTS)
@@ -1186,26 +1188,48 @@ struct lsb_sell_tmpls *lsb_sell16_templates(const struct lsb_sell *S, const stru
     struct lsb_sell_tmpl t;
     memset(&t, 0, sizeof t);
     t.nslots = (int)len;
-    int ok = 1, nkept = 0, vb = -1;
+    int ok = 1, nkept = 0, nmk = 0, vb = -1;
+    unsigned long long mk[2 * LSB_TMPL_SLOTS];
     for (unsigned j = 0; j < len && ok; j++) {
       const int *r = V->slots + 4 * ((size_t)q0 + j);
       ok = r[1] < 0 && (j == 0 || r[0] > t.base[j - 1]); /* code-free, ascending */
       t.base[j] = r[0];
       if (r[2] < 0) {
         t.kidx[j] = -1, t.cst[j] = V->vconst[(size_t)q0 + j];
+        continue;
+      }
+      /* keeps its values: one number or zero?  then a mask will do */
+      const double *v = V->vals + (size_t)r[2] * LSB_SELL_ROWS;
+      double k = 0.0;
+      int one = 1;
+      unsigned long long m0 = 0, m1 = 0;
+      for (unsigned l = 0; l < LSB_SELL_ROWS && one; l++)
+        if (v[l] != 0.0) {
+          if (k == 0.0)
+            k = v[l];
+          one = memcmp(&k, &v[l], sizeof k) == 0;
+          if (l < 64)
+            m0 |= 1ull << l;
+          else
+            m1 |= 1ull << (l - 64);
+        }
+      if (one && k != 0.0 && !getenv("LSBENCH_HIP_NO_MASKS")) {
+        t.kind[j] = 2, t.kidx[j] = nmk, t.cst[j] = k;
+        mk[2 * nmk] = m0, mk[2 * nmk + 1] = m1, nmk++;
       } else {
         if (vb < 0)
           vb = r[2];
-        ok = ok && r[2] == vb + nkept; /* the slice's kept slots are consecutive value slots */
-        t.kidx[j] = nkept++;
+        /* (kept slots of a slice are consecutive value slots as long as no masked one sits
+         * between them -- a masked slot still owns its value slot: index by difference) */
+        t.kind[j] = 1, t.kidx[j] = r[2] - vb, nkept++;
       }
     }
     if (!ok)
       continue;
-    /* kept slots only as the neighbours c-1 / c+1 of a constant centre, far slots constant */
+    /* kept / masked slots only as the neighbours c-1 / c+1 of a constant centre, far slots constant */
     const int c = tmpl_centre(t.base, (int)len);
     for (int j = 0; j < (int)len && ok; j++)
-      if (t.kidx[j] >= 0 && !(c >= 1 && (j == c - 1 || j == c + 1)))
+      if (t.kind[j] != 0 && !(c >= 1 && (j == c - 1 || j == c + 1)))
         ok = 0;
     if (!ok)
       continue;
@@ -1217,7 +1241,14 @@ struct lsb_sell_tmpls *lsb_sell16_templates(const struct lsb_sell *S, const stru
         continue; /* table full: the slice goes the per-slot way */
       T->t[T->ntmpl++] = t;
     }
-    T->tid[s] = (unsigned char)id, T->vbase[s] = vb < 0 ? 0u : (unsigned)vb, count[id]++, T->covered++;
+    T->tid[s] = (unsigned char)id, count[id]++, T->covered++;
+    T->vbase[2 * s] = vb < 0 ? 0u : (unsigned)vb, T->vbase[2 * s + 1] = (unsigned)nmask;
+    if (nmask + (size_t)nmk + 1 > mcap) {
+      mcap = 2 * mcap + (size_t)nmk;
+      mask = (unsigned long long *)realloc(mask, 2 * mcap * sizeof *mask);
+    }
+    memcpy(mask + 2 * nmask, mk, 2 * (size_t)nmk * sizeof *mask);
+    nmask += (size_t)nmk;
   }
   /* the set's shape: the nfar (<= 2, the same on both sides) most slices have */
   unsigned long long by_nfar[3] = {0, 0, 0};
@@ -1236,21 +1267,35 @@ struct lsb_sell_tmpls *lsb_sell16_templates(const struct lsb_sell *S, const stru
     if (c >= 1 && (unsigned)(c - 1) == nf && (unsigned)(n - c - 2) == nf)
       T->t[id].shaped = 1, T->shaped += count[id];
   }
-  /* a template that keeps values has to be shaped (only that path loads them): the others'
-   * slices go back to the per-slot way */
+  /* a template that is not all-constant has to be shaped (only that path reads values or
+   * masks): the others' slices go back to the per-slot way */
   for (unsigned s = 0; s < ns; s++)
     if (T->tid[s] != 255) {
       const struct lsb_sell_tmpl *t = &T->t[T->tid[s]];
-      int kept = 0;
+      int special = 0;
       for (int j = 0; j < t->nslots; j++)
-        kept |= t->kidx[j] >= 0;
-      if (kept && !t->shaped)
+        special |= t->kind[j] != 0;
+      if (special && !t->shaped)
         T->tid[s] = 255, T->covered--;
     }
+  /* value slots a launch of the template kernel still reads */
+  for (unsigned s = 0; s < ns; s++) {
+    const unsigned q0 = S->sptr[s] / LSB_SELL_ROWS, len = (S->sptr[s + 1] - S->sptr[s]) / LSB_SELL_ROWS;
+    if (T->tid[s] == 255) {
+      for (unsigned j = 0; j < len; j++)
+        T->kept_read += V->slots[4 * ((size_t)q0 + j) + 2] >= 0;
+    } else {
+      const struct lsb_sell_tmpl *t = &T->t[T->tid[s]];
+      for (int j = 0; j < t->nslots; j++)
+        T->kept_read += t->kind[j] == 1;
+    }
+  }
+  T->nmask = nmask, T->mask = mask;
   free(count);
   if (getenv("LSBENCH_HIP_TMPL_DEBUG"))
-    fprintf(stderr, "lsb_sell16_templates: %u slices, %u templates, %llu covered, %llu shaped (nfar %u)\n", ns,
-            T->ntmpl, T->covered, T->shaped, T->nfar);
+    fprintf(stderr, "lsb_sell16_templates: %u slices, %u templates, %llu covered, %llu shaped (nfar %u), %llu masks, "
+                    "%llu value slots still read\n", ns, T->ntmpl, T->covered, T->shaped, T->nfar, T->nmask,
+            T->kept_read);
   if (T->covered * 8 < (unsigned long long)ns * 7 || T->shaped * 4 < (unsigned long long)ns * 3) {
     lsb_sell_tmpls_free(T);
     return NULL;
@@ -1261,7 +1306,7 @@ struct lsb_sell_tmpls *lsb_sell16_templates(const struct lsb_sell *S, const stru
 void lsb_sell_tmpls_free(struct lsb_sell_tmpls *T) {
   if (!T)
     return;
-  free(T->tid), free(T->vbase), free(T->t), free(T);
+  free(T->tid), free(T->vbase), free(T->mask), free(T->t), free(T);
 }
 
 void lsb_sell_vc_free(struct lsb_sell_vc *V) {

@@ -58,7 +58,8 @@ int main(void) {
       }
       lsb_pb_free(P);
     }
-    for (int pw = 1; pw <= 3; pw++) { /* FSAI pattern: rows end in their diagonal, ascending, within the cap */
+    for (int pw = 1; pw <= (k >= 2 && k != 4 && k != 6 ? 3 : 2); pw++) { /* FSAI pattern: rows end in their diagonal, ascending, within the cap
+                                        (the third power only where it stays small: the grids) */
       struct lsb_fsai_pattern *F = lsb_csr_fsai_pattern(A, pw, pw == 3 ? 7 : LSB_FSAI_CAP);
       for (unsigned i = 0; i < F->n; i++) {
         const unsigned a = F->offs[i], b = F->offs[i + 1];

@@ -52,7 +52,7 @@ def test_hot_kernels_have_no_spills_and_full_occupancy(tmp_path):
         assert v["ScratchSize"] == 0 and v["VGPRs"] <= 80 and v["Occupancy"] >= 6, (k, v)
         assert v["LDS Size"] <= 192, (k, v)     # reductions + the folded all-reduce tail; no staging
     tm = {k: v for k, v in info.items() if "k_spmv_tmpl" in k}
-    assert len(tm) == 9                  # 0, 1, 2 far slots per side x {plain, Chebyshev epilogue, direction update folded in}
+    assert len(tm) == 6                                           # 0, 1, 2 far slots per side x {plain, Chebyshev epilogue}
     for k, v in tm.items():                                       # straight-line gathers, >= 6 workgroups per CU
         assert v["ScratchSize"] == 0 and v["VGPRs"] <= 80 and v["Occupancy"] >= 6, (k, v)
         assert v["LDS Size"] <= 192, (k, v)

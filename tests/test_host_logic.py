@@ -673,10 +673,12 @@ def test_sell16_value_slots(spec, frac_kept):
 
 
 def test_templates_cover_a_structured_grid():
+    """lsb_sell16_templates on the host: a structured grid has a handful of templates, nearly all
+    slices share a shaped one [far][c-1, c, c+1][far]; where a grid line ends inside a slice the
+    +-1 slots are MASKED constants (the number in the template, 128 bits per slice and slot);
+    every template stands exactly for the slot records, constants and values of its slices;
+    general values have none."""
     hip = la
-    """lsb_sell16_templates on the host: the 5-point operator has a handful of templates, all
-    interior slices share the shaped one [far][c-1, c, c+1][far]; general values have none."""
-    import ctypes as C
     lib = hip._lib.load()
     for spec, nfar in (("lap2d:nx=411,ny=203", 1), ("lap3d:nx=64,ny=64,nz=40", 2), ("lap2d:nx=9000,ny=1", 0)):
         A = hip.lsbench_matrix_synth(spec)
@@ -690,28 +692,44 @@ def test_templates_cover_a_structured_grid():
         tid = np.ctypeslib.as_array(t.tid, (t.nslice,))
         assert tid.max() == 255 or t.covered == t.nslice
         assert int((tid != 255).sum()) == t.covered
-        shaped = [t.t[k] for k in range(t.ntmpl) if t.t[k].shaped]
-        for q in shaped:
-            c = nfar + 1
-            assert q.nslots == 2 * nfar + 3 and q.base[c - 1] + 1 == q.base[c] == q.base[c + 1] - 1
-            kept = [j for j in range(q.nslots) if q.kidx[j] >= 0]
-            assert set(kept) <= {c - 1, c + 1} and [q.kidx[j] for j in kept] == list(range(len(kept)))
-        for k in set(int(v) for v in np.unique(tid) if v != 255):  # all-gathered templates IN USE keep nothing
-            if not t.t[k].shaped:
-                assert all(t.t[k].kidx[j] < 0 for j in range(t.t[k].nslots))
-        vb = np.ctypeslib.as_array(t.vbase, (t.nslice,))
+        for k in set(int(v) for v in np.unique(tid) if v != 255):
+            q = t.t[k]
+            special = [j for j in range(q.nslots) if q.kind[j] != 0]
+            if q.shaped:
+                c = nfar + 1
+                assert q.nslots == 2 * nfar + 3 and q.base[c - 1] + 1 == q.base[c] == q.base[c + 1] - 1
+                assert set(special) <= {c - 1, c + 1}
+            else:                                                  # all-gathered templates keep nothing
+                assert not special
+            assert all((q.kidx[j] >= 0) == (q.kind[j] != 0) for j in range(q.nslots))
+        vb = np.ctypeslib.as_array(t.vbase, (2 * t.nslice,)).reshape(-1, 2)
+        mask = np.ctypeslib.as_array(t.mask, (2 * max(int(t.nmask), 1),))
         sp = np.ctypeslib.as_array(H.contents.sptr, (t.nslice + 1,)) // 128
         rec = np.ctypeslib.as_array(V.contents.slots, (V.contents.nslots * 4,)).reshape(-1, 4)
-        for sl in np.nonzero(tid != 255)[0][::7]:                  # the records a template stands for
-            q = t.t[int(tid[sl])]
+        vals = np.ctypeslib.as_array(V.contents.vals, ((V.contents.nval_slots + 1) * 128,)).reshape(-1, 128)
+        nmask = kept = 0
+        for sl in range(t.nslice):                                 # the records a template stands for
             r = rec[sp[sl]:sp[sl + 1]]
+            if tid[sl] == 255:
+                kept += int((r[:, 2] >= 0).sum())
+                continue
+            q = t.t[int(tid[sl])]
             assert q.nslots == len(r) and list(q.base)[:len(r)] == r[:, 0].tolist() and np.all(r[:, 1] < 0)
             for j in range(len(r)):
-                assert (q.kidx[j] < 0) == (r[j, 2] < 0)
-                if q.kidx[j] >= 0:
-                    assert vb[sl] + q.kidx[j] == r[j, 2]
+                if q.kind[j] == 0:
+                    assert r[j, 2] < 0 and q.cst[j] == V.contents.vconst[sp[sl] + j]
+                elif q.kind[j] == 1:
+                    assert vb[sl, 0] + q.kidx[j] == r[j, 2]
+                    kept += 1
                 else:
-                    assert q.cst[j] == V.contents.vconst[sp[sl] + j]
+                    v = vals[r[j, 2]]
+                    m = mask[2 * (vb[sl, 1] + q.kidx[j]):2 * (vb[sl, 1] + q.kidx[j]) + 2]
+                    bits = np.array([(int(m[i // 64]) >> (i % 64)) & 1 for i in range(128)], bool)
+                    assert np.array_equal(bits, v != 0) and np.all(v[bits] == q.cst[j]) and bits.any()
+                    nmask += 1
+        assert nmask <= t.nmask and kept == t.kept_read   # (a slice sent back to the per-slot way leaves its masks behind)
+        if "lap" in spec and nfar:
+            assert t.nmask > 0 and t.kept_read < V.contents.nval_slots    # constant coefficients: masks, few values
         lib.lsb_sell_tmpls_free(T), lib.lsb_sell_vc_free(V), lib.lsb_sell_free(H)
     A = hip.lsbench_matrix_synth("lap2d:nx=411,ny=203,coef=1")
     H = lib.lsb_csr_sellize16(A.ptr, 0)
