@@ -27,12 +27,17 @@ step pmc_fetch_powerlaw 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-f
 step pmc_write_powerlaw 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write_powerlaw" -- python3 bench.py --workload powerlaw --steps 1 $Q
 for v in 7 6 1; do step bench_powerlaw_v$v 400 python bench.py --workload powerlaw --spmv $v $Q; done
 step cfg5_spd_cg 600 python bench.py --workload "powerlaw:n=8000000,gamma=1.585350372615855,max=4096,seed=20240607,spd=1" --tol 1e-10 --steps 3 $Q
+step trace_cfg2_fsai 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_cfg2_fsai" -- python3 bench.py --workload $F --tol 1e-12 --steps 20 --warmup 2 --persistent 0 --precond fsai $Q
 step trace_cfg2 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_cfg2" -- python3 bench.py --workload $F --tol 1e-12 --steps 20 --warmup 2 --persistent 0 $Q
 C2="--workload $F --tol 1e-12 --steps 100 --warmup 5 --cfg4 0 --verify 0"
 step cfg2_launches 300 python bench.py $C2 --persistent 0
 step cfg2_persistent 300 python bench.py $C2 --persistent 1 --cpu-seconds 0
 step cfg2_dense_inverse 300 python bench.py $C2 --persistent 0 --precond bj --block-size 1000000 --cpu-seconds 0
 step cfg2_cheb4 300 python bench.py $C2 --persistent 0 --precond cheb --cheb-degree 4 --cpu-seconds 0
+step cfg2_fsai2 300 python bench.py $C2 --persistent 0 --precond fsai --fsai-power 2 --cpu-seconds 0
+step cfg2_fsai3 300 python bench.py $C2 --persistent 0 --precond fsai --fsai-power 3 --cpu-seconds 0
+LSBENCH_HIP_NO_FSAI_FUSE=1 step cfg2_fsai3_six_launches 300 python bench.py $C2 --persistent 0 --precond fsai --fsai-power 3 --cpu-seconds 0
+LSBENCH_HIP_NO_TMPL=1 step cfg3_no_templates 400 python bench.py --steps 2 $Q
 step cfg3_fp32 400 python bench.py --precision fp32 --steps 2 $Q
 step cfg3_cheb4 400 python bench.py --precond cheb --cheb-degree 4 --steps 2 $Q
 step cfg3_cheb16 400 python bench.py --precond cheb --cheb-degree 16 --steps 2 $Q

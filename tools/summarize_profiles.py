@@ -17,7 +17,7 @@ def one(pattern):
     return g[-1] if g else None  # newest run wins
 
 
-for tag in ("trace", "trace_coef", "trace_lap3d", "trace_cfg2", "trace_powerlaw"):
+for tag in ("trace", "trace_coef", "trace_lap3d", "trace_cfg2", "trace_cfg2_fsai", "trace_powerlaw"):
     f = one(tag + "/*/*kernel_stats.csv")
     if f:
         shutil.copyfile(f, os.path.join(out, "%s_%s_kernel_stats.csv" % (rnd, tag)))
@@ -108,7 +108,7 @@ if traffic:
     json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 # bench lines
 names = ["bench", "bench_coef", "bench_powerlaw", "bench_powerlaw_v7", "bench_powerlaw_v6", "bench_powerlaw_v1", "cfg5_spd_cg", "cfg2_launches", "cfg2_persistent",
-         "cfg2_dense_inverse", "cfg2_cheb4", "cfg3_fp32", "cfg3_cheb4", "cfg3_cheb16", "cfg3_bj8"]
+         "cfg2_dense_inverse", "cfg2_cheb4", "cfg2_fsai2", "cfg2_fsai3", "cfg2_fsai3_six_launches", "cfg3_no_templates", "cfg3_fp32", "cfg3_cheb4", "cfg3_cheb16", "cfg3_bj8"]
 with open(os.path.join(out, "%s_bench.jsonl" % rnd), "w") as fo:
     for tag in names:
         f = os.path.join(src, tag + ".log")
