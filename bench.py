@@ -392,6 +392,9 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
                             "traffic_source": traffic_src,
                             "kernel": kernel + (" (panels)" if solver.spmv_variant == la.SPMV_PANEL else ""),
                             "launch_ms": ms, "algorithmic_bytes": bytes_spmv,
+                            "bytes_basis": "SURVEY 8(d): 12 B per non-zero + 20 B per row + 4; the multi-pass forms "
+                                           "(two-phase, binned) move more than that by design -- traffic says how much",
+                            "value_slots": dict(zip(("kept", "all"), vslots)), "kernels_sha16": kernels_sha16(),
                             "measured": "hipEvents around %d back-to-back SpMVs" % (steps * 20)}}
         solver.destroy()
         return rec
