@@ -475,6 +475,7 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
                    if (a.verify and a.fixed_iters == 0) else "recurrence residual"},
         "iterations_per_sec": iters / dt,
         "setup_seconds": t_setup,
+        "blas1_nt_mask": solver.blas1_nt,  # which sweep operands are loaded nontemporal (timed at creation)
         "comm": comm,
         "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": gbps / HBM_PEAK_GBPS, "traffic": traffic,

@@ -569,6 +569,10 @@ unsigned long long lsb_hip_solver_spmv_layout_bytes(const lsb_hip_solver *s);
  * NEXT iteration's SpMV launch, formed for every gathered operand (the sub-wavefront form of
  * launch-bound operators). */
 int lsb_hip_solver_fused_p(const lsb_hip_solver *s);
+/* Which operands of the BLAS-1 sweeps this solver loads nontemporal (bit 0 x, 1 p and q, 2 r in
+ * k_pcg_update_xr; 3 r, 4 p in k_pcg_update_p; 5 k_cg1_update): timed at creation on the solver's
+ * first shard, or LSBENCH_HIP_BLAS1_NT. */
+int lsb_hip_solver_blas1_nt(const lsb_hip_solver *s);
 /* hipStream_t of the backend (as void*), for callers that time with events. */
 void *lsb_hip_stream(void);
 

@@ -327,6 +327,11 @@ class Solver:
         return int(L.load().lsb_hip_solver_fused_p(self._h))
 
     @property
+    def blas1_nt(self):
+        """mask of the sweeps' nontemporal operands (see lsbench_hip.h)"""
+        return int(L.load().lsb_hip_solver_blas1_nt(self._h))
+
+    @property
     def comm_plan(self):
         """The exchange plan of this process's first shard (see lsbench_hip.h)."""
         p = (C.c_ulonglong * 8)()

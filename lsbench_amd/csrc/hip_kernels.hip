@@ -611,7 +611,11 @@ __device__ __forceinline__ void st2(d2v *p, d2v v) {
 }
 
 // alpha = rz/pq ; x += alpha p ; r -= alpha q ; partials (r.dinv.r, r.r)
-template <bool V2, bool NT>
+// NTX / NTPQ / NTR: which operands are loaded nontemporal -- x (also stored so), p and q (and the
+// Jacobi diagonal), r.  Which of them should bypass the caches is a matter of what the NEXT launches
+// read again (LSBENCH_HIP_BLAS1_NT is the mask: bit 0 x, 1 p and q, 2 r here; 3 r, 4 p in
+// k_pcg_update_p; 1 = all of them, the setting measured in rounds 1 and 2).
+template <bool V2, bool NTX, bool NTPQ, bool NTR>
 __global__ __launch_bounds__(WG) void k_pcg_update_xr(
     unsigned n, const double *__restrict__ p, const double *__restrict__ q,
     const double *__restrict__ dinv, double dc, double *__restrict__ x,
@@ -633,8 +637,8 @@ __global__ __launch_bounds__(WG) void k_pcg_update_xr(
   d2v pv = {0.0, 0.0}, qv = pv, dv = pv, xv = pv, rv = pv;
   const bool first = V2 && gtid < n2;
   if (first) {
-    pv = ld2<NT>(p2 + gtid), qv = ld2<NT>(q2 + gtid), dv = ldd<NT>(d2, gtid, dc);
-    xv = ld2<NT>(x2 + gtid), rv = ld2<NT>(r2 + gtid);
+    pv = ld2<NTPQ>(p2 + gtid), qv = ld2<NTPQ>(q2 + gtid), dv = ldd<NTPQ>(d2, gtid, dc);
+    xv = ld2<NTX>(x2 + gtid), rv = ld2<NTR>(r2 + gtid);
   }
   double pqv[1];
   wg_sum_partials<1>(pq_parts, npq, pqv, sred);
@@ -656,7 +660,7 @@ __global__ __launch_bounds__(WG) void k_pcg_update_xr(
       for (;;) {
         xv.x += alpha * pv.x, xv.y += alpha * pv.y;
         rv.x -= alpha * qv.x, rv.y -= alpha * qv.y;
-        st2<NT>(x2 + i, xv), r2[i] = rv;
+        st2<NTX>(x2 + i, xv), r2[i] = rv;
         acc[0] += rv.x * (dv.x * rv.x);
         acc[0] += rv.y * (dv.y * rv.y);
         acc[1] += rv.x * rv.x;
@@ -664,8 +668,8 @@ __global__ __launch_bounds__(WG) void k_pcg_update_xr(
         i += gsz;
         if (i >= n2)
           break;
-        pv = ld2<NT>(p2 + i), qv = ld2<NT>(q2 + i), dv = ldd<NT>(d2, i, dc);
-        xv = ld2<NT>(x2 + i), rv = ld2<NT>(r2 + i);
+        pv = ld2<NTPQ>(p2 + i), qv = ld2<NTPQ>(q2 + i), dv = ldd<NTPQ>(d2, i, dc);
+        xv = ld2<NTX>(x2 + i), rv = ld2<NTR>(r2 + i);
       }
     }
     if ((n & 1) && gtid == gsz - 1) {
@@ -696,7 +700,7 @@ __global__ __launch_bounds__(WG) void k_pcg_update_xr(
 // 2048 workgroups x 256 lanes x 32 B = 16.8 MB, about what 8 TB/s x 2 us of latency needs, and
 // the sweep ran at 0.73 of peak where its five-operand sibling k_pcg_update_xr (64-80 B per
 // lane) reaches 0.84 (profiles/r02_trace_kernel_stats.csv).
-template <bool V2, bool NT, bool X2>
+template <bool V2, bool NTR, bool NTP, bool X2>
 __global__ __launch_bounds__(WG) void k_pcg_update_p(
     unsigned n, const double *__restrict__ r, const double *__restrict__ dinv, double dc,
     const double *pin, double *p, lsb_pcg_state *__restrict__ st, int parity,
@@ -717,9 +721,9 @@ __global__ __launch_bounds__(WG) void k_pcg_update_p(
   const bool first = V2 && gtid < n2;
   bool second = X2 && V2 && gtid + gsz < n2;
   if (first)
-    rv = ld2<NT>(r2 + gtid), dv = ldd<NT>(d2, gtid, dc), pv = ld2<NT>(pi2 + gtid);
+    rv = ld2<NTR>(r2 + gtid), dv = ldd<NTR>(d2, gtid, dc), pv = ld2<NTP>(pi2 + gtid);
   if (second)
-    rw = ld2<NT>(r2 + gtid + gsz), dw = ldd<NT>(d2, gtid + gsz, dc), pw = ld2<NT>(pi2 + gtid + gsz);
+    rw = ld2<NTR>(r2 + gtid + gsz), dw = ldd<NTR>(d2, gtid + gsz, dc), pw = ld2<NTP>(pi2 + gtid + gsz);
   double v[2];
   wg_sum_partials<2>(parts2, nparts2, v, sred);
   if (stopped)
@@ -756,11 +760,11 @@ __global__ __launch_bounds__(WG) void k_pcg_update_p(
         i += step;
         if (i >= n2)
           break;
-        rv = ld2<NT>(r2 + i), dv = ldd<NT>(d2, i, dc), pv = ld2<NT>(pi2 + i);
+        rv = ld2<NTR>(r2 + i), dv = ldd<NTR>(d2, i, dc), pv = ld2<NTP>(pi2 + i);
         if (X2) {
           second = i + gsz < n2;
           if (second)
-            rw = ld2<NT>(r2 + i + gsz), dw = ldd<NT>(d2, i + gsz, dc), pw = ld2<NT>(pi2 + i + gsz);
+            rw = ld2<NTR>(r2 + i + gsz), dw = ldd<NTR>(d2, i + gsz, dc), pw = ld2<NTP>(pi2 + i + gsz);
         }
       }
     }
@@ -967,7 +971,8 @@ static inline unsigned div_up(unsigned a, unsigned b) { return (a + b - 1) / b; 
 static inline unsigned round_up(unsigned a, unsigned b) { return div_up(a, b) * b; }
 static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
-static int g_blas1_nt = 1;
+static __thread int g_blas1_nt = 63; /* mask, see k_pcg_update_xr; bit 5: k_cg1_update.  Per host thread =
+                                         per rank: set by the solver that enqueues (tune_blas1_nt) */
 
 // --------------------------------------------------------------------------
 // ONE ROUNDING RULE for the sliced-ELL kernels (k_spmv_sell, k_spmv_sell16, k_spmv_tmpl): a
@@ -1692,7 +1697,8 @@ __global__ __launch_bounds__(WG) void k_spmv_binned(
 
 extern "C" {
 
-void lsb_k_set_blas1_nt(int on) { g_blas1_nt = on ? 1 : 0; }
+void lsb_k_set_blas1_nt(int on) { g_blas1_nt = on == 1 ? 63 : on; } /* 1 = every operand (bits 0..5) */
+int lsb_k_get_blas1_nt(void) { return g_blas1_nt; }
 
 /* one bin of the binned form: chunks [c0, c0 + nchunk) */
 void lsb_k_spmv_binned(unsigned flags, unsigned chunk_cap, const unsigned *chunk_begin, unsigned c0,
@@ -2108,14 +2114,22 @@ void lsb_k_pcg_update_xr(unsigned n, const double *p, const double *q,
   const unsigned g = lsb_k_blas1_grid(n);
   *npartials = g;
   if (aligned16(p) && aligned16(q) && aligned16(dinv) && aligned16(x) && aligned16(r)) {
-    if (g_blas1_nt)
-      k_pcg_update_xr<true, true><<<g, WG, 0, (hipStream_t)stream>>>(
-          n, p, q, dinv, dc, x, r, st, parity, pq_parts, npq, partials2);
-    else
-      k_pcg_update_xr<true, false><<<g, WG, 0, (hipStream_t)stream>>>(
-          n, p, q, dinv, dc, x, r, st, parity, pq_parts, npq, partials2);
+#define LSB_XR(A, B, C)                                                                           \
+  k_pcg_update_xr<true, A, B, C><<<g, WG, 0, (hipStream_t)stream>>>(n, p, q, dinv, dc, x, r, st, parity, pq_parts, \
+                                                                  npq, partials2)
+    switch (g_blas1_nt & 7) {
+    case 0: LSB_XR(false, false, false); break;
+    case 1: LSB_XR(true, false, false); break;
+    case 2: LSB_XR(false, true, false); break;
+    case 3: LSB_XR(true, true, false); break;
+    case 4: LSB_XR(false, false, true); break;
+    case 5: LSB_XR(true, false, true); break;
+    case 6: LSB_XR(false, true, true); break;
+    default: LSB_XR(true, true, true); break;
+    }
+#undef LSB_XR
   } else {
-    k_pcg_update_xr<false, false><<<g, WG, 0, (hipStream_t)stream>>>(
+    k_pcg_update_xr<false, false, false, false><<<g, WG, 0, (hipStream_t)stream>>>(
         n, p, q, dinv, dc, x, r, st, parity, pq_parts, npq, partials2);
   }
 }
@@ -2141,13 +2155,13 @@ void lsb_k_cg1_update(unsigned n, double *u, const double *w, const double *dinv
   if (!u) { /* implicit u = dc r: r is the gather vector (needs the constant diagonal) */
     if (dinv)
       errx(EXIT_FAILURE, "lsb_k_cg1_update: implicit u needs a constant diagonal");
-    if (v2 && g_blas1_nt)
+    if (v2 && (g_blas1_nt & 32))
       LSB_CG1(true, true, true);
     else if (v2)
       LSB_CG1(true, false, true);
     else
       LSB_CG1(false, false, true);
-  } else if (v2 && g_blas1_nt)
+  } else if (v2 && (g_blas1_nt & 32))
     LSB_CG1(true, true, false);
   else if (v2)
     LSB_CG1(true, false, false);
@@ -2166,21 +2180,27 @@ void lsb_k_pcg_update_p(unsigned n, const double *r, const double *dinv, double 
     x2 = e ? atoi(e) != 0 : 1;
   }
   hipStream_t s = (hipStream_t)stream;
-#define LSB_UPD_P(V2, NT, X2) k_pcg_update_p<V2, NT, X2><<<g, WG, 0, s>>>(n, r, dinv, dc, pin, p, st, parity, parts2, nparts2)
+#define LSB_UPD_P(V2, NTR, NTP, X2) \
+  k_pcg_update_p<V2, NTR, NTP, X2><<<g, WG, 0, s>>>(n, r, dinv, dc, pin, p, st, parity, parts2, nparts2)
+#define LSB_UPD_P2(NTR, NTP)          \
+  do {                                \
+    if (big)                          \
+      LSB_UPD_P(true, NTR, NTP, true); \
+    else                              \
+      LSB_UPD_P(true, NTR, NTP, false); \
+  } while (0)
   if (aligned16(r) && aligned16(dinv) && aligned16(p) && aligned16(pin)) {
     const bool big = x2 && (size_t)n / 2 > (size_t)g * WG; /* a second pair exists at all */
-    if (g_blas1_nt) {
-      if (big)
-        LSB_UPD_P(true, true, true);
-      else
-        LSB_UPD_P(true, true, false);
-    } else if (big)
-      LSB_UPD_P(true, false, true);
-    else
-      LSB_UPD_P(true, false, false);
+    switch ((g_blas1_nt >> 3) & 3) {
+    case 0: LSB_UPD_P2(false, false); break;
+    case 1: LSB_UPD_P2(true, false); break;
+    case 2: LSB_UPD_P2(false, true); break;
+    default: LSB_UPD_P2(true, true); break;
+    }
   } else {
-    LSB_UPD_P(false, false, false);
+    LSB_UPD_P(false, false, false, false);
   }
+#undef LSB_UPD_P2
 #undef LSB_UPD_P
 }
 

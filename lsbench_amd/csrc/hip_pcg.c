@@ -423,6 +423,69 @@ void drain_stream(lsb_hip_solver *sv, const char *what) {
   wait_event(sv, sv->ev_poll[0], what);
 }
 
+/* Which operands of the two BLAS-1 sweeps should be loaded NONTEMPORAL is a matter of what the next
+ * launches read again, and that depends on how the vectors compare with the 256 MB Infinity Cache:
+ * measured per iteration of the classic form (tools/gpu_nt_masks.sh, profiles/r03_nt_masks.txt;
+ * mask bits: 0 x, 1 p and q, 2 r in k_pcg_update_xr; 3 r, 4 p in k_pcg_update_p)
+ *                                   all (rounds 1, 2)   x + r of the p-sweep (9)   none (0)
+ *   config 3, 80 MB vectors              156.7 us            137.0 us            147.6 us
+ *   1/8 of config 3, 10 MB vectors        30.5                28.7                26.9
+ *   config 4, 512 MB vectors            1297.9              1292.1              1235.8
+ *   config 3's pattern, general values   248.9               238.0               253.5
+ * -- with the direction p loaded nontemporal by the p-sweep the SpMV that follows finds it nowhere
+ * near and runs 39-44 us on config 3; left in the caches, 25.4 us.  So the solver times a few
+ * iterations of its own first shard (local launches only: no exchange, no all-reduce) under each
+ * candidate at creation -- untimed set-up, like the SpMV's timing pass -- and keeps the fastest.
+ * LSBENCH_HIP_BLAS1_NT=<mask> fixes it (1 = everything, the old setting). */
+void tune_blas1_nt(lsb_hip_solver *sv) {
+  struct shard *s = &sv->sh[0];
+  const char *e = getenv("LSBENCH_HIP_BLAS1_NT");
+  sv->nt_mask = e ? (atoi(e) == 1 ? 63 : atoi(e)) : 63; /* not the previous solver's choice */
+  if (e || getenv("LSBENCH_HIP_NO_NT_TUNE") || s->nnz < 4000000ull)
+    return;
+  static const int cand[] = {63, 9, 5, 0};
+  const unsigned n = s->n;
+  double *d_b = (double *)lsb_hip_malloc((size_t)n * sizeof(double));
+  double *d_x = (double *)lsb_hip_malloc((size_t)n * sizeof(double));
+  double *p = s->d_pfull + s->row_begin;
+  lsb_k_fill_index(n, 1u, d_b, g_stream);
+  float best = 1e30f;
+  int bm = sv->nt_mask;
+  for (unsigned c = 0; c < sizeof cand / sizeof cand[0]; c++) {
+    unsigned np2 = 0, npq = 0;
+    lsb_k_set_blas1_nt(cand[c]);
+    lsb_k_pcg_init(n, d_b, DINV(s), d_x, s->d_r, p, s->d_parts2, &np2, g_stream);
+    lsb_k_pcg_init_state(s->d_st, s->d_parts2, np2, 0.0, 1 << 30, g_stream);
+    const int warm = 4, reps = 20;
+    for (int i = 0; i < warm + reps; i++) {
+      if (i == warm)
+        LSB_CHK_HIP(hipEventRecord(sv->ev_t0, g_stream));
+      spmv_shard(s, s->d_pfull, s->d_q, p, s->d_parts_pq, &npq, s->d_st);
+      lsb_k_pcg_update_xr(n, p, s->d_q, DINV(s), d_x, s->d_r, s->d_st, i & 1, s->d_parts_pq, npq, s->d_parts2, &np2,
+                          g_stream);
+      lsb_k_pcg_update_p(n, s->d_r, DINV(s), p, p, s->d_st, i & 1, s->d_parts2, np2, g_stream);
+    }
+    LSB_CHK_HIP(hipEventRecord(sv->ev_t1, g_stream));
+    LSB_CHK_HIP(hipEventSynchronize(sv->ev_t1));
+    float ms = 0.f;
+    LSB_CHK_HIP(hipEventElapsedTime(&ms, sv->ev_t0, sv->ev_t1));
+    if (sv->o.verbose > 1)
+      fprintf(stderr, "hip_cdna4: nontemporal mask %2d: %.1f us per iteration of the first shard\n", cand[c],
+              ms * 1e3f / reps);
+    if (ms < best)
+      best = ms, bm = cand[c];
+  }
+  /* the single-reduction sweep (k_cg1_update) goes with the classic ones: nontemporal unless
+   * "none" won */
+  sv->nt_mask = bm == 0 ? 0 : (bm | 32);
+  lsb_k_set_blas1_nt(sv->nt_mask);
+  /* leave the shard as the upload left it */
+  LSB_CHK_HIP(hipMemsetAsync(s->d_pfull, 0, (size_t)sv->n_glob * sizeof(double), g_stream));
+  LSB_CHK_HIP(hipMemsetAsync(s->d_st, 0, sizeof(struct lsb_pcg_state), g_stream));
+  LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+  lsb_hip_free(d_b), lsb_hip_free(d_x);
+}
+
 /* hipGraph of `iters` PCG iterations writing to d_x; two cached entries (the
  * hinted whole-solve graph and the small continuation chunk). */
 static hipGraphExec_t get_graph(lsb_hip_solver *sv, int iters, double *d_x) {
@@ -776,6 +839,7 @@ int solve_core(lsb_hip_solver *sv, const double *d_b, double *d_x,
                       struct lsb_hip_result *res) {
   if (sv->o.krylov == LSB_KRYLOV_GMRES)
     return gmres_solve_dev(sv, d_b, d_x, res);
+  lsb_k_set_blas1_nt(sv->nt_mask); /* this solver's choice (the launchers read a per-thread word) */
   const double t0 = wall_seconds();
   struct lsb_hip_result r;
   /* Mixed precision: the CG runs see S~ = fp32(S) (fp64 vectors and sums) and

@@ -499,6 +499,7 @@ void solver_finish_setup(lsb_hip_solver *sv) {
     }
     sv->cg1_implicit = same;
   }
+  tune_blas1_nt(sv);
   precond_setup(sv);
   p2p_setup(sv);
   persist_setup(sv);
@@ -723,6 +724,7 @@ void lsb_hip_solver_comm_plan(const lsb_hip_solver *s, unsigned long long plan[8
   plan[7] = (unsigned long long)can_overlap(s);
 }
 int lsb_hip_solver_fused_p(const lsb_hip_solver *s) { return lsb_fuse_p_kind(s); }
+int lsb_hip_solver_blas1_nt(const lsb_hip_solver *s) { return s->nt_mask; }
 unsigned long long lsb_hip_solver_spmv_layout_bytes(const lsb_hip_solver *s) {
   const struct shard *h = &s->sh[0];
   unsigned long long m = 12ull * h->nnz + 4ull * ((unsigned long long)h->n + 1); /* the CSR arrays */

@@ -195,6 +195,7 @@ struct lsb_hip_solver {
    * rank has the same constant Jacobi diagonal (k_cg1_update<UI>) */
   int cg1_implicit;
   int pcur, rcur; /* launch-bound fused paths: which direction / residual buffer is current */
+  int nt_mask;    /* which operands of the BLAS-1 sweeps are loaded nontemporal (tune_blas1_nt) */
 #define LSB_CHEB_MAX 32
   int cheb_m, cheb_fused; /* fused: the steps ride in the SpMV's epilogue (one shard, 16-bit sliced-ELL) */
   double cheb_lmin, cheb_lmax, cheb_c0, cheb_a[LSB_CHEB_MAX], cheb_b[LSB_CHEB_MAX];
@@ -264,6 +265,7 @@ LSB_INTERNAL void exchange_and_spmv(lsb_hip_solver *sv, int sample);
 LSB_INTERNAL double true_resid2(lsb_hip_solver *sv, const double *d_b, const double *d_x);
 /* hip_pcg.c */
 LSB_INTERNAL int lsb_fuse_p_kind(const lsb_hip_solver *sv);
+LSB_INTERNAL void tune_blas1_nt(lsb_hip_solver *sv);
 LSB_INTERNAL void drop_graphs(lsb_hip_solver *sv);
 LSB_INTERNAL void persist_setup(lsb_hip_solver *sv);
 LSB_INTERNAL int solve_core(lsb_hip_solver *sv, const double *d_b, double *d_x,

@@ -179,7 +179,9 @@ void lsb_k_cg1_update(unsigned n, double *u, const double *w, const double *dinv
                       const struct lsb_ar_collect *collect, double *partials2, unsigned *npartials,
                       void *stream);
 unsigned lsb_k_blas1_grid(unsigned n);
-void lsb_k_set_blas1_nt(int on);
+void lsb_k_set_blas1_nt(int on); /* mask: bit 0 x, 1 p and q, 2 r (k_pcg_update_xr); 3 r, 4 p (k_pcg_update_p);
+                                    5 k_cg1_update; 1 = all; per host thread */
+int lsb_k_get_blas1_nt(void);
 void lsb_k_fill_index(unsigned n, unsigned first, double *v, void *stream);
 void lsb_k_perm_gather(unsigned n, const int *perm, const double *src, double *dst,
                        void *stream);
