@@ -360,6 +360,8 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
               }.get(solver.spmv_variant, "?")
     # (the committed PMC profile is of the fp64 forms: no traffic figure for fp32 values)
     vslots = solver.sell_value_slots
+    if solver.spmv_flags & la.SPMV_FLAG_TMPL and kernel == "k_spmv_sell16":
+        kernel = "k_spmv_tmpl"
     traffic, traffic_src = pmc_traffic(key if world == 1 and a.precision == "fp64" else None, kernel, vslots)
     # Bytes the roofline figure is quoted on.  SURVEY 8(d)'s CSR count is the figure for a
     # CSR SpMV whose values are streamed.  A layout that ELIDES values (constant slots: one
@@ -367,8 +369,6 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
     # is what that layout must move in one launch -- its arrays as stored + x once + y once.
     layout_bytes = solver.spmv_layout_bytes
     fused_p = False
-    if solver.spmv_flags & la.SPMV_FLAG_TMPL and kernel == "k_spmv_sell16":
-        kernel = "k_spmv_tmpl"
     # A roofline fraction is quoted on bytes the kernel must MOVE: the layout's arrays as stored +
     # x once + y once (lsb_hip_solver_spmv_layout_bytes).  SURVEY 8(d)'s CSR count (12 B per non-zero
     # + 20 B per row) is what a CSR kernel moves; the sliced-ELL layouts move less (8 B per entry

@@ -441,7 +441,10 @@ void tune_blas1_nt(lsb_hip_solver *sv) {
   struct shard *s = &sv->sh[0];
   const char *e = getenv("LSBENCH_HIP_BLAS1_NT");
   sv->nt_mask = e ? (atoi(e) == 1 ? 63 : atoi(e)) : 63; /* not the previous solver's choice */
-  if (e || getenv("LSBENCH_HIP_NO_NT_TUNE") || s->nnz < 4000000ull)
+  /* (the iterations with z = M^-1 r as a vector run other sweeps around the SpMV -- dot2, the
+   * Chebyshev recurrence in the epilogue: the classic form's winner cost them 8-10 % on config 3
+   * (profiles/r03_bench.jsonl history); they keep every operand nontemporal, as measured in round 2) */
+  if (e || getenv("LSBENCH_HIP_NO_NT_TUNE") || s->nnz < 4000000ull || generic_precond(sv))
     return;
   static const int cand[] = {63, 9, 5, 0};
   const unsigned n = s->n;
