@@ -368,6 +368,7 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
     # value per slot whose 128 entries are equal) does not move them, so for it the count
     # is what that layout must move in one launch -- its arrays as stored + x once + y once.
     layout_bytes = solver.spmv_layout_bytes
+    it_bytes = solver.iteration_bytes
     fused_p = False
     # A roofline fraction is quoted on bytes the kernel must MOVE: the layout's arrays as stored +
     # x once + y once (lsb_hip_solver_spmv_layout_bytes).  SURVEY 8(d)'s CSR count (12 B per non-zero
@@ -476,6 +477,13 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
         "iterations_per_sec": iters / dt,
         "setup_seconds": t_setup,
         "blas1_nt_mask": solver.blas1_nt,  # which sweep operands are loaded nontemporal (timed at creation)
+        # the whole iteration against the same peak: SpMV layout bytes + 8 B per row and vector pass
+        # of the sweeps (lsb_hip_solver_iteration_bytes), over the wall-clock time per iteration
+        "iteration": ({"bytes": it_bytes, "us": dt / iters * 1e6, "GBps": it_bytes * iters / dt / 1e9,
+                       "frac": it_bytes * iters / dt / 1e9 / HBM_PEAK_GBPS,
+                       "basis": "SpMV layout bytes + every vector pass of the sweeps behind it, on wall-clock "
+                                "time per iteration (launch gaps, reductions and the stop test included)"}
+                      if it_bytes and iters and world == 1 else None),
         "comm": comm,
         "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": gbps / HBM_PEAK_GBPS, "traffic": traffic,
@@ -525,7 +533,7 @@ def main():
         r4 = run_workload(a, c, "lap3d", a.cfg4_steps, 1, cpu_leg=False)
         line["cfg4"] = {k: r4[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup",
                                            "ms_per_step", "scaling", "iterations_per_sec",
-                                           "setup_seconds", "comm")}
+                                           "setup_seconds", "comm", "iteration")}
         line["cfg4"]["config"] = r4["config"]
         line["cfg4"]["spmv"] = {k: r4["roofline"][k] for k in ("kernel", "launch_ms", "achieved", "frac",
                                                                "algorithmic_bytes", "bytes_basis", "csr_count",
@@ -537,7 +545,8 @@ def main():
             and spec == WORKLOADS["lap2d"] and a.precision == "fp64" and a.fixed_iters == 0):
         rg = run_workload(a, c, "lap2d_coef", a.general_values_steps, 1, cpu_leg=False)
         line["general_values"] = {k: rg[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup",
-                                                     "ms_per_step", "iterations_per_sec", "setup_seconds")}
+                                                     "ms_per_step", "iterations_per_sec", "setup_seconds",
+                                                     "iteration")}
         line["general_values"]["config"] = rg["config"]
         line["general_values"]["spmv"] = {k: rg["roofline"][k] for k in (
             "kernel", "launch_ms", "back_to_back_launch_ms", "achieved", "peak", "unit", "frac", "algorithmic_bytes",

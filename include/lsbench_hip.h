@@ -565,6 +565,12 @@ void lsb_hip_solver_comm_plan(const lsb_hip_solver *s, unsigned long long plan[8
  * and value arrays as stored) + x read once + y written once, first shard; 0 for the
  * multi-pass forms (binned, two-phase).  SURVEY 8(d)'s CSR count is 12 nnz + 20 n + 4. */
 unsigned long long lsb_hip_solver_spmv_layout_bytes(const lsb_hip_solver *s);
+/* Bytes one iteration of the Krylov loop must move on this rank's first shard: the SpMV's layout
+ * bytes + 8 B per row and vector pass of the sweeps (classic PCG: 9 passes, + 2 where the inverse
+ * diagonal is a vector; single-reduction PCG: 9 or 11 + 1).  0 where the iteration has another
+ * shape (GMRES, Chebyshev / block-Jacobi / FSAI, the fused forms of small operators, fp32 values,
+ * multi-pass SpMV forms).  bench.py divides it by the measured time per iteration. */
+unsigned long long lsb_hip_solver_iteration_bytes(const lsb_hip_solver *s);
 /* 0: an iteration's direction update p = D^-1 r + beta p is a launch of its own; 1: it rides in the
  * NEXT iteration's SpMV launch, formed for every gathered operand (the sub-wavefront form of
  * launch-bound operators). */

@@ -322,6 +322,12 @@ class Solver:
         return int(L.load().lsb_hip_solver_spmv_layout_bytes(self._h))
 
     @property
+    def iteration_bytes(self):
+        """Bytes one Krylov iteration must move (SpMV layout + the sweeps' vector passes); 0 where
+        the iteration has another shape (see lsbench_hip.h)."""
+        return int(L.load().lsb_hip_solver_iteration_bytes(self._h))
+
+    @property
     def fused_p(self):
         """0 / 1 / 2: the direction update rides in the next SpMV launch (see lsbench_hip.h)."""
         return int(L.load().lsb_hip_solver_fused_p(self._h))

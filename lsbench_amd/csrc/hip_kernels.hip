@@ -1004,7 +1004,7 @@ static __thread int g_blas1_nt = 63; /* mask, see k_pcg_update_xr; bit 5: k_cg1_
 // of 3.6 MB next to the matrix stream in a 4 MiB L2; PMC 5.59 -> see DESIGN.md).
 // Placement is a speed matter only; every slice is taken exactly once.
 struct sell_deal {
-  unsigned turns, base, L, period, full, total;
+  unsigned turns, base, L, period, full, total, colturns;
 };
 // (Tried in round 3 and taken out: MARCHING along z -- inside its eighth of every plane a wave keeps
 // ONE position and walks plane after plane, so that the +-plane operands of a step are what the
@@ -1014,7 +1014,7 @@ struct sell_deal {
 // profiles/r03_cfg4_dealing.txt.)
 __device__ __forceinline__ sell_deal sell_deal_init(unsigned ns, unsigned period, unsigned xcd) {
   sell_deal d;
-  d.period = period, d.full = 0, d.total = 0;
+  d.period = period, d.full = 0, d.total = 0, d.colturns = 0;
   if (!period) {
     const unsigned ngrp = (ns + 3) / 4, chunk = (ngrp + NXCD - 1) / NXCD;
     const unsigned g0 = min(xcd * chunk, ngrp), g1 = min(g0 + chunk, ngrp);
@@ -1027,7 +1027,13 @@ __device__ __forceinline__ sell_deal sell_deal_init(unsigned ns, unsigned period
     d.L = qhi - qlo, d.base = qlo;
     d.full = d.L * planes;
     d.total = d.full + (rem > qlo ? min(qhi, rem) - qlo : 0u);
-    d.turns = (d.total + 3) / 4;
+    // z-COLUMNS: while four whole planes are left, the four waves of a workgroup take the SAME
+    // position of four consecutive planes -- their +-plane operands meet in one CU at one time
+    // instead of relying on other workgroups of the XCD being at the neighbouring plane just then
+    // (64 M-row 7-point, k_spmv_tmpl<2>: FETCH 1166 -> 704 MB per launch for 527 MB of compulsory
+    // reads; the launch time does not move, profiles/r03_cfg4_dealing.txt)
+    d.colturns = (planes / 4) * d.L;
+    d.turns = d.colturns + (d.total - 4 * d.colturns + 3) / 4;
   }
   return d;
 }
@@ -1037,6 +1043,8 @@ __device__ __forceinline__ unsigned sell_deal_slice(const sell_deal &d, unsigned
     const unsigned si = d.base + it * 4 + wave;
     return si < ns ? si : 0xFFFFFFFFu;
   }
+  if (it < d.colturns)
+    return ((it / d.L) * 4 + wave) * d.period + d.base + it % d.L;
   const unsigned m = it * 4 + wave;
   if (m >= d.total)
     return 0xFFFFFFFFu;
@@ -1319,22 +1327,23 @@ __device__ __forceinline__ double lane_below(double v) { // the value lane + 1 h
   return __hiloint2double(hi, lo);
 }
 
-// values of the slots c-1 / c+1 of a shaped template where they are not plain constants
-__device__ __forceinline__ void tmpl_side_values(const lsb_sell_tmpl *T, int NF, unsigned s, unsigned lane,
-                                                 const unsigned *__restrict__ vbase,
-                                                 const unsigned long long *__restrict__ mask,
+// values of the slots c-1 / c+1 of a shaped template where they are not plain constants.
+// Masked slots (kind 2): the slice's 128-bit mask arrives in SCALAR registers (mk[side][0..1],
+// loaded by the caller beside the gathers -- as two dependent vector loads behind them they
+// were half of a turn's latency on the 7-point grid, where every slice holds a line end).
+__device__ __forceinline__ void tmpl_side_values(const lsb_sell_tmpl *T, int NF, unsigned vb, unsigned lane,
+                                                 const int (&side_k)[2], const int (&side_kd)[2],
+                                                 const unsigned long long (&mk)[2][2],
                                                  const void *__restrict__ vals, int f32, double &vm0, double &vm1,
                                                  double &vp0, double &vp1) {
-  const unsigned vb = __builtin_amdgcn_readfirstlane(vbase[2 * s]);
-  const unsigned mb = __builtin_amdgcn_readfirstlane(vbase[2 * s + 1]);
 #pragma unroll
   for (int side = 0; side < 2; side++) {
-    const int j = NF + 2 * side, k = T->kidx[j], kd = T->kind[j];
+    const int j = NF + 2 * side, k = side_k[side], kd = side_kd[side];
     if (k < 0)
       continue;
     double v0, v1;
     if (kd == 2) { // bit r of the slice's mask: row r holds the template's number
-      const unsigned long long w = mask[2 * ((size_t)mb + (unsigned)k) + (lane >> 5)];
+      const unsigned long long w = (lane & 32u) ? mk[side][1] : mk[side][0];
       const unsigned sh = (2u * lane) & 63u;
       v0 = (w >> sh) & 1ull ? T->cst[j] : 0.0;
       v1 = (w >> (sh + 1u)) & 1ull ? T->cst[j] : 0.0;
@@ -1353,12 +1362,12 @@ __device__ __forceinline__ void tmpl_side_values(const lsb_sell_tmpl *T, int NF,
   }
 }
 
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
 template <int NF, bool CHEB>
 __global__ __launch_bounds__(WG, 6) void k_spmv_tmpl(
     const unsigned *__restrict__ sptr, unsigned s0, unsigned ns, unsigned period, unsigned n,
-    unsigned row_begin, unsigned xlen, const unsigned char *__restrict__ tid8,
-    const unsigned *__restrict__ vbase, const unsigned long long *__restrict__ mask,
-    const lsb_sell_tmpl *__restrict__ td,
+    unsigned row_begin, unsigned xlen, const u4v *__restrict__ srec,
+    const unsigned long long *__restrict__ mask, const lsb_sell_tmpl *__restrict__ td,
     const int *__restrict__ sbase, const void *__restrict__ vals, int f32,
     const double *__restrict__ vconst, const double *__restrict__ x, double *__restrict__ y,
     const double *__restrict__ xdot, int dot_is_x, double *__restrict__ partials,
@@ -1374,15 +1383,24 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_tmpl(
     if (si == 0xFFFFFFFFu)
       continue;
     const unsigned s = s0 + si;
-    const unsigned t = __builtin_amdgcn_readfirstlane((unsigned)tid8[s]);
+    // the slice's record {template id (255: none), first kept value slot, first mask, 0}: ONE
+    // 16-byte scalar load (a byte array of ids + a pair array cost two dependent round trips, the
+    // byte one through the vector path).  (Asking for it one turn ahead, beside the gathers of the
+    // turn before: 320 -> 304 us on the 64 M-row 7-point operator, 25 -> 28 us on the 10 M-row
+    // 5-point one whose records stay in L2 -- not kept.)
+    const u4v rec = srec[s];
+    const unsigned t = __builtin_amdgcn_readfirstlane(rec.x), vb = __builtin_amdgcn_readfirstlane(rec.y);
+    const unsigned mb = __builtin_amdgcn_readfirstlane(rec.z);
     const unsigned row = s * LSB_SELL_ROWS + 2 * lane;
     const int grow = (int)(row + row_begin);
     double a0 = 0.0, a1 = 0.0;
     sell_d2v xd = {0.0, 0.0};
     bool have_xd = CHEB || !xdot;
-    if (t != 255u && td[t].shaped) {
-      const lsb_sell_tmpl *T = td + t;
+    const lsb_sell_tmpl *T = td + (t == 255u ? 0u : t);
+    if (t != 255u && T->shaped) {
       const int bc = T->base[NF + 1];
+      // (everything the masks' addresses need, in the same batch of scalar loads as the bases)
+      const int side_k[2] = {T->kidx[NF], T->kidx[NF + 2]}, side_kd[2] = {T->kind[NF], T->kind[NF + 2]};
       sell_d2u lo[NF > 0 ? NF : 1], hi[NF > 0 ? NF : 1];
 #pragma unroll
       for (int k = 0; k < NF; k++)
@@ -1408,6 +1426,15 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_tmpl(
           xd.x = xdot[row];
         have_xd = true;
       }
+      // the masks of masked slots c-1 / c+1: wave-uniform, 16 bytes each, by scalar loads that
+      // travel while the gathers do
+      unsigned long long mk[2][2] = {{0ull, 0ull}, {0ull, 0ull}};
+#pragma unroll
+      for (int side = 0; side < 2; side++)
+        if (side_k[side] >= 0 && side_kd[side] == 2) {
+          const unsigned long long *mp = mask + 2 * ((size_t)mb + (unsigned)side_k[side]);
+          mk[side][0] = mp[0], mk[side][1] = mp[1];
+        }
       if (stopped)
         return;
       double up = lane_above(c.y), dn = lane_below(c.x);
@@ -1427,8 +1454,8 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_tmpl(
         // be MASKED: the template's number where the slice's 128-bit mask says so, else zero
         // (looked up here, behind the far slots' products: their registers are free by now)
         double vm0 = T->cst[NF], vm1 = vm0, vp0 = T->cst[NF + 2], vp1 = vp0;
-        if (T->kidx[NF] >= 0 || T->kidx[NF + 2] >= 0)
-          tmpl_side_values(T, NF, s, lane, vbase, mask, vals, f32, vm0, vm1, vp0, vp1);
+        if (side_k[0] >= 0 || side_k[1] >= 0)
+          tmpl_side_values(T, NF, vb, lane, side_k, side_kd, mk, vals, f32, vm0, vm1, vp0, vp1);
         // value 0 = padding: no operand, an exact 0 (the rule of k_spmv_sell16)
         const double vc = T->cst[NF + 1];
         a0 = fma(vm0, vm0 != 0.0 ? up : 0.0, a0), a1 = fma(vm1, vm1 != 0.0 ? c.x : 0.0, a1); // slot c-1: x[. - 1], x[.]
@@ -1449,7 +1476,6 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_tmpl(
         have_xd = true;
       }
       if (t != 255u) { // a pure slice of another shape (first / last grid line): every slot gathered
-        const lsb_sell_tmpl *T = td + t;
         const int cnt = T->nslots;
         if (stopped)
           return;
@@ -1971,8 +1997,8 @@ void lsb_k_spmv_sell(unsigned flags, unsigned grid_cap, unsigned period, const u
 /* The constant-slot layout through slice templates (k_spmv_tmpl).  vals: the kept value slots
  * (fp32 when flags & LSB_SP_F32; the templates' constants are then fp32-rounded by the caller). */
 void lsb_k_spmv_tmpl(unsigned flags, unsigned grid_cap, unsigned period, const unsigned *sptr, unsigned s0,
-                     unsigned ns, unsigned n, unsigned row_begin, unsigned xlen, const unsigned char *tid8,
-                     const unsigned *vbase, const unsigned long long *mask, const struct lsb_sell_tmpl *td,
+                     unsigned ns, unsigned n, unsigned row_begin, unsigned xlen, const unsigned *srec,
+                     const unsigned long long *mask, const struct lsb_sell_tmpl *td,
                      unsigned nfar, const int *sbase, const void *vals,
                      const double *vconst, const double *x, double *y, const double *xdot,
                      double *partials, unsigned *npartials, const struct lsb_pcg_state *st,
@@ -1995,10 +2021,10 @@ void lsb_k_spmv_tmpl(unsigned flags, unsigned grid_cap, unsigned period, const u
 #define LSB_TMPL(NF)                                                                                 \
   do {                                                                                               \
     if (epi.zout)                                                                                    \
-      k_spmv_tmpl<NF, true><<<g, WG, 0, s>>>(sptr, s0, ns, period, n, row_begin, xlen, tid8, vbase, mask, td, sbase, vals, f32, \
+      k_spmv_tmpl<NF, true><<<g, WG, 0, s>>>(sptr, s0, ns, period, n, row_begin, xlen, (const u4v *)srec, mask, td, sbase, vals, f32, \
                                              vconst, x, y, xdot, dot_is_x, partials, st, tail, epi);   \
     else                                                                                             \
-      k_spmv_tmpl<NF, false><<<g, WG, 0, s>>>(sptr, s0, ns, period, n, row_begin, xlen, tid8, vbase, mask, td, sbase, vals, f32, \
+      k_spmv_tmpl<NF, false><<<g, WG, 0, s>>>(sptr, s0, ns, period, n, row_begin, xlen, (const u4v *)srec, mask, td, sbase, vals, f32, \
                                               vconst, x, y, xdot, dot_is_x, partials, st, tail, epi);  \
   } while (0)
   switch (nfar) {

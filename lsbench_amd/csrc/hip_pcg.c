@@ -183,6 +183,24 @@ int lsb_fuse_p_kind(const lsb_hip_solver *sv) {
 }
 static int fuse_p(const lsb_hip_solver *sv) { return lsb_fuse_p_kind(sv) != 0; }
 
+/* Bytes ONE iteration of the Krylov loop must move on shard 0: the SpMV's layout bytes
+ * (lsb_hip_solver_spmv_layout_bytes) + every vector pass of the sweeps behind it.  Classic PCG:
+ * k_pcg_update_xr reads x p q r and writes x r, k_pcg_update_p reads r p and writes p -- 9 passes,
+ * + 2 reads of the inverse diagonal where it is a vector; the single-reduction form: 9 passes with
+ * a constant diagonal (u = dc r never stored), else 11 + the diagonal.  0 where the iteration is
+ * something else (GMRES, a polynomial / block / FSAI preconditioner, the one-launch and
+ * two-launch forms of small operators, fp32 values, the multi-pass SpMV forms). */
+unsigned long long lsb_hip_solver_iteration_bytes(const lsb_hip_solver *sv) {
+  const struct shard *s = &sv->sh[0];
+  const unsigned long long sp = lsb_hip_solver_spmv_layout_bytes(sv), n8 = 8ull * s->n;
+  if (!sp || sv->o.krylov == LSB_KRYLOV_GMRES || generic_precond(sv) || s->mixed || sv->ps.use || fuse_p(sv))
+    return 0;
+  const unsigned vec = s->dinv_uniform ? 0u : 1u;
+  if (use_cg1(sv))
+    return sp + n8 * (sv->cg1_implicit ? 9u : 11u + vec);
+  return sp + n8 * (9u + 2u * vec);
+}
+
 static void fused_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int pos) {
   struct shard *s = &sv->sh[0];
   double *buf[2] = {s->d_pfull, s->d_p1};

@@ -64,6 +64,9 @@ static void precond_shard_fsai(struct shard *s, const int *offs, const int *cols
   struct lsb_fsai_pattern *P = lsb_csr_fsai_pattern(&view, power, LSB_FSAI_CAP);
   if (!P)
     errx(EXIT_FAILURE, "hip_cdna4: cannot build the FSAI pattern");
+  if (P->nnz > 0x7fffffffull) /* G and G^T go through the int-offset CSR kernels */
+    errx(EXIT_FAILURE, "hip_cdna4: the FSAI pattern has %llu entries, more than 2^31 - 1; choose a smaller "
+                       "--fsai-power", P->nnz);
   /* rows by size class: a wavefront per row up to 32 entries, a workgroup beyond */
   unsigned *small = (unsigned *)malloc((size_t)n * sizeof(unsigned)), *big = (unsigned *)malloc((size_t)n * sizeof(unsigned));
   unsigned nsmall = 0, nbig = 0, maxrow = 0;

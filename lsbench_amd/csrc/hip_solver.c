@@ -328,15 +328,23 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
               for (unsigned t = 0; t < TT->ntmpl; t++)
                 for (int j = 0; j < TT->t[t].nslots; j++)
                   TT->t[t].cst[j] = (double)(float)TT->t[t].cst[j];
-            s->d_tid8 = (unsigned char *)dev_upload(TT->tid, (size_t)TT->nslice + 8);
-            s->d_vbase = (unsigned *)dev_upload(TT->vbase, 2 * ((size_t)TT->nslice + 8) * sizeof(unsigned));
+            { /* per slice ONE 16-byte record {template id, first kept value slot, first mask, 0}: a
+               * single scalar load in the kernel */
+              unsigned *rec = lsb_calloc(unsigned, 4 * ((size_t)TT->nslice + 1));
+              for (unsigned k = 0; k < TT->nslice; k++)
+                rec[4 * (size_t)k] = TT->tid[k], rec[4 * (size_t)k + 1] = TT->vbase[2 * (size_t)k],
+                               rec[4 * (size_t)k + 2] = TT->vbase[2 * (size_t)k + 1];
+              s->d_srec = (unsigned *)dev_upload(rec, 4 * ((size_t)TT->nslice + 1) * sizeof(unsigned));
+              LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+              free(rec);
+            }
             s->d_tmask = (unsigned long long *)dev_upload(TT->mask, 2 * ((size_t)TT->nmask + 1) * sizeof(unsigned long long));
             s->d_tmpl = (struct lsb_sell_tmpl *)dev_upload(TT->t, (size_t)TT->ntmpl * sizeof(struct lsb_sell_tmpl));
             s->tmpl_nfar = TT->nfar, s->tmpl_count = TT->ntmpl;
             s->tmpl_pure = TT->covered, s->tmpl_shaped = TT->shaped;
-            /* what a launch streams with templates: a byte per slice, the templates, and for the
+            /* what a launch streams with templates: 16 bytes per slice, the templates, and for the
              * slices without one their slot records, constants and two offsets */
-            s->tmpl_bytes = 9ull * TT->nslice + (unsigned long long)TT->ntmpl * sizeof(struct lsb_sell_tmpl) +
+            s->tmpl_bytes = 16ull * TT->nslice + (unsigned long long)TT->ntmpl * sizeof(struct lsb_sell_tmpl) +
                             16ull * TT->nmask +
                             TT->kept_read * LSB_SELL_ROWS * (s->mixed ? 4ull : 8ull); /* the values it still reads */
             for (unsigned k = 0; k < H->nslice; k++)
@@ -433,7 +441,7 @@ void shard_free(struct shard *s) {
   lsb_hip_free(s->d_sptr), lsb_hip_free(s->d_scols), lsb_hip_free(s->d_svals);
   lsb_hip_free(s->d_sptr16), lsb_hip_free(s->d_scodes), lsb_hip_free(s->d_sbase);
   lsb_hip_free(s->d_svals16), lsb_hip_free(s->d_svconst);
-  lsb_hip_free(s->d_tid8), lsb_hip_free(s->d_tmpl), lsb_hip_free(s->d_vbase), lsb_hip_free(s->d_tmask);
+  lsb_hip_free(s->d_srec), lsb_hip_free(s->d_tmpl), lsb_hip_free(s->d_tmask);
   free(s->h_pblk);
   lsb_hip_free(s->bd_chunk), lsb_hip_free(s->bd_rows), lsb_hip_free(s->bd_cols);
   lsb_hip_free(s->bd_vals);
@@ -730,7 +738,7 @@ unsigned long long lsb_hip_solver_spmv_layout_bytes(const lsb_hip_solver *s) {
   unsigned long long m = 12ull * h->nnz + 4ull * ((unsigned long long)h->n + 1); /* the CSR arrays */
   if (h->variant == LSB_SPMV_SELL)
     m = (h->sp_flags & LSB_SP_C16) && h->d_scodes
-            ? ((h->sp_flags & LSB_SP_TMPL) && h->d_tid8 ? h->tmpl_bytes : h->sell16_bytes)
+            ? ((h->sp_flags & LSB_SP_TMPL) && h->d_srec ? h->tmpl_bytes : h->sell16_bytes)
             : h->sell32_bytes;
   else if (h->variant == LSB_SPMV_TWOPHASE || h->variant == LSB_SPMV_BINNED)
     return 0; /* more than one pass over intermediate data: no single-pass figure */
@@ -750,9 +758,9 @@ void sell_launch(struct shard *s, unsigned s0, unsigned ns, const double *xfull,
                         const double *xdot, double *partials, unsigned *np,
                         const struct lsb_pcg_state *st) {
   const unsigned f32 = s->mixed ? LSB_SP_F32 : 0u; /* the value arrays hold floats then */
-  if ((s->sp_flags & LSB_SP_C16) && (s->sp_flags & LSB_SP_TMPL) && s->d_tid8 && s->d_scodes)
+  if ((s->sp_flags & LSB_SP_C16) && (s->sp_flags & LSB_SP_TMPL) && s->d_srec && s->d_scodes)
     lsb_k_spmv_tmpl(s->sp_flags | f32, s->sp_grid, s->sp_period, s->d_sptr16, s0, ns, s->n, s->row_begin, s->n_glob,
-                    s->d_tid8, s->d_vbase, s->d_tmask, s->d_tmpl, s->tmpl_nfar, s->d_sbase, s->d_svals16, s->d_svconst, xfull, y, xdot, partials, np, st,
+                    s->d_srec, s->d_tmask, s->d_tmpl, s->tmpl_nfar, s->d_sbase, s->d_svals16, s->d_svconst, xfull, y, xdot, partials, np, st,
                     &s->tail, &s->epi, g_stream);
   else if ((s->sp_flags & LSB_SP_C16) && s->d_scodes)
     lsb_k_spmv_sell(s->sp_flags | f32, s->sp_grid, s->sp_period, s->d_sptr16, s0, ns, s->n, s->row_begin, s->d_scodes,
@@ -897,7 +905,7 @@ void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
         cand[ncand].v = LSB_SPMV_SELL, cand[ncand].f = c16, cand[ncand].p = s->sell_period,
         cand[ncand++].g = grid0;
       }
-      if (c16 && s->d_tid8) { /* slice templates (no stream to load nontemporally: NT only marks the
+      if (c16 && s->d_srec) { /* slice templates (no stream to load nontemporally: NT only marks the
                                  flavour as "solve-like" for the 3 % rule below) */
         const unsigned f = c16 | LSB_SP_NT | LSB_SP_TMPL;
         cand[ncand].v = LSB_SPMV_SELL, cand[ncand].f = f, cand[ncand++].g = grid0;
@@ -960,8 +968,8 @@ void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
     s->d_sptr16 = NULL, s->d_scodes = NULL, s->d_sbase = NULL, s->d_svals16 = NULL, s->d_svconst = NULL;
   }
   if (!(bv == LSB_SPMV_SELL && (bf & LSB_SP_TMPL))) {
-    lsb_hip_free(s->d_tid8), lsb_hip_free(s->d_tmpl), lsb_hip_free(s->d_vbase), lsb_hip_free(s->d_tmask);
-    s->d_tid8 = NULL, s->d_tmpl = NULL, s->d_vbase = NULL, s->d_tmask = NULL;
+    lsb_hip_free(s->d_srec), lsb_hip_free(s->d_tmpl), lsb_hip_free(s->d_tmask);
+    s->d_srec = NULL, s->d_tmpl = NULL, s->d_tmask = NULL;
   }
   if (any && !(bv == LSB_SPMV_SELL && !(bf & LSB_SP_C16))) {
     lsb_hip_free(s->d_scols), lsb_hip_free(s->d_svals);

@@ -87,8 +87,7 @@ struct shard {
   unsigned sell_vslots, sell_slots;
   unsigned long long sell16_bytes, sell32_bytes; /* matrix-side bytes one launch of the form streams */
   /* slice templates of the constant-slot layout (lsb_sell16_templates; LSB_SP_TMPL in sp_flags) */
-  unsigned char *d_tid8;
-  unsigned *d_vbase;
+  unsigned *d_srec; /* per slice {template id (255: none), first kept value slot, first mask, 0} */
   unsigned long long *d_tmask;
   unsigned n_glob; /* columns of the operator = length of the gather vector */
   struct lsb_sell_tmpl *d_tmpl;

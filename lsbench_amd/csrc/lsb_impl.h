@@ -111,8 +111,8 @@ void lsb_k_spmv_sell(unsigned flags, unsigned grid_cap, unsigned period, const u
                      const struct lsb_cheb_epi *epi, void *stream);
 #define LSB_SP_TMPL 64u /* 16-bit sliced-ELL with constant slots: slice templates (k_spmv_tmpl) */
 void lsb_k_spmv_tmpl(unsigned flags, unsigned grid_cap, unsigned period, const unsigned *sptr, unsigned s0,
-                     unsigned ns, unsigned n, unsigned row_begin, unsigned xlen, const unsigned char *tid8,
-                     const unsigned *vbase, const unsigned long long *mask, const struct lsb_sell_tmpl *td,
+                     unsigned ns, unsigned n, unsigned row_begin, unsigned xlen, const unsigned *srec,
+                     const unsigned long long *mask, const struct lsb_sell_tmpl *td,
                      unsigned nfar, const int *sbase, const void *vals,
                      const double *vconst, const double *x, double *y, const double *xdot,
                      double *partials, unsigned *npartials, const struct lsb_pcg_state *st,

@@ -213,6 +213,11 @@ def test_bench_line_contract():
     assert rf["traffic"] is None or (0.3 < rf["frac_hbm"] <= 1.0 and rf["traffic"] >= 0.9 * rf["algorithmic_bytes"])
     assert rf["traffic_source"] and len(rf["kernels_sha16"]) == 16
     assert d["comm"]["rccl_ranks"] == 0 and d["comm"]["recv_peers"] == 0   # one shard: no communicator
+    # the whole iteration on the same peak: SpMV layout bytes + the sweeps' 9 vector passes (constant
+    # diagonal), over wall-clock time per iteration -- a fraction too
+    it = d["iteration"]
+    assert it["bytes"] == rf["layout_bytes"] + 72 * 9998244 and 0.3 < it["frac"] <= 1.0
+    assert abs(it["frac"] - it["bytes"] / it["us"] / 1e3 / 8000.0) < 1e-9
     # the thing the metric names: the same pattern with general values, every value streamed.  The
     # fraction is on the bytes the layout moves (8 B of value per entry, no column index on a
     # diagonal slot) -- <= 1 by construction, target >= 0.6; the same launch on SURVEY 8(d)'s CSR
@@ -225,6 +230,8 @@ def test_bench_line_contract():
     assert 8 * 49978572 + 16 * 9998244 <= gs["algorithmic_bytes"] == gs["layout_bytes"] < csr
     assert abs(gs["frac"] - gs["achieved"] / 8000.0) < 1e-12 and 0.6 <= gs["frac"] <= 1.0
     assert gs["csr_count"]["ratio_to_peak"] >= 0.85           # a CSR kernel would need this rate
+    assert g["iteration"]["bytes"] == gs["layout_bytes"] + 88 * 9998244     # + the diagonal, read twice
+    assert 0.3 < g["iteration"]["frac"] <= 1.0
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
     c4 = d["cfg4"]
