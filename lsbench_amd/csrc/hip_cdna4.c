@@ -377,7 +377,7 @@ int lsb_hip_spmv_csr_f64(int variant, unsigned n, const int *d_offs,
   if (variant == LSB_SPMV_SELL) {
     if ((flags & LSB_SP_C16) && !d_rowblk)
       return 2; /* the 16-bit form needs its slot bases */
-    lsb_k_spmv_sell(flags, 0, 0, (const unsigned *)d_offs, 0, nblk, n, 0, d_cols, d_rowblk, d_vals, NULL, 0,
+    lsb_k_spmv_sell(flags, 0, 0, (const unsigned *)d_offs, 0, nblk, n, 0, n, d_cols, d_rowblk, d_vals, NULL, 0,
                     d_x, d_y, d_dot ? d_xdot : NULL, d_dot ? d_work : NULL, &np, NULL, NULL, NULL, stream);
   } else
   lsb_k_spmv(variant, n, d_offs, d_cols, d_vals, d_rowblk, d_blklanes, nblk, L, flags, 0,

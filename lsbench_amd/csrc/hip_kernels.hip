@@ -1139,7 +1139,7 @@ typedef short s2v __attribute__((ext_vector_type(2)));
 template <int FLAGS, class VT = double, bool CHEB = false>
 __global__ __launch_bounds__(WG, 6) void k_spmv_sell16(
     const unsigned *__restrict__ sptr, unsigned s0, unsigned ns, unsigned period, unsigned n,
-    unsigned row_begin, const short *__restrict__ codes, const int *__restrict__ sbase,
+    unsigned row_begin, unsigned xlen, const short *__restrict__ codes, const int *__restrict__ sbase,
     const VT *__restrict__ vals, const double *__restrict__ vconst, unsigned ulen,
     const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ xdot,
     double *__restrict__ partials,
@@ -1213,21 +1213,27 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_sell16(
             continue;
           }
         }
+        // Per slot: record (scalar), codes, values AND the gathers, all asked for before any of them
+        // is waited for.  The gather's address does not look at the value (it used to: padding has
+        // value 0 and was given address 0, which made every gather wait for its value's trip to
+        // HBM): the index is clamped into x instead and the operand of a padding entry is dropped
+        // at the product, an exact 0 as before.  pair: both rows of every lane gather at the same
+        // offset AND the wave's 129 operands lie inside x -- one 16-byte gather per lane.
         s2v c[SELL_U];
         v2t v[SELL_U];
-        int b[SELL_U];
-        bool pair[SELL_U]; // wave-uniform: both rows of every lane gather at the same offset
+        sell_d2u t[SELL_U];
+        const long long g0 = (long long)s * LSB_SELL_ROWS + row_begin; // global row of lane 0's first row
 #pragma unroll
         for (int u = 0; u < SELL_U; u++)
           if (j0 + u < len) {
             const unsigned q = q0 + j0 + u;
-            int kc, kv; // wave-uniform: scalar loads
+            int b, kc, kv; // wave-uniform: scalar loads
             if (vconst) {
               const i4v bk = ((const i4v *)sbase)[q];
-              b[u] = bk.x, kc = bk.y, kv = bk.z;
+              b = bk.x, kc = bk.y, kv = bk.z;
             } else {
               const i2v bk = ((const i2v *)sbase)[q]; // {base, code slot or -1}
-              b[u] = bk.x, kc = bk.y, kv = (int)q;
+              b = bk.x, kc = bk.y, kv = (int)q;
             }
             c[u] = (s2v){0, 0};
             if (kc >= 0) { // slots with one common code carry none
@@ -1241,26 +1247,23 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_sell16(
               const VT cv = (VT)vconst[q];
               v[u] = (v2t){cv, cv};
             }
-            // a constant slot has no padding; with one common code as well, rows 2l and
-            // 2l + 1 read x at grow + b and grow + b + 1: ONE 16-byte gather per lane
-            pair[u] = kv < 0 && kc < 0;
+            const bool pair = kc < 0 && g0 + b >= 0 && g0 + b + (long long)LSB_SELL_ROWS <= (long long)xlen;
+            if (pair) {
+              t[u] = *(const sell_d2u *)(x + (grow + b));
+            } else {
+              long long e0 = (long long)grow + b + (int)c[u].x, e1 = (long long)grow + 1 + b + (int)c[u].y;
+              e0 = e0 < 0 ? 0 : (e0 >= (long long)xlen ? (long long)xlen - 1 : e0);
+              e1 = e1 < 0 ? 0 : (e1 >= (long long)xlen ? (long long)xlen - 1 : e1);
+              t[u].x = x[e0], t[u].y = x[e1];
+            }
           }
         if (stopped)
           return;
 #pragma unroll
         for (int u = 0; u < SELL_U; u++)
-          if (j0 + u < len) {
-            if (pair[u]) {
-              const sell_d2u t = *(const sell_d2u *)(x + (grow + b[u]));
-              a0 = fma((double)v[u].x, t.x, a0);
-              a1 = fma((double)v[u].y, t.y, a1);
-            } else {
-              const bool p0 = v[u].x != (VT)0, p1 = v[u].y != (VT)0;
-              const double t0 = x[p0 ? grow + b[u] + (int)c[u].x : 0];
-              const double t1 = x[p1 ? grow + 1 + b[u] + (int)c[u].y : 0];
-              a0 = fma((double)v[u].x, p0 ? t0 : 0.0, a0);
-              a1 = fma((double)v[u].y, p1 ? t1 : 0.0, a1);
-            }
+          if (j0 + u < len) { // value 0 = padding: no operand, an exact 0
+            a0 = fma((double)v[u].x, v[u].x != (VT)0 ? t[u].x : 0.0, a0);
+            a1 = fma((double)v[u].y, v[u].y != (VT)0 ? t[u].y : 0.0, a1);
           }
       }
       if (CHEB) { // d = a d + b D^-1 (r - w); z' = z + d -- k_cheb_step's expression
@@ -1929,7 +1932,8 @@ void lsb_k_spmv_subwave_p(unsigned n, const int *offs, const int *cols, const do
  * the 16-bit code array and `sbase` the slot bases (row_begin = global index
  * of local row 0); else `cols` holds 32-bit column ids and sbase is unused. */
 void lsb_k_spmv_sell(unsigned flags, unsigned grid_cap, unsigned period, const unsigned *sptr,
-                     unsigned s0, unsigned ns, unsigned n, unsigned row_begin, const void *cols,
+                     unsigned s0, unsigned ns, unsigned n, unsigned row_begin, unsigned xlen,
+                     const void *cols,
                      const int *sbase, const double *vals, const double *vconst, unsigned ulen,
                      const double *x, double *y, const double *xdot, double *partials,
                      unsigned *npartials,
@@ -1952,14 +1956,14 @@ void lsb_k_spmv_sell(unsigned flags, unsigned grid_cap, unsigned period, const u
   if (period && (period < NXCD || ns < period))
     period = 0; /* less than a plane: contiguous dealing */
 #define LSB_SELL16(FL, VT, V)                                                                  \
-  k_spmv_sell16<FL, VT><<<g, WG, 0, s>>>(sptr, s0, ns, period, n, row_begin, (const short *)cols, \
+  k_spmv_sell16<FL, VT><<<g, WG, 0, s>>>(sptr, s0, ns, period, n, row_begin, xlen, (const short *)cols, \
                                          sbase, V, vconst, ulen, x, y, xdot, partials, st, tail, epi)
 #define LSB_SELL32(FL, VT, V)                                                                  \
   k_spmv_sell<FL, VT><<<g, WG, 0, s>>>(sptr, s0, ns, period, n, (const int *)cols, V, x, y, xdot, \
                                        partials, st, tail)
   if (epi.zout) {
 #define LSB_SELL16C(FL, VT, V)                                                                            \
-  k_spmv_sell16<FL, VT, true><<<g, WG, 0, s>>>(sptr, s0, ns, period, n, row_begin, (const short *)cols, \
+  k_spmv_sell16<FL, VT, true><<<g, WG, 0, s>>>(sptr, s0, ns, period, n, row_begin, xlen, (const short *)cols, \
                                                sbase, V, vconst, ulen, x, y, xdot, partials, st, tail, epi)
     if (flags & LSB_SP_F32) {
       if (nt)

@@ -763,11 +763,11 @@ void sell_launch(struct shard *s, unsigned s0, unsigned ns, const double *xfull,
                     s->d_srec, s->d_tmask, s->d_tmpl, s->tmpl_nfar, s->d_sbase, s->d_svals16, s->d_svconst, xfull, y, xdot, partials, np, st,
                     &s->tail, &s->epi, g_stream);
   else if ((s->sp_flags & LSB_SP_C16) && s->d_scodes)
-    lsb_k_spmv_sell(s->sp_flags | f32, s->sp_grid, s->sp_period, s->d_sptr16, s0, ns, s->n, s->row_begin, s->d_scodes,
+    lsb_k_spmv_sell(s->sp_flags | f32, s->sp_grid, s->sp_period, s->d_sptr16, s0, ns, s->n, s->row_begin, s->n_glob, s->d_scodes,
                     s->d_sbase, s->d_svals16, s->d_svconst, s->sell_ulen, xfull, y, xdot, partials, np, st, &s->tail, &s->epi,
                     g_stream);
   else
-    lsb_k_spmv_sell((s->sp_flags & ~LSB_SP_C16) | f32, s->sp_grid, s->sp_period, s->d_sptr, s0, ns, s->n, s->row_begin,
+    lsb_k_spmv_sell((s->sp_flags & ~LSB_SP_C16) | f32, s->sp_grid, s->sp_period, s->d_sptr, s0, ns, s->n, s->row_begin, s->n_glob,
                     s->d_scols, NULL, s->d_svals, NULL, 0, xfull, y, xdot, partials, np, st, &s->tail, NULL, g_stream);
 }
 

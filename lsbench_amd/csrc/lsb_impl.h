@@ -103,7 +103,8 @@ unsigned lsb_k_spmv_grid(int variant, unsigned n, unsigned nblk,
 #define LSB_SP_C16 4u /* sliced-ELL only: 16-bit column codes */
 #define LSB_SP_F32 32u /* the values pointer holds fp32 (opts.precision = LSB_PREC_MIXED) */
 void lsb_k_spmv_sell(unsigned flags, unsigned grid_cap, unsigned period, const unsigned *sptr,
-                     unsigned s0, unsigned ns, unsigned n, unsigned row_begin, const void *cols,
+                     unsigned s0, unsigned ns, unsigned n, unsigned row_begin, unsigned xlen,
+                     const void *cols,
                      const int *sbase, const double *vals, const double *vconst, unsigned ulen,
                      const double *x, double *y, const double *xdot, double *partials,
                      unsigned *npartials,

@@ -542,7 +542,7 @@ int main(int argc, char **argv) {
       char nm[64];
       snprintf(nm, sizeof nm, "prod flags=%u cap=%u", fl, cap);
       run(nm, g, [&] {
-        lsb_k_spmv_sell(fl, cap, 0, d_sptr, 0, ns, n, 0, d_codes, d_rec, d_vals, d_vc, 0, dx, dy, dx, dparts, &np,
+        lsb_k_spmv_sell(fl, cap, 0, d_sptr, 0, ns, n, 0, n, d_codes, d_rec, d_vals, d_vc, 0, dx, dy, dx, dparts, &np,
                         NULL, &notail, NULL, st);
       }, true);
     }
