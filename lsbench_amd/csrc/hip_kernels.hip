@@ -1775,8 +1775,21 @@ unsigned lsb_k_blas1_grid(unsigned n) {
     if (g < 256)
       g = 256;
   }
-  if (g > LSB_MAX_PARTIALS)
-    g = LSB_MAX_PARTIALS;
+  // ... and at three workgroups per CU: beyond that the sweeps get SLOWER the more of them stream
+  // at once -- round 3, iteration of the 64 M-row 7-point operator (vectors of 512 MB: nothing
+  // comes out of the Infinity Cache) 1211-1238 us with 2048 workgroups, 1075-1077 us with 768
+  // (256 / 512 / 1024: 1081-1104 / 1082-1090 / 1103-1110), the 10 M-row 5-point one 140-142 ->
+  // 136-137 us; y = 4 x over 512 MB vectors: 178 us with 1024 workgroups, 204-207 us with
+  // 2048 / 4096 (profiles/r03_sweep_grid.txt).  LSBENCH_HIP_BLAS1_GRID overrides (experiments).
+  static int cap = -1;
+  if (cap < 0) {
+    const char *e = getenv("LSBENCH_HIP_BLAS1_GRID");
+    cap = e && atoi(e) > 0 ? atoi(e) : LSB_STREAM_GRID_CAP;
+    if (cap > LSB_MAX_PARTIALS)
+      cap = LSB_MAX_PARTIALS;
+  }
+  if (g > (unsigned)cap)
+    g = (unsigned)cap;
   return g ? g : 1;
 }
 
@@ -2056,15 +2069,15 @@ void lsb_k_reduce_final2(const double *pa, unsigned na, unsigned wa, double *out
 void lsb_k_dot(unsigned n, const double *a, const double *b, double *partials,
                unsigned *npartials, void *stream) {
   unsigned g = div_up(n ? n : 1, WG * 4);
-  if (g > LSB_MAX_PARTIALS)
-    g = LSB_MAX_PARTIALS;
+  if (g > LSB_STREAM_GRID_CAP)
+    g = LSB_STREAM_GRID_CAP;
   *npartials = g;
   k_dot<<<g, WG, 0, (hipStream_t)stream>>>(n, a, b, partials);
 }
 
 static unsigned ew_grid(unsigned n) {
   unsigned g = div_up(n ? n : 1, WG * 4);
-  return g > 2048 ? 2048 : g;
+  return g > LSB_STREAM_GRID_CAP ? LSB_STREAM_GRID_CAP : g;
 }
 
 void lsb_k_axpy(unsigned n, const double *alpha, const double *x, double *y,

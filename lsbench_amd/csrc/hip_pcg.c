@@ -461,7 +461,11 @@ void tune_blas1_nt(lsb_hip_solver *sv) {
   sv->nt_mask = e ? (atoi(e) == 1 ? 63 : atoi(e)) : 63; /* not the previous solver's choice */
   /* (the iterations with z = M^-1 r as a vector run other sweeps around the SpMV -- dot2, the
    * Chebyshev recurrence in the epilogue: the classic form's winner cost them 8-10 % on config 3
-   * (profiles/r03_bench.jsonl history); they keep every operand nontemporal, as measured in round 2) */
+   * (profiles/r03_bench.jsonl history).  They keep every operand nontemporal but the direction the
+   * SpMV behind k_pcg_update_p gathers: outer SpMV 39 -> 29-33 us, Chebyshev 4 / 16 and block-Jacobi 8
+   * on config 3 0.971 / 1.285 / 0.399 -> 0.974 / 1.289 / 0.408 solves/s, tools/gpu_nt_generic.sh) */
+  if (!e && generic_precond(sv) && s->nnz >= 4000000ull)
+    sv->nt_mask = 63 & ~16;
   if (e || getenv("LSBENCH_HIP_NO_NT_TUNE") || s->nnz < 4000000ull || generic_precond(sv))
     return;
   static const int cand[] = {63, 9, 5, 0};

@@ -247,7 +247,7 @@ extern "C" {
 
 static unsigned pgrid(size_t n) {
   size_t g = (n + WG * 4 - 1) / (WG * 4);
-  return (unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+  return (unsigned)(g < 1 ? 1 : (g > LSB_STREAM_GRID_CAP ? LSB_STREAM_GRID_CAP : g));
 }
 
 void lsb_k_dot2(unsigned n, const double *r, const double *z, double *partials2,

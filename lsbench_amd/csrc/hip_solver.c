@@ -918,6 +918,8 @@ void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
         }
       }
     }
+  if (ncand > (int)(sizeof cand / sizeof cand[0]))
+    errx(EXIT_FAILURE, "hip_cdna4: SpMV timing pass: candidate table too small");
   for (int ci = 0; ci < ncand; ci++) {
     s->variant = cand[ci].v, s->sp_flags = cand[ci].f, s->sp_grid = cand[ci].g, s->sp_period = cand[ci].p;
     spmv_shard(s, s->d_pfull, s->d_q, s->d_pfull + s->row_begin, s->d_parts_pq, &np, NULL);

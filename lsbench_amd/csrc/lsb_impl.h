@@ -79,6 +79,9 @@ struct lsb_gmres_state {
 /* Upper bound on per-launch partial sums any reduction kernel writes; the
  * consumer kernels re-reduce them in fixed order (deterministic). */
 #define LSB_MAX_PARTIALS 2048
+/* Workgroups of a launch that only streams vectors: three per CU.  More of them stream SLOWER once
+ * the vectors come out of HBM (lsb_k_blas1_grid, profiles/r03_sweep_grid.txt). */
+#define LSB_STREAM_GRID_CAP 768
 /* Non-zeros staged in LDS per row block of the adaptive SpMV (16 KiB). */
 #define LSB_BLOCK_NNZ 2048
 
