@@ -369,6 +369,7 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
     # is what that layout must move in one launch -- its arrays as stored + x once + y once.
     layout_bytes = solver.spmv_layout_bytes
     it_bytes = solver.iteration_bytes
+    single_red = solver.single_reduction
     fused_p = False
     # A roofline fraction is quoted on bytes the kernel must MOVE: the layout's arrays as stored +
     # x once + y once (lsb_hip_solver_spmv_layout_bytes).  SURVEY 8(d)'s CSR count (12 B per non-zero
@@ -465,8 +466,8 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
         "config": {"workload": name, "rows": n, "nnz": n_tot_nnz,
                    "solver": {"jacobi": "PCG+Jacobi", "l1": "PCG+l1-Jacobi", "none": "CG", "bj": "PCG+block-Jacobi(%d)"
                               % a.block_size, "cheb": "PCG+Chebyshev(%d)" % a.cheb_degree,
-                              "fsai": "PCG+FSAI(tril(S^%d))" % a.fsai_power}[a.precond] + (" (single-reduction form)" if (
-                       a.krylov == "cg1" or (a.krylov == "auto" and world > 1)) else ""),
+                              "fsai": "PCG+FSAI(tril(S^%d))" % a.fsai_power}[a.precond] + (
+                                  " (single-reduction form)" if single_red else ""),
                    "tol": tol, "rhs": "b_i=i", "partition": "row-range x%d" % world,
                    "iterations_per_solve": its, "relres": res.relres,
                    "true_relres": true_relres,

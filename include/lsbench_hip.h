@@ -571,6 +571,10 @@ unsigned long long lsb_hip_solver_spmv_layout_bytes(const lsb_hip_solver *s);
  * shape (GMRES, Chebyshev / block-Jacobi / FSAI, the fused forms of small operators, fp32 values,
  * multi-pass SpMV forms).  bench.py divides it by the measured time per iteration. */
 unsigned long long lsb_hip_solver_iteration_bytes(const lsb_hip_solver *s);
+/* 1: the PCG iteration runs in its single-reduction form (Chronopoulos & Gear; two launches, one
+ * reduction per iteration) -- every sharded solve under krylov = auto, and one-shard solves of
+ * large operators whose Jacobi diagonal is one constant; 0: the classic form (or GMRES). */
+int lsb_hip_solver_single_reduction(const lsb_hip_solver *s);
 /* 0: an iteration's direction update p = D^-1 r + beta p is a launch of its own; 1: it rides in the
  * NEXT iteration's SpMV launch, formed for every gathered operand (the sub-wavefront form of
  * launch-bound operators). */

@@ -219,6 +219,7 @@ SIGNATURES = {
     "lsb_hip_solver_spmv_layout_bytes": (C.c_ulonglong, [_vp]),
     "lsb_hip_solver_fused_p": (_i, [_vp]),
     "lsb_hip_solver_iteration_bytes": (C.c_ulonglong, [_vp]),
+    "lsb_hip_solver_single_reduction": (_i, [_vp]),
     "lsb_hip_solver_blas1_nt": (_i, [_vp]),
     "lsb_hip_solver_comm": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "lsb_hip_stream": (_vp, []),

@@ -328,6 +328,11 @@ class Solver:
         return int(L.load().lsb_hip_solver_iteration_bytes(self._h))
 
     @property
+    def single_reduction(self):
+        """True where the PCG iteration runs in its single-reduction form (see lsbench_hip.h)."""
+        return bool(L.load().lsb_hip_solver_single_reduction(self._h))
+
+    @property
     def fused_p(self):
         """0 / 1 / 2: the direction update rides in the next SpMV launch (see lsbench_hip.h)."""
         return int(L.load().lsb_hip_solver_fused_p(self._h))

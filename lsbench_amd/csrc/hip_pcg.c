@@ -292,8 +292,18 @@ static int use_cg1(const lsb_hip_solver *sv) {
     return 0;
   /* measured on one GPU: no gain for small operators (tests/xn3b_A_18.txt: 390 vs
    * 400 solves/s, the fused sweep is as long as the two it replaces) and +6 % time
-   * on the 10M-row operator (96 n vs 88 n bytes); what it saves is a collective */
+   * on the 10M-row operator where the diagonal is a vector (96 n vs 88 n bytes; round 3, general
+   * values: 251 against 236-241 us per iteration); what it saves there is a collective.
+   * With ONE constant diagonal (u = c r never stored) it moves the classic form's 72 n in two
+   * launches instead of three; since its sweep loads the gather vector the plain way
+   * (k_cg1_update, round 3: the SpMV behind it 40 -> 24 us on config 3) it is level with the
+   * classic form on one GPU -- config 3 through bench.py 136.8-138.0 against 136.0-139.8 us per
+   * iteration, config 4 1186-1188 against 1182-1191 (tools/gpu_krylov_ab.sh) -- so one shard
+   * keeps the classic form, the reference's algorithm as written. */
   return sv->multi;
+}
+int lsb_hip_solver_single_reduction(const lsb_hip_solver *sv) {
+  return sv->o.krylov != LSB_KRYLOV_GMRES && use_cg1(sv);
 }
 
 static void cg1_enqueue_init(lsb_hip_solver *sv, const double *d_b, double *d_x) {

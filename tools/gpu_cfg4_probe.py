@@ -12,7 +12,10 @@ spec = sys.argv[3] if len(sys.argv) > 3 else "lap3d:nx=400,ny=400,nz=400"
 assert la.hip_cdna4_init() == 0
 A = la.lsbench_matrix_synth(spec)
 n = A.nrows
-o = la.default_opts(op_mode=la.OP_RAW, tol=1e-30, maxit=iters, verify=0, sample_spmv=16)
+kw = {}
+if os.environ.get("PROBE_KRYLOV") == "cg1":
+    kw["krylov"] = la.KRYLOV_PCG1
+o = la.default_opts(op_mode=la.OP_RAW, tol=1e-30, maxit=iters, verify=0, sample_spmv=16, **kw)
 s = la.Solver(A, o)
 ms = s.time_spmv(10, 100)
 d_b = torch.arange(n, dtype=torch.float64, device="cuda")
