@@ -176,17 +176,20 @@ def test_tuning_pass_picks_among_forms(hip):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nvirt,overlap,comm", [(1, 0, 0), (4, 0, 1), (4, 1, 1), (4, 1, 2), (2, 1, 2)])
-def test_plane_periodic_dealing_of_a_3d_stencil(hip, nvirt, overlap, comm, monkeypatch):
+@pytest.mark.parametrize("nz,nvirt,overlap,comm", [(64, 1, 0, 0), (64, 4, 0, 1), (64, 4, 1, 1), (64, 4, 1, 2),
+                                                   (64, 2, 1, 2), (67, 1, 0, 0), (67, 3, 1, 1), (21, 2, 1, 2)])
+def test_plane_periodic_dealing_of_a_3d_stencil(hip, nz, nvirt, overlap, comm, monkeypatch):
     """sell_deal (hip_kernels.hip): every XCD takes the same eighth of every plane of a
-    3-D stencil instead of a contiguous eighth of the rows.  A placement matter only:
-    the same SpMV element for element and the same solve, on one shard, over row-range
-    shards (whole planes each) and with the SpMV split into interior and boundary
+    3-D stencil instead of a contiguous eighth of the rows, and while four whole planes are left
+    the four waves of a workgroup take one position of four consecutive planes (z-columns).  A
+    placement matter only: the same SpMV element for element and the same solve, on one shard,
+    over row-range shards (whole planes each, or cut inside a plane: nz = 67 over 3 shards, planes
+    left over after the last group of four) and with the SpMV split into interior and boundary
     launches around the halo exchange -- the form config 4 runs in at 8 GPUs."""
     import torch
     monkeypatch.setenv("LSBENCH_HIP_FORCE_PERIOD", "1")
-    A = hip.lsbench_matrix_synth("lap3d:nx=128,ny=64,nz=64")        # plane = 8192 rows = 64 slices
-    offs, cols, vals = O.lap3d(128, 64, 64)
+    A = hip.lsbench_matrix_synth("lap3d:nx=128,ny=64,nz=%d" % nz)   # plane = 8192 rows = 64 slices
+    offs, cols, vals = O.lap3d(128, 64, nz)
     b = O.rhs(A.nrows)
     xo, ito, relo, sto = O.pcg_jacobi(offs, cols, vals, b, 1e-10)
     s = hip.Solver(A, hip.default_opts(op_mode=hip.OP_RAW, spmv_variant=hip.SPMV_SELL, nvirt=nvirt,
