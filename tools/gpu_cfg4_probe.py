@@ -15,6 +15,11 @@ n = A.nrows
 kw = {}
 if os.environ.get("PROBE_KRYLOV") == "cg1":
     kw["krylov"] = la.KRYLOV_PCG1
+if os.environ.get("PROBE_TUNE"):
+    kw["spmv_variant"] = la.SPMV_SELL
+    kw["spmv_tune"] = int(os.environ["PROBE_TUNE"])
+if os.environ.get("PROBE_GRID"):
+    kw["spmv_grid"] = int(os.environ["PROBE_GRID"])
 o = la.default_opts(op_mode=la.OP_RAW, tol=1e-30, maxit=iters, verify=0, sample_spmv=16, **kw)
 s = la.Solver(A, o)
 ms = s.time_spmv(10, 100)
