@@ -1369,7 +1369,10 @@ __device__ __forceinline__ void tmpl_side_values(const lsb_sell_tmpl *T, int NF,
 }
 
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
-template <int NF, bool CHEB>
+#ifndef DEFER_DEPTH
+#define DEFER_DEPTH 1 // turns a wave's y waits in LDS (2: 272-274 against 276-287 us on the 64 M-row 7-point operator, 29.7 against 28.2 us on the 10 M-row 5-point one)
+#endif
+template <int NF, bool CHEB, bool DEFER = false>
 __global__ __launch_bounds__(WG, 6) void k_spmv_tmpl(
     const unsigned *__restrict__ sptr, unsigned s0, unsigned ns, unsigned period, unsigned n,
     unsigned row_begin, unsigned xlen, const u4v *__restrict__ srec,
@@ -1379,12 +1382,40 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_tmpl(
     const double *__restrict__ xdot, int dot_is_x, double *__restrict__ partials,
     const lsb_pcg_state *__restrict__ st, const lsb_ar_tail tail, const lsb_cheb_epi epi) {
   __shared__ double sred[4];
+  // DEFERRED STORE.  vmcnt counts loads and stores in ONE order (gfx9), so a wave's first wait for a
+  // gather also waits until the 1 KB of y it stored at the end of the turn before has been
+  // acknowledged -- quick where the vectors sit in the Infinity Cache, slow where every line
+  // written pushes a dirty one out to HBM (a turn of the 64 M-row 7-point operator: 4.0 us, of its
+  // 50-plane slab 2.75 us; neither less traffic nor look-ahead touches changed that,
+  // profiles/r03_cfg4_dealing.txt).  So a turn parks its two results per lane in LDS and the NEXT
+  // turn stores them, behind its own gathers: the store is then the youngest operation in flight
+  // when the gathers are waited for, and has a whole turn to complete.
+  __shared__ sell_d2v ypark[DEFER ? DEFER_DEPTH * WG : 1];
   const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const unsigned gx = gridDim.x / NXCD, xcd = blockIdx.x % NXCD, slot = blockIdx.x / NXCD;
   const sell_deal deal = sell_deal_init(ns, period, xcd);
   const int stopped = st ? st->status : 0; // tested behind the first loads
   double dot = 0.0;
-  for (unsigned g = slot; g < deal.turns; g += gx) {
+  // first row of the slice whose results sit in ypark[k] (wave-uniform); slot = turn % DEFER_DEPTH
+  unsigned parked[DEFER_DEPTH], pslot = 0;
+#pragma unroll
+  for (int k = 0; k < DEFER_DEPTH; k++)
+    parked[k] = 0xFFFFFFFFu;
+#define TMPL_UNPARK_SLOT(K)                                                                    \
+  do {                                                                                         \
+    if (DEFER && parked[K] != 0xFFFFFFFFu) {                                                   \
+      *(sell_d2v *)(y + parked[K] + 2 * lane) = ypark[(K) * WG + tid];                         \
+      parked[K] = 0xFFFFFFFFu;                                                                 \
+    }                                                                                          \
+  } while (0)
+#define TMPL_UNPARK()                                                                          \
+  do {                                                                                         \
+    if (DEFER_DEPTH == 1 || pslot == 0)                                                        \
+      TMPL_UNPARK_SLOT(0);                                                                     \
+    else                                                                                       \
+      TMPL_UNPARK_SLOT(DEFER_DEPTH - 1);                                                       \
+  } while (0)
+  for (unsigned g = slot; g < deal.turns; g += gx, pslot ^= 1u) {
     const unsigned si = __builtin_amdgcn_readfirstlane(sell_deal_slice(deal, g, wave, ns));
     if (si == 0xFFFFFFFFu)
       continue;
@@ -1393,7 +1424,7 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_tmpl(
     // 16-byte scalar load (a byte array of ids + a pair array cost two dependent round trips, the
     // byte one through the vector path).  (Asking for it one turn ahead, beside the gathers of the
     // turn before: 320 -> 304 us on the 64 M-row 7-point operator, 25 -> 28 us on the 10 M-row
-    // 5-point one whose records stay in L2 -- not kept.)
+    // 5-point one whose records stay in L2; on top of the deferred store 276-287 -> 291-295 us -- not kept.)
     const u4v rec = srec[s];
     const unsigned t = __builtin_amdgcn_readfirstlane(rec.x), vb = __builtin_amdgcn_readfirstlane(rec.y);
     const unsigned mb = __builtin_amdgcn_readfirstlane(rec.z);
@@ -1441,6 +1472,8 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_tmpl(
           const unsigned long long *mp = mask + 2 * ((size_t)mb + (unsigned)side_k[side]);
           mk[side][0] = mp[0], mk[side][1] = mp[1];
         }
+      TMPL_UNPARK(); // the turn before's y: behind this turn's gathers (and behind the masks' scalar
+                     // loads, whose counter the LDS read shares: in front of them measured no better)
       if (stopped)
         return;
       double up = lane_above(c.y), dn = lane_below(c.x);
@@ -1474,6 +1507,7 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_tmpl(
         a0 = fma(v, hi[k].x, a0), a1 = fma(v, hi[k].y, a1);
       }
     } else {
+      TMPL_UNPARK();
       if (!have_xd) {
         if (row + 1 < n)
           xd = *(const sell_d2v *)(xdot + row);
@@ -1538,6 +1572,16 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_tmpl(
         epi.d[row] = v0;
         epi.zout[row] = x[grow] + v0;
       }
+    } else if (DEFER && s * LSB_SELL_ROWS + LSB_SELL_ROWS <= n) { // a whole slice: parked, stored by the next turn
+      const sell_d2v o = {a0, a1};
+      if (DEFER_DEPTH == 1 || pslot == 0)
+        ypark[tid] = o, parked[0] = s * LSB_SELL_ROWS;
+      else
+        ypark[(DEFER_DEPTH - 1) * WG + tid] = o, parked[DEFER_DEPTH - 1] = s * LSB_SELL_ROWS;
+      if (xdot) {
+        dot = fma(a0, xd.x, dot);
+        dot = fma(a1, xd.y, dot);
+      }
     } else if (row + 1 < n) {
       const sell_d2v o = {a0, a1};
       *(sell_d2v *)(y + row) = o;
@@ -1551,6 +1595,11 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_tmpl(
         dot = fma(a0, xd.x, dot);
     }
   }
+#pragma unroll
+  for (int k = 0; k < DEFER_DEPTH; k++)
+    TMPL_UNPARK_SLOT(k);
+#undef TMPL_UNPARK
+#undef TMPL_UNPARK_SLOT
   if (stopped)
     return;
   spmv_publish(partials, dot, sred, tail);
@@ -2043,6 +2092,9 @@ void lsb_k_spmv_tmpl(unsigned flags, unsigned grid_cap, unsigned period, const u
     if (epi.zout)                                                                                    \
       k_spmv_tmpl<NF, true><<<g, WG, 0, s>>>(sptr, s0, ns, period, n, row_begin, xlen, (const u4v *)srec, mask, td, sbase, vals, f32, \
                                              vconst, x, y, xdot, dot_is_x, partials, st, tail, epi);   \
+    else if (flags & LSB_SP_DEFER)                                                                   \
+      k_spmv_tmpl<NF, false, true><<<g, WG, 0, s>>>(sptr, s0, ns, period, n, row_begin, xlen, (const u4v *)srec, mask, td, sbase, vals, f32, \
+                                                    vconst, x, y, xdot, dot_is_x, partials, st, tail, epi); \
     else                                                                                             \
       k_spmv_tmpl<NF, false><<<g, WG, 0, s>>>(sptr, s0, ns, period, n, row_begin, xlen, (const u4v *)srec, mask, td, sbase, vals, f32, \
                                               vconst, x, y, xdot, dot_is_x, partials, st, tail, epi);  \

@@ -850,7 +850,7 @@ void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
   if (getenv("LSBENCH_HIP_FORCE_PERIOD")) /* tests: the plane-periodic dealing on small operators */
     s->sp_period = s->sell_period;
   if (o->spmv_tune >= 0) {
-    s->sp_flags = (unsigned)o->spmv_tune & (31u | LSB_SP_TMPL); /* bit 2: 16-bit codes, where that copy exists;
+    s->sp_flags = (unsigned)o->spmv_tune & (31u | LSB_SP_TMPL | LSB_SP_DEFER); /* bit 2: 16-bit codes, where that copy exists;
                                                    bits 3, 4: binned form's gather flavour; bit 6: slice
                                                    templates, where the constant-slot layout has them */
     return;
@@ -915,6 +915,14 @@ void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
           cand[ncand].v = LSB_SPMV_SELL, cand[ncand].f = f, cand[ncand].p = s->sell_period, cand[ncand++].g = grid0;
           if (o->spmv_grid <= 0)
             cand[ncand].v = LSB_SPMV_SELL, cand[ncand].f = f, cand[ncand].p = s->sell_period, cand[ncand++].g = 1536;
+        }
+        /* the same with y parked in LDS and stored one turn later (k_spmv_tmpl<.., DEFER>): pays where
+         * the vectors come out of HBM, costs ~2 us where they sit in the Infinity Cache */
+        if (s->tmpl_nfar >= 1 && s->nnz >= 16000000ull && !getenv("LSBENCH_HIP_NO_DEFER")) {
+          const unsigned fd = f | LSB_SP_DEFER, gd = o->spmv_grid <= 0 ? 1536u : grid0;
+          cand[ncand].v = LSB_SPMV_SELL, cand[ncand].f = fd, cand[ncand++].g = gd;
+          if (s->sell_period && !getenv("LSBENCH_HIP_NO_PERIOD"))
+            cand[ncand].v = LSB_SPMV_SELL, cand[ncand].f = fd, cand[ncand].p = s->sell_period, cand[ncand++].g = gd;
         }
       }
     }

@@ -237,7 +237,9 @@ def test_constant_slots_change_no_bit(hip, monkeypatch, spec, nvirt, precision):
     products in the same order -- SpMV, fused dot and the whole solve bit for bit; over
     shards (split interior / boundary launches included) and with fp32 matrix values; 5-point
     (one far slot per side), 7-point (two), tridiagonal (none), pentadiagonal; with general
-    values nothing is constant, no template exists and the template flag changes nothing."""
+    values nothing is constant, no template exists and the template flag changes nothing.  The
+    template kernel also with the deferred store (LSB_SP_DEFER: a turn's y waits in LDS for the
+    wave's next turn) -- the last slice of every wave, ragged ends and split launches included."""
     import torch
     if spec.startswith("penta"):
         A = hip.Matrix.from_arrays(*_penta(50000))
@@ -246,7 +248,8 @@ def test_constant_slots_change_no_bit(hip, monkeypatch, spec, nvirt, precision):
     b = O.rhs(A.nrows)
     xs = np.sin(np.arange(A.nrows, dtype=np.float64))
     out = {}
-    for name, off, tune in (("full", "1", 6), ("const", None, 6), ("tmpl", None, 6 | 64)):
+    for name, off, tune in (("full", "1", 6), ("const", None, 6), ("tmpl", None, 6 | 64),
+                            ("defer", None, 6 | 64 | 128)):      # + y parked in LDS, stored a turn later
         if off:
             monkeypatch.setenv("LSBENCH_HIP_NO_VCONST", off)
         else:
@@ -272,7 +275,7 @@ def test_constant_slots_change_no_bit(hip, monkeypatch, spec, nvirt, precision):
         lb = s.spmv_layout_bytes
         s.destroy()
         out[name] = (d_y.cpu().numpy(), x, int(r.iters), r.relres, lb)
-    for name in ("const", "tmpl"):
+    for name in ("const", "tmpl", "defer"):
         assert np.array_equal(out["full"][0], out[name][0]) and np.array_equal(out["full"][1], out[name][1])
         assert out["full"][2:4] == out[name][2:4]
     if "coef" not in spec:
