@@ -426,8 +426,9 @@ void lsb_sell_vc_free(struct lsb_sell_vc *V);
  * descriptions cover everything: slices with identical records share ONE template, tid[slice]
  * says which (255 = none: the slice goes the per-slot way) and vbase[slice] where the slice's
  * kept value slots start (they are consecutive: the k-th kept slot of the slice is value slot
- * vbase + k).  The kernel then reads five bytes per slice and the template out of the scalar
- * cache instead of 24 bytes of cold records per slot.  Where a template holds a slot c with
+ * vbase + k).  The device copy packs {tid, vbase, first mask, 0} into ONE 16-byte record per slice
+ * (a single scalar load); the kernel then reads that and the template out of the scalar cache
+ * instead of 24 bytes of cold records per slot.  Where a template holds a slot c with
  * base[c-1] = base[c]-1 and base[c+1] = base[c]+1 (the three inner diagonals of a stencil) it
  * is SHAPED: [nfar far slots][c-1, c, c+1][nfar far slots] with the set's one nfar -- lanes
  * take the operands of c-1 and c+1 from the centre's 16-byte pair by a lane shift: three

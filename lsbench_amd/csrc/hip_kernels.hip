@@ -1308,12 +1308,13 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_sell16(
 // chain of dependent loads per slice (cold slot records -> gathers), not by bytes: 176 MB in
 // 41-48 us.  Measured on the 10 M-row 5-point operator (tools/stencil_lab.hip, back to back):
 //   slot records by scalar loads per slice, five gathers (k_spmv_sell16)        40.8-48.0 us
-//   one byte per slice + the template out of the scalar cache, five gathers     32.5 us
+//   one record per slice + the template out of the scalar cache, five gathers   32.5 us
 //   + the +-1 diagonals from the centre's pair by a lane shift (three aligned
 //     gathers, the dot's operand = the centre pair), straight-line              24.6-26.9 us
 //   y = 4 x with the fused dot (the HBM floor of these bytes)                   23.2-24.6 us
-// A wave takes a slice per turn as above.  tid8[slice] names its template (255: none --
-// the slice keeps values somewhere, e.g. where a grid line ends, and goes the per-slot way);
+// A wave takes a slice per turn as above.  srec[slice] (16 bytes, one scalar load) names its
+// template (255: none -- the slice keeps values in a far slot or has more than 8 slots, and goes
+// the per-slot way), its first kept value slot and its first mask;
 // a SHAPED template is [NF far slots][c-1, c, c+1][NF far slots]: lanes gather the far slots
 // and the centre c, and form the operands of c-1 / c+1 from the centre pair of the
 // neighbouring lane (DPP wave shift; lane 0 and lane 63 fetch the one element beyond the

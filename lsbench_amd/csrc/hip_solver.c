@@ -320,7 +320,7 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
           s->sell_vslots = V->nval_slots, s->sell_slots = (unsigned)V->nslots;
           s->sell16_bytes = (unsigned long long)V->nslots * 24; /* slot record + the slot's constant */
           /* slices with identical constant records share a template (a structured grid has a
-           * handful): a byte per slice instead of 24 per slot, and the three inner diagonals
+           * handful): a 16-byte record per slice instead of 24 per slot, and the three inner diagonals
            * from one gather (k_spmv_tmpl) */
           struct lsb_sell_tmpls *TT = getenv("LSBENCH_HIP_NO_TMPL") ? NULL : lsb_sell16_templates(H, V);
           if (TT) {

@@ -233,7 +233,7 @@ def test_constant_slots_change_no_bit(hip, monkeypatch, spec, nvirt, precision):
     """Three layouts of the 16-bit sliced-ELL form, forced (spmv_tune): every value stored
     (LSBENCH_HIP_NO_VCONST=1); constant slots (lsb_sell16_value_slots: one value per slot
     whose 128 entries are equal); constant slots through slice TEMPLATES (k_spmv_tmpl: a
-    byte per slice, the three inner diagonals from one gather by lane shifts).  The same
+    record per slice, the three inner diagonals from one gather by lane shifts).  The same
     products in the same order -- SpMV, fused dot and the whole solve bit for bit; over
     shards (split interior / boundary launches included) and with fp32 matrix values; 5-point
     (one far slot per side), 7-point (two), tridiagonal (none), pentadiagonal; with general
