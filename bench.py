@@ -30,14 +30,28 @@ Others:
     --workload file:tests/golden/matrices/xn3b_A_18.txt.gz   configs[1]
 
 The JSON line also carries
-  roofline      dominant kernel (SpMV): algorithmic bytes 12*nnz + 20*n + 4 per
-                launch / mean launch time, HIP events on the library's stream,
-                sampled INSIDE the timed solves; peak 8000 GB/s
+  roofline      dominant kernel (SpMV): bytes the stored layout must move per launch
+                / mean launch time, HIP events on the library's stream, sampled
+                INSIDE the timed solves; peak 8000 GB/s
   cpu_baseline  the oracle's OpenMP Jacobi-PCG (a CPU port of the same
                 algorithm, oracle/lsb_oracle.c) on this host's cores, timed on
                 a bounded number of iterations of the SAME operator and scaled
                 to whole solves; rank 0, N = 1 only.  CHOLMOD, the reference's
                 own CPU solver, is not installable here.
+and, at N = 1, one sub-record per remaining BASELINE.json config and claim:
+  csr_kernel    SURVEY 8(d) to the letter: on config 3's pattern with general values,
+                the kernels that stream 12 B per non-zero -- k_spmv_adaptive on the CSR
+                arrays (offs / cols / vals) and k_spmv_sell with 32-bit columns --
+                >= 100 back-to-back launches after >= 10 warm-ups, frac =
+                (12 nnz + 20 n + 4) / t / 8 TB/s (<= 1 by construction)
+  cfg2          configs[1]: tests/xn3b_A_18.txt, tol 1e-12, `trials` = 100 warm-up +
+                100 timed solves (the reference's protocol, src/cholmod-impl.h:44-63),
+                Jacobi-PCG and FSAI(3)-PCG, x against the golden solution, beside
+                cpu_direct_baseline (cached-factor direct solve on one host core)
+  cfg5          configs[4]: the power-law SpMV (two-phase form), GB/s on SURVEY's bytes
+  cfg4, general_values   as before.
+`--only NAME[,NAME]` runs just those sub-records (profiling); `--krylov gmres` times
+GMRES(--restart) with its Gram-Schmidt passes counted in `iteration.bytes`.
 """
 import argparse
 import ctypes
@@ -74,9 +88,21 @@ def parse():
     p.add_argument("--tol", type=float, default=1e-8)
     p.add_argument("--maxit", type=int, default=100000)
     p.add_argument("--spmv", type=int, default=0, help="LSB_SPMV_* variant (0 = auto)")
-    p.add_argument("--krylov", default="auto", choices=["cg", "cg1", "auto"],
+    p.add_argument("--krylov", default="auto", choices=["cg", "cg1", "auto", "gmres"],
                    help="cg = classic PCG; cg1 = single-reduction PCG (2 launches, 1 reduction "
-                        "per iteration); auto = cg1 when the operator spans several GPUs")
+                        "per iteration); auto = cg1 when the operator spans several GPUs; gmres = "
+                        "restarted GMRES(--restart), right Jacobi preconditioning")
+    p.add_argument("--restart", type=int, default=30, help="GMRES restart length (1..32)")
+    p.add_argument("--operator", default="upper", choices=["upper", "raw"],
+                   help="file: workloads -- upper = S = triu(A) + triu(A,1)^T, the operator CHOLMOD "
+                        "factorises (src/cholmod-impl.h:5-16); raw = the file matrix as it is (GMRES)")
+    p.add_argument("--only", default="",
+                   help="comma list of sub-records to run INSTEAD of the headline (csr_kernel, cfg2, cfg5): "
+                        "one JSON line with just those -- what the PMC / trace passes profile")
+    p.add_argument("--csr-kernel", type=int, default=1, help="N = 1: 1 = the line carries `csr_kernel`")
+    p.add_argument("--cfg2", type=int, default=1, help="N = 1: 1 = the line carries `cfg2` (configs[1])")
+    p.add_argument("--cfg2-trials", type=int, default=100)
+    p.add_argument("--cfg5", type=int, default=1, help="N = 1: 1 = the line carries `cfg5` (configs[4])")
     p.add_argument("--comm", default="auto", choices=["auto", "rccl", "p2p"],
                    help="N>1: auto = direct xGMI stores where they pass the self-test and beat "
                         "RCCL; rccl / p2p force one")
@@ -265,14 +291,15 @@ def kernels_sha16():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(workload, kernel, value_slots):
-    """HBM bytes per launch of `kernel` on `workload` from the committed PMC profile
+def pmc_traffic(workload, kernel, value_slots, spmv_flags=None, period=None):
+    """Fabric-side bytes per launch of `kernel` on `workload` from the committed PMC profile
     (profiles/pmc_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3
     passes of this same command, tools/gpu_profiles.sh).  The bench process cannot
     read hardware counters itself, so the figure is tied to what it was measured
-    on: the entry must name this kernel, the hash of the kernel / layout sources
-    and the layout's kept / all value slots of THIS run -- any mismatch prints
-    traffic null and says why in `traffic_source`."""
+    on: the entry must name this kernel, the hash of the kernel / layout sources,
+    the layout's kept / all value slots AND the flavour the timing pass picked
+    (spmv_flags, xcd_period_slices) of THIS run -- any mismatch prints traffic null
+    and says why in `traffic_source`."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             t = json.load(f).get(workload)
@@ -289,7 +316,33 @@ def pmc_traffic(workload, kernel, value_slots):
     if list(t.get("value_slots", [0, 0])) != list(value_slots):
         return None, ("stale: committed PMC profile kept %s value slots, this run %s"
                       % (t.get("value_slots"), list(value_slots)))
+    if spmv_flags is not None and (t.get("spmv_flags") != spmv_flags or t.get("xcd_period_slices") != period):
+        return None, ("other flavour: the committed PMC profile is of spmv_flags %s / xcd_period_slices %s, this "
+                      "run's timing pass picked %s / %s" % (t.get("spmv_flags"), t.get("xcd_period_slices"),
+                                                           spmv_flags, period))
     return t["bytes"], t.get("source", "profiles/pmc_traffic.json")
+
+
+FABRIC_NOTE = ("traffic = FETCH_SIZE x 2 + WRITE_SIZE of the committed rocprofv3 --pmc passes: bytes through the "
+               "L2's fabric side, INCLUDING what the 256 MB Infinity Cache served (MI355X_MICROARCH.md: the "
+               "counters sit in front of it) -- an upper bound of what the HBM moved, not the HBM's own count")
+
+
+def gmres_bytes(n, sp, m, steps):
+    """Bytes `steps` inner steps of GMRES(m) move (hip_gmres_drv.c): per step j of a cycle (basis of
+    j + 1 vectors) k_gm_scale_prec 32 n (v_j and the diagonal read, v_j and z written), the SpMV's
+    layout bytes, two k_gm_multidot passes of 8 n (j + 2) and two k_gm_update_w passes of 8 n (j + 3);
+    per cycle k_gm_resid 24 n, k_gm_finish_cycle 8 n (steps of the cycle + 3) and, from the second
+    cycle on, the copy of x into the gather vector + one more SpMV."""
+    tot, done, cycle = 0, 0, 0
+    while done < steps:
+        k = min(m, steps - done)
+        tot += 24 * n + 8 * n * (k + 3) + ((16 * n + sp) if cycle else 0)
+        for j in range(k):
+            tot += 32 * n + sp + 2 * 8 * n * (j + 2) + 2 * 8 * n * (j + 3)
+        done += k
+        cycle += 1
+    return tot
 
 
 def run_workload(a, c, workload, steps, warmup, cpu_leg):
@@ -301,7 +354,8 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
     key = workload
     if workload.startswith("file:"):
         Afile = read_file_matrix(workload[5:])
-        A = la.lsb_csr_symmetrize_upper(Afile)  # the operator CHOLMOD factorises
+        # the operator CHOLMOD factorises, or (--operator raw, GMRES) the file matrix as it is
+        A = la.lsb_csr_symmetrize_upper(Afile) if a.operator == "upper" else la.lsb_csr_copy_base0(Afile)
         n = A.nrows
         name = os.path.basename(workload[5:])
         if c.dist_on:
@@ -327,7 +381,8 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
                            spmv_tune=a.spmv_tune, overlap=a.overlap,
                            comm={"auto": la.COMM_AUTO, "rccl": la.COMM_RCCL, "p2p": la.COMM_P2P}[a.comm],
                            krylov={"cg": la.KRYLOV_PCG, "cg1": la.KRYLOV_PCG1,
-                                   "auto": la.KRYLOV_AUTO}[a.krylov],
+                                   "auto": la.KRYLOV_AUTO, "gmres": la.KRYLOV_GMRES}[a.krylov],
+                           restart=a.restart,
                            precond=la.PRECOND_NONE if spmv_only else {
                                "jacobi": la.PRECOND_JACOBI, "l1": la.PRECOND_L1JACOBI,
                                "none": la.PRECOND_NONE, "cheb": la.PRECOND_CHEBYSHEV,
@@ -335,7 +390,7 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
                            cheb_degree=a.cheb_degree, block_size=a.block_size, fsai_power=a.fsai_power,
                            precision=la.PREC_MIXED if a.precision == "fp32" else la.PREC_FP64,
                            persistent=a.persistent, verbose=a.verbose,
-                           verify=1 if (a.verify and a.fixed_iters == 0) else 0)
+                           verify=1 if (a.verify and a.fixed_iters == 0 and a.krylov != "gmres") else 0)
     if c.dist_on:
         solver = la.Solver(Aloc, opts, row_begin=r0, n_global=n)
     else:
@@ -362,7 +417,8 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
     vslots = solver.sell_value_slots
     if solver.spmv_flags & la.SPMV_FLAG_TMPL and kernel == "k_spmv_sell16":
         kernel = "k_spmv_tmpl"
-    traffic, traffic_src = pmc_traffic(key if world == 1 and a.precision == "fp64" else None, kernel, vslots)
+    traffic, traffic_src = pmc_traffic(key if world == 1 and a.precision == "fp64" else None, kernel, vslots,
+                                       solver.spmv_flags, solver.spmv_period)
     # Bytes the roofline figure is quoted on.  SURVEY 8(d)'s CSR count is the figure for a
     # CSR SpMV whose values are streamed.  A layout that ELIDES values (constant slots: one
     # value per slot whose 128 entries are equal) does not move them, so for it the count
@@ -390,8 +446,9 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
                "config": {"workload": name, "rows": n, "nnz_per_gpu": nnz_loc},
                "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS,
                             "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS, "traffic": traffic,
-                            "frac_hbm": (traffic / ms / 1e6 / HBM_PEAK_GBPS) if traffic else None,
-                            "traffic_source": traffic_src,
+                            "frac_fabric": (traffic / ms / 1e6 / HBM_PEAK_GBPS) if traffic else None,
+                            "traffic_source": traffic_src, "traffic_note": FABRIC_NOTE,
+                            "spmv_flags": solver.spmv_flags, "xcd_period_slices": solver.spmv_period,
                             "kernel": kernel + (" (panels)" if solver.spmv_variant == la.SPMV_PANEL else ""),
                             "launch_ms": ms, "algorithmic_bytes": bytes_spmv,
                             "bytes_basis": "SURVEY 8(d): 12 B per non-zero + 20 B per row + 4; the multi-pass forms "
@@ -415,6 +472,7 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
         spmv_n += res.spmv_samples
     barrier()
     dt = time.perf_counter() - t0
+    dt_own = dt
     if c.dist_on:
         tt = torch.tensor([dt], dtype=torch.float64, device=c.cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -433,7 +491,9 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
         dist.all_reduce(sq)
     true_relres = float((sq[0] / sq[1]).sqrt())
     del d_y
-    if a.verify and a.fixed_iters == 0 and not true_relres <= tol * (1 + 1e-6):
+    if a.krylov == "gmres" and a.fixed_iters == 0 and not true_relres <= 10 * tol:
+        sys.exit("GMRES: true residual %.3e against tol %.1e: no valid number" % (true_relres, tol))
+    if a.verify and a.krylov != "gmres" and a.fixed_iters == 0 and not true_relres <= tol * (1 + 1e-6):
         sys.exit("true residual %.3e above tol %.1e after a verified solve: no valid number"
                  % (true_relres, tol))
 
@@ -446,6 +506,14 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
         how = "hipEvents around 200 back-to-back launches after the timed solves"
     gbps = bytes_alg / spmv_avg_ms / 1e6
     gbps_csr = bytes_spmv / spmv_avg_ms / 1e6
+    it_basis = ("SpMV layout bytes + every vector pass of the sweeps behind it, on wall-clock "
+                "time per iteration (launch gaps, reductions and the stop test included)")
+    if a.krylov == "gmres" and layout_bytes and iters:
+        # per inner step: mean over the steps actually run (Gram-Schmidt passes grow with the basis)
+        it_bytes = gmres_bytes(nl, layout_bytes, max(1, min(a.restart, 32)), iters) // iters
+        it_basis = ("GMRES(%d), mean per inner step: SpMV layout bytes + k_gm_scale_prec + two k_gm_multidot "
+                    "and two k_gm_update_w passes over the basis (CGS2) + the per-cycle passes, on wall-clock "
+                    "time per inner step" % a.restart)
     # SURVEY.md section 8(d)'s protocol as well: >= 100 back-to-back launches after >= 10
     # warm-ups (warmer caches than inside the solve; reported, not used for `frac`)
     b2b_ms = solver.time_spmv(10, 100) if spmv_n else spmv_avg_ms
@@ -456,6 +524,18 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
         n_tot_nnz = int(tt.item())
     comm = dict(zip(("mode", "selftest_direct_us", "selftest_rccl_us"), solver.comm),
                 modes="0 one shard, 1 RCCL, 2 direct xGMI all-reduce, 3 direct xGMI halos too")
+    per_rank = None
+    if c.dist_on:
+        # load balance of a sharded line: every rank's own wall-clock per iteration (before the MAX),
+        # its SpMV launch inside the solve, its rows and non-zeros
+        mine = torch.tensor([dt_own / max(iters, 1) * 1e6, spmv_avg_ms * 1e3, float(nl), float(nnz_loc)],
+                            dtype=torch.float64, device=c.cdev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        allr = torch.stack(allr).cpu()
+        per_rank = {"iteration_us": {"min": float(allr[:, 0].min()), "max": float(allr[:, 0].max())},
+                    "spmv_us": {"min": float(allr[:, 1].min()), "max": float(allr[:, 1].max())},
+                    "rows": [int(v) for v in allr[:, 2]], "nnz": [int(v) for v in allr[:, 3]]}
     comm.update(solver.comm_plan)  # rccl_ranks = ncclCommCount; rank 0's halo plan
     rec = {
         "metric": "cg_solves_per_sec", "value": steps / dt, "unit": "solves/s",
@@ -464,7 +544,8 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
         "vs_baseline": None, "dtype": "f64",
         "data": "synthetic" if not workload.startswith("file:") else "reference tests/ matrix",
         "config": {"workload": name, "rows": n, "nnz": n_tot_nnz,
-                   "solver": {"jacobi": "PCG+Jacobi", "l1": "PCG+l1-Jacobi", "none": "CG", "bj": "PCG+block-Jacobi(%d)"
+                   "solver": ("GMRES(%d), right Jacobi" % a.restart) if a.krylov == "gmres" else
+                             {"jacobi": "PCG+Jacobi", "l1": "PCG+l1-Jacobi", "none": "CG", "bj": "PCG+block-Jacobi(%d)"
                               % a.block_size, "cheb": "PCG+Chebyshev(%d)" % a.cheb_degree,
                               "fsai": "PCG+FSAI(tril(S^%d))" % a.fsai_power}[a.precond] + (
                                   " (single-reduction form)" if single_red else ""),
@@ -474,7 +555,7 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
                    "stop": ("||b - S x|| <= tol ||b|| verified on the residual recomputed from x, "
                             "inside the timed region (%d correction solve(s) per solve; their "
                             "iterations are counted)" % (corr // max(steps, 1)))
-                   if (a.verify and a.fixed_iters == 0) else "recurrence residual"},
+                   if (a.verify and a.fixed_iters == 0 and a.krylov != "gmres") else "recurrence residual"},
         "iterations_per_sec": iters / dt,
         "setup_seconds": t_setup,
         "blas1_nt_mask": solver.blas1_nt,  # which sweep operands are loaded nontemporal (timed at creation)
@@ -482,16 +563,15 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
         # of the sweeps (lsb_hip_solver_iteration_bytes), over the wall-clock time per iteration
         "iteration": ({"bytes": it_bytes, "us": dt / iters * 1e6, "GBps": it_bytes * iters / dt / 1e9,
                        "frac": it_bytes * iters / dt / 1e9 / HBM_PEAK_GBPS,
-                       "basis": "SpMV layout bytes + every vector pass of the sweeps behind it, on wall-clock "
-                                "time per iteration (launch gaps, reductions and the stop test included)"}
+                       "basis": it_basis}
                       if it_bytes and iters and world == 1 else None),
-        "comm": comm,
+        "comm": comm, "per_rank": per_rank,
         "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": gbps / HBM_PEAK_GBPS, "traffic": traffic,
-                     # what the HBM actually moved: PMC bytes of the committed profile of this
-                     # command and these kernel sources / this run's launch time, over peak
-                     "frac_hbm": (traffic / spmv_avg_ms / 1e6 / HBM_PEAK_GBPS) if traffic else None,
-                     "traffic_source": traffic_src,
+                     # fabric-side traffic (L2 <-> Infinity Cache / HBM) of the committed profile of this
+                     # command, these kernel sources and this flavour / this run's launch time, over peak
+                     "frac_fabric": (traffic / spmv_avg_ms / 1e6 / HBM_PEAK_GBPS) if traffic else None,
+                     "traffic_source": traffic_src, "traffic_note": FABRIC_NOTE,
                      "algorithmic_bytes": bytes_alg,
                      "bytes_basis": ("layout: what the stored layout must move in one launch -- its index / code / "
                                      "slot / template arrays and the values it keeps (value_slots kept / all: one "
@@ -525,9 +605,119 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
     return rec
 
 
+def csr_kernel_record(a, c):
+    """SURVEY 8(d) to the letter, N = 1: the fp64 SpMV kernels that stream 12 B per non-zero, on
+    config 3's pattern with general values (nothing for a layout to elide).  k_spmv_adaptive reads
+    the CSR arrays themselves (row offsets, 32-bit columns, fp64 values -- what the reference hands
+    its Krylov solver, src/ginkgo.cpp:26-34); k_spmv_sell reads the same 12 B per entry in sliced-ELL
+    order (no row offsets: 16 instead of 20 B per row).  >= 100 back-to-back launches after >= 10
+    warm-ups, HIP events on the library's stream; frac = (12 nnz + 20 n + 4) / t / 8 TB/s."""
+    A = la.lsbench_matrix_synth(WORKLOADS["lap2d_coef"])
+    n, nnz = A.nrows, A.nnz
+    bytes_csr = 12 * nnz + 20 * n + 4
+    out = {"workload": WORKLOADS["lap2d_coef"], "rows": n, "nnz": nnz, "algorithmic_bytes": bytes_csr,
+           "bytes_basis": "SURVEY 8(d): 12 B per non-zero + 20 B per row + 4", "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+           "warmup_launches": 10, "timed_launches": 100, "kernels_sha16": kernels_sha16(),
+           "measured": "hipEvents around 100 back-to-back launches (fused p.q as in the solve) after 10 warm-ups",
+           "kernels": {}}
+    for name, variant, tune, grid in (("k_spmv_adaptive", la.SPMV_ADAPTIVE, -1, 0), ("k_spmv_sell", la.SPMV_SELL, 2, 1536)):
+        # (adaptive: its own timing pass over {plain, prefetch, nontemporal, both}; sell: 32-bit columns
+        # forced -- spmv_tune bit 2 would be the 16-bit codes)
+        sv = la.Solver(A, la.default_opts(op_mode=la.OP_RAW, spmv_variant=variant, spmv_tune=tune, spmv_grid=grid,
+                                          use_graph=0, verbose=a.verbose))
+        if sv.spmv_variant != variant or (variant == la.SPMV_SELL and sv.spmv_flags & la.SPMV_FLAG_C16):
+            sys.exit("csr_kernel: asked for variant %d, the solver runs %d / flags %d" % (variant, sv.spmv_variant, sv.spmv_flags))
+        ms = sv.time_spmv(10, 100)
+        moved = sv.spmv_layout_bytes
+        key = "csr_kernel:" + name
+        traffic, src = pmc_traffic(key, name, sv.sell_value_slots, sv.spmv_flags, sv.spmv_period)
+        out["kernels"][name] = {
+            "launch_us": ms * 1e3, "achieved": bytes_csr / ms / 1e6, "frac": bytes_csr / ms / 1e6 / HBM_PEAK_GBPS,
+            "layout_bytes": moved, "frac_layout": moved / ms / 1e6 / HBM_PEAK_GBPS,
+            "spmv_flags": sv.spmv_flags, "grid": sv.spmv_grid, "traffic": traffic,
+            "frac_fabric": (traffic / ms / 1e6 / HBM_PEAK_GBPS) if traffic else None, "traffic_source": src}
+        sv.destroy()
+        torch.cuda.empty_cache()
+    k = out["kernels"]["k_spmv_adaptive"]
+    out.update(kernel="k_spmv_adaptive (CSR arrays: offs, cols, vals)", launch_us=k["launch_us"],
+               achieved=k["achieved"], frac=k["frac"], traffic=k["traffic"], traffic_note=FABRIC_NOTE)
+    return out
+
+
+def cfg2_record(a, c):
+    """BASELINE.json configs[1], N = 1: tests/xn3b_A_18.txt (3461 rows), operator S = triu(A) + triu(A,1)^T,
+    b_i = i, tol 1e-12 -- the reference's protocol (src/cholmod-impl.h:44-63): set-up untimed, `trials`
+    warm-up solves, `trials` timed solves, solves/s = trials / elapsed; Jacobi-PCG (the headline
+    algorithm) and FSAI(3)-PCG (set up once, like the reference's factorisation); x against the golden
+    direct solution; beside it the CPU's cached-factor direct solve on the same box."""
+    import numpy as np
+    path = os.path.join(ROOT, "tests", "golden", "matrices", "xn3b_A_18.txt.gz")
+    A = la.lsb_csr_symmetrize_upper(read_file_matrix(path))
+    n, trials = A.nrows, max(1, a.cfg2_trials)
+    gold = np.fromfile(os.path.join(ROOT, "tests", "golden", "x", "xn3b_A_18.x.f64"), dtype="<f8")
+    d_b = torch.arange(n, dtype=torch.float64, device="cuda")
+    d_x = torch.zeros(n, dtype=torch.float64, device="cuda")
+    out = {"workload": "tests/xn3b_A_18.txt", "rows": n, "nnz": A.nnz, "tol": 1e-12, "trials": trials,
+           "protocol": "set-up untimed, %d warm-up + %d timed solves (src/cholmod-impl.h:44-63), x reset to 0 "
+                       "before every solve" % (trials, trials), "solvers": {}}
+    for name, kw in (("PCG+Jacobi", dict(precond=la.PRECOND_JACOBI)),
+                     ("PCG+FSAI(tril(S^3))", dict(precond=la.PRECOND_FSAI, fsai_power=3))):
+        t = time.perf_counter()
+        sv = la.Solver(A, la.default_opts(op_mode=la.OP_RAW, tol=1e-12, maxit=20000, use_graph=1, persistent=0,
+                                          verbose=a.verbose, **kw))
+        torch.cuda.synchronize()
+        t_setup = time.perf_counter() - t
+        for _ in range(trials):
+            res = sv.solve_dev(d_b, d_x)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(trials):
+            res = sv.solve_dev(d_b, d_x)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        if res.status != la.STATUS_CONVERGED:
+            sys.exit("cfg2 %s: status %d after %d iterations" % (name, res.status, res.iters))
+        err = float(np.linalg.norm(d_x.cpu().numpy() - gold) / np.linalg.norm(gold))
+        if not err <= 1e-10:
+            sys.exit("cfg2 %s: x is %.2e away from the golden solution (bar 1e-10)" % (name, err))
+        out["solvers"][name] = {"value": trials / dt, "unit": "solves/s", "iterations_per_solve": int(res.iters),
+                                "us_per_iteration": dt / trials / max(res.iters, 1) * 1e6, "relres": res.relres,
+                                "err_vs_golden": err, "setup_seconds": t_setup}
+        sv.destroy()
+    out["value"] = out["solvers"]["PCG+Jacobi"]["value"]
+    out["unit"] = "solves/s"
+    out["cpu_direct_baseline"] = cpu_direct_baseline(A, trials)
+    return out
+
+
+def cfg5_record(a, c):
+    """BASELINE.json configs[4], N = 1: the 8 M-row power-law operator (mean 32, max 4096 non-zeros
+    per row, unsymmetric): SpMV only, GB/s on SURVEY 8(d)'s bytes; the form is the timing pass's
+    choice (the two-phase form on every box so far)."""
+    r = run_workload(a, c, "powerlaw", 3, 1, cpu_leg=False)
+    out = {k: r[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step")}
+    out["config"] = r["config"]
+    out["spmv"] = r["roofline"]
+    out["note"] = ("spmv.frac is on SURVEY 8(d)'s count (12 B per non-zero + 20 B per row); the two-phase form moves "
+                   "28.2 B per non-zero by design (products written once, read once), so its ceiling on that count "
+                   "is 0.41 x what its launches stream at -- DESIGN.md section 4, 'What bounds the two-phase form'")
+    return out
+
+
 def main():
     a = parse()
     c = setup_ranks(a)
+    subs = (("csr_kernel", csr_kernel_record), ("cfg2", cfg2_record), ("cfg5", cfg5_record))
+    if a.only:
+        want = a.only.split(",")
+        if c.world != 1 or any(w not in dict(subs) for w in want):
+            sys.exit("--only takes %s, on one GPU" % ", ".join(k for k, _ in subs))
+        line = {"metric": "sub-records only", "n_gpus": 1, "only": want}
+        for k, f in subs:
+            if k in want:
+                line[k] = f(a, c)
+        print(json.dumps(line), flush=True)
+        return
     line = run_workload(a, c, a.workload, a.steps, a.warmup, cpu_leg=True)
     spec = WORKLOADS.get(a.workload, a.workload)
     if a.cfg4 and line["metric"] == "cg_solves_per_sec" and not spec.startswith("lap3d"):
@@ -538,7 +728,7 @@ def main():
         line["cfg4"]["config"] = r4["config"]
         line["cfg4"]["spmv"] = {k: r4["roofline"][k] for k in ("kernel", "launch_ms", "achieved", "frac",
                                                                "algorithmic_bytes", "bytes_basis", "csr_count",
-                                                               "traffic", "frac_hbm", "traffic_source",
+                                                               "traffic", "frac_fabric", "traffic_source",
                                                                "value_slots", "xcd_period_slices", "spmv_flags")}
         line["cfg4"]["note"] = ("BASELINE.json configs[3] on the same %d GPU(s): strong scaling of ONE 64 M-row "
                                 "operator; the >= 6x target is cfg4.value(N=8) / cfg4.value(N=1)" % c.world)
@@ -551,7 +741,7 @@ def main():
         line["general_values"]["config"] = rg["config"]
         line["general_values"]["spmv"] = {k: rg["roofline"][k] for k in (
             "kernel", "launch_ms", "back_to_back_launch_ms", "achieved", "peak", "unit", "frac", "algorithmic_bytes",
-            "bytes_basis", "csr_count", "traffic", "frac_hbm", "traffic_source", "layout_bytes", "value_slots",
+            "bytes_basis", "csr_count", "traffic", "frac_fabric", "traffic_source", "layout_bytes", "value_slots",
             "spmv_flags", "measured")}
         line["general_values"]["note"] = (
             "BASELINE.json configs[2]'s pattern (3162^2 5-point, 49,978,572 nnz) with GENERAL values: one hashed "
@@ -560,6 +750,12 @@ def main():
             "is on the bytes the kernel's layout moves (8 B of value per entry, no column index where a slot is "
             "one diagonal); spmv.csr_count is the same launch on SURVEY 8(d)'s CSR byte count (12 B per entry), "
             "the figure a CSR kernel would have to reach.")
+    if (c.world == 1 and not c.dist_on and line["metric"] == "cg_solves_per_sec" and spec == WORKLOADS["lap2d"]
+            and a.precision == "fp64" and a.fixed_iters == 0 and a.krylov != "gmres" and a.precond == "jacobi"):
+        # the remaining BASELINE.json configs and the SURVEY 8(d) SpMV figure, driver-run (N = 1)
+        for k, f in subs:
+            if getattr(a, k):
+                line[k] = f(a, c)
     if c.rank == 0:
         print(json.dumps(line), flush=True)
     if c.dist_on:

@@ -464,6 +464,13 @@ struct lsb_sell_tmpls {
  * or the copy has code slots (not a structured grid). */
 struct lsb_sell_tmpls *lsb_sell16_templates(const struct lsb_sell *S, const struct lsb_sell_vc *V);
 void lsb_sell_tmpls_free(struct lsb_sell_tmpls *T);
+/* Host-side check of the bounds k_spmv_sell16's constant-slot path and k_spmv_tmpl rely on (their
+ * unguarded 16-byte gathers; value-slot, mask and template indices), for the shard whose first
+ * global row is row_begin, that holds nrows rows and gathers from a vector of xlen entries.  0 =
+ * every rule holds; else a rule number, the rule in `why`.  T may be NULL (no templates).  Run by
+ * the backend at every upload; deep != 0 also walks values and masks. */
+int lsb_tmpl_check(const struct lsb_sell *S, const struct lsb_sell_vc *V, const struct lsb_sell_tmpls *T,
+                   unsigned row_begin, unsigned nrows, unsigned xlen, int deep, char *why, size_t whylen);
 /* mean |col - (row + row_begin)| over a sample of the rows */
 double lsb_csr_mean_scatter(const struct csr *A, unsigned row_begin);
 /* [lo,hi) column range referenced by A (0-based). */

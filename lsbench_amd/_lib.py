@@ -191,6 +191,8 @@ SIGNATURES = {
     "lsb_fsai_pattern_free": (None, [C.POINTER(FsaiPattern)]),
     "lsb_sell16_templates": (C.POINTER(SellTmpls), [C.POINTER(Sell), C.POINTER(SellVc)]),
     "lsb_sell_tmpls_free": (None, [C.POINTER(SellTmpls)]),
+    "lsb_tmpl_check": (_i, [C.POINTER(Sell), C.POINTER(SellVc), C.POINTER(SellTmpls), _u, _u, _u, _i,
+                            C.c_char_p, C.c_size_t]),
     "lsb_csr_mean_scatter": (_d, [_csrp, _u]),
     "lsb_csr_col_hull": (None, [_csrp, C.POINTER(_u), C.POINTER(_u)]),
     "lsb_plan_exchange": (None, [_i, _i, C.POINTER(_u), C.POINTER(Xfer), C.POINTER(_i),

@@ -108,7 +108,8 @@ static const struct optchoice CH_PRECOND[] = {{"jacobi", LSB_PRECOND_JACOBI},   
                                               {"bj", LSB_PRECOND_BLOCKJACOBI},  {"fsai", LSB_PRECOND_FSAI},
                                               {NULL, 0}};
 static const struct optchoice CH_COMM[] = {{"auto", LSB_COMM_AUTO}, {"rccl", LSB_COMM_RCCL}, {"p2p", LSB_COMM_P2P}, {NULL, 0}};
-static const struct optchoice CH_KRYLOV[] = {{"cg", LSB_KRYLOV_PCG},     {"cg1", LSB_KRYLOV_PCG1},
+static const struct optchoice CH_KRYLOV[] = {{"cg", LSB_KRYLOV_PCG},     {"pcg", LSB_KRYLOV_PCG}, /* (alias) */
+                                             {"cg1", LSB_KRYLOV_PCG1},   {"pcg1", LSB_KRYLOV_PCG1},
                                              {"auto", LSB_KRYLOV_AUTO},  {"gmres", LSB_KRYLOV_GMRES}, {NULL, 0}};
 static const struct optchoice CH_PRECISION[] = {{"fp64", LSB_PREC_FP64}, {"fp32", LSB_PREC_MIXED},
                                                 {"mixed", LSB_PREC_MIXED}, {NULL, 0}};

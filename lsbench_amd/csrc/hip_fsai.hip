@@ -259,14 +259,21 @@ void lsb_k_fsai_rows(const unsigned *rows, unsigned nrows, unsigned mcap, const 
     return;
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = (size_t)mcap * mcap * 8 + (size_t)mcap * 8 + (size_t)mcap * 4;
-  static __thread int attr_set = 0;
-  if (!attr_set) { /* more than 64 KB of LDS per workgroup has to be asked for */
-    LSB_CHK_HIP(hipFuncSetAttribute((const void *)k_fsai_rows<256>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    LSB_FSAI_CAP * LSB_FSAI_CAP * 8 + LSB_FSAI_CAP * 12));
-    attr_set = 1;
-  }
   if (mcap > LSB_FSAI_CAP)
     errx(EXIT_FAILURE, "lsb_k_fsai_rows: %u pattern entries per row, at most %d", mcap, LSB_FSAI_CAP);
+  static __thread int attr_set = 0;
+  if (mcap > 32 && !attr_set) { /* the workgroup class only: more than 64 KB of LDS per workgroup has to be
+                                   asked for, and the device has to have it */
+    const int want = LSB_FSAI_CAP * LSB_FSAI_CAP * 8 + LSB_FSAI_CAP * 12;
+    int dev = 0, have = 0;
+    LSB_CHK_HIP(hipGetDevice(&dev));
+    LSB_CHK_HIP(hipDeviceGetAttribute(&have, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
+    if (have < want)
+      errx(EXIT_FAILURE, "lsb_k_fsai_rows: FSAI rows of up to %d entries need %d bytes of LDS per workgroup, this "
+                         "device offers %d (use a smaller --fsai-power)", LSB_FSAI_CAP, want, have);
+    LSB_CHK_HIP(hipFuncSetAttribute((const void *)k_fsai_rows<256>, hipFuncAttributeMaxDynamicSharedMemorySize, want));
+    attr_set = 1;
+  }
   if (mcap <= 32)
     k_fsai_rows<64><<<nrows, 64, lds, s>>>(rows, mcap, offs, cols, vals, row_begin, poffs, pcols, gvals, bad);
   else

@@ -323,6 +323,12 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
            * handful): a 16-byte record per slice instead of 24 per slot, and the three inner diagonals
            * from one gather (k_spmv_tmpl) */
           struct lsb_sell_tmpls *TT = getenv("LSBENCH_HIP_NO_TMPL") ? NULL : lsb_sell16_templates(H, V);
+          { /* the bounds the constant-slot and template kernels rely on (unguarded 16-byte gathers,
+             * value-slot / mask / template indices), against this shard's rows and gather vector */
+            char why[256];
+            if (lsb_tmpl_check(H, V, TT, row_begin, n, n_glob, 0, why, sizeof why))
+              errx(EXIT_FAILURE, "hip_cdna4: sliced-ELL layout breaks a bound its kernels rely on: %s", why);
+          }
           if (TT) {
             if (s->mixed) /* fp32 matrix values: the constants as the fp32 kernels see them */
               for (unsigned t = 0; t < TT->ntmpl; t++)
@@ -877,57 +883,62 @@ void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
   memset(cand, 0, sizeof cand);
   int ncand = 0;
   const int any = o->spmv_variant == LSB_SPMV_AUTO;
+  /* (the bound is checked BEFORE every write) */
+#define CAND(V, F, G, P)                                                                       \
+  do {                                                                                         \
+    if (ncand >= (int)(sizeof cand / sizeof cand[0]))                                          \
+      errx(EXIT_FAILURE, "hip_cdna4: SpMV timing pass: candidate table too small");            \
+    cand[ncand].v = (V), cand[ncand].f = (F), cand[ncand].g = (G), cand[ncand].p = (P), ncand++; \
+  } while (0)
   if (any || s->variant == LSB_SPMV_ADAPTIVE)
     for (unsigned f = 0; f < 4; f++)
-      cand[ncand].v = LSB_SPMV_ADAPTIVE, cand[ncand].f = f, cand[ncand++].g = grid0;
+      CAND(LSB_SPMV_ADAPTIVE, f, grid0, 0);
   if (s->pn && (any || s->variant == LSB_SPMV_PANEL))
     for (unsigned f = 0; f < 4; f++)
-      cand[ncand].v = LSB_SPMV_PANEL, cand[ncand].f = f, cand[ncand++].g = grid0;
+      CAND(LSB_SPMV_PANEL, f, grid0, 0);
   if (s->tp_bins && (any || s->variant == LSB_SPMV_TWOPHASE))
-    cand[ncand].v = LSB_SPMV_TWOPHASE, cand[ncand].f = 0, cand[ncand++].g = grid0;
+    CAND(LSB_SPMV_TWOPHASE, 0, grid0, 0);
   if (s->bn && (any || s->variant == LSB_SPMV_BINNED)) {
     /* stream loads {nontemporal, plain}; the gather of x stays a plain load: L1-
      * bypassing (sc1) gathers measured the same, nontemporal ones 1.7x slower
      * (flags 8 / 16, kept for experiments through opts.spmv_tune) */
     static const unsigned bf[] = {LSB_SP_NT, 0};
     for (unsigned k = 0; k < sizeof bf / sizeof bf[0]; k++)
-      cand[ncand].v = LSB_SPMV_BINNED, cand[ncand].f = bf[k], cand[ncand++].g = grid0;
+      CAND(LSB_SPMV_BINNED, bf[k], grid0, 0);
   }
+  const int periodic = s->sell_period && !getenv("LSBENCH_HIP_NO_PERIOD");
   if (s->d_sptr && (any || s->variant == LSB_SPMV_SELL))
     for (unsigned c16 = 0; c16 <= (s->d_scodes ? LSB_SP_C16 : 0u); c16 += LSB_SP_C16) {
-      cand[ncand].v = LSB_SPMV_SELL, cand[ncand].f = c16 | LSB_SP_NT, cand[ncand++].g = grid0;
-      cand[ncand].v = LSB_SPMV_SELL, cand[ncand].f = c16, cand[ncand++].g = grid0;
+      CAND(LSB_SPMV_SELL, c16 | LSB_SP_NT, grid0, 0);
+      CAND(LSB_SPMV_SELL, c16, grid0, 0);
       if (o->spmv_grid <= 0)
-        cand[ncand].v = LSB_SPMV_SELL, cand[ncand].f = c16 | LSB_SP_NT, cand[ncand++].g = 1536;
-      if (s->sell_period && !getenv("LSBENCH_HIP_NO_PERIOD")) { /* every XCD an eighth of every plane */
-        cand[ncand].v = LSB_SPMV_SELL, cand[ncand].f = c16 | LSB_SP_NT, cand[ncand].p = s->sell_period,
-        cand[ncand++].g = grid0;
-        cand[ncand].v = LSB_SPMV_SELL, cand[ncand].f = c16, cand[ncand].p = s->sell_period,
-        cand[ncand++].g = grid0;
+        CAND(LSB_SPMV_SELL, c16 | LSB_SP_NT, 1536, 0);
+      if (periodic) { /* every XCD an eighth of every plane */
+        CAND(LSB_SPMV_SELL, c16 | LSB_SP_NT, grid0, s->sell_period);
+        CAND(LSB_SPMV_SELL, c16, grid0, s->sell_period);
       }
       if (c16 && s->d_srec) { /* slice templates (no stream to load nontemporally: NT only marks the
                                  flavour as "solve-like" for the 3 % rule below) */
         const unsigned f = c16 | LSB_SP_NT | LSB_SP_TMPL;
-        cand[ncand].v = LSB_SPMV_SELL, cand[ncand].f = f, cand[ncand++].g = grid0;
+        CAND(LSB_SPMV_SELL, f, grid0, 0);
         if (o->spmv_grid <= 0)
-          cand[ncand].v = LSB_SPMV_SELL, cand[ncand].f = f, cand[ncand++].g = 1536;
-        if (s->sell_period && !getenv("LSBENCH_HIP_NO_PERIOD")) {
-          cand[ncand].v = LSB_SPMV_SELL, cand[ncand].f = f, cand[ncand].p = s->sell_period, cand[ncand++].g = grid0;
+          CAND(LSB_SPMV_SELL, f, 1536, 0);
+        if (periodic) {
+          CAND(LSB_SPMV_SELL, f, grid0, s->sell_period);
           if (o->spmv_grid <= 0)
-            cand[ncand].v = LSB_SPMV_SELL, cand[ncand].f = f, cand[ncand].p = s->sell_period, cand[ncand++].g = 1536;
+            CAND(LSB_SPMV_SELL, f, 1536, s->sell_period);
         }
         /* the same with y parked in LDS and stored one turn later (k_spmv_tmpl<.., DEFER>): pays where
          * the vectors come out of HBM, costs ~2 us where they sit in the Infinity Cache */
         if (s->tmpl_nfar >= 1 && s->nnz >= 16000000ull && !getenv("LSBENCH_HIP_NO_DEFER")) {
           const unsigned fd = f | LSB_SP_DEFER, gd = o->spmv_grid <= 0 ? 1536u : grid0;
-          cand[ncand].v = LSB_SPMV_SELL, cand[ncand].f = fd, cand[ncand++].g = gd;
-          if (s->sell_period && !getenv("LSBENCH_HIP_NO_PERIOD"))
-            cand[ncand].v = LSB_SPMV_SELL, cand[ncand].f = fd, cand[ncand].p = s->sell_period, cand[ncand++].g = gd;
+          CAND(LSB_SPMV_SELL, fd, gd, 0);
+          if (periodic)
+            CAND(LSB_SPMV_SELL, fd, gd, s->sell_period);
         }
       }
     }
-  if (ncand > (int)(sizeof cand / sizeof cand[0]))
-    errx(EXIT_FAILURE, "hip_cdna4: SpMV timing pass: candidate table too small");
+#undef CAND
   for (int ci = 0; ci < ncand; ci++) {
     s->variant = cand[ci].v, s->sp_flags = cand[ci].f, s->sp_grid = cand[ci].g, s->sp_period = cand[ci].p;
     spmv_shard(s, s->d_pfull, s->d_q, s->d_pfull + s->row_begin, s->d_parts_pq, &np, NULL);

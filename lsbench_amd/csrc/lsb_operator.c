@@ -6,6 +6,11 @@
  */
 #include "lsb_impl.h"
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#else
+static inline int omp_get_max_threads(void) { return 1; }
+#endif
 
 static struct csr *csr_alloc(unsigned nrows, unsigned long long nnz) {
   if (nnz > 0xFFFFFFFFull)
@@ -869,10 +874,17 @@ struct lsb_fsai_pattern *lsb_csr_fsai_pattern(const struct csr *S, int power, un
       if (!P->cols)
         errx(EXIT_FAILURE, "out of host memory for the FSAI pattern");
     }
-#pragma omp parallel
+    /* 8 n bytes per thread (stamps + list): the team is capped so that they stay below 2 GiB in all
+     * (10 M rows on a 256-thread host would otherwise ask for 20 GB) */
+    int team = omp_get_max_threads();
+    while (team > 1 && (unsigned long long)team * n * 8ull > (2ull << 30))
+      team--;
+#pragma omp parallel num_threads(team)
     {
-      unsigned *stamp = lsb_calloc(unsigned, (size_t)n); /* stamp[j] == i + 1: j reached from row i */
+      unsigned *stamp = (unsigned *)calloc((size_t)n, sizeof(unsigned)); /* stamp[j] == i + 1: j reached from row i */
       unsigned *list = (unsigned *)malloc((size_t)n * sizeof(unsigned));
+      if (!stamp || !list)
+        errx(EXIT_FAILURE, "out of host memory for the FSAI pattern's work arrays (%u rows, %d threads)", n, team);
 #pragma omp for schedule(dynamic, 256)
       for (long long ii = 0; ii < (long long)n; ii++) {
         const unsigned i = (unsigned)ii;
@@ -1301,6 +1313,126 @@ struct lsb_sell_tmpls *lsb_sell16_templates(const struct lsb_sell *S, const stru
     return NULL;
   }
   return T;
+}
+
+/* The bounds k_spmv_sell16's constant-slot path and k_spmv_tmpl rely on, as host assertions (run at
+ * every upload by shard_upload; deep under tests/asan_host.c).  Both kernels issue UNGUARDED 16-byte
+ * gathers x[g + base .. g + base + 1] for the two rows of every lane wherever a slot is constant --
+ * legitimate only because a slot that is constant has 128 real entries, i.e. 128 columns inside the
+ * operator.  This function checks exactly that instead of trusting the builder:
+ *   every slice (constant-slot layout V): a constant slot (value slot -1) carries no code slot and
+ *     0 <= g0 + base, g0 + base + 128 <= xlen with g0 = row_begin + 128 s; a kept slot names a value
+ *     slot < nval_slots; (deep) every non-zero kept value's column g0 + l + base lies in [0, xlen);
+ *   every slice with a template (T): id < ntmpl; template slots ascending, nslots <= 8; constant
+ *     template slots obey the same 128-column rule; a shaped template is [nfar][c-1, c, c+1][nfar]
+ *     with constant far slots and centre and base[c-1] + 1 = base[c] = base[c+1] - 1; only c-1 / c+1
+ *     may be kept (kind 1: vbase + k < nval_slots) or masked (kind 2: first mask + k < nmask); an
+ *     unshaped template is all-constant; the template agrees with the slice's slot records
+ *     (bases; constants bit for bit; (deep) masks and kept values reproduce the slice's 128 values);
+ *   rows >= nrows of the last slice hold no constant slot.
+ * Returns 0 or a rule number with the violated rule in `why`.  Round 3's GPU memory fault
+ * (gpurun_out/r3_probe18) was a probe variant that issued a template's far
+ * gathers for a slice without one: x[row - nx] for rows < nx, the page below the allocation. */
+int lsb_tmpl_check(const struct lsb_sell *S, const struct lsb_sell_vc *V, const struct lsb_sell_tmpls *T,
+                   unsigned row_begin, unsigned nrows, unsigned xlen, int deep, char *why, size_t whylen) {
+#define TC_FAIL(code, ...)                                                                     \
+  do {                                                                                         \
+    if (why && whylen)                                                                         \
+      snprintf(why, whylen, __VA_ARGS__);                                                      \
+    return code;                                                                               \
+  } while (0)
+  if (!S || !V || !S->sptr)
+    TC_FAIL(1, "no layout");
+  const unsigned ns = S->nslice;
+  if ((unsigned long long)ns * LSB_SELL_ROWS < nrows || V->nslots != S->stored / LSB_SELL_ROWS)
+    TC_FAIL(2, "%u slices for %u rows, %llu slot records for %llu slots", ns, nrows, V->nslots,
+            S->stored / LSB_SELL_ROWS);
+  if (T && T->nslice != ns)
+    TC_FAIL(3, "templates of %u slices for a copy of %u", T->nslice, ns);
+  if (T && (T->ntmpl > 254 || T->nfar > 2))
+    TC_FAIL(4, "%u templates (at most 254), %u far slots per side (at most 2)", T->ntmpl, T->nfar);
+  for (unsigned s = 0; s < ns; s++) {
+    const unsigned q0 = S->sptr[s] / LSB_SELL_ROWS, len = (S->sptr[s + 1] - S->sptr[s]) / LSB_SELL_ROWS;
+    const long long g0 = (long long)row_begin + (long long)s * LSB_SELL_ROWS;
+    if (S->sptr[s + 1] < S->sptr[s] || S->sptr[s] % LSB_SELL_ROWS || (unsigned long long)q0 + len > V->nslots)
+      TC_FAIL(5, "slice %u: slots [%u, %u + %u) of %llu", s, q0, q0, len, V->nslots);
+    const unsigned live = nrows - s * LSB_SELL_ROWS < LSB_SELL_ROWS ? nrows - s * LSB_SELL_ROWS : LSB_SELL_ROWS;
+    for (unsigned j = 0; j < len; j++) {
+      const int *r = V->slots + 4 * ((size_t)q0 + j);
+      if (r[2] < 0) { /* constant: the kernels gather all 128 operands without a look at anything */
+        if (r[1] >= 0)
+          TC_FAIL(6, "slice %u slot %u: constant but with code slot %d", s, j, r[1]);
+        if (g0 + r[0] < 0 || g0 + r[0] + LSB_SELL_ROWS > (long long)xlen)
+          TC_FAIL(7, "slice %u slot %u: constant slot gathers x[%lld, %lld) of %u", s, j, g0 + r[0],
+                  g0 + r[0] + LSB_SELL_ROWS, xlen);
+        if (live < LSB_SELL_ROWS)
+          TC_FAIL(8, "slice %u slot %u: constant in a slice that holds only %u rows", s, j, live);
+        if (V->vconst[(size_t)q0 + j] == 0.0)
+          TC_FAIL(9, "slice %u slot %u: constant 0 (padding is never constant)", s, j);
+      } else {
+        if ((unsigned)r[2] >= V->nval_slots)
+          TC_FAIL(10, "slice %u slot %u: value slot %d of %u", s, j, r[2], V->nval_slots);
+        if (r[1] >= 0 && (unsigned)r[1] >= S->ncode_slots)
+          TC_FAIL(11, "slice %u slot %u: code slot %d of %u", s, j, r[1], S->ncode_slots);
+        if (deep && r[1] < 0) {
+          const double *v = V->vals + (size_t)r[2] * LSB_SELL_ROWS;
+          for (unsigned l = 0; l < LSB_SELL_ROWS; l++)
+            if (v[l] != 0.0 && (l >= live || g0 + l + r[0] < 0 || g0 + l + r[0] >= (long long)xlen))
+              TC_FAIL(12, "slice %u slot %u row %u: entry at column %lld of %u (rows in the slice: %u)", s, j, l,
+                      g0 + l + r[0], xlen, live);
+        }
+      }
+    }
+    if (!T || T->tid[s] == 255)
+      continue;
+    if (T->tid[s] >= T->ntmpl)
+      TC_FAIL(13, "slice %u: template %u of %u", s, T->tid[s], T->ntmpl);
+    const struct lsb_sell_tmpl *t = &T->t[T->tid[s]];
+    if (t->nslots < 1 || t->nslots > LSB_TMPL_SLOTS || (unsigned)t->nslots != len)
+      TC_FAIL(14, "slice %u: template of %d slots for a slice of %u", s, t->nslots, len);
+    const int nf = (int)T->nfar, c = nf + 1;
+    if (t->shaped && (t->nslots != 2 * nf + 3 || t->base[c - 1] != t->base[c] - 1 || t->base[c + 1] != t->base[c] + 1))
+      TC_FAIL(15, "slice %u: shaped template without the [%d][c-1, c, c+1][%d] shape", s, nf, nf);
+    const unsigned vb = T->vbase[2 * (size_t)s], mb = T->vbase[2 * (size_t)s + 1];
+    for (int j = 0; j < t->nslots; j++) {
+      const int *r = V->slots + 4 * ((size_t)q0 + j);
+      if (j && t->base[j] <= t->base[j - 1])
+        TC_FAIL(16, "slice %u: template bases not ascending at slot %d", s, j);
+      if (t->base[j] != r[0] || r[1] >= 0)
+        TC_FAIL(17, "slice %u slot %d: template base %d, slot record {%d, %d}", s, j, t->base[j], r[0], r[1]);
+      const int side = t->shaped && (j == c - 1 || j == c + 1);
+      if (t->kind[j] != 0 && !side)
+        TC_FAIL(18, "slice %u slot %d: kind %d outside the slots c-1 / c+1 of a shaped template", s, j, t->kind[j]);
+      if (t->kind[j] == 0) {
+        if (t->kidx[j] != -1 || r[2] >= 0 || memcmp(&t->cst[j], &V->vconst[(size_t)q0 + j], sizeof(double)))
+          TC_FAIL(19, "slice %u slot %d: template constant %g, slot record {value slot %d, constant %g}", s, j,
+                  t->cst[j], r[2], V->vconst[(size_t)q0 + j]);
+        /* (its 128-column rule was checked on the slot record above: same base) */
+      } else if (t->kind[j] == 1) {
+        if (t->kidx[j] < 0 || (unsigned long long)vb + (unsigned)t->kidx[j] >= V->nval_slots ||
+            r[2] != (int)(vb + (unsigned)t->kidx[j]))
+          TC_FAIL(20, "slice %u slot %d: kept slot %u + %d, slot record names %d of %u", s, j, vb, t->kidx[j], r[2],
+                  V->nval_slots);
+      } else if (t->kind[j] == 2) {
+        if (t->kidx[j] < 0 || (unsigned long long)mb + (unsigned)t->kidx[j] >= T->nmask || r[2] < 0 ||
+            (unsigned)r[2] >= V->nval_slots || t->cst[j] == 0.0)
+          TC_FAIL(21, "slice %u slot %d: mask %u + %d of %llu (value slot %d, number %g)", s, j, mb, t->kidx[j],
+                  T->nmask, r[2], t->cst[j]);
+        if (deep) { /* the mask and the number reproduce the slot's 128 values bit for bit */
+          const unsigned long long *m = T->mask + 2 * ((size_t)mb + (unsigned)t->kidx[j]);
+          const double *v = V->vals + (size_t)r[2] * LSB_SELL_ROWS;
+          for (unsigned l = 0; l < LSB_SELL_ROWS; l++) {
+            const double want = (m[l >> 6] >> (l & 63u)) & 1ull ? t->cst[j] : 0.0;
+            if (memcmp(&want, &v[l], sizeof want) && !(want == 0.0 && v[l] == 0.0))
+              TC_FAIL(22, "slice %u slot %d row %u: mask gives %g, the slot holds %g", s, j, l, want, v[l]);
+          }
+        }
+      } else
+        TC_FAIL(23, "slice %u slot %d: kind %d", s, j, t->kind[j]);
+    }
+  }
+  return 0;
+#undef TC_FAIL
 }
 
 void lsb_sell_tmpls_free(struct lsb_sell_tmpls *T) {

@@ -74,6 +74,37 @@ int main(void) {
       if (H16) {
         struct lsb_sell_vc *Vc = lsb_sell16_value_slots(H16);
         struct lsb_sell_tmpls *Tm = lsb_sell16_templates(H16, Vc);
+        /* the template kernel's bounds (deep), and three broken rules must be CAUGHT: a gather vector
+         * one entry short, a far base one grid line too far, a mask index past the array */
+        char why[256];
+        if (lsb_tmpl_check(H16, Vc, Tm, 0, A->nrows, n, 1, why, sizeof why)) { printf("tmpl_check: %s\n", why); return 1; }
+        if (lsb_tmpl_check(H16, Vc, NULL, 0, A->nrows, n, 1, why, sizeof why)) { printf("tmpl_check (no templates): %s\n", why); return 1; }
+        if (Tm && Tm->covered) {
+          long long reach = -1; /* one past the last column a constant slot's 128 gathers touch */
+          for (unsigned s = 0; s < H16->nslice; s++)
+            for (unsigned q = H16->sptr[s] / LSB_SELL_ROWS; q < H16->sptr[s + 1] / LSB_SELL_ROWS; q++)
+              if (Vc->slots[4 * (size_t)q + 2] < 0 && (long long)s * LSB_SELL_ROWS + Vc->slots[4 * (size_t)q] + LSB_SELL_ROWS > reach)
+                reach = (long long)s * LSB_SELL_ROWS + Vc->slots[4 * (size_t)q] + LSB_SELL_ROWS;
+          if (reach > 0 && (reach > (long long)n || lsb_tmpl_check(H16, Vc, Tm, 0, A->nrows, (unsigned)reach - 1, 0, why, sizeof why) != 7)) {
+            printf("tmpl_check accepted a gather vector one entry short of a constant slot's reach\n"); return 1; }
+          for (unsigned s = 0; s < Tm->nslice; s++)
+            if (Tm->tid[s] != 255) {
+              struct lsb_sell_tmpl *t = &Tm->t[Tm->tid[s]];
+              const int keep = t->base[0];
+              t->base[0] -= 1;
+              const int rc = lsb_tmpl_check(H16, Vc, Tm, 0, A->nrows, n, 0, why, sizeof why);
+              t->base[0] = keep;
+              if (rc == 0) { printf("tmpl_check accepted a template base that disagrees with its slice\n"); return 1; }
+              break;
+            }
+          if (Tm->nmask) {
+            const unsigned long long keep = Tm->nmask;
+            Tm->nmask = 0;
+            const int rc = lsb_tmpl_check(H16, Vc, Tm, 0, A->nrows, n, 0, why, sizeof why);
+            Tm->nmask = keep;
+            if (rc != 21) { printf("tmpl_check accepted a mask index past the mask array (rc %d)\n", rc); return 1; }
+          }
+        }
         lsb_sell_tmpls_free(Tm), lsb_sell_vc_free(Vc), lsb_sell_free(H16);
       }
     }

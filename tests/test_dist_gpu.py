@@ -111,6 +111,11 @@ def test_bench_two_ranks_on_one_gpu():
     assert abs(two["config"]["iterations_per_solve"] - one["config"]["iterations_per_solve"]) <= 2
     assert two["config"]["relres"] <= 1e-8 and "single-reduction" in two["config"]["solver"]
     assert two["config"]["nnz"] == one["config"]["nnz"]
+    # load balance of a sharded line: per-rank time per iteration and SpMV launch (min / max), rows, non-zeros
+    pr = two["per_rank"]
+    assert one["per_rank"] is None and len(pr["rows"]) == 2 and sum(pr["rows"]) == 350000
+    assert sum(pr["nnz"]) == two["config"]["nnz"] and 0 < pr["iteration_us"]["min"] <= pr["iteration_us"]["max"]
+    assert 0 <= pr["spmv_us"]["min"] <= pr["spmv_us"]["max"]
 
 
 @pytest.mark.parametrize("ngpus,comm,matrix", [

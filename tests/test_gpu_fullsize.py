@@ -175,9 +175,10 @@ def test_lap3d_64m_rows(hip):
 
 
 def test_bench_line_contract():
-    """`python bench.py` end to end at full size (config 3 + the cfg4 sub-record):
-    ONE JSON line with the contract's keys, the roofline and cpu_baseline objects,
-    a solve that is converged on the residual recomputed from x."""
+    """`python bench.py` end to end at full size: ONE JSON line with the contract's keys, the
+    roofline and cpu_baseline objects, a solve that is converged on the residual recomputed from
+    x -- and a sub-record for every other BASELINE.json config (cfg2, cfg4, cfg5; general_values)
+    plus csr_kernel, the SpMV figure that follows SURVEY 8(d) to the letter."""
     import json
     import os
     import subprocess
@@ -192,7 +193,7 @@ def test_bench_line_contract():
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
               "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "cfg4",
-              "general_values"):
+              "general_values", "csr_kernel", "cfg2", "cfg5"):
         assert k in d, k
     assert d["metric"] == "cg_solves_per_sec" and d["unit"] == "solves/s" and d["n_gpus"] == 1
     assert d["dtype"] == "f64" and d["vs_baseline"] is None and d["higher_is_better"] is True
@@ -210,7 +211,8 @@ def test_bench_line_contract():
     csr = 12 * 49978572 + 20 * 9998244 + 4
     assert rf["csr_count"]["bytes"] == csr and rf["algorithmic_bytes"] == rf["layout_bytes"] < csr // 3
     assert rf["algorithmic_bytes"] >= 16 * 9998244            # x once + y once at the very least
-    assert rf["traffic"] is None or (0.3 < rf["frac_hbm"] <= 1.0 and rf["traffic"] >= 0.9 * rf["algorithmic_bytes"])
+    assert rf["traffic"] is None or (0.3 < rf["frac_fabric"] <= 1.0 and rf["traffic"] >= 0.9 * rf["algorithmic_bytes"])
+    assert "frac_hbm" not in rf and "Infinity Cache" in rf["traffic_note"]
     assert rf["traffic_source"] and len(rf["kernels_sha16"]) == 16
     assert d["comm"]["rccl_ranks"] == 0 and d["comm"]["recv_peers"] == 0   # one shard: no communicator
     # the whole iteration on the same peak: SpMV layout bytes + the sweeps' 9 vector passes (constant
@@ -238,6 +240,30 @@ def test_bench_line_contract():
     assert c4["config"]["rows"] == 64000000 and c4["config"]["nnz"] == 447040000 and c4["value"] > 0
     assert c4["config"]["true_relres"] <= c4["config"]["tol"] * (1 + 1e-6) and c4["n_gpus"] == 1
     assert "pcg_iteration_GBps" not in d
+    # SURVEY 8(d) to the letter: kernels that stream 12 B per non-zero, on the CSR byte count, after
+    # >= 10 warm-ups over >= 100 launches -- a fraction (<= 1) by construction, target >= 0.6
+    ck = d["csr_kernel"]
+    assert ck["algorithmic_bytes"] == csr and ck["workload"].endswith("coef=1") and ck["timed_launches"] >= 100
+    assert ck["warmup_launches"] >= 10 and ck["kernel"].startswith("k_spmv_adaptive")
+    assert abs(ck["frac"] - csr / ck["launch_us"] / 1e3 / 8000.0) < 1e-9 and 0.55 <= ck["frac"] <= 1.0
+    for name, k in ck["kernels"].items():
+        assert 0.55 <= k["frac"] <= 1.0 and k["layout_bytes"] >= 12 * 49978572 + 16 * 9998244, name
+        assert k["layout_bytes"] <= csr + 8 * 9998244 and not k["spmv_flags"] & 4          # 32-bit columns
+    assert set(ck["kernels"]) == {"k_spmv_adaptive", "k_spmv_sell"}
+    # configs[1]: the reference's protocol on its own test matrix, x against the golden direct solve
+    c2 = d["cfg2"]
+    assert c2["rows"] == 3461 and c2["tol"] == 1e-12 and c2["trials"] == 100
+    for name in ("PCG+Jacobi", "PCG+FSAI(tril(S^3))"):
+        sv = c2["solvers"][name]
+        assert sv["value"] > 50 and sv["err_vs_golden"] <= 1e-10 and sv["relres"] <= 1e-12
+    assert abs(c2["solvers"]["PCG+Jacobi"]["iterations_per_solve"] - 267) <= 2
+    assert c2["solvers"]["PCG+FSAI(tril(S^3))"]["iterations_per_solve"] < 80
+    assert c2["cpu_direct_baseline"]["cores"] == 1 and c2["cpu_direct_baseline"]["value"] > 0
+    # configs[4]: the power-law SpMV on SURVEY's bytes
+    c5 = d["cfg5"]
+    assert c5["metric"] == "fp64_csr_spmv_GBps" and c5["config"]["rows"] == 8000000
+    assert c5["spmv"]["algorithmic_bytes"] == 12 * c5["config"]["nnz_per_gpu"] + 20 * 8000000 + 4
+    assert 0.1 < c5["spmv"]["frac"] <= 1.0 and abs(c5["value"] - c5["spmv"]["achieved"]) < 1e-6 * c5["value"]
 
 
 def test_powerlaw_spd_8m_rows_cg(hip):

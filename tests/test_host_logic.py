@@ -736,3 +736,49 @@ def test_templates_cover_a_structured_grid():
     V = lib.lsb_sell16_value_slots(H)
     assert not lib.lsb_sell16_templates(H, V)
     lib.lsb_sell_vc_free(V), lib.lsb_sell_free(H)
+
+
+def test_tmpl_check_states_the_template_kernels_bounds():
+    """lsb_tmpl_check (run by the backend at every upload): every unguarded 16-byte gather of
+    k_spmv_sell16's constant-slot path and of k_spmv_tmpl stays inside the gather vector, every
+    value-slot / mask / template index inside its array -- on whole operators and on shards cut
+    inside a plane (row_begin > 0, column ids global).  And the access behind round 3's GPU memory
+    fault (gpurun_out/r3_probe18: a template's far gathers issued for a slice that has no template,
+    x[row - nx] for rows < nx) is exactly what rule 7 refuses: a constant far slot put on the first
+    slice, or a gather vector that starts later than the operator's column 0."""
+    import ctypes as C
+    lib = la._lib.load()
+    why = C.create_string_buffer(256)
+    for spec in ("lap2d:nx=411,ny=203", "lap3d:nx=64,ny=64,nz=40", "lap3d:nx=40,ny=36,nz=30", "lap2d:nx=9000,ny=1",
+                 "lap2d:nx=411,ny=203,coef=1"):
+        n = la.lsbench_matrix_synth(spec, 0, 1).n_global
+        for r0, r1 in ((0, n), (n // 3 & ~1, 2 * n // 3 & ~1), (2 * n // 3 & ~1, n)):
+            A = la.lsbench_matrix_synth(spec, r0, r1)
+            H = lib.lsb_csr_sellize16(A.ptr, r0)
+            V = lib.lsb_sell16_value_slots(H)
+            T = lib.lsb_sell16_templates(H, V)                     # NULL for general values / small shards
+            for deep in (0, 1):
+                assert lib.lsb_tmpl_check(H, V, T, r0, A.nrows, n, deep, why, 256) == 0, (spec, r0, why.value)
+            # one entry less than the columns the shard references: refused wherever a CONSTANT slot
+            # reaches the last column it may (rule 7), or a kept value does (rule 12, deep)
+            hi = int(A.cols.max()) + 1
+            assert lib.lsb_tmpl_check(H, V, T, r0, A.nrows, hi - 1, 1, why, 256) in (7, 12), (spec, r0)
+            if T and r0 == 0:
+                t, v = T.contents, V.contents
+                # the first slice of the operator has no template (its -nx slot is padding) ...
+                assert t.tid[0] == 255 or "ny=1" in spec
+                # ... and a constant slot reaching below column 0 there is refused
+                q0 = H.contents.sptr[0] // 128
+                keep = (v.slots[4 * q0], v.slots[4 * q0 + 2], v.vconst[q0])
+                v.slots[4 * q0], v.slots[4 * q0 + 2], v.vconst[q0] = -5, -1, -1.0
+                rc = lib.lsb_tmpl_check(H, V, T, r0, A.nrows, n, 0, why, 256)
+                v.slots[4 * q0], v.slots[4 * q0 + 2], v.vconst[q0] = keep
+                assert rc == 7 and b"gathers x[-5" in why.value
+            if T:                                                  # a mask / value index one past its array
+                t = T.contents
+                if t.nmask:
+                    keep, t.nmask = t.nmask, 0
+                    assert lib.lsb_tmpl_check(H, V, T, r0, A.nrows, n, 0, why, 256) == 21
+                    t.nmask = keep
+                lib.lsb_sell_tmpls_free(T)
+            lib.lsb_sell_vc_free(V), lib.lsb_sell_free(H)

@@ -285,3 +285,38 @@ def test_constant_slots_change_no_bit(hip, monkeypatch, spec, nvirt, precision):
             assert out["tmpl"][4] < out["const"][4]
     yo = O.spmv(A.offs, A.cols, A.vals, xs)
     assert np.allclose(out["tmpl"][0], yo, rtol=1e-13, atol=1e-13)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spec", ["lap2d:nx=2050,ny=60", "lap3d:nx=64,ny=64,nz=40", "lap2d:nx=50001,ny=1"])
+def test_template_solves_repeat_under_graph_replay_sampling_and_a_maxit_cut(hip, spec):
+    """The conditions of round 3's unexplained failure (gpurun_out/r3_mask: the removed k_spmv_tmpl_p
+    test -- second solve of one solver 1e-5 away from the first on the 64 x 64 x 40 grid once masked
+    slots came in), replayed on what ships: the template kernel with masked slots (spmv_tune 6|64)
+    and its deferred-store form (|128), under {launches, SpMV sampling, hipGraph replay, a run cut by
+    maxit}, every solve twice on one solver (the second on the first one's iteration hint, i.e.
+    through the hinted whole-solve graph) -- x, iteration count, status and residual bit for bit,
+    equal across all forms, and the converged ones equal to the oracle's PCG."""
+    A = hip.lsbench_matrix_synth(spec)
+    b = O.rhs(A.nrows)
+    out = {}
+    for tune in (6 | 64, 6 | 64 | 128):
+        for graph, sample, maxit in ((0, 0, 20000), (0, 5, 20000), (1, 0, 20000), (0, 0, 5), (1, 0, 5)):
+            s = hip.Solver(A, hip.default_opts(op_mode=hip.OP_RAW, spmv_variant=hip.SPMV_SELL, tol=1e-10,
+                                               spmv_tune=tune, use_graph=graph, sample_spmv=sample, maxit=maxit))
+            assert s.spmv_flags == tune
+            x, r = s.solve(b)
+            for _ in range(2):
+                x2, r2 = s.solve(b)
+                assert np.array_equal(x, x2) and r.iters == r2.iters and r.relres == r2.relres, (tune, graph, sample, maxit)
+            s.destroy()
+            assert r.status == (hip.STATUS_MAXIT if maxit == 5 else hip.STATUS_CONVERGED)
+            if sample:
+                assert r.spmv_samples > 0 and r.spmv_ms > 0
+            out[(tune, graph, sample, maxit)] = (x, int(r.iters), r.relres)
+    for key, val in out.items():
+        ref = out[(6 | 64, 0, 0, key[3])]
+        assert np.array_equal(val[0], ref[0]) and val[1:] == ref[1:], key
+    xo, ito, relo, sto = O.pcg_jacobi(A.offs, A.cols, A.vals, b, 1e-10)
+    x, it, rel = out[(6 | 64, 1, 0, 20000)]
+    assert abs(it - ito) <= 2 and np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-8

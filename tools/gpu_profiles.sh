@@ -7,7 +7,7 @@ OUT=gpurun_out/${1:-profiles}; mkdir -p $OUT; export TMPDIR=/tmp
 step() { local name=$1 secs=$2; shift 2
   echo "=== $name"; timeout -k 10 "$secs" "$@" > "$OUT/$name.log" 2>&1; local rc=$?
   echo "rc=$rc"; if [ $rc -ge 124 ]; then echo "step $name killed: stopping"; exit $rc; fi; }
-Q="--cpu-seconds 0 --cfg4 0 --general-values 0"
+Q="--cpu-seconds 0 --cfg4 0 --general-values 0 --csr-kernel 0 --cfg2 0 --cfg5 0"
 F=file:tests/golden/matrices/xn3b_A_18.txt.gz
 step bench 600 python bench.py
 step trace 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --steps 1 --warmup 0 $Q
@@ -18,6 +18,17 @@ step bench_coef 400 python bench.py $G --steps 2 $Q
 step trace_coef 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_coef" -- python3 bench.py $G --fixed-iters 200 --steps 1 --warmup 0 $Q
 step pmc_fetch_coef 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch_coef" -- python3 bench.py $G --fixed-iters 60 --steps 1 --warmup 0 $Q
 step pmc_write_coef 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write_coef" -- python3 bench.py $G --fixed-iters 60 --steps 1 --warmup 0 $Q
+step bench_coef_fp32 400 python bench.py $G --precision fp32 --steps 2 $Q
+step trace_coef_fp32 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_coef_fp32" -- python3 bench.py $G --precision fp32 --fixed-iters 200 --steps 1 --warmup 0 $Q
+# SURVEY 8(d) to the letter: the kernels that stream 12 B per non-zero (bench.py's csr_kernel record)
+step trace_csr 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_csr" -- python3 bench.py --only csr_kernel
+step pmc_fetch_csr 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch_csr" -- python3 bench.py --only csr_kernel
+step pmc_write_csr 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write_csr" -- python3 bench.py --only csr_kernel
+# GMRES(30): throughput on config 3's pattern with general values (a fixed number of inner steps), and to
+# the tolerance on the raw, unsymmetrised tests/xn3b_A_18.txt
+step gmres_coef 400 python bench.py $G --krylov gmres --restart 30 --fixed-iters 300 --steps 2 --warmup 1 $Q
+step trace_gmres 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_gmres" -- python3 bench.py $G --krylov gmres --restart 30 --fixed-iters 120 --steps 1 --warmup 0 $Q
+step gmres_xn3b_raw 300 python bench.py --workload $F --operator raw --krylov gmres --restart 30 --tol 1e-10 --steps 20 --warmup 2 --verify 0 $Q
 step trace_lap3d 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_lap3d" -- python3 bench.py --workload lap3d --fixed-iters 100 --steps 1 --warmup 0 $Q
 step pmc_fetch_lap3d 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch_lap3d" -- python3 bench.py --workload lap3d --fixed-iters 40 --steps 1 --warmup 0 $Q
 step pmc_write_lap3d 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write_lap3d" -- python3 bench.py --workload lap3d --fixed-iters 40 --steps 1 --warmup 0 $Q

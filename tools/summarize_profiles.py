@@ -17,7 +17,8 @@ def one(pattern):
     return g[-1] if g else None  # newest run wins
 
 
-for tag in ("trace", "trace_coef", "trace_lap3d", "trace_cfg2", "trace_cfg2_fsai", "trace_powerlaw"):
+for tag in ("trace", "trace_coef", "trace_lap3d", "trace_cfg2", "trace_cfg2_fsai", "trace_powerlaw", "trace_csr",
+            "trace_gmres", "trace_coef_fp32"):
     f = one(tag + "/*/*kernel_stats.csv")
     if f:
         shutil.copyfile(f, os.path.join(out, "%s_%s_kernel_stats.csv" % (rnd, tag)))
@@ -102,14 +103,54 @@ for wl, suffix in (("lap2d", ""), ("lap2d_coef", "_coef"), ("lap3d", "_lap3d"), 
         traffic[wl] = {"bytes": best[2], "kernel": best[0], "launches": best[1],
                        "kernels_sha16": roof.get("kernels_sha16"),
                        "value_slots": [vs.get("kept", 0), vs.get("all", 0)],
+                       # the flavour the timing pass of the profiled run picked: bench.py quotes the
+                       # figure only for a run that picked the same
+                       "spmv_flags": roof.get("spmv_flags"), "xcd_period_slices": roof.get("xcd_period_slices"),
                        "source": "profiles/%s_pmc_traffic_%s.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                  "separate passes of this command; FETCH_SIZE x 2)" % (rnd, wl)}
     print(wl)
     print("\n".join(lines))
+# csr_kernel (bench.py --only csr_kernel): the two kernels that stream 12 B per non-zero
+pmc = {}
+for cname, tag in (("FETCH_SIZE", "pmc_fetch_csr"), ("WRITE_SIZE", "pmc_write_csr")):
+    f = one(tag + "/*/*counter_collection.csv")
+    if not f:
+        continue
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == cname:
+            agg[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        v.sort()
+        pmc.setdefault(k, {})[cname] = (v[len(v) // 2], len(v))
+line = (bench_line_of("pmc_fetch_csr") or {}).get("csr_kernel")
+if pmc and line:
+    lines = ["kernel,launches,FETCH_SIZE_KB(median),fetch_bytes_corrected_x2,WRITE_SIZE_KB(median),write_bytes,hbm_bytes_per_launch"]
+    for short in ("k_spmv_adaptive", "k_spmv_sell"):
+        best = None
+        for k, d in pmc.items():
+            if k.split("<")[0].split()[-1] == short and "FETCH_SIZE" in d and "WRITE_SIZE" in d and d["FETCH_SIZE"][1] > 20:
+                if best is None or d["FETCH_SIZE"][1] > best[1]["FETCH_SIZE"][1]:
+                    best = (k, d)
+        if not best:
+            continue
+        fb, wb = 2 * best[1]["FETCH_SIZE"][0] * 1024, best[1]["WRITE_SIZE"][0] * 1024
+        lines.append("%s,%d,%.1f,%.0f,%.1f,%.0f,%.0f" % (best[0], best[1]["FETCH_SIZE"][1], best[1]["FETCH_SIZE"][0], fb,
+                                                         best[1]["WRITE_SIZE"][0], wb, fb + wb))
+        kk = line["kernels"][short]
+        traffic["csr_kernel:" + short] = {
+            "bytes": fb + wb, "kernel": short, "launches": best[1]["FETCH_SIZE"][1],
+            "kernels_sha16": line.get("kernels_sha16"), "value_slots": [0, 0],
+            "spmv_flags": kk["spmv_flags"], "xcd_period_slices": 0,
+            "source": "profiles/%s_pmc_traffic_csr_kernel.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes "
+                      "of `bench.py --only csr_kernel`; FETCH_SIZE x 2)" % rnd}
+    open(os.path.join(out, "%s_pmc_traffic_csr_kernel.csv" % rnd), "w").write("\n".join(lines) + "\n")
+    print("csr_kernel")
+    print("\n".join(lines))
 if traffic:
     json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 # bench lines
-names = ["bench", "bench_coef", "bench_powerlaw", "bench_powerlaw_v7", "bench_powerlaw_v6", "bench_powerlaw_v1", "cfg5_spd_cg", "cfg2_launches", "cfg2_persistent",
+names = ["bench", "bench_coef", "bench_coef_fp32", "gmres_coef", "gmres_xn3b_raw", "only_subrecords", "bench_powerlaw", "bench_powerlaw_v7", "bench_powerlaw_v6", "bench_powerlaw_v1", "cfg5_spd_cg", "cfg2_launches", "cfg2_persistent",
          "cfg2_dense_inverse", "cfg2_cheb4", "cfg2_fsai2", "cfg2_fsai3", "cfg2_fsai3_six_launches", "cfg3_no_templates", "cfg3_fp32", "cfg3_cheb4", "cfg3_cheb16", "cfg3_bj8"]
 with open(os.path.join(out, "%s_bench.jsonl" % rnd), "w") as fo:
     for tag in names:
