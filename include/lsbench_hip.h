@@ -569,6 +569,11 @@ int lsb_hip_solver_comm(const lsb_hip_solver *s, double *p2p_us, double *rccl_us
  * all-gather (every shard needs every row), 0 for point-to-point halos, plan[6] shards
  * in this process, plan[7] 1 when the halo travels behind the interior rows. */
 void lsb_hip_solver_comm_plan(const lsb_hip_solver *s, unsigned long long plan[8]);
+/* opts.overlap = -1: the creation-time timing of the sharded SpMV's two forms on the real
+ * communicator (hip_dist.c overlap_setup): us[0] per iteration with the SpMV behind the exchange,
+ * us[1] with the interior rows in front of the halo (slowest rank's, 0 where the pass did not run).
+ * Returns the form in use: 1 split, 0 plain. */
+int lsb_hip_solver_overlap(const lsb_hip_solver *s, double us[2]);
 /* Matrix-side bytes ONE launch of the SpMV form in use must stream (its index, code, slot
  * and value arrays as stored) + x read once + y written once, first shard; 0 for the
  * multi-pass forms (binned, two-phase).  SURVEY 8(d)'s CSR count is 12 nnz + 20 n + 4. */

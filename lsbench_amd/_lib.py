@@ -27,6 +27,7 @@ SELL_ROWS = 128
 BIN_CHUNK = 2048
 PB_COLS, PB_ROWS = 8192, 2048
 SPMV_FLAG_PREFETCH, SPMV_FLAG_NT, SPMV_FLAG_C16, SPMV_FLAG_TMPL, SPMV_FLAG_DEFER = 1, 2, 4, 64, 128
+SPMV_FLAG_DEEP2, SPMV_FLAG_DEEP4 = 256, 512
 STATUS_RUNNING, STATUS_CONVERGED, STATUS_BREAKDOWN, STATUS_MAXIT = 0, 1, 2, 3
 STATUS_COMM = 4
 COMM_AUTO, COMM_RCCL, COMM_P2P = 0, 1, 2
@@ -217,6 +218,7 @@ SIGNATURES = {
     "lsb_hip_solver_spmv_period": (_u, [_vp]),
     "lsb_hip_solver_sell_value_slots": (None, [_vp, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
     "lsb_hip_solver_overlaps": (_i, [_vp]),
+    "lsb_hip_solver_overlap": (_i, [_vp, C.POINTER(C.c_double)]),
     "lsb_hip_solver_comm_plan": (None, [_vp, C.POINTER(C.c_ulonglong)]),
     "lsb_hip_solver_spmv_layout_bytes": (C.c_ulonglong, [_vp]),
     "lsb_hip_solver_fused_p": (_i, [_vp]),

@@ -347,10 +347,14 @@ class Solver:
         """The exchange plan of this process's first shard (see lsbench_hip.h)."""
         p = (C.c_ulonglong * 8)()
         L.load().lsb_hip_solver_comm_plan(self._h, p)
+        us = (C.c_double * 2)()
+        L.load().lsb_hip_solver_overlap(self._h, us)
         return {"rccl_ranks": int(p[0]), "recv_peers": int(p[1]), "send_peers": int(p[2]),
                 "bytes_recv_per_exchange": int(p[3]), "bytes_sent_per_exchange": int(p[4]),
                 "pattern": "all-gather" if p[5] else "halos (point-to-point)",
-                "shards_in_process": int(p[6]), "overlap": bool(p[7])}
+                "shards_in_process": int(p[6]), "overlap": bool(p[7]),
+                # opts.overlap = -1: both forms of the sharded SpMV timed on this communicator at creation
+                "overlap_timed_us": {"plain": us[0], "split": us[1]} if us[0] > 0 else None}
 
     @property
     def comm(self):

@@ -139,13 +139,81 @@ int can_overlap(const lsb_hip_solver *sv) {
     if (!(s->variant == LSB_SPMV_ADAPTIVE && s->ov_ok) && !(s->variant == LSB_SPMV_SELL && s->ov_sok))
       return 0;
   }
-  /* auto: the split SpMV costs 2 launches (direct path) or 2 launches and two
-   * cross-stream events (RCCL), 6-20 us; a halo of >= 64 Ki doubles takes
-   * longer than that on one xGMI link.  agree_halo is the largest halo of ANY
-   * rank, so every rank takes the same branch. */
+  /* auto: the split SpMV costs 2 launches (direct path) or 2 launches and two cross-stream events
+   * (RCCL) -- 18-25 us per iteration on one device -- and can only win what a halo transfer takes,
+   * which no rule of thumb knows: both forms are TIMED on the real communicator at creation
+   * (overlap_setup) and every rank takes the decision from the same all-gathered numbers.  Until
+   * that pass has run (and where it cannot): no split. */
   if (sv->o.overlap < 0)
-    return sv->agree_halo >= 65536u;
+    return sv->overlap_on > 0;
   return 1;
+}
+
+/* opts.overlap = -1: which form of the sharded SpMV is faster HERE -- the plain one behind the
+ * exchange, or interior rows while the halo travels, boundary rows behind it.  24 iterations of the
+ * solver's own iteration (exchange, all-reduce, everything) each way on b_i = i, best of two after a
+ * warm-up, the slowest rank's time decides (all-gathered: every rank takes the same branch).  Untimed
+ * set-up, like the transport's self-test.  Round 3 decided by halo size (>= 64 Ki doubles: split),
+ * which every one-device measurement contradicted (config 4 as 8 virtual shards: 185 / 223 us split
+ * against 167 / 198 plain, profiles/r03_cfg4_share.txt). */
+void overlap_setup(lsb_hip_solver *sv) {
+  sv->overlap_on = -1, sv->overlap_us[0] = sv->overlap_us[1] = 0.0;
+  if (!sv->multi || sv->o.overlap >= 0 || sv->o.krylov == LSB_KRYLOV_GMRES || getenv("LSBENCH_HIP_NO_OVERLAP_TUNE"))
+    return;
+  unsigned can = 1; /* the split needs the prefix / interior / suffix shape on every shard of every rank */
+  for (int i = 0; i < sv->nshard; i++) {
+    const struct shard *s = &sv->sh[i];
+    can &= (s->variant == LSB_SPMV_ADAPTIVE && s->ov_ok) || (s->variant == LSB_SPMV_SELL && s->ov_sok);
+  }
+  const int P = sv->dist ? lsb_hip_comm_size() : 1;
+  unsigned *all = lsb_calloc(unsigned, 2 * (size_t)P), mine[2] = {can, 0};
+  if (sv->dist)
+    lsb_hip_comm_allgather_u32(mine, 1, all);
+  else
+    all[0] = can;
+  for (int q = 0; q < P; q++)
+    can &= all[q];
+  if (!can) {
+    free(all);
+    return;
+  }
+  double *d_b = (double *)lsb_hip_malloc((size_t)sv->n_here * sizeof(double));
+  double *d_x = (double *)lsb_hip_malloc((size_t)sv->n_here * sizeof(double));
+  lsb_k_fill_index(sv->n_here, sv->row_first + 1u, d_b, g_stream);
+  const struct lsb_hip_opts keep = sv->o;
+  const int iters = 24;
+  sv->o.tol = 0.0, sv->o.maxit = (unsigned)iters, sv->o.verify = 0, sv->o.sample_spmv = 0;
+  for (int form = 0; form < 2; form++) {
+    sv->overlap_on = form;
+    double best = 1e30;
+    for (int rep = 0; rep < 3; rep++) {
+      struct lsb_hip_result r;
+      solve_core(sv, d_b, d_x, &r);
+      if (rep && r.seconds < best)
+        best = r.seconds;
+    }
+    mine[form] = (unsigned)(best * 1e9 / iters); /* ns per iteration */
+  }
+  if (sv->dist)
+    lsb_hip_comm_allgather_u32(mine, 2, all);
+  else
+    all[0] = mine[0], all[1] = mine[1];
+  unsigned t[2] = {0, 0};
+  for (int q = 0; q < P; q++)
+    for (int f = 0; f < 2; f++)
+      if (all[2 * q + f] > t[f])
+        t[f] = all[2 * q + f];
+  free(all);
+  sv->o = keep;
+  memset(sv->hint_iters, 0, sizeof sv->hint_iters);
+  drop_graphs(sv);
+  sv->overlap_us[0] = t[0] * 1e-3, sv->overlap_us[1] = t[1] * 1e-3;
+  sv->overlap_on = t[1] < t[0];
+  if (sv->o.verbose)
+    fprintf(stderr, "hip_cdna4: sharded SpMV: %.1f us per iteration behind the exchange, %.1f us with the interior "
+                    "rows in front of the halo -> %s\n", sv->overlap_us[0], sv->overlap_us[1],
+            sv->overlap_on ? "split" : "plain");
+  lsb_hip_free(d_b), lsb_hip_free(d_x);
 }
 
 /* part 0: the rows that need no halo; 1 / 2: the ones before / after them */

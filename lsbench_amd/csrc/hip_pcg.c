@@ -144,7 +144,7 @@ static void pcg_enqueue_init(lsb_hip_solver *sv, const double *d_b, double *d_x)
     lsb_k_pcg_init(s->n, d_b + o, DINV(s), d_x + o, s->d_r, s->d_pfull + s->row_begin,
                    s->d_parts2, &np2, g_stream);
     if (!s->d_p1 && fuse_p(sv)) /* second direction buffer of the two-launch iteration */
-      s->d_p1 = (double *)lsb_hip_malloc((size_t)s->n * sizeof(double));
+      s->d_p1 = shard_vec(s, s->n);
     if (sv->multi)
       lsb_k_reduce_final(s->d_parts2, np2, 2, s->d_scal + 1, 0, NULL, g_stream);
   }
@@ -312,8 +312,8 @@ static void cg1_enqueue_init(lsb_hip_solver *sv, const double *d_b, double *d_x)
     struct shard *s = &sv->sh[i];
     const size_t o = s->row_begin - sv->row_first, bytes = (size_t)s->n * sizeof(double);
     if (!s->d_p1) {
-      s->d_p1 = (double *)lsb_hip_malloc(bytes);
-      s->d_s1 = (double *)lsb_hip_malloc(bytes);
+      s->d_p1 = shard_vec(s, s->n);
+      s->d_s1 = shard_vec(s, s->n);
     }
     /* x = 0, r = b, u = D^-1 b (into the gather vector), partials (r.u, b.b);
      * implicit u (constant diagonal): r itself goes into the gather vector and
@@ -473,53 +473,25 @@ static float time_local_iters(lsb_hip_solver *sv, double *d_b, double *d_x, int 
   LSB_CHK_HIP(hipEventSynchronize(sv->ev_t1));
   float ms = 0.f;
   LSB_CHK_HIP(hipEventElapsedTime(&ms, sv->ev_t0, sv->ev_t1));
-  return ms;
+  /* a run that left RUNNING (exact convergence, a p.q breakdown) turned its later launches into
+   * no-ops: such a sample says nothing */
+  int status = 0;
+  LSB_CHK_HIP(hipMemcpy(&status, &s->d_st->status, sizeof status, hipMemcpyDeviceToHost));
+  return status == LSB_STATUS_RUNNING ? ms : -1.f;
 }
 
-/* WHERE the vectors land.  The iteration of config 3 comes in two speeds -- 136 and 143-144 us,
- * SpMV in the solve 25.5 and 32 us -- from one solver to the next of ONE process, each exactly
- * repeatable for as long as the solver lives (tools/gpu_placement_probe.py: 2 of 8 solvers slow).
- * r, q and the gather vector are 240 MB of the 256 MB Infinity Cache; which of their lines fight
- * for the same sets is decided by the physical pages the allocator happens to hand out.  Nothing
- * here can choose pages -- but it can ask again: up to five more sets of the three vectors are
- * allocated (the earlier ones held, so that the allocator has to give others), each timed over 40
- * local iterations, the fastest kept and the rest freed.  Untimed set-up; only where the vectors
- * are of the cache's scale (8 MB ... 160 MB each) and the solver has one shard. */
-static void tune_placement(lsb_hip_solver *sv, double *d_b, double *d_x) {
-  struct shard *s = &sv->sh[0];
-  const size_t vb = (size_t)s->n * sizeof(double), gb = (size_t)sv->n_glob * sizeof(double);
-  if (sv->nshard != 1 || vb < (8u << 20) || vb > (160u << 20) || getenv("LSBENCH_HIP_NO_PLACEMENT"))
-    return;
-  enum { TRIES = 6 };
-  struct { double *r, *q, *pf; float ms; } c[TRIES];
-  int nc = 0, best = 0;
-  for (int k = 0; k < TRIES; k++) {
-    if (k) {
-      c[k].r = (double *)lsb_hip_malloc(vb), c[k].q = (double *)lsb_hip_malloc(vb);
-      c[k].pf = (double *)lsb_hip_malloc(gb);
-      LSB_CHK_HIP(hipMemsetAsync(c[k].pf, 0, gb, g_stream));
-      s->d_r = c[k].r, s->d_q = c[k].q, s->d_pfull = c[k].pf;
-    } else
-      c[k].r = s->d_r, c[k].q = s->d_q, c[k].pf = s->d_pfull;
-    c[k].ms = time_local_iters(sv, d_b, d_x, 40);
-    nc = k + 1;
-    if (c[k].ms < c[best].ms)
-      best = k;
-    if (sv->o.verbose > 1)
-      fprintf(stderr, "hip_cdna4: placement %d of the vectors: %.1f us per local iteration\n", k, c[k].ms * 1e3f / 40);
-    /* three placements within 1.5 % of each other at the top: that is the fast kind, and the
-     * best of three of it */
-    int close = 0;
-    for (int j = 0; j < nc; j++)
-      close += c[j].ms <= c[best].ms * 1.015f;
-    if (close >= 3)
-      break;
-  }
-  s->d_r = c[best].r, s->d_q = c[best].q, s->d_pfull = c[best].pf;
-  for (int k = 0; k < nc; k++)
-    if (k != best)
-      lsb_hip_free(c[k].r), lsb_hip_free(c[k].q), lsb_hip_free(c[k].pf);
-}
+/* WHERE the vectors land.  Round 3 found the iteration of config 3 in two speeds -- 136 and 143-144 us,
+ * SpMV in the solve 25.5 and 32 us -- from one solver to the next of ONE process: r, q and the gather
+ * vector are 240 MB of the 256 MB Infinity Cache, and which of their lines fight for the same sets was
+ * decided by the physical pages three separate hipMallocs happened to get.  Round 3 drew placements
+ * until three fast ones agreed (up to six sets, 1.2 GB of transient allocations).  Round 4 removes the
+ * draw: the shard's vectors are carved out of ONE allocation (shard_vec, hip_solver.c), a contiguous
+ * run of addresses covers the cache's sets evenly, and every solver of every process runs at the fast
+ * speed by construction -- 8 fresh solvers in a row 136.4-136.8 us per iteration, against 136.7-142.7
+ * from separate allocations and 136.3-137.4 with round 3's lottery (tools/gpu_r4_place.sh,
+ * profiles/r04_placement.txt; general values 234.8-235.9 against 235.4-238.2).  It serves every
+ * configuration (shards, Chebyshev / block-Jacobi, any vector size) and costs nothing.
+ * LSBENCH_HIP_NO_SLAB=1 is the A/B switch. */
 
 /* Which operands of the two BLAS-1 sweeps should be loaded NONTEMPORAL is a matter of what the next
  * launches read again, and that depends on how the vectors compare with the 256 MB Infinity Cache:
@@ -546,17 +518,13 @@ void tune_blas1_nt(lsb_hip_solver *sv) {
    * on config 3 0.971 / 1.285 / 0.399 -> 0.974 / 1.289 / 0.408 solves/s, tools/gpu_nt_generic.sh) */
   if (!e && generic_precond(sv) && s->nnz >= 4000000ull)
     sv->nt_mask = 63 & ~16;
-  if (s->nnz < 4000000ull || generic_precond(sv))
-    return;
+  if (s->nnz < 4000000ull || generic_precond(sv) || sv->o.krylov == LSB_KRYLOV_GMRES)
+    return; /* (GMRES runs none of these sweeps) */
   static const int cand[] = {63, 9, 5, 0};
   const unsigned n = s->n;
   double *d_b = (double *)lsb_hip_malloc((size_t)n * sizeof(double));
   double *d_x = (double *)lsb_hip_malloc((size_t)n * sizeof(double));
   lsb_k_fill_index(n, 1u, d_b, g_stream);
-  /* first WHERE the vectors are (under the mask that usually wins, or the one asked for), then
-   * which operands bypass the caches */
-  lsb_k_set_blas1_nt(e ? sv->nt_mask : 9);
-  tune_placement(sv, d_b, d_x);
   float best = 1e30f;
   int bm = sv->nt_mask;
   const int reps = 20;
@@ -566,7 +534,7 @@ void tune_blas1_nt(lsb_hip_solver *sv) {
     if (sv->o.verbose > 1)
       fprintf(stderr, "hip_cdna4: nontemporal mask %2d: %.1f us per iteration of the first shard\n", cand[c],
               ms * 1e3f / reps);
-    if (ms < best)
+    if (ms >= 0.f && ms < best)
       best = ms, bm = cand[c];
   }
   /* the single-reduction sweep (k_cg1_update) goes with the classic ones: nontemporal unless

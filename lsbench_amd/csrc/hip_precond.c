@@ -115,7 +115,7 @@ static void precond_shard_fsai(struct shard *s, const int *offs, const int *cols
       tcols[at] = i, tvals[at] = g[e];
     }
   fsai_upload_csr(&s->fs_gt, n, toffs, tcols, tvals);
-  s->d_fst = (double *)lsb_hip_malloc((size_t)n * sizeof(double));
+  s->d_fst = shard_vec(s, n);
   if (o->verbose)
     fprintf(stderr, "hip_cdna4: FSAI on the pattern of tril(S^%d): %llu entries (%.1f per row, longest %u%s), "
                     "%u rows by wavefronts, %u by workgroups\n", power, P->nnz, (double)P->nnz / n, maxrow,
@@ -234,18 +234,18 @@ void precond_setup(lsb_hip_solver *sv) {
   if (sv->o.precond == LSB_PRECOND_FSAI) { /* buffers of the three-launch iteration */
     struct shard *s = &sv->sh[0];
     if (!s->d_p1)
-      s->d_p1 = (double *)lsb_hip_malloc((size_t)s->n * sizeof(double));
-    s->d_r1 = (double *)lsb_hip_malloc((size_t)s->n * sizeof(double));
+      s->d_p1 = shard_vec(s, s->n);
+    s->d_r1 = shard_vec(s, s->n);
   }
   for (int i = 0; i < sv->nshard; i++) {
     struct shard *s = &sv->sh[i];
     /* z lives in a gather vector of its own: Chebyshev multiplies it by S */
     const size_t len = sv->o.precond == LSB_PRECOND_CHEBYSHEV ? (size_t)sv->n_glob : (size_t)s->n;
-    s->d_zfull = (double *)lsb_hip_malloc(len * sizeof(double));
+    s->d_zfull = shard_vec(s, len);
     LSB_CHK_HIP(hipMemsetAsync(s->d_zfull, 0, len * sizeof(double), g_stream));
     s->d_z = sv->o.precond == LSB_PRECOND_CHEBYSHEV ? s->d_zfull + s->row_begin : s->d_zfull;
     if (sv->o.precond == LSB_PRECOND_CHEBYSHEV)
-      s->d_chd = (double *)lsb_hip_malloc((size_t)s->n * sizeof(double));
+      s->d_chd = shard_vec(s, s->n);
   }
   if (sv->o.precond != LSB_PRECOND_CHEBYSHEV)
     return;
@@ -320,7 +320,7 @@ void precond_setup(lsb_hip_solver *sv) {
     }
     for (int i = 0; i < sv->nshard && sv->cheb_fused; i++) {
       struct shard *s = &sv->sh[i];
-      s->d_zfull2 = (double *)lsb_hip_malloc((size_t)sv->n_glob * sizeof(double));
+      s->d_zfull2 = shard_vec(s, sv->n_glob);
       LSB_CHK_HIP(hipMemsetAsync(s->d_zfull2, 0, (size_t)sv->n_glob * sizeof(double), g_stream));
       s->d_z = ((m & 1) ? s->d_zfull2 : s->d_zfull) + s->row_begin;
     }
@@ -402,7 +402,7 @@ void precond_apply(lsb_hip_solver *sv, int after_update) {
 }
 
 void precond_free_shard(struct shard *s) {
-  lsb_hip_free(s->d_binv), lsb_hip_free(s->d_bjpart), lsb_hip_free(s->d_zfull), lsb_hip_free(s->d_chd);
-  lsb_hip_free(s->d_zfull2);
-  fsai_free_csr(&s->fs_g), fsai_free_csr(&s->fs_gt), lsb_hip_free(s->d_fst), lsb_hip_free(s->d_r1);
+  lsb_hip_free(s->d_binv), lsb_hip_free(s->d_bjpart), shard_vec_free(s, s->d_zfull), shard_vec_free(s, s->d_chd);
+  shard_vec_free(s, s->d_zfull2);
+  fsai_free_csr(&s->fs_g), fsai_free_csr(&s->fs_gt), shard_vec_free(s, s->d_fst), shard_vec_free(s, s->d_r1);
 }

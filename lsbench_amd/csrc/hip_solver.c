@@ -145,6 +145,21 @@ static void shard_build_twophase(struct shard *s, const struct csr *view, unsign
   lsb_pb_free(P);
 }
 
+/* count doubles out of the shard's vector slab (256-byte aligned), or a hipMalloc of their own */
+double *shard_vec(struct shard *s, size_t count) {
+  const size_t bytes = ((count ? count : 1) * sizeof(double) + 255u) & ~(size_t)255u;
+  if (s->d_slab && s->slab_used + bytes <= s->slab_cap) {
+    double *p = (double *)(s->d_slab + s->slab_used);
+    s->slab_used += bytes;
+    return p;
+  }
+  return (double *)lsb_hip_malloc(bytes);
+}
+void shard_vec_free(struct shard *s, void *p) {
+  if (p && !(s->d_slab && (char *)p >= s->d_slab && (char *)p < s->d_slab + s->slab_cap))
+    lsb_hip_free(p);
+}
+
 /* Upload rows [r0,r1) of the 0-based operator `S` (global column ids) as one
  * shard.  When `S` holds only the shard's rows, pass local=1. */
 void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
@@ -337,9 +352,18 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
             { /* per slice ONE 16-byte record {template id, first kept value slot, first mask, 0}: a
                * single scalar load in the kernel */
               unsigned *rec = lsb_calloc(unsigned, 4 * ((size_t)TT->nslice + 1));
-              for (unsigned k = 0; k < TT->nslice; k++)
+              for (unsigned k = 0; k < TT->nslice; k++) {
                 rec[4 * (size_t)k] = TT->tid[k], rec[4 * (size_t)k + 1] = TT->vbase[2 * (size_t)k],
                                rec[4 * (size_t)k + 2] = TT->vbase[2 * (size_t)k + 1];
+                /* bit 0 of the fourth word: the slice may go k_spmv_tmpl_deep's pipelined way -- whole
+                 * (128 rows), a shaped template, slots c-1 / c+1 constant or masked, the centre the
+                 * diagonal (base 0: the centre pair is the fused dot's operand) */
+                if (TT->tid[k] != 255 && ((unsigned long long)k + 1) * LSB_SELL_ROWS <= n) {
+                  const struct lsb_sell_tmpl *t = &TT->t[TT->tid[k]];
+                  const int c = (int)TT->nfar + 1;
+                  rec[4 * (size_t)k + 3] = t->shaped && t->kind[c - 1] != 1 && t->kind[c + 1] != 1 && t->base[c] == 0;
+                }
+              }
               s->d_srec = (unsigned *)dev_upload(rec, 4 * ((size_t)TT->nslice + 1) * sizeof(unsigned));
               LSB_CHK_HIP(hipStreamSynchronize(g_stream));
               free(rec);
@@ -382,10 +406,26 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
   LSB_CHK_HIP(hipStreamSynchronize(g_stream)); /* host staging is freed next */
   free(rb), free(offs), free(cols), free(lanes);
 
-  s->d_dinv = (double *)lsb_hip_malloc((size_t)n * sizeof(double));
-  s->d_r = (double *)lsb_hip_malloc((size_t)n * sizeof(double));
-  s->d_q = (double *)lsb_hip_malloc((size_t)n * sizeof(double));
-  s->d_pfull = (double *)lsb_hip_malloc((size_t)n_glob * sizeof(double));
+  { /* the vector slab: everything this configuration's iteration streams, in one allocation */
+    size_t cnt = 3 * (size_t)n + n_glob;                       /* r, q, the diagonal; the gather vector */
+    if (n_glob > n || o->nvirt > 1 || o->krylov == LSB_KRYLOV_PCG1)
+      cnt += 2 * (size_t)n;                                    /* p, s of the single-reduction form */
+    if (o->precond == LSB_PRECOND_CHEBYSHEV)
+      cnt += 2 * (size_t)n_glob + (size_t)n;                   /* two gather vectors of z, the recurrence's d */
+    else if (o->precond == LSB_PRECOND_BLOCKJACOBI)
+      cnt += (size_t)n;                                        /* z */
+    else if (o->precond == LSB_PRECOND_FSAI)
+      cnt += 4 * (size_t)n;                                    /* z, t = G r, the second r / p buffers */
+    if (o->krylov != LSB_KRYLOV_GMRES && !getenv("LSBENCH_HIP_NO_SLAB")) {
+      s->slab_cap = cnt * sizeof(double) + 16 * 256;
+      if (hipMalloc((void **)&s->d_slab, s->slab_cap) != hipSuccess) /* no room for one piece: pieces then */
+        s->d_slab = NULL, s->slab_cap = 0, (void)hipGetLastError();
+    }
+  }
+  s->d_r = shard_vec(s, n);
+  s->d_q = shard_vec(s, n);
+  s->d_pfull = shard_vec(s, n_glob);
+  s->d_dinv = shard_vec(s, n);
   LSB_CHK_HIP(hipMemsetAsync(s->d_pfull, 0, (size_t)n_glob * sizeof(double), g_stream));
   s->d_parts_pq = (double *)lsb_hip_malloc(3 * LSB_MAX_PARTIALS * sizeof(double));
   /* two buffers: k_cg1_update reads the previous launch's partials while
@@ -438,9 +478,9 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
 void shard_free(struct shard *s) {
   lsb_hip_free(s->d_offs), lsb_hip_free(s->d_cols), lsb_hip_free(s->d_vals), lsb_hip_free(s->d_vals32);
   lsb_hip_free(s->d_rowblk), lsb_hip_free(s->d_blklanes);
-  lsb_hip_free(s->d_dinv), lsb_hip_free(s->d_r);
-  lsb_hip_free(s->d_q), lsb_hip_free(s->d_pfull), lsb_hip_free(s->d_parts_pq);
-  lsb_hip_free(s->d_p1), lsb_hip_free(s->d_s1);
+  shard_vec_free(s, s->d_dinv), shard_vec_free(s, s->d_r);
+  shard_vec_free(s, s->d_q), shard_vec_free(s, s->d_pfull), lsb_hip_free(s->d_parts_pq);
+  shard_vec_free(s, s->d_p1), shard_vec_free(s, s->d_s1);
   lsb_hip_free(s->d_parts2), lsb_hip_free(s->d_st), lsb_hip_free(s->d_st_aux);
   lsb_hip_free(s->pd_offs), lsb_hip_free(s->pd_cols), lsb_hip_free(s->pd_vals);
   lsb_hip_free(s->pd_rowmap), lsb_hip_free(s->pd_rowblk), lsb_hip_free(s->pd_blklanes);
@@ -457,6 +497,8 @@ void shard_free(struct shard *s) {
   lsb_hip_free(s->tp_colw), lsb_hip_free(s->tp_roww), lsb_hip_free(s->tp_vals);
   lsb_hip_free(s->tp_prod), lsb_hip_free(s->tp_binparts);
   precond_free_shard(s);
+  lsb_hip_free(s->d_slab); /* behind everything that may point into it */
+  s->d_slab = NULL;
   free(s->recv), free(s->send);
 }
 
@@ -515,7 +557,9 @@ void solver_finish_setup(lsb_hip_solver *sv) {
   }
   tune_blas1_nt(sv);
   precond_setup(sv);
+  sv->overlap_on = -1;
   p2p_setup(sv);
+  overlap_setup(sv);
   persist_setup(sv);
 }
 
@@ -737,6 +781,11 @@ void lsb_hip_solver_comm_plan(const lsb_hip_solver *s, unsigned long long plan[8
   }
   plan[7] = (unsigned long long)can_overlap(s);
 }
+int lsb_hip_solver_overlap(const lsb_hip_solver *s, double us[2]) {
+  if (us)
+    us[0] = s->overlap_us[0], us[1] = s->overlap_us[1];
+  return can_overlap(s);
+}
 int lsb_hip_solver_fused_p(const lsb_hip_solver *s) { return lsb_fuse_p_kind(s); }
 int lsb_hip_solver_blas1_nt(const lsb_hip_solver *s) { return s->nt_mask; }
 unsigned long long lsb_hip_solver_spmv_layout_bytes(const lsb_hip_solver *s) {
@@ -856,7 +905,7 @@ void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
   if (getenv("LSBENCH_HIP_FORCE_PERIOD")) /* tests: the plane-periodic dealing on small operators */
     s->sp_period = s->sell_period;
   if (o->spmv_tune >= 0) {
-    s->sp_flags = (unsigned)o->spmv_tune & (31u | LSB_SP_TMPL | LSB_SP_DEFER); /* bit 2: 16-bit codes, where that copy exists;
+    s->sp_flags = (unsigned)o->spmv_tune & (31u | LSB_SP_TMPL | LSB_SP_DEFER | LSB_SP_DEEP2 | LSB_SP_DEEP4); /* bit 2: 16-bit codes, where that copy exists;
                                                    bits 3, 4: binned form's gather flavour; bit 6: slice
                                                    templates, where the constant-slot layout has them */
     return;

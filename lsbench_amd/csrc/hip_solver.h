@@ -47,6 +47,15 @@ LSB_INTERNAL int bench_multi(double *x, struct csr *A, const double *r, const st
 #define LSB_NGRAPH 4 /* cached hipGraphs: whole-solve + continuation chunk, solve proper + correction */
 
 struct shard {
+  /* ONE allocation for the vectors the iteration streams (r, q, the gather vector, the Jacobi
+   * diagonal, the single-reduction form's p / s, the preconditioners' z vectors): their placement
+   * relative to one another is then the same in every solver of every process -- which of their
+   * lines compete for the same sets of the 256 MB Infinity Cache no longer depends on which
+   * physical pages a dozen separate hipMallocs happened to get ("Where the
+   * vectors land").  shard_vec() carves 256-byte aligned pieces; what does not fit (or arrives with
+   * LSBENCH_HIP_NO_SLAB=1) is a hipMalloc of its own; shard_vec_free() tells the two apart. */
+  char *d_slab;
+  size_t slab_cap, slab_used;
   unsigned row_begin, n;
   unsigned long long nnz;
   int *d_offs, *d_cols, *d_rowblk;
@@ -172,6 +181,11 @@ struct lsb_hip_solver {
   double *d_vr, *d_ve; /* opts.verify: right-hand side and solution of a correction run */
   unsigned agree_nnz, agree_n; /* distributed: largest shard, identical on all ranks */
   unsigned agree_halo;         /* largest halo (doubles) any shard receives from one peer */
+  /* opts.overlap = -1: the split SpMV (interior rows while the halo travels) against the plain one,
+   * timed on the real communicator at creation (overlap_setup): -1 undecided, else the choice; the
+   * two timings in us per iteration (max over ranks), 0 where the pass did not run */
+  int overlap_on;
+  double overlap_us[2];
   /* reordering: d_perm[new] = old; b and x are permuted through d_bp / d_xp */
   int *d_perm;
   double *d_bp, *d_xp;
@@ -241,6 +255,8 @@ LSB_INTERNAL void wait_event(lsb_hip_solver *sv, hipEvent_t ev, const char *what
 LSB_INTERNAL void *dev_upload(const void *h, size_t bytes);
 /* hip_solver.c */
 LSB_INTERNAL unsigned pow2_ceil(unsigned v);
+LSB_INTERNAL double *shard_vec(struct shard *s, size_t count);
+LSB_INTERNAL void shard_vec_free(struct shard *s, void *p);
 LSB_INTERNAL void sell_launch(struct shard *s, unsigned s0, unsigned ns, const double *xfull, double *y,
                               const double *xdot, double *partials, unsigned *np,
                               const struct lsb_pcg_state *st);
@@ -252,6 +268,7 @@ LSB_INTERNAL void spmv_shard_exact(struct shard *s, const double *xfull, double 
 LSB_INTERNAL void tune_spmv(lsb_hip_solver *sv, struct shard *s);
 /* hip_dist.c */
 LSB_INTERNAL void p2p_setup(lsb_hip_solver *sv);
+LSB_INTERNAL void overlap_setup(lsb_hip_solver *sv);
 LSB_INTERNAL void exchange_on(lsb_hip_solver *sv, hipStream_t stream);
 LSB_INTERNAL void exchange_p(lsb_hip_solver *sv, int gated);
 LSB_INTERNAL void check_aux_status(lsb_hip_solver *sv, const char *where);

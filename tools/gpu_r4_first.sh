@@ -6,9 +6,8 @@ step() { local name=$1 secs=$2; shift 2
   echo "=== $name"; timeout -k 10 "$secs" "$@" > "$OUT/$name.log" 2> "$OUT/$name.err"; local rc=$?
   echo "rc=$rc"; tail -c 600 "$OUT/$name.log"; tail -n 3 "$OUT/$name.err"
   if [ $rc -ge 124 ]; then echo "step $name killed: stopping"; exit $rc; fi; }
-step pytest_new 600 python -m pytest tests/test_sell.py tests/test_host_logic.py -m gpu -x -q
-/usr/bin/time -v -o $OUT/bench.time timeout -k 10 600 python bench.py --verbose 2 > $OUT/bench.log 2> $OUT/bench.err; rc=$?
-echo "bench rc=$rc"; grep -E "Elapsed|Maximum resident" $OUT/bench.time; tail -c 3000 $OUT/bench.log; tail -n 5 $OUT/bench.err
+T0=$(date +%s); timeout -k 10 600 python bench.py --verbose 2 > $OUT/bench.log 2> $OUT/bench.err; rc=$?
+echo "bench rc=$rc wall=$(( $(date +%s) - T0 )) s"; tail -c 3000 $OUT/bench.log; tail -n 5 $OUT/bench.err
 if [ $rc -ge 124 ]; then exit $rc; fi
 Q="--cpu-seconds 0 --cfg4 0 --general-values 0 --csr-kernel 0 --cfg2 0 --cfg5 0"
 G="--workload lap2d_coef"
