@@ -27,7 +27,6 @@ SELL_ROWS = 128
 BIN_CHUNK = 2048
 PB_COLS, PB_ROWS = 8192, 2048
 SPMV_FLAG_PREFETCH, SPMV_FLAG_NT, SPMV_FLAG_C16, SPMV_FLAG_TMPL, SPMV_FLAG_DEFER = 1, 2, 4, 64, 128
-SPMV_FLAG_DEEP2, SPMV_FLAG_DEEP4 = 256, 512
 STATUS_RUNNING, STATUS_CONVERGED, STATUS_BREAKDOWN, STATUS_MAXIT = 0, 1, 2, 3
 STATUS_COMM = 4
 COMM_AUTO, COMM_RCCL, COMM_P2P = 0, 1, 2

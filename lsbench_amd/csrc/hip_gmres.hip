@@ -120,7 +120,13 @@ __global__ __launch_bounds__(WG) void k_gm_scale_prec(unsigned n, const double *
   }
 }
 
-// partial h_k = sum_i V[k][i] * w[i], k < cnt, one record of GM_MAXV per block
+// partial h_k = sum_i V[k][i] * w[i], k < cnt, one record of GM_MAXV per block.
+// Round 4 (first timed: 0.40 of peak over a GMRES(30) step): 16 bytes per lane and operand (the
+// basis columns start on 16-byte boundaries: ld is even), the columns taken four at a time with
+// their loads issued together, <= 768 workgroups (three per CU: what streams fastest out of HBM,
+// DESIGN.md section 4 "How many workgroups stream a vector").  A lane adds its elements in index
+// order, pair after pair -- fixed by n and the grid, so bitwise repeatable run to run.
+typedef double gm_d2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(WG) void k_gm_multidot(unsigned n, const double *__restrict__ V,
                                                     size_t ld, int cnt,
                                                     const double *__restrict__ w,
@@ -133,12 +139,28 @@ __global__ __launch_bounds__(WG) void k_gm_multidot(unsigned n, const double *__
 #pragma unroll
   for (int k = 0; k < GM_MAXV; k++)
     acc[k] = 0.0;
-  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n; i += (size_t)gridDim.x * WG) {
-    const double wi = w[i];
+  const size_t npair = n / 2;
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < npair; i += (size_t)gridDim.x * WG) {
+    const gm_d2 wi = ((const gm_d2 *)w)[i];
 #pragma unroll
-    for (int k = 0; k < GM_MAXV; k++)
+    for (int k0 = 0; k0 < GM_MAXV; k0 += 4)
+      if (k0 < cnt) { // (wave-uniform)
+        gm_d2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) // (columns past cnt: column cnt - 1 again, result dropped)
+          v[u] = ((const gm_d2 *)(V + (size_t)(k0 + u < cnt ? k0 + u : cnt - 1) * ld))[i];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (k0 + u < GM_MAXV && k0 + u < cnt)
+            acc[k0 + u] = fma(v[u].y, wi.y, fma(v[u].x, wi.x, acc[k0 + u]));
+      }
+  }
+  if ((n & 1u) && blockIdx.x == 0 && threadIdx.x == 0) { // the odd last element
+    const double wi = w[n - 1];
+#pragma unroll
+    for (int k = 0; k < GM_MAXV; k++) // (unrolled: the accumulators are registers)
       if (k < cnt)
-        acc[k] += V[(size_t)k * ld + i] * wi;
+        acc[k] += V[(size_t)k * ld + (n - 1)] * wi;
   }
   gm_wg_sum<GM_MAXV>(acc, sred);
   if (threadIdx.x == 0) {
@@ -166,7 +188,8 @@ __global__ __launch_bounds__(WG) void k_gm_multidot_final(const double *__restri
   }
 }
 
-// w -= sum_k h[k] V[k]; partial sum of w^2 after the update
+// w -= sum_k h[k] V[k]; partial sum of w^2 after the update (16 bytes per lane and operand, four
+// columns' loads in flight together, subtracted in column order)
 __global__ __launch_bounds__(WG) void k_gm_update_w(unsigned n, const double *__restrict__ V,
                                                     size_t ld, int cnt,
                                                     const double *__restrict__ h,
@@ -176,16 +199,33 @@ __global__ __launch_bounds__(WG) void k_gm_update_w(unsigned n, const double *__
   if (gm_idle(st))
     return;
   __shared__ double sred[4];
-  __shared__ double sh[GM_MAXV];
-  if (threadIdx.x < GM_MAXV)
+  __shared__ double sh[GM_MAXV + 3];
+  if (threadIdx.x < GM_MAXV + 3)
     sh[threadIdx.x] = (int)threadIdx.x < cnt ? h[threadIdx.x] : 0.0;
   __syncthreads();
   double acc[1] = {0.0};
-  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n; i += (size_t)gridDim.x * WG) {
-    double wi = w[i];
+  const size_t npair = n / 2;
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < npair; i += (size_t)gridDim.x * WG) {
+    gm_d2 wi = ((const gm_d2 *)w)[i];
+    for (int k0 = 0; k0 < cnt; k0 += 4) {
+      gm_d2 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        v[u] = ((const gm_d2 *)(V + (size_t)(k0 + u < cnt ? k0 + u : cnt - 1) * ld))[i];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { // (h is 0 past cnt)
+        wi.x = fma(-sh[k0 + u], v[u].x, wi.x);
+        wi.y = fma(-sh[k0 + u], v[u].y, wi.y);
+      }
+    }
+    ((gm_d2 *)w)[i] = wi;
+    acc[0] = fma(wi.y, wi.y, fma(wi.x, wi.x, acc[0]));
+  }
+  if ((n & 1u) && blockIdx.x == 0 && threadIdx.x == 0) {
+    double wi = w[n - 1];
     for (int k = 0; k < cnt; k++)
-      wi -= sh[k] * V[(size_t)k * ld + i];
-    w[i] = wi;
+      wi -= sh[k] * V[(size_t)k * ld + (n - 1)];
+    w[n - 1] = wi;
     acc[0] += wi * wi;
   }
   gm_wg_sum<1>(acc, sred);
@@ -286,6 +326,8 @@ static unsigned gm_grid(unsigned n) {
   unsigned g = (n + WG * 4 - 1) / (WG * 4);
   if (g > LSB_GMRES_PARTIALS)
     g = LSB_GMRES_PARTIALS;
+  if (g > 768u) /* three workgroups per CU stream vectors fastest out of HBM (LSB_STREAM_GRID_CAP) */
+    g = 768u;
   return g ? g : 1;
 }
 
