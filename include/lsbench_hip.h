@@ -207,6 +207,10 @@ struct lsb_hip_opts {
   int fsai_power;    /* LSB_PRECOND_FSAI: G lives on the pattern of tril(S^k),
                         k = 1..3 (rows of more than 128 pattern entries are cut
                         to the 128 nearest the diagonal)                    [3] */
+  int blas1_nt;      /* which operands of the BLAS-1 sweeps are loaded nontemporal:
+                        -1 = timed per solver at creation (tune_blas1_nt); else a mask
+                        (bit 0 x, 1 p and q, 2 r in k_pcg_update_xr; 3 r, 4 p in
+                        k_pcg_update_p; 5 k_cg1_update; 1 = all)              [-1] */
 };
 enum { LSB_PREC_FP64 = 0, LSB_PREC_MIXED = 1 };
 

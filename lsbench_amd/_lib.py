@@ -61,7 +61,7 @@ class Opts(C.Structure):
                 ("restart", C.c_int), ("verbose", C.c_int),
                 ("ngpus", C.c_int), ("verify", C.c_int), ("cheb_degree", C.c_int),
                 ("block_size", C.c_int), ("precision", C.c_int), ("persistent", C.c_int),
-                ("comm_deadline_s", C.c_double), ("fsai_power", C.c_int)]
+                ("comm_deadline_s", C.c_double), ("fsai_power", C.c_int), ("blas1_nt", C.c_int)]
 
 
 class Result(C.Structure):

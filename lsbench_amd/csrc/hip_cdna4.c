@@ -91,6 +91,7 @@ void lsb_hip_opts_default(struct lsb_hip_opts *o) {
   o->persistent = 0; /* measured: 2x slower than the two-launch iteration */
   o->comm_deadline_s = 120.0;
   o->fsai_power = 3;
+  o->blas1_nt = -1;
 }
 
 /* ONE typed table for everything a caller may set by name: the command line of a host
@@ -144,6 +145,7 @@ static const struct optdef {
     OPT("persistent", OT_INT, persistent, NULL),
     OPT("comm-deadline-s", OT_DBL, comm_deadline_s, NULL),
     OPT("fsai-power", OT_INT, fsai_power, NULL),
+    OPT("blas1-nt", OT_INT, blas1_nt, NULL),
 };
 #undef OPT
 #define NOPTS (sizeof OPTS / sizeof OPTS[0])
@@ -204,8 +206,6 @@ static void opts_from_env(struct lsb_hip_opts *o) {
     if ((e = getenv(var)) && opt_assign(o, &OPTS[k], e))
       warnx("hip_cdna4: %s=%s is not a value of option `%s'; ignored", var, e, OPTS[k].name);
   }
-  if ((e = getenv("LSBENCH_HIP_BLAS1_NT")))
-    lsb_k_set_blas1_nt(atoi(e));
 }
 
 /* Set one option of hip_cdna4_bench by name ("tol", "maxit", "ngpus", "krylov", "operator",

@@ -1845,16 +1845,9 @@ unsigned lsb_k_blas1_grid(unsigned n) {
   // comes out of the Infinity Cache) 1211-1238 us with 2048 workgroups, 1075-1077 us with 768
   // (256 / 512 / 1024: 1081-1104 / 1082-1090 / 1103-1110), the 10 M-row 5-point one 140-142 ->
   // 136-137 us; y = 4 x over 512 MB vectors: 178 us with 1024 workgroups, 204-207 us with
-  // 2048 / 4096 (profiles/r03_sweep_grid.txt).  LSBENCH_HIP_BLAS1_GRID overrides (experiments).
-  static int cap = -1;
-  if (cap < 0) {
-    const char *e = getenv("LSBENCH_HIP_BLAS1_GRID");
-    cap = e && atoi(e) > 0 ? atoi(e) : LSB_STREAM_GRID_CAP;
-    if (cap > LSB_MAX_PARTIALS)
-      cap = LSB_MAX_PARTIALS;
-  }
-  if (g > (unsigned)cap)
-    g = (unsigned)cap;
+  // 2048 / 4096 (profiles/r03_sweep_grid.txt).
+  if (g > LSB_STREAM_GRID_CAP)
+    g = LSB_STREAM_GRID_CAP;
   return g ? g : 1;
 }
 
@@ -2285,11 +2278,7 @@ void lsb_k_pcg_update_p(unsigned n, const double *r, const double *dinv, double 
                         const double *pin, double *p, struct lsb_pcg_state *st, int parity,
                         const double *parts2, unsigned nparts2, void *stream) {
   const unsigned g = lsb_k_blas1_grid(n);
-  static int x2 = -1; /* A/B switch: LSBENCH_HIP_UPD_P_X2=0 keeps one pair per lane in flight */
-  if (x2 < 0) {
-    const char *e = getenv("LSBENCH_HIP_UPD_P_X2");
-    x2 = e ? atoi(e) != 0 : 1;
-  }
+  const int x2 = 1; /* two pairs per operand in flight (one: 40.6 against 40.4 us, round 3 -- no difference) */
   hipStream_t s = (hipStream_t)stream;
 #define LSB_UPD_P(V2, NTR, NTP, X2) \
   k_pcg_update_p<V2, NTR, NTP, X2><<<g, WG, 0, s>>>(n, r, dinv, dc, pin, p, st, parity, parts2, nparts2)

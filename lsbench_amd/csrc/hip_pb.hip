@@ -209,8 +209,7 @@ void lsb_k_spmv_twophase(unsigned nitems, const unsigned *item, const double *va
     errx(EXIT_FAILURE, "lsb_k_spmv_twophase: tiling %u x %u does not fit the LDS", cols, rows);
   /* products leave through nontemporal stores: nobody reads them before 2 GB more have
    * gone by (1.55-1.70 against 1.61-1.71 ms on the 8 M-row power-law operator) */
-  const char *ent = getenv("LSBENCH_HIP_PB_NTSTORE");
-  const int nt = ent ? atoi(ent) : 1;
+  const int nt = 1;
   if (nitems) {
     if (cols > 8192)
       k_pb_products<1024><<<nitems, 1024, (size_t)cols * 8, s>>>(item, vals, colw, grp_first, grp_mask,

@@ -509,8 +509,8 @@ static float time_local_iters(lsb_hip_solver *sv, double *d_b, double *d_x, int 
  * LSBENCH_HIP_BLAS1_NT=<mask> fixes it (1 = everything, the old setting). */
 void tune_blas1_nt(lsb_hip_solver *sv) {
   struct shard *s = &sv->sh[0];
-  const char *e = getenv("LSBENCH_HIP_BLAS1_NT");
-  sv->nt_mask = e ? (atoi(e) == 1 ? 63 : atoi(e)) : 63; /* not the previous solver's choice */
+  const int e = sv->o.blas1_nt >= 0; /* a mask was asked for (opts.blas1_nt, LSBENCH_HIP_BLAS1_NT): no timing */
+  sv->nt_mask = e ? (sv->o.blas1_nt == 1 ? 63 : sv->o.blas1_nt & 63) : 63; /* not the previous solver's choice */
   /* (the iterations with z = M^-1 r as a vector run other sweeps around the SpMV -- dot2, the
    * Chebyshev recurrence in the epilogue: the classic form's winner cost them 8-10 % on config 3
    * (profiles/r03_bench.jsonl history).  They keep every operand nontemporal but the direction the
@@ -528,7 +528,7 @@ void tune_blas1_nt(lsb_hip_solver *sv) {
   float best = 1e30f;
   int bm = sv->nt_mask;
   const int reps = 20;
-  for (unsigned c = 0; c < sizeof cand / sizeof cand[0] && !e && !getenv("LSBENCH_HIP_NO_NT_TUNE"); c++) {
+  for (unsigned c = 0; c < sizeof cand / sizeof cand[0] && !e; c++) {
     lsb_k_set_blas1_nt(cand[c]);
     const float ms = time_local_iters(sv, d_b, d_x, reps);
     if (sv->o.verbose > 1)
@@ -539,7 +539,7 @@ void tune_blas1_nt(lsb_hip_solver *sv) {
   }
   /* the single-reduction sweep (k_cg1_update) goes with the classic ones: nontemporal unless
    * "none" won */
-  if (!e && !getenv("LSBENCH_HIP_NO_NT_TUNE"))
+  if (!e)
     sv->nt_mask = bm == 0 ? 0 : (bm | 32);
   lsb_k_set_blas1_nt(sv->nt_mask);
   /* leave the shard as the upload left it */

@@ -284,12 +284,7 @@ void precond_setup(lsb_hip_solver *sv) {
    * resolves a wider interval, and the eigenvalues below it are CG's job; measured on the
    * 10 M-row 5-point operator (solves/s, fixed ratio 30 -> this rule): m = 4: 0.82 -> 0.90,
    * 8: 0.80 -> 1.04, 16: 0.64 -> 1.15 (profiles/r02_chebyshev.txt) */
-  double ratio = 16.0 * m * m > CHEB_RATIO ? 16.0 * m * m : CHEB_RATIO;
-  {
-    const char *e = getenv("LSBENCH_HIP_CHEB_RATIO"); /* lmax / lmin of the interval (experiments) */
-    if (e && atof(e) > 1.0)
-      ratio = atof(e);
-  }
+  const double ratio = 16.0 * m * m > CHEB_RATIO ? 16.0 * m * m : CHEB_RATIO;
   sv->cheb_lmax = CHEB_SAFETY * lam, sv->cheb_lmin = sv->cheb_lmax / ratio;
   const double theta = 0.5 * (sv->cheb_lmax + sv->cheb_lmin), delta = 0.5 * (sv->cheb_lmax - sv->cheb_lmin);
   const double sigma = theta / delta;

@@ -238,8 +238,7 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
     const int forced = o->spmv_variant == LSB_SPMV_PANEL;
     const int scattered = s->nnz > 4000000ull && (double)(hi - lo) * 8.0 > 16.0e6 &&
                           lsb_csr_mean_scatter(&gview, row_begin) > 1.0e6;
-    if (width && (forced || (o->spmv_variant == LSB_SPMV_AUTO && scattered &&
-                             getenv("LSBENCH_HIP_PANELS")))) /* superseded by the binned form */
+    if (width && forced) /* (no longer built on its own accord: superseded by the binned form) */
       shard_build_panels(s, &gview, width);
     if (width && (o->spmv_variant == LSB_SPMV_BINNED ||
                   (o->spmv_variant == LSB_SPMV_AUTO && scattered)))
@@ -247,7 +246,7 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
     /* the two-phase form: 1.59 ms against the binned form's 2.79 ms on the 8 M-row
      * power-law operator; the timing pass decides per shard */
     if (o->spmv_variant == LSB_SPMV_TWOPHASE ||
-        (o->spmv_variant == LSB_SPMV_AUTO && scattered && !getenv("LSBENCH_HIP_NO_TWOPHASE")))
+        (o->spmv_variant == LSB_SPMV_AUTO && scattered))
       shard_build_twophase(s, &gview, n_glob);
   }
   /* Near-uniform row lengths (stencils, meshes): also keep a sliced-ELL copy;
@@ -319,7 +318,7 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
           for (unsigned k = 0; k < H->nslice && ul; k++)
             if ((H->sptr[k + 1] - H->sptr[k]) / LSB_SELL_ROWS != ul)
               ul = 0;
-          s->sell_ulen = getenv("LSBENCH_HIP_NO_ULEN") ? 0 : ul;
+          s->sell_ulen = ul;
         }
         struct lsb_sell_vc *V = getenv("LSBENCH_HIP_NO_VCONST") ? NULL : lsb_sell16_value_slots(H);
         if (V && (unsigned long long)V->nval_slots * 8 > V->nslots * 7) {
@@ -946,7 +945,7 @@ void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
     for (unsigned k = 0; k < sizeof bf / sizeof bf[0]; k++)
       CAND(LSB_SPMV_BINNED, bf[k], grid0, 0);
   }
-  const int periodic = s->sell_period && !getenv("LSBENCH_HIP_NO_PERIOD");
+  const int periodic = s->sell_period != 0;
   if (s->d_sptr && (any || s->variant == LSB_SPMV_SELL))
     for (unsigned c16 = 0; c16 <= (s->d_scodes ? LSB_SP_C16 : 0u); c16 += LSB_SP_C16) {
       CAND(LSB_SPMV_SELL, c16 | LSB_SP_NT, grid0, 0);
@@ -970,7 +969,7 @@ void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
         }
         /* the same with y parked in LDS and stored one turn later (k_spmv_tmpl<.., DEFER>): pays where
          * the vectors come out of HBM, costs ~2 us where they sit in the Infinity Cache */
-        if (s->tmpl_nfar >= 1 && s->nnz >= 16000000ull && !getenv("LSBENCH_HIP_NO_DEFER")) {
+        if (s->tmpl_nfar >= 1 && s->nnz >= 16000000ull) {
           const unsigned fd = f | LSB_SP_DEFER, gd = o->spmv_grid <= 0 ? 1536u : grid0;
           CAND(LSB_SPMV_SELL, fd, gd, 0);
           if (periodic)

@@ -515,8 +515,7 @@ struct lsb_binned *lsb_csr_binize(const struct csr *A, unsigned width) {
     cnt[b + 1] += cnt[b];
   struct lsb_binned *B = lsb_calloc(struct lsb_binned, 1);
   B->nbins = nb, B->width = width, B->nrows = n, B->nnz = nnz;
-  const char *ce = getenv("LSBENCH_HIP_BIN_CHUNK");
-  const unsigned CAP = ce && (atoi(ce) == 1024 || atoi(ce) == 1536) ? (unsigned)atoi(ce) : LSB_BIN_CHUNK;
+  const unsigned CAP = LSB_BIN_CHUNK; /* (1024 / 1536 measured no better: DESIGN.md section 4) */
   B->chunk_cap = CAP;
   B->rows = (unsigned *)malloc((size_t)(nnz ? nnz : 1) * sizeof(unsigned));
   B->cols = (unsigned *)malloc((size_t)(nnz ? nnz : 1) * sizeof(unsigned));
@@ -579,7 +578,7 @@ void lsb_binned_free(struct lsb_binned *B) {
 /* ------------------------------------------------------------------------ */
 /* Two-phase form (LSB_SPMV_TWOPHASE): see include/lsbench_hip.h.             */
 /* ------------------------------------------------------------------------ */
-/* entries of a phase-1 work item (a multiple of 64; LSBENCH_HIP_PB_ITEM).  Measured on the
+/* entries of a phase-1 work item (a multiple of 64).  Measured on the
  * 8 M-row power-law operator, phase 1: 131072 -> 1322 us, 32768 -> 1247, 8192 -> 1201 (the
  * window of x is loaded once per item -- 64 KB out of L2 -- but the last workgroups of the
  * launch finish together) */
@@ -588,8 +587,7 @@ struct lsb_pb *lsb_csr_pbize2(const struct csr *A, unsigned C, unsigned R) {
   if (!A || A->nrows == 0)
     return NULL;
   C = C ? C : LSB_PB_COLS, R = R ? R : LSB_PB_ROWS;
-  const char *eitem = getenv("LSBENCH_HIP_PB_ITEM");
-  const unsigned PB_ITEM = eitem && atoi(eitem) >= 64 ? ((unsigned)atoi(eitem) + 63u) & ~63u : PB_ITEM_DEFAULT;
+  const unsigned PB_ITEM = PB_ITEM_DEFAULT;
   if (C > 16384 || R > 4096 || C % 64 || R % 64)
     errx(EXIT_FAILURE, "two-phase operator: %u columns x %u rows per piece is not a usable tiling", C, R);
   const unsigned n = A->nrows, base = A->base;
@@ -1225,7 +1223,7 @@ struct lsb_sell_tmpls *lsb_sell16_templates(const struct lsb_sell *S, const stru
           else
             m1 |= 1ull << (l - 64);
         }
-      if (one && k != 0.0 && !getenv("LSBENCH_HIP_NO_MASKS")) {
+      if (one && k != 0.0) {
         t.kind[j] = 2, t.kidx[j] = nmk, t.cst[j] = k;
         mk[2 * nmk] = m0, mk[2 * nmk + 1] = m1, nmk++;
       } else {
@@ -1304,10 +1302,6 @@ struct lsb_sell_tmpls *lsb_sell16_templates(const struct lsb_sell *S, const stru
   }
   T->nmask = nmask, T->mask = mask;
   free(count);
-  if (getenv("LSBENCH_HIP_TMPL_DEBUG"))
-    fprintf(stderr, "lsb_sell16_templates: %u slices, %u templates, %llu covered, %llu shaped (nfar %u), %llu masks, "
-                    "%llu value slots still read\n", ns, T->ntmpl, T->covered, T->shaped, T->nfar, T->nmask,
-            T->kept_read);
   if (T->covered * 8 < (unsigned long long)ns * 7 || T->shaped * 4 < (unsigned long long)ns * 3) {
     lsb_sell_tmpls_free(T);
     return NULL;

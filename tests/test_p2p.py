@@ -67,22 +67,40 @@ def test_maxit_and_scattered_operator(hip):
     assert abs(r.relres - relo) <= 1e-6 * relo
 
 
-def test_overlap_is_automatic_for_large_halos(hip):
-    """opts.overlap = -1 (default): split the SpMV only where a halo is at least
-    64 Ki doubles."""
+def test_overlap_is_decided_by_timing_both_forms(hip, monkeypatch):
+    """opts.overlap = -1 (default): both forms of the sharded SpMV -- plain behind the exchange, or
+    interior rows in front of the halo -- are TIMED on the solver's own communicator at creation
+    (hip_dist.c overlap_setup) and the faster one runs; the numbers travel in the comm plan.  Round
+    3's rule of thumb (split where a halo is >= 64 Ki doubles) is gone: every one-device
+    measurement contradicted it.  Forced on / off and the untimed fallback still work; the
+    iterates do not depend on the form."""
     big = hip.lsbench_matrix_synth("lap3d:nx=260,ny=260,nz=8")      # plane = 67600 rows
     small = hip.lsbench_matrix_synth("lap3d:nx=100,ny=100,nz=54")   # plane = 10000 rows
-    for A, want in ((big, True), (small, False)):
+    for A in (big, small):
         s = hip.Solver(A, hip.default_opts(op_mode=hip.OP_RAW, nvirt=2, maxit=40, tol=1e-30,
                                            spmv_variant=hip.SPMV_ADAPTIVE))
-        assert s.overlaps == want
+        t = s.comm_plan["overlap_timed_us"]
+        assert t and t["plain"] > 0 and t["split"] > 0
+        assert s.overlaps == (t["split"] < t["plain"]) == s.comm_plan["overlap"]
         x, r = s.solve(O.rhs(A.nrows))
         s.destroy()
         s1 = hip.Solver(A, hip.default_opts(op_mode=hip.OP_RAW, maxit=40, tol=1e-30))
+        assert s1.comm_plan["overlap_timed_us"] is None and not s1.overlaps     # one shard: nothing to decide
         x1, r1 = s1.solve(O.rhs(A.nrows))
         s1.destroy()
         assert r.iters == r1.iters == 40
         assert np.linalg.norm(x - x1) / np.linalg.norm(x1) <= 1e-11
+        for ov in (0, 1):                                                       # forced: no timing
+            s = hip.Solver(A, hip.default_opts(op_mode=hip.OP_RAW, nvirt=2, maxit=40, tol=1e-30, overlap=ov,
+                                               spmv_variant=hip.SPMV_ADAPTIVE))
+            assert s.overlaps == bool(ov) and s.comm_plan["overlap_timed_us"] is None
+            x2, r2 = s.solve(O.rhs(A.nrows))
+            s.destroy()
+            assert r2.iters == 40 and np.linalg.norm(x2 - x1) / np.linalg.norm(x1) <= 1e-11
+    monkeypatch.setenv("LSBENCH_HIP_NO_OVERLAP_TUNE", "1")
+    s = hip.Solver(big, hip.default_opts(op_mode=hip.OP_RAW, nvirt=2, spmv_variant=hip.SPMV_ADAPTIVE))
+    assert not s.overlaps and s.comm_plan["overlap_timed_us"] is None
+    s.destroy()
 
 
 @pytest.mark.parametrize("variant,nvirt,overlap", [("SELL", 4, 0), ("SELL", 3, 1), ("ADAPTIVE", 5, 1),
