@@ -876,7 +876,10 @@ static int pcg_run(lsb_hip_solver *sv, const double *d_b, double *d_x, struct ls
       float pair = 0.f;
       LSB_CHK_HIP(hipEventElapsedTime(&ms, sv->ev[4 * k], sv->ev[4 * k + 1]));
       LSB_CHK_HIP(hipEventElapsedTime(&pair, sv->ev[4 * k + 2], sv->ev[4 * k + 3]));
-      tot += ms - pair, used++;
+      /* (a host hiccup between the two bare markers can make their distance exceed the bracketed
+       * launch's on a launch of a few microseconds: such a sample says nothing) */
+      if (ms > pair)
+        tot += ms - pair, used++;
     }
     r.spmv_ms = used ? tot / used : 0.0;
     r.spmv_samples = (unsigned)used;

@@ -4,12 +4,18 @@
 # forms as bench lines.  Condensed into profiles/ by tools/summarize_profiles.py.
 cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=gpurun_out/${1:-profiles}; mkdir -p $OUT; export TMPDIR=/tmp
+# usage: gpu_profiles.sh <dir> [part]   part = A | B | C | all (a gpurun call is capped at 20 minutes: one part per call)
+PART=${2:-all}; CUR=A
+part() { CUR=$1; }
 step() { local name=$1 secs=$2; shift 2
+  if [ "$PART" != all ] && [ "$PART" != "$CUR" ]; then return 0; fi
   echo "=== $name"; timeout -k 10 "$secs" "$@" > "$OUT/$name.log" 2>&1; local rc=$?
   echo "rc=$rc"; if [ $rc -ge 124 ]; then echo "step $name killed: stopping"; exit $rc; fi; }
 Q="--cpu-seconds 0 --cfg4 0 --general-values 0 --csr-kernel 0 --cfg2 0 --cfg5 0"
 F=file:tests/golden/matrices/xn3b_A_18.txt.gz
 step bench 600 python bench.py
+# the driver's own command line (BENCH_rNN.json): 20 timed solves after 5 warm-ups, every sub-record
+T0=$(date +%s); step bench_driver 600 python bench.py --gpus 1 --steps 20 --warmup 5; echo "bench_driver wall $(( $(date +%s) - T0 )) s"
 step trace 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --steps 1 --warmup 0 $Q
 step pmc_fetch 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py --fixed-iters 60 --steps 1 --warmup 0 $Q
 step pmc_write 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -- python3 bench.py --fixed-iters 60 --steps 1 --warmup 0 $Q
@@ -29,6 +35,7 @@ step pmc_write_csr 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format
 step gmres_coef 400 python bench.py $G --krylov gmres --restart 30 --fixed-iters 300 --steps 2 --warmup 1 $Q
 step trace_gmres 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_gmres" -- python3 bench.py $G --krylov gmres --restart 30 --fixed-iters 120 --steps 1 --warmup 0 $Q
 step gmres_xn3b_raw 300 python bench.py --workload $F --operator raw --krylov gmres --restart 30 --tol 1e-10 --steps 20 --warmup 2 --verify 0 $Q
+part B
 step trace_lap3d 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_lap3d" -- python3 bench.py --workload lap3d --fixed-iters 100 --steps 1 --warmup 0 $Q
 step pmc_fetch_lap3d 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch_lap3d" -- python3 bench.py --workload lap3d --fixed-iters 40 --steps 1 --warmup 0 $Q
 step pmc_write_lap3d 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write_lap3d" -- python3 bench.py --workload lap3d --fixed-iters 40 --steps 1 --warmup 0 $Q
@@ -36,6 +43,7 @@ step bench_powerlaw 400 python bench.py --workload powerlaw $Q
 step trace_powerlaw 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_powerlaw" -- python3 bench.py --workload powerlaw --steps 1 $Q
 step pmc_fetch_powerlaw 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch_powerlaw" -- python3 bench.py --workload powerlaw --steps 1 $Q
 step pmc_write_powerlaw 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write_powerlaw" -- python3 bench.py --workload powerlaw --steps 1 $Q
+part C
 for v in 7 6 1; do step bench_powerlaw_v$v 400 python bench.py --workload powerlaw --spmv $v $Q; done
 step cfg5_spd_cg 600 python bench.py --workload "powerlaw:n=8000000,gamma=1.585350372615855,max=4096,seed=20240607,spd=1" --tol 1e-10 --steps 3 $Q
 step trace_cfg2_fsai 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_cfg2_fsai" -- python3 bench.py --workload $F --tol 1e-12 --steps 20 --warmup 2 --persistent 0 --precond fsai $Q
@@ -54,4 +62,4 @@ step cfg3_cheb4 400 python bench.py --precond cheb --cheb-degree 4 --steps 2 $Q
 step cfg3_cheb16 400 python bench.py --precond cheb --cheb-degree 16 --steps 2 $Q
 step cfg3_bj8 400 python bench.py --precond bj --block-size 8 --steps 2 $Q
 find "$OUT" -name '*kernel_trace.csv' -size +12M -delete 2>/dev/null
-tail -n 3 $OUT/bench.log
+[ -f $OUT/bench.log ] && tail -c 400 $OUT/bench.log

@@ -150,7 +150,7 @@ if pmc and line:
 if traffic:
     json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 # bench lines
-names = ["bench", "bench_coef", "bench_coef_fp32", "gmres_coef", "gmres_xn3b_raw", "only_subrecords", "bench_powerlaw", "bench_powerlaw_v7", "bench_powerlaw_v6", "bench_powerlaw_v1", "cfg5_spd_cg", "cfg2_launches", "cfg2_persistent",
+names = ["bench", "bench_driver", "bench_coef", "bench_coef_fp32", "gmres_coef", "gmres_xn3b_raw", "only_subrecords", "bench_powerlaw", "bench_powerlaw_v7", "bench_powerlaw_v6", "bench_powerlaw_v1", "cfg5_spd_cg", "cfg2_launches", "cfg2_persistent",
          "cfg2_dense_inverse", "cfg2_cheb4", "cfg2_fsai2", "cfg2_fsai3", "cfg2_fsai3_six_launches", "cfg3_no_templates", "cfg3_fp32", "cfg3_cheb4", "cfg3_cheb16", "cfg3_bj8"]
 with open(os.path.join(out, "%s_bench.jsonl" % rnd), "w") as fo:
     for tag in names:
