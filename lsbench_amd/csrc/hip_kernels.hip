@@ -189,6 +189,13 @@ __global__ __launch_bounds__(WG, 8) void k_spmv_adaptive(
 }
 #undef LSB_ISSUE_BLOCK
 
+// (Round 4, measured and taken out: k_spmv_rows -- one row per lane straight off the CSR arrays for
+// operators of short rows, eight entries per trip on clamped indices, tiles of 256 rows dealt like row
+// blocks; the idea: no LDS round trip, no barriers, neighbouring lanes read neighbouring 40-60 byte runs
+// and re-use their lines out of L1.  10 M-row 5-point pattern with general values: 223 us (378 us with
+// nontemporal stream loads, which forgo exactly that re-use) against 160 us for k_spmv_adaptive in the
+// same timing pass -- a wave instruction that touches 20 lines costs the L1 more than the barriers cost
+// the row-blocked form.  The CSR figure of the bench line stays k_spmv_adaptive's.)
 // --------------------------------------------------------------------------
 // a2-1  SpMV, L lanes per row (L = 2..64; L = 64 is the classic
 // one-wavefront-per-row kernel), rows dealt to workgroups in contiguous,
