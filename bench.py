@@ -302,25 +302,30 @@ def pmc_traffic(workload, kernel, value_slots, spmv_flags=None, period=None):
     and says why in `traffic_source`."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            t = json.load(f).get(workload)
+            ts = json.load(f).get(workload)
     except (OSError, ValueError):
         return None, "no profiles/pmc_traffic.json"
-    if not isinstance(t, dict):
+    if isinstance(ts, dict):
+        ts = [ts]
+    if not isinstance(ts, list) or not ts:
         return None, "no committed PMC profile of this workload"
-    if t.get("kernel") != kernel:
-        return None, "stale: committed PMC profile is of %s, this run used %s" % (t.get("kernel"), kernel)
-    sha = kernels_sha16()
-    if t.get("kernels_sha16") != sha:
-        return None, ("stale: committed PMC profile was taken on kernel sources %s, these are %s"
-                      % (t.get("kernels_sha16"), sha))
-    if list(t.get("value_slots", [0, 0])) != list(value_slots):
-        return None, ("stale: committed PMC profile kept %s value slots, this run %s"
-                      % (t.get("value_slots"), list(value_slots)))
-    if spmv_flags is not None and (t.get("spmv_flags") != spmv_flags or t.get("xcd_period_slices") != period):
-        return None, ("other flavour: the committed PMC profile is of spmv_flags %s / xcd_period_slices %s, this "
-                      "run's timing pass picked %s / %s" % (t.get("spmv_flags"), t.get("xcd_period_slices"),
-                                                           spmv_flags, period))
-    return t["bytes"], t.get("source", "profiles/pmc_traffic.json")
+    sha, why = kernels_sha16(), None
+    for t in ts:   # one entry per profiled flavour of the workload's SpMV: the one this run's timing pass picked
+        if t.get("kernel") != kernel:
+            why = why or "stale: committed PMC profile is of %s, this run used %s" % (t.get("kernel"), kernel)
+        elif t.get("kernels_sha16") != sha:
+            why = why or ("stale: committed PMC profile was taken on kernel sources %s, these are %s"
+                          % (t.get("kernels_sha16"), sha))
+        elif list(t.get("value_slots", [0, 0])) != list(value_slots):
+            why = why or ("stale: committed PMC profile kept %s value slots, this run %s"
+                          % (t.get("value_slots"), list(value_slots)))
+        elif spmv_flags is not None and (t.get("spmv_flags") != spmv_flags or t.get("xcd_period_slices") != period):
+            why = ("other flavour: the committed PMC profiles are of spmv_flags / xcd_period_slices %s, this run's "
+                   "timing pass picked %s / %s" % (sorted({(e.get("spmv_flags"), e.get("xcd_period_slices")) for e in ts}),
+                                                   spmv_flags, period))
+        else:
+            return t["bytes"], t.get("source", "profiles/pmc_traffic.json")
+    return None, why
 
 
 FABRIC_NOTE = ("traffic = FETCH_SIZE x 2 + WRITE_SIZE of the committed rocprofv3 --pmc passes: bytes through the "

@@ -35,7 +35,13 @@ def bench_line_of(tag):
     return None
 
 
-for wl, suffix in (("lap2d", ""), ("lap2d_coef", "_coef"), ("lap3d", "_lap3d"), ("powerlaw", "_powerlaw")):
+# (workload, directory suffix): the un-forced pass of every workload, then passes with the SpMV flavour FORCED
+# (tools/gpu_profiles.sh part D) -- the timing pass picks per box, and bench.py quotes the entry of the
+# flavour its own run picked
+VARIANTS = [("lap2d", "", ""), ("lap2d_coef", "_coef", ""), ("lap3d", "_lap3d", ""), ("powerlaw", "_powerlaw", ""),
+            ("lap2d", "_f70", "_f70"), ("lap2d", "_f198", "_f198"), ("lap3d", "_lap3d_f198", "_f198"),
+            ("lap3d", "_lap3d_f198p", "_f198p"), ("lap3d", "_lap3d_f70", "_f70"), ("lap3d", "_lap3d_f70p", "_f70p")]
+for wl, suffix, vtag in VARIANTS:
     pmc = {}
     for cname, tag in (("FETCH_SIZE", "pmc_fetch" + suffix), ("WRITE_SIZE", "pmc_write" + suffix)):
         f = one(tag + "/*/*counter_collection.csv")
@@ -93,22 +99,27 @@ for wl, suffix in (("lap2d", ""), ("lap2d_coef", "_coef"), ("lap3d", "_lap3d"), 
                     best = ("k_spmv_binned", nf, tot)
                 lines.append("# k_spmv_binned per SpMV = %d windows x mean launch (%d launches in the FETCH "
                              "pass, %d in the WRITE pass): %.0f bytes" % (nbins, nf, nw, tot))
-    open(os.path.join(out, "%s_pmc_traffic_%s.csv" % (rnd, wl)), "w").write("\n".join(lines) + "\n")
+    csvname = "%s_pmc_traffic_%s%s.csv" % (rnd, wl, vtag)
+    open(os.path.join(out, csvname), "w").write("\n".join(lines) + "\n")
     if best:
         d = bench_line_of("pmc_fetch" + suffix) or {}
         roof = d.get("roofline", {})
         vs = roof.get("value_slots", {})
         if not roof.get("kernels_sha16"):  # (a line of an older bench.py: the same call, the same sources)
             roof["kernels_sha16"] = (bench_line_of("pmc_fetch") or {}).get("roofline", {}).get("kernels_sha16")
-        traffic[wl] = {"bytes": best[2], "kernel": best[0], "launches": best[1],
+        entry = {"bytes": best[2], "kernel": best[0], "launches": best[1],
                        "kernels_sha16": roof.get("kernels_sha16"),
                        "value_slots": [vs.get("kept", 0), vs.get("all", 0)],
                        # the flavour the timing pass of the profiled run picked: bench.py quotes the
                        # figure only for a run that picked the same
                        "spmv_flags": roof.get("spmv_flags"), "xcd_period_slices": roof.get("xcd_period_slices"),
-                       "source": "profiles/%s_pmc_traffic_%s.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                                 "separate passes of this command; FETCH_SIZE x 2)" % (rnd, wl)}
-    print(wl)
+                       "source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                                 "separate passes of this command; FETCH_SIZE x 2)" % csvname}
+        have = traffic.setdefault(wl, [])
+        if not any((e["spmv_flags"], e["xcd_period_slices"], e["kernel"]) ==
+                   (entry["spmv_flags"], entry["xcd_period_slices"], entry["kernel"]) for e in have):
+            have.append(entry)
+    print(wl, suffix)
     print("\n".join(lines))
 # csr_kernel (bench.py --only csr_kernel): the two kernels that stream 12 B per non-zero
 pmc = {}
@@ -138,12 +149,12 @@ if pmc and line:
         lines.append("%s,%d,%.1f,%.0f,%.1f,%.0f,%.0f" % (best[0], best[1]["FETCH_SIZE"][1], best[1]["FETCH_SIZE"][0], fb,
                                                          best[1]["WRITE_SIZE"][0], wb, fb + wb))
         kk = line["kernels"][short]
-        traffic["csr_kernel:" + short] = {
+        traffic["csr_kernel:" + short] = [{
             "bytes": fb + wb, "kernel": short, "launches": best[1]["FETCH_SIZE"][1],
             "kernels_sha16": line.get("kernels_sha16"), "value_slots": [0, 0],
             "spmv_flags": kk["spmv_flags"], "xcd_period_slices": 0,
             "source": "profiles/%s_pmc_traffic_csr_kernel.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes "
-                      "of `bench.py --only csr_kernel`; FETCH_SIZE x 2)" % rnd}
+                      "of `bench.py --only csr_kernel`; FETCH_SIZE x 2)" % rnd}]
     open(os.path.join(out, "%s_pmc_traffic_csr_kernel.csv" % rnd), "w").write("\n".join(lines) + "\n")
     print("csr_kernel")
     print("\n".join(lines))
