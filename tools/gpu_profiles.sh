@@ -4,7 +4,7 @@
 # forms as bench lines.  Condensed into profiles/ by tools/summarize_profiles.py.
 cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=gpurun_out/${1:-profiles}; mkdir -p $OUT; export TMPDIR=/tmp
-# usage: gpu_profiles.sh <dir> [part]   part = A | B | C | D | all (a gpurun call is capped at 20 minutes: one part per call)
+# usage: gpu_profiles.sh <dir> [part]   part = A | B | C | D | E | all (a gpurun call is capped at 20 minutes: one part per call)
 PART=${2:-all}; CUR=A
 part() { CUR=$1; }
 step() { local name=$1 secs=$2; shift 2
@@ -76,4 +76,6 @@ export LSBENCH_HIP_FORCE_PERIOD=1
 pmc2 _lap3d_f198p --workload lap3d --fixed-iters 40 --spmv 5 --spmv-tune 198
 pmc2 _lap3d_f70p --workload lap3d --fixed-iters 40 --spmv 5 --spmv-tune 70
 unset LSBENCH_HIP_FORCE_PERIOD
-[ -f $OUT/bench.log ] && tail -c 400 $OUT/bench.log
+part E
+pmc2 _coef_f6 --workload lap2d_coef --fixed-iters 60 --spmv 5 --spmv-tune 6
+if [ -f $OUT/bench.log ]; then tail -c 400 $OUT/bench.log; fi
