@@ -1613,252 +1613,18 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_tmpl(
   spmv_publish(partials, dot, sred, tail);
 }
 
-// --------------------------------------------------------------------------
-// The template SpMV with DEPTH slices of a wave in flight (LSB_SP_DEEP; round 4).  On operators whose
-// vectors come out of HBM (64 M-row 7-point: 512 MB each) k_spmv_tmpl is bound by bytes IN FLIGHT,
-// not by traffic: a wave has one slice -- 5 KB of gathers, ~1.3 KB of them cold -- in flight per turn
-// of ~4 us, 24 waves per CU, and the launch ran exactly 24/16 longer with 16 gathering waves
-// ("What the launch waits for").  The register file is the larger pool (512 KB
-// per CU against 120 KB of gather destinations in use), so this kernel spends registers on depth
-// instead of on waves: a wave takes its next DEPTH turns AT ONCE -- all slice records by scalar loads
-// in one go, then all DEPTH x (2 NF + 1) 16-byte gathers, the edge elements and the masks, then the
-// stores of the turns before (parked in LDS: behind the gathers, so that no gather waits for a store's
-// acknowledgement -- one vmcnt for both), then the row sums slice after slice.  3 waves per SIMD with
-// DEPTH = 4: 48 slices in flight per CU instead of 24.
-// The slices a wave takes, their order, a row's fma chain and the order in which a lane adds up its
-// dot products are k_spmv_tmpl's: bit-identical results, fused dot included (tests/test_sell.py).
-// A group of DEPTH turns goes the pipelined way when every slice of it is whole (128 rows) and has a
-// SHAPED template; any other group (first / last grid lines and planes, the operator's ragged end --
-// about 1 % of a 3-D grid) goes slice by slice through tmpl_slice_slow below.
-// --------------------------------------------------------------------------
-// One slice, generic and unpipelined: the row sums of the lane's rows 2l and 2l + 1 in slot order.
-template <int NF>
-__device__ __forceinline__ void tmpl_slice_slow(
-    unsigned s, unsigned lane, unsigned n, unsigned row_begin, unsigned xlen, const unsigned *__restrict__ sptr,
-    const u4v *__restrict__ srec, const unsigned long long *__restrict__ mask, const lsb_sell_tmpl *__restrict__ td,
-    const int *__restrict__ sbase, const void *__restrict__ vals, int f32, const double *__restrict__ vconst,
-    const double *__restrict__ x, double &a0, double &a1) {
-  const u4v rec = srec[s];
-  const unsigned t = __builtin_amdgcn_readfirstlane(rec.x), vb = __builtin_amdgcn_readfirstlane(rec.y);
-  const unsigned mb = __builtin_amdgcn_readfirstlane(rec.z);
-  const unsigned row = s * LSB_SELL_ROWS + 2 * lane;
-  const int grow = (int)(row + row_begin);
-  a0 = 0.0, a1 = 0.0;
-  if (t != 255u) { // a template: constant slots gather pairs; kept / masked slots (c-1, c+1 of a shaped one) per element
-    const lsb_sell_tmpl *T = td + t;
-    for (int j = 0; j < T->nslots; j++) {
-      const int kd = T->kind[j], k = T->kidx[j], b = T->base[j];
-      if (kd == 0) {
-        const double cv = T->cst[j];
-        const sell_d2u v = *(const sell_d2u *)(x + (grow + b));
-        a0 = fma(cv, v.x, a0), a1 = fma(cv, v.y, a1);
-      } else {
-        double v0, v1;
-        if (kd == 2) {
-          const unsigned long long *mp = mask + 2 * ((size_t)mb + (unsigned)k);
-          const unsigned long long w = (lane & 32u) ? mp[1] : mp[0];
-          const unsigned sh = (2u * lane) & 63u;
-          v0 = (w >> sh) & 1ull ? T->cst[j] : 0.0;
-          v1 = (w >> (sh + 1u)) & 1ull ? T->cst[j] : 0.0;
-        } else if (f32) {
-          const vt2<float>::type v = *((const vt2<float>::type *)((const float *)vals + (size_t)(vb + (unsigned)k) * LSB_SELL_ROWS) + lane);
-          v0 = (double)v.x, v1 = (double)v.y;
-        } else {
-          const sell_d2v v = *((const sell_d2v *)((const double *)vals + (size_t)(vb + (unsigned)k) * LSB_SELL_ROWS) + lane);
-          v0 = v.x, v1 = v.y;
-        }
-        long long e0 = (long long)grow + b, e1 = e0 + 1; // value 0 = padding: no operand (index clamped), an exact 0
-        e0 = e0 < 0 ? 0 : (e0 >= (long long)xlen ? (long long)xlen - 1 : e0);
-        e1 = e1 < 0 ? 0 : (e1 >= (long long)xlen ? (long long)xlen - 1 : e1);
-        const double t0 = x[e0], t1 = x[e1];
-        a0 = fma(v0, v0 != 0.0 ? t0 : 0.0, a0), a1 = fma(v1, v1 != 0.0 ? t1 : 0.0, a1);
-      }
-    }
-  } else { // no template: slot by slot off the slot records (k_spmv_tmpl's last path)
-    const unsigned q0 = sptr[s] / LSB_SELL_ROWS, len = (sptr[s + 1] - sptr[s]) / LSB_SELL_ROWS;
-    for (unsigned j = 0; j < len; j++) {
-      const i4v r = ((const i4v *)sbase)[q0 + j];
-      if (r.z < 0) {
-        const double k = vconst[q0 + j];
-        const sell_d2u v = *(const sell_d2u *)(x + (grow + r.x));
-        a0 = fma(k, v.x, a0), a1 = fma(k, v.y, a1);
-      } else {
-        double v0, v1;
-        if (f32) {
-          const vt2<float>::type v = *((const vt2<float>::type *)((const float *)vals + (size_t)r.z * LSB_SELL_ROWS) + lane);
-          v0 = (double)v.x, v1 = (double)v.y;
-        } else {
-          const sell_d2v v = *((const sell_d2v *)((const double *)vals + (size_t)r.z * LSB_SELL_ROWS) + lane);
-          v0 = v.x, v1 = v.y;
-        }
-        const bool p0 = v0 != 0.0, p1 = v1 != 0.0;
-        const double t0 = x[p0 ? grow + r.x : 0], t1 = x[p1 ? grow + 1 + r.x : 0];
-        a0 = fma(v0, p0 ? t0 : 0.0, a0), a1 = fma(v1, p1 ? t1 : 0.0, a1);
-      }
-    }
-  }
-}
-
-template <int NF, int DEPTH>
-__global__ __launch_bounds__(WG, (DEPTH <= 2 ? 4 : 3)) void k_spmv_tmpl_deep(
-    const unsigned *__restrict__ sptr, unsigned s0, unsigned ns, unsigned period, unsigned n,
-    unsigned row_begin, unsigned xlen, const u4v *__restrict__ srec,
-    const unsigned long long *__restrict__ mask, const lsb_sell_tmpl *__restrict__ td,
-    const int *__restrict__ sbase, const void *__restrict__ vals, int f32,
-    const double *__restrict__ vconst, const double *__restrict__ x, double *__restrict__ y,
-    const double *__restrict__ xdot, int dot_is_x, double *__restrict__ partials,
-    const lsb_pcg_state *__restrict__ st, const lsb_ar_tail tail) {
-  __shared__ double sred[4];
-  __shared__ sell_d2v ypark[DEPTH * WG]; // a group's results wait here for the next group's gathers to be out
-  const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const unsigned gx = gridDim.x / NXCD, xcd = blockIdx.x % NXCD, slot = blockIdx.x / NXCD;
-  const sell_deal deal = sell_deal_init(ns, period, xcd);
-  const int stopped = st ? st->status : 0;
-  double dot = 0.0;
-  unsigned parked[DEPTH]; // first row of the slice whose results sit in ypark[d * WG ..) (wave-uniform)
-#pragma unroll
-  for (int d = 0; d < DEPTH; d++)
-    parked[d] = 0xFFFFFFFFu;
-#define DEEP_UNPARK()                                                                          \
-  do {                                                                                         \
-    _Pragma("unroll") for (int d_ = 0; d_ < DEPTH; d_++) if (parked[d_] != 0xFFFFFFFFu) {      \
-      *(sell_d2v *)(y + parked[d_] + 2 * lane) = ypark[d_ * WG + tid];                         \
-      parked[d_] = 0xFFFFFFFFu;                                                                \
-    }                                                                                          \
-  } while (0)
-  for (unsigned g = slot; g < deal.turns; g += DEPTH * gx) {
-    unsigned sl[DEPTH];
-    u4v rec[DEPTH];
-    bool fast = true;
-#pragma unroll
-    for (int d = 0; d < DEPTH; d++) {
-      const unsigned it = g + (unsigned)d * gx;
-      const unsigned si = it < deal.turns ? __builtin_amdgcn_readfirstlane(sell_deal_slice(deal, it, wave, ns)) : 0xFFFFFFFFu;
-      sl[d] = si == 0xFFFFFFFFu ? si : s0 + si;
-      fast = fast && si != 0xFFFFFFFFu && sl[d] * LSB_SELL_ROWS + LSB_SELL_ROWS <= n;
-    }
-    if (fast) {
-#pragma unroll
-      for (int d = 0; d < DEPTH; d++)
-        rec[d] = srec[sl[d]]; // DEPTH 16-byte scalar loads, one round trip
-      // every slice DEEP-ELIGIBLE (bit 0 of the record's fourth word, set on the host, hip_solver.c: a
-      // shaped template whose slots c-1 / c+1 are constant or masked -- kept values would be loads
-      // under a condition -- and whose centre is the diagonal, so that the centre pair is the dot's
-      // operand).  One batch of scalar loads, one test
-      unsigned ok = 1u;
-#pragma unroll
-      for (int d = 0; d < DEPTH; d++)
-        ok &= rec[d].w;
-      ok = __builtin_amdgcn_readfirstlane(ok) & (unsigned)(!xdot || dot_is_x);
-      fast = ok != 0u;
-    }
-    if (fast) {
-      sell_d2u lo[DEPTH][NF > 0 ? NF : 1], hi[DEPTH][NF > 0 ? NF : 1], c[DEPTH];
-      double edge[DEPTH];
-      unsigned mword[DEPTH][2]; // the lane's 32 bits of the masks of slots c-1 / c+1 (vector loads: they ride with the gathers)
-      // every load of the group unconditional and in one batch: far slots, centre, the element beyond
-      // either end of the wave's 128 operands (lane 63: behind, every other lane: in front -- two
-      // addresses per wave), the masks (an unmasked slot reads the slice's first mask word and ignores it)
-#pragma unroll
-      for (int d = 0; d < DEPTH; d++) {
-        const lsb_sell_tmpl *T = td + __builtin_amdgcn_readfirstlane(rec[d].x);
-        const unsigned mb = __builtin_amdgcn_readfirstlane(rec[d].z);
-        const int g0 = (int)(sl[d] * LSB_SELL_ROWS + row_begin), grow = g0 + 2 * (int)lane, bc = T->base[NF + 1];
-#pragma unroll
-        for (int k = 0; k < NF; k++)
-          lo[d][k] = *(const sell_d2u *)(x + (grow + T->base[k]));
-        c[d] = *(const sell_d2u *)(x + (grow + bc));
-#pragma unroll
-        for (int k = 0; k < NF; k++)
-          hi[d][k] = *(const sell_d2u *)(x + (grow + T->base[NF + 3 + k]));
-        long long e = (long long)g0 + bc + (lane == 63 ? (long long)LSB_SELL_ROWS : -1ll);
-        e = e < 0 ? 0 : (e >= (long long)xlen ? (long long)xlen - 1 : e);
-        edge[d] = x[e];
-#pragma unroll
-        for (int side = 0; side < 2; side++) {
-          const int k = T->kidx[NF + 2 * side];
-          mword[d][side] = ((const unsigned *)(mask + 2 * ((size_t)mb + (unsigned)(k > 0 ? k : 0))))[lane >> 4];
-        }
-      }
-      DEEP_UNPARK(); // the group before's y: the youngest operations in flight when the gathers are waited for
-      if (stopped)
-        return;
-#pragma unroll
-      for (int d = 0; d < DEPTH; d++) {
-        const lsb_sell_tmpl *T = td + __builtin_amdgcn_readfirstlane(rec[d].x);
-        double a0 = 0.0, a1 = 0.0;
-        double up = lane_above(c[d].y), dn = lane_below(c[d].x);
-        if (lane == 0)
-          up = edge[d];
-        if (lane == 63)
-          dn = edge[d];
-#pragma unroll
-        for (int k = 0; k < NF; k++) {
-          const double v = T->cst[k];
-          a0 = fma(v, lo[d][k].x, a0), a1 = fma(v, lo[d][k].y, a1);
-        }
-        // slots c-1 / c+1: the template's number, under the slice's mask where the slot is masked
-        double vs[2][2];
-#pragma unroll
-        for (int side = 0; side < 2; side++) {
-          const int j = NF + 2 * side;
-          const double cv = T->cst[j];
-          const unsigned sh = (2u * lane) & 31u;
-          const unsigned w = T->kind[j] == 2 ? mword[d][side] : 0xFFFFFFFFu;
-          vs[side][0] = (w >> sh) & 1u ? cv : 0.0;
-          vs[side][1] = (w >> (sh + 1u)) & 1u ? cv : 0.0;
-        }
-        const double vc = T->cst[NF + 1];
-        a0 = fma(vs[0][0], vs[0][0] != 0.0 ? up : 0.0, a0), a1 = fma(vs[0][1], vs[0][1] != 0.0 ? c[d].x : 0.0, a1);
-        a0 = fma(vc, c[d].x, a0), a1 = fma(vc, c[d].y, a1);
-        a0 = fma(vs[1][0], vs[1][0] != 0.0 ? c[d].y : 0.0, a0), a1 = fma(vs[1][1], vs[1][1] != 0.0 ? dn : 0.0, a1);
-#pragma unroll
-        for (int k = 0; k < NF; k++) {
-          const double v = T->cst[NF + 3 + k];
-          a0 = fma(v, hi[d][k].x, a0), a1 = fma(v, hi[d][k].y, a1);
-        }
-        ypark[d * WG + tid] = (sell_d2v){a0, a1};
-        parked[d] = sl[d] * LSB_SELL_ROWS;
-        if (xdot) { // the centre pair IS the dot's operand (a condition of this path)
-          dot = fma(a0, c[d].x, dot);
-          dot = fma(a1, c[d].y, dot);
-        }
-      }
-    } else { // a group with a slice that is ragged, has no template or an unshaped one: slice by slice
-      DEEP_UNPARK();
-      if (stopped)
-        return;
-#pragma unroll 1
-      for (int d = 0; d < DEPTH; d++) {
-        const unsigned it = g + (unsigned)d * gx;
-        const unsigned si = it < deal.turns ? __builtin_amdgcn_readfirstlane(sell_deal_slice(deal, it, wave, ns)) : 0xFFFFFFFFu;
-        if (si == 0xFFFFFFFFu)
-          continue;
-        const unsigned s = s0 + si, row = s * LSB_SELL_ROWS + 2 * lane;
-        double a0, a1;
-        tmpl_slice_slow<NF>(s, lane, n, row_begin, xlen, sptr, srec, mask, td, sbase, vals, f32, vconst, x, a0, a1);
-        if (row + 1 < n) {
-          *(sell_d2v *)(y + row) = (sell_d2v){a0, a1};
-          if (xdot) {
-            const sell_d2v q = *(const sell_d2v *)(xdot + row);
-            dot = fma(a0, q.x, dot);
-            dot = fma(a1, q.y, dot);
-          }
-        } else if (row < n) {
-          y[row] = a0;
-          if (xdot)
-            dot = fma(a0, xdot[row], dot);
-        }
-      }
-    }
-  }
-  DEEP_UNPARK();
-#undef DEEP_UNPARK
-  if (stopped)
-    return;
-  spmv_publish(partials, dot, sred, tail);
-}
-
+// (Round 4, measured and taken out again: k_spmv_tmpl_deep -- a wave takes 2 or 4 of its turns AT ONCE,
+// all their slice records in one batch of scalar loads, all 10 / 20 gathers, edge elements and mask
+// words in flight together, the stores of the group before behind them; 90 / 136 VGPRs, 5 / 3 waves per
+// SIMD, 40 / 48 slices in flight per CU instead of 24; bit-identical, fused dot included.  64 M-row
+// 7-point operator, same box: 332 / 336 us back to back against 302 us for the deferred-store form
+// below and 345 us for the plain one; 10 M-row 5-point: 28.3 / 32.5 against 25.9 us.  So the launch
+// is NOT short of bytes in flight -- round 3's reading -- and the counters agree: its fabric reads wait
+// 1200-1450 L2 cycles where the sweeps' wait 2300-2700 at 1.4-2x the requests outstanding.  What a
+// slice costs is mostly there when everything sits in the Infinity Cache too (0.45 of 0.60 ns per
+// slice): ~110 vector and ~120 scalar instructions per slice and wave, five L1->L2 round trips of
+// which three hit L2.  profiles/r04_cfg4_spmv.txt; the kernel is in the history
+// at commit "Vectors of a shard carved out of one allocation".)
 // --------------------------------------------------------------------------
 // a2-1, binned form (LSB_SPMV_BINNED, host side lsb_csr_binize) -- for operators
 // whose rows scatter over far more of x than an XCD's L2 holds (power-law
@@ -2334,23 +2100,6 @@ void lsb_k_spmv_tmpl(unsigned flags, unsigned grid_cap, unsigned period, const u
   if (period && (period < NXCD || ns < period))
     period = 0;
   const int f32 = (flags & LSB_SP_F32) != 0, dot_is_x = xdot && xdot == x + row_begin;
-  if ((flags & (LSB_SP_DEEP2 | LSB_SP_DEEP4)) && !epi.zout) { /* DEPTH slices of a wave in flight */
-#define LSB_DEEP(NF, D)                                                                              \
-  k_spmv_tmpl_deep<NF, D><<<g, WG, 0, s>>>(sptr, s0, ns, period, n, row_begin, xlen, (const u4v *)srec, mask, td, sbase, \
-                                           vals, f32, vconst, x, y, xdot, dot_is_x, partials, st, tail)
-    const int deep4 = (flags & LSB_SP_DEEP4) != 0;
-    switch (nfar * 2 + deep4) {
-    case 0: LSB_DEEP(0, 2); break;
-    case 1: LSB_DEEP(0, 4); break;
-    case 2: LSB_DEEP(1, 2); break;
-    case 3: LSB_DEEP(1, 4); break;
-    case 4: LSB_DEEP(2, 2); break;
-    case 5: LSB_DEEP(2, 4); break;
-    default: errx(EXIT_FAILURE, "lsb_k_spmv_tmpl: %u far slots per side", nfar);
-    }
-#undef LSB_DEEP
-    return;
-  }
 #define LSB_TMPL(NF)                                                                                 \
   do {                                                                                               \
     if (epi.zout)                                                                                    \

@@ -351,18 +351,9 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
             { /* per slice ONE 16-byte record {template id, first kept value slot, first mask, 0}: a
                * single scalar load in the kernel */
               unsigned *rec = lsb_calloc(unsigned, 4 * ((size_t)TT->nslice + 1));
-              for (unsigned k = 0; k < TT->nslice; k++) {
+              for (unsigned k = 0; k < TT->nslice; k++)
                 rec[4 * (size_t)k] = TT->tid[k], rec[4 * (size_t)k + 1] = TT->vbase[2 * (size_t)k],
                                rec[4 * (size_t)k + 2] = TT->vbase[2 * (size_t)k + 1];
-                /* bit 0 of the fourth word: the slice may go k_spmv_tmpl_deep's pipelined way -- whole
-                 * (128 rows), a shaped template, slots c-1 / c+1 constant or masked, the centre the
-                 * diagonal (base 0: the centre pair is the fused dot's operand) */
-                if (TT->tid[k] != 255 && ((unsigned long long)k + 1) * LSB_SELL_ROWS <= n) {
-                  const struct lsb_sell_tmpl *t = &TT->t[TT->tid[k]];
-                  const int c = (int)TT->nfar + 1;
-                  rec[4 * (size_t)k + 3] = t->shaped && t->kind[c - 1] != 1 && t->kind[c + 1] != 1 && t->base[c] == 0;
-                }
-              }
               s->d_srec = (unsigned *)dev_upload(rec, 4 * ((size_t)TT->nslice + 1) * sizeof(unsigned));
               LSB_CHK_HIP(hipStreamSynchronize(g_stream));
               free(rec);
@@ -904,7 +895,7 @@ void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
   if (getenv("LSBENCH_HIP_FORCE_PERIOD")) /* tests: the plane-periodic dealing on small operators */
     s->sp_period = s->sell_period;
   if (o->spmv_tune >= 0) {
-    s->sp_flags = (unsigned)o->spmv_tune & (31u | LSB_SP_TMPL | LSB_SP_DEFER | LSB_SP_DEEP2 | LSB_SP_DEEP4); /* bit 2: 16-bit codes, where that copy exists;
+    s->sp_flags = (unsigned)o->spmv_tune & (31u | LSB_SP_TMPL | LSB_SP_DEFER); /* bit 2: 16-bit codes, where that copy exists;
                                                    bits 3, 4: binned form's gather flavour; bit 6: slice
                                                    templates, where the constant-slot layout has them */
     return;

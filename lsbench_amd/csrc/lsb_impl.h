@@ -115,8 +115,6 @@ void lsb_k_spmv_sell(unsigned flags, unsigned grid_cap, unsigned period, const u
                      const struct lsb_cheb_epi *epi, void *stream);
 #define LSB_SP_TMPL 64u /* 16-bit sliced-ELL with constant slots: slice templates (k_spmv_tmpl) */
 #define LSB_SP_DEFER 128u /* k_spmv_tmpl: a turn's y is parked in LDS and stored by the wave's next turn */
-#define LSB_SP_DEEP2 256u /* k_spmv_tmpl_deep: a wave takes 2 (DEEP2) or 4 (DEEP4) of its turns at once -- all their */
-#define LSB_SP_DEEP4 512u /* gathers in flight together, the stores of the group before behind them */
 void lsb_k_spmv_tmpl(unsigned flags, unsigned grid_cap, unsigned period, const unsigned *sptr, unsigned s0,
                      unsigned ns, unsigned n, unsigned row_begin, unsigned xlen, const unsigned *srec,
                      const unsigned long long *mask, const struct lsb_sell_tmpl *td,
