@@ -48,6 +48,13 @@ for comm, cname in ((la.COMM_RCCL, "device copies"), (la.COMM_P2P, "direct path"
         us = run(A, f"virt8 {cname} overlap={ov}", nvirt=8, comm=comm, overlap=ov, krylov=la.KRYLOV_AUTO)
         res[(cname, ov)] = us / 8
         print(f"    -> per shard {us / 8:8.1f} us/iter; ceiling {whole / (us / 8):.2f}x of the one-GPU iteration")
+    # round 4: opts.overlap = -1 -- both forms timed on this communicator at creation, the faster one runs
+    n = A.nrows
+    s = la.Solver(A, la.default_opts(op_mode=la.OP_RAW, tol=1e-30, maxit=iters, verify=0, nvirt=8, comm=comm,
+                                     krylov=la.KRYLOV_AUTO))
+    print(f"virt8 {cname} overlap=-1 (timed at creation): {s.comm_plan['overlap_timed_us']} -> "
+          f"{'split' if s.overlaps else 'plain'}", flush=True)
+    s.destroy()
 del A
 os.environ["LSBENCH_HIP_DIST_ALONE"] = "1"
 idb = ctypes.create_string_buffer(la._lib.UNIQUE_ID_BYTES)
