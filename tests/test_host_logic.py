@@ -782,3 +782,47 @@ def test_tmpl_check_states_the_template_kernels_bounds():
                     t.nmask = keep
                 lib.lsb_sell_tmpls_free(T)
             lib.lsb_sell_vc_free(V), lib.lsb_sell_free(H)
+
+
+def test_bench_quotes_pmc_traffic_only_for_what_it_was_measured_on(tmp_path, monkeypatch):
+    """bench.py's roofline.traffic comes from profiles/pmc_traffic.json -- a LIST of profiled flavours
+    per workload -- and is quoted only where kernel name, hash of the kernel sources, kept / all value
+    slots AND the flavour the timing pass picked (spmv_flags, xcd_period_slices) are those of the run;
+    anything else reads null with the reason (VERDICT r3 weak #8)."""
+    import importlib.util, json, os, sys
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    saved = sys.argv
+    sys.argv = ["bench.py"]
+    try:
+        bench = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bench)
+    finally:
+        sys.argv = saved
+    sha = bench.kernels_sha16()
+    (tmp_path / "profiles").mkdir()
+    entries = {"lap3d": [dict(bytes=1833e6, kernel="k_spmv_tmpl", kernels_sha16=sha, value_slots=[3, 9], spmv_flags=198,
+                              xcd_period_slices=0, source="a.csv"),
+                         dict(bytes=1389e6, kernel="k_spmv_tmpl", kernels_sha16=sha, value_slots=[3, 9], spmv_flags=198,
+                              xcd_period_slices=1250, source="b.csv")],
+               "old": dict(bytes=1.0, kernel="k_spmv_tmpl", kernels_sha16="0" * 16, value_slots=[3, 9], spmv_flags=70,
+                           xcd_period_slices=0)}
+    (tmp_path / "profiles" / "pmc_traffic.json").write_text(json.dumps(entries))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "kernels_sha16", lambda: sha)
+    assert bench.pmc_traffic("lap3d", "k_spmv_tmpl", (3, 9), 198, 1250) == (1389e6, "b.csv")
+    assert bench.pmc_traffic("lap3d", "k_spmv_tmpl", (3, 9), 198, 0) == (1833e6, "a.csv")
+    t, why = bench.pmc_traffic("lap3d", "k_spmv_tmpl", (3, 9), 70, 0)
+    assert t is None and "other flavour" in why and "(198, 1250)" in why
+    t, why = bench.pmc_traffic("lap3d", "k_spmv_sell16", (3, 9), 198, 0)
+    assert t is None and "k_spmv_sell16" in why
+    t, why = bench.pmc_traffic("lap3d", "k_spmv_tmpl", (4, 9), 198, 0)
+    assert t is None and "value slots" in why
+    t, why = bench.pmc_traffic("old", "k_spmv_tmpl", (3, 9), 70, 0)          # (a dict of earlier rounds: one entry)
+    assert t is None and "kernel sources" in why
+    assert bench.pmc_traffic("nothing", "k", (0, 0), 0, 0)[0] is None and bench.pmc_traffic(None, "k", (0, 0))[0] is None
+    # GMRES(m) bytes: the first step of a cycle reads one basis column per Gram-Schmidt pass, the 30th thirty
+    n, sp = 1000, 5000
+    one = bench.gmres_bytes(n, sp, 30, 1)
+    assert one == 24 * n + 8 * n * 4 + 32 * n + sp + 2 * 8 * n * 2 + 2 * 8 * n * 3
+    assert bench.gmres_bytes(n, sp, 30, 31) - bench.gmres_bytes(n, sp, 30, 30) == one + 16 * n + sp + 8 * n * (1 - 30) + 8 * n * 30 - 8 * n
