@@ -406,7 +406,12 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
       cnt += (size_t)n;                                        /* z */
     else if (o->precond == LSB_PRECOND_FSAI)
       cnt += 4 * (size_t)n;                                    /* z, t = G r, the second r / p buffers */
-    if (o->krylov != LSB_KRYLOV_GMRES && !getenv("LSBENCH_HIP_NO_SLAB")) {
+    /* ... where the vectors are of the Infinity Cache's scale or below (n <= 20 M rows): that is where
+     * their relative placement decides which lines fight for the same sets.  Vectors that fit no cache
+     * gain nothing from it and measured 5 % SLOWER out of one allocation (64 M-row 7-point operator:
+     * 1098-1163 us per iteration against 1067-1096 from separate allocations, SpMV 300-305 against
+     * 283-293 us, whatever padding was put between them; profiles/r04_placement.txt) */
+    if (o->krylov != LSB_KRYLOV_GMRES && !getenv("LSBENCH_HIP_NO_SLAB") && (size_t)n * sizeof(double) <= ((size_t)160 << 20)) {
       s->slab_cap = cnt * sizeof(double) + 16 * 256;
       if (hipMalloc((void **)&s->d_slab, s->slab_cap) != hipSuccess) /* no room for one piece: pieces then */
         s->d_slab = NULL, s->slab_cap = 0, (void)hipGetLastError();

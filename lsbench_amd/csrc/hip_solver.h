@@ -52,7 +52,8 @@ struct shard {
    * relative to one another is then the same in every solver of every process -- which of their
    * lines compete for the same sets of the 256 MB Infinity Cache no longer depends on which
    * physical pages a dozen separate hipMallocs happened to get ("Where the
-   * vectors land").  shard_vec() carves 256-byte aligned pieces; what does not fit (or arrives with
+   * vectors land"); used where the vectors are of that cache's scale (<= 160 MB each: larger ones measured
+   * slower out of one allocation).  shard_vec() carves 256-byte aligned pieces; what does not fit (or arrives with
    * LSBENCH_HIP_NO_SLAB=1) is a hipMalloc of its own; shard_vec_free() tells the two apart. */
   char *d_slab;
   size_t slab_cap, slab_used;
