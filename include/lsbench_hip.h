@@ -475,6 +475,39 @@ void lsb_sell_tmpls_free(struct lsb_sell_tmpls *T);
  * the backend at every upload; deep != 0 also walks values and masks. */
 int lsb_tmpl_check(const struct lsb_sell *S, const struct lsb_sell_vc *V, const struct lsb_sell_tmpls *T,
                    unsigned row_begin, unsigned nrows, unsigned xlen, int deep, char *why, size_t whylen);
+/* Z-COLUMNS of the template layout (k_spmv_tmpl_col).  On a 3-D stencil whose planes are whole
+ * slices (period = slices per plane) the outermost far slots of a shaped template reach exactly
+ * one plane down and up: base[0] = base[c] - 128 period, base[last] = base[c] + 128 period.  The
+ * operand pair a lane gathers for slot 0 of slice s + period is then the very pair it gathered for
+ * the centre of slice s, and the centre pair of s + period is what slot `last` of s asked for: a
+ * wavefront that walks s, s + period, s + 2 period, ... keeps three centre pairs in registers and
+ * gathers ONE new plane per step instead of three.  A column is a run of 2..kmax such slices that
+ * share one template and one set of mask words (the host checks it: every interior z-column of a
+ * structured grid qualifies), so the template and the masks are looked at once per column.
+ * Everything else -- first / last plane, slices that keep values, ragged ends -- is an item of
+ * one slice and goes slot by slot off the slot records.
+ * item[4i..4i+3] = {first slice, slices (1: a single slice; >= 2: a column), template id, first
+ * mask}; the items of XCD k are [xbeg[k], xbeg[k+1]): the same eighth of every plane, z-group
+ * after z-group (kmax planes each), positions ascending -- the order the chip sweeps them in.
+ * Lossless: the same operands and products in the same order as k_spmv_tmpl / k_spmv_sell16. */
+#define LSB_TMPL_COL_MAX 16
+struct lsb_tmpl_cols {
+  unsigned nitem, kmax, period;
+  unsigned xbeg[9];
+  unsigned *item;               /* 4 * (nitem + 1) */
+  unsigned long long in_cols;   /* slices inside columns (the rest are single items) */
+  int centre0;                  /* every column's centre slot has base 0 (the diagonal): where the fused
+                                   dot is with the gathered vector itself, the centre pair is its operand */
+};
+/* NULL where the layout has no such columns (period < 8, no shaped template with plane-reaching
+ * far slots) or fewer than 3/4 of the slices fall inside columns. */
+struct lsb_tmpl_cols *lsb_sell_tmpl_columns(const struct lsb_sell_tmpls *T, unsigned period, unsigned kmax);
+void lsb_tmpl_cols_free(struct lsb_tmpl_cols *C);
+/* The rules k_spmv_tmpl_col relies on, as host assertions (run at every upload): every slice in
+ * exactly one item; a column's slices s + k period exist, share the item's template -- shaped,
+ * constant or masked slots only, outermost far slots one plane away -- and its mask words bit
+ * for bit.  0 or a rule number with the rule in `why`. */
+int lsb_tmpl_cols_check(const struct lsb_sell_tmpls *T, const struct lsb_tmpl_cols *C, char *why, size_t whylen);
 /* mean |col - (row + row_begin)| over a sample of the rows */
 double lsb_csr_mean_scatter(const struct csr *A, unsigned row_begin);
 /* [lo,hi) column range referenced by A (0-based). */
@@ -556,6 +589,9 @@ unsigned lsb_hip_solver_spmv_grid(const lsb_hip_solver *s);
 /* sliced-ELL: slices per plane the XCD dealing follows (every XCD the same eighth
  * of every plane of a 3-D stencil), 0 = contiguous eighths of the rows. */
 unsigned lsb_hip_solver_spmv_period(const lsb_hip_solver *s);
+/* slices the first shard's z-column plan walks in columns (k_spmv_tmpl_col, LSB_SP_COL of the
+ * flags: a 3-D stencil whose planes are whole slices); 0 = no plan, the flag changes nothing */
+unsigned long long lsb_hip_solver_spmv_col_slices(const lsb_hip_solver *s);
 /* 16-bit sliced-ELL form in use: slots that keep their 128 values / all slots of the
  * first shard (lsb_sell16_value_slots); 0 / 0 for every other form */
 void lsb_hip_solver_sell_value_slots(const lsb_hip_solver *s, unsigned *kept, unsigned *total);

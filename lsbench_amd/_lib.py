@@ -114,6 +114,12 @@ class SellTmpls(C.Structure):
                 ("mask", C.POINTER(C.c_ulonglong)), ("t", C.POINTER(SellTmpl))]
 
 
+class TmplCols(C.Structure):
+    """struct lsb_tmpl_cols."""
+    _fields_ = [("nitem", C.c_uint), ("kmax", C.c_uint), ("period", C.c_uint), ("xbeg", C.c_uint * 9),
+                ("item", C.POINTER(C.c_uint)), ("in_cols", C.c_ulonglong), ("centre0", C.c_int)]
+
+
 class Binned(C.Structure):
     """struct lsb_binned."""
     _fields_ = [("nbins", C.c_uint), ("width", C.c_uint), ("nrows", C.c_uint), ("nchunks", C.c_uint),
@@ -193,6 +199,9 @@ SIGNATURES = {
     "lsb_sell_tmpls_free": (None, [C.POINTER(SellTmpls)]),
     "lsb_tmpl_check": (_i, [C.POINTER(Sell), C.POINTER(SellVc), C.POINTER(SellTmpls), _u, _u, _u, _i,
                             C.c_char_p, C.c_size_t]),
+    "lsb_sell_tmpl_columns": (C.POINTER(TmplCols), [C.POINTER(SellTmpls), _u, _u]),
+    "lsb_tmpl_cols_free": (None, [C.POINTER(TmplCols)]),
+    "lsb_tmpl_cols_check": (_i, [C.POINTER(SellTmpls), C.POINTER(TmplCols), C.c_char_p, C.c_size_t]),
     "lsb_csr_mean_scatter": (_d, [_csrp, _u]),
     "lsb_csr_col_hull": (None, [_csrp, C.POINTER(_u), C.POINTER(_u)]),
     "lsb_plan_exchange": (None, [_i, _i, C.POINTER(_u), C.POINTER(Xfer), C.POINTER(_i),
@@ -215,6 +224,7 @@ SIGNATURES = {
     "lsb_hip_solver_spmv_flags": (_u, [_vp]),
     "lsb_hip_solver_spmv_grid": (_u, [_vp]),
     "lsb_hip_solver_spmv_period": (_u, [_vp]),
+    "lsb_hip_solver_spmv_col_slices": (C.c_ulonglong, [_vp]),
     "lsb_hip_solver_sell_value_slots": (None, [_vp, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
     "lsb_hip_solver_overlaps": (_i, [_vp]),
     "lsb_hip_solver_overlap": (_i, [_vp, C.POINTER(C.c_double)]),

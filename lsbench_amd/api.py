@@ -303,6 +303,11 @@ class Solver:
         return L.load().lsb_hip_solver_spmv_grid(self._h)
 
     @property
+    def spmv_col_slices(self):
+        """Slices shard 0's z-column plan walks in columns (k_spmv_tmpl_col); 0 = no plan."""
+        return int(L.load().lsb_hip_solver_spmv_col_slices(self._h))
+
+    @property
     def spmv_period(self):
         return L.load().lsb_hip_solver_spmv_period(self._h)
 

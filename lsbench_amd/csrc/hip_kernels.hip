@@ -1613,6 +1613,219 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_tmpl(
   spmv_publish(partials, dot, sred, tail);
 }
 
+// --------------------------------------------------------------------------
+// a2-1, the template layout walked in Z-COLUMNS (LSB_SP_COL; host side lsb_sell_tmpl_columns,
+// include/lsbench_hip.h).  On a 3-D stencil whose planes are whole slices the outermost far slots
+// of a slice reach exactly one plane down and up, so the pair a lane gathers for slot 0 of the
+// slice one plane up IS the centre pair of this slice, and this slice's last slot is that one's
+// centre: a wave that walks a column s, s + period, s + 2 period, ... keeps three centre pairs in
+// registers and gathers ONE new plane per step -- 3 instead of 5 gathers per 7-point slice, and
+// every element of x leaves memory (K + 2) / K times instead of "three times unless the L2 still
+// has it" (k_spmv_tmpl on the 64 M-row 7-point operator: FETCH 1.30 GB for 0.53 GB of compulsory
+// reads).  The template, its constants and the masks of the slots c-1 / c+1 are looked at once
+// per column (the host has checked that all its slices share them): a step is ~40 vector
+// instructions against ~110 + ~120 scalar ones per slice of k_spmv_tmpl.
+// Pipeline of a column (vmcnt counts loads and stores in one order on gfx9): a step issues the
+// NEXT step's gathers, then stores the PREVIOUS step's y out of registers, then waits for its own
+// operands -- which are older than both, so neither the new gathers nor the store are waited for,
+// and a store has a whole step to be acknowledged (the job of LSB_SP_DEFER's LDS parking).
+// Items of one slice (first / last plane, ragged ends) go slot by slot off the slot records.
+// The same operands and products in the same order as k_spmv_tmpl / k_spmv_sell16: y bit for
+// bit; the fused dot's partial sums follow this kernel's own (fixed) dealing.
+// DOT: 0 none, 1 the centre pair is the dot's operand (xdot = x + row_begin, centre base 0), 2 loaded.
+// --------------------------------------------------------------------------
+template <int NF> struct col_ops { // what a step needs besides the three centre pairs
+  sell_d2u lo[NF > 1 ? NF - 1 : 1], hi[NF > 1 ? NF - 1 : 1];
+  double edge;
+  sell_d2v xd;
+};
+template <int NF> struct col_tmpl { // the column's template, in scalar registers
+  int bc, bl[NF > 1 ? NF - 1 : 1], bh[NF > 1 ? NF - 1 : 1];
+  double k0, kl[NF > 1 ? NF - 1 : 1], kc, kh[NF > 1 ? NF - 1 : 1], kL;
+};
+// gu = global row of lane 0's first row in this step's slice; lrow = its local row
+template <int NF, int DOT>
+__device__ __forceinline__ void col_issue(col_ops<NF> &o, sell_d2u &cnext, const col_tmpl<NF> &T, const double *__restrict__ x,
+                                          const double *__restrict__ xdot, long long gu, unsigned lrow, unsigned P,
+                                          unsigned xlen, unsigned lane, bool with_next) {
+  if (with_next)
+    cnext = *(const sell_d2u *)(x + (gu + T.bc + (long long)P) + 2 * lane);
+#pragma unroll
+  for (int k = 0; k < NF - 1; k++) {
+    o.lo[k] = *(const sell_d2u *)(x + (gu + T.bl[k]) + 2 * lane);
+    o.hi[k] = *(const sell_d2u *)(x + (gu + T.bh[k]) + 2 * lane);
+  }
+  // the element in front of the wave's 128 centre operands (lanes 0..31 ask for it) and the one
+  // behind them (lanes 32..63): every lane loads, two addresses per wave -- no divergent branch
+  // around a load, whose join would make the compiler wait for everything in flight
+  // (clamped: at the operator's first / last row the slot c-1 / c+1 is masked there and whatever is
+  // read is dropped at the product)
+  long long el = gu + T.bc - 1, er = gu + T.bc + (long long)LSB_SELL_ROWS; // wave-uniform
+  el = el < 0 ? 0 : el, er = er >= (long long)xlen ? (long long)xlen - 1 : er;
+  o.edge = x[lane < 32u ? el : er];
+  if (DOT == 2)
+    o.xd = *(const sell_d2v *)(xdot + lrow + 2 * lane);
+}
+template <int NF, int DOT>
+__device__ __forceinline__ void col_compute(const col_ops<NF> &o, const sell_d2u &cm, const sell_d2u &c, const sell_d2u &cp,
+                                            const col_tmpl<NF> &T, double vm0, double vm1, double vp0, double vp1,
+                                            unsigned lane, double &a0, double &a1, double &dot) {
+  double up = lane_above(c.y), dn = lane_below(c.x);
+  if (lane == 0)
+    up = o.edge;
+  if (lane == 63)
+    dn = o.edge;
+  a0 = fma(T.k0, cm.x, 0.0), a1 = fma(T.k0, cm.y, 0.0); // slot 0: one plane down = the centre of the step before
+#pragma unroll
+  for (int k = 0; k < NF - 1; k++)
+    a0 = fma(T.kl[k], o.lo[k].x, a0), a1 = fma(T.kl[k], o.lo[k].y, a1);
+  // value 0 = padding: no operand, an exact 0 (the rule of k_spmv_sell16)
+  a0 = fma(vm0, vm0 != 0.0 ? up : 0.0, a0), a1 = fma(vm1, vm1 != 0.0 ? c.x : 0.0, a1); // slot c-1
+  a0 = fma(T.kc, c.x, a0), a1 = fma(T.kc, c.y, a1);                                     // slot c
+  a0 = fma(vp0, vp0 != 0.0 ? c.y : 0.0, a0), a1 = fma(vp1, vp1 != 0.0 ? dn : 0.0, a1); // slot c+1
+#pragma unroll
+  for (int k = 0; k < NF - 1; k++)
+    a0 = fma(T.kh[k], o.hi[k].x, a0), a1 = fma(T.kh[k], o.hi[k].y, a1);
+  a0 = fma(T.kL, cp.x, a0), a1 = fma(T.kL, cp.y, a1); // last slot: one plane up = the centre of the step after
+  if (DOT == 1)
+    dot = fma(a0, c.x, dot), dot = fma(a1, c.y, dot);
+  else if (DOT == 2)
+    dot = fma(a0, o.xd.x, dot), dot = fma(a1, o.xd.y, dot);
+}
+
+#define LSB_COL_HEAD 16 // unsigneds in front of the items: xbeg[NXCD + 1]
+template <int NF, int DOT>
+__global__ __launch_bounds__(WG, 6) void k_spmv_tmpl_col(
+    const unsigned *__restrict__ plan, unsigned period, unsigned n, unsigned row_begin, unsigned xlen,
+    const unsigned *__restrict__ sptr, const unsigned long long *__restrict__ mask,
+    const lsb_sell_tmpl *__restrict__ td, const int *__restrict__ sbase, const void *__restrict__ vals, int f32,
+    const double *__restrict__ vconst, const double *__restrict__ x, double *__restrict__ y,
+    const double *__restrict__ xdot, double *__restrict__ partials, const lsb_pcg_state *__restrict__ st,
+    const lsb_ar_tail tail) {
+  static_assert(NF >= 1 && NF <= 2, "one or two far slots per side");
+  __shared__ double sred[4];
+  const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const unsigned gx = gridDim.x / NXCD, xcd = blockIdx.x % NXCD, slot = blockIdx.x / NXCD;
+  const unsigned i0 = plan[xcd], i1 = plan[xcd + 1];
+  const u4v *__restrict__ items = (const u4v *)(plan + LSB_COL_HEAD);
+  const int stopped = st ? st->status : 0; // tested behind the first loads
+  const unsigned P = period * LSB_SELL_ROWS; // rows of a plane
+  double dot = 0.0;
+  for (unsigned g = slot; i0 + 4 * g < i1; g += gx) {
+    const unsigned it = __builtin_amdgcn_readfirstlane(i0 + 4 * g + wave);
+    if (it >= i1)
+      continue;
+    const u4v rec = items[it];
+    const unsigned s = __builtin_amdgcn_readfirstlane(rec.x), K = __builtin_amdgcn_readfirstlane(rec.y);
+    if (K >= 2) {
+      const unsigned t = __builtin_amdgcn_readfirstlane(rec.z), mb = __builtin_amdgcn_readfirstlane(rec.w);
+      const lsb_sell_tmpl *T = td + t;
+      col_tmpl<NF> C;
+      C.bc = T->base[NF + 1];
+      C.k0 = T->cst[0], C.kc = T->cst[NF + 1], C.kL = T->cst[2 * NF + 2];
+#pragma unroll
+      for (int k = 0; k < NF - 1; k++) {
+        C.bl[k] = T->base[1 + k], C.bh[k] = T->base[NF + 3 + k];
+        C.kl[k] = T->cst[1 + k], C.kh[k] = T->cst[NF + 3 + k];
+      }
+      const int side_k[2] = {T->kidx[NF], T->kidx[NF + 2]}, side_kd[2] = {T->kind[NF], T->kind[NF + 2]};
+      long long gu = (long long)s * LSB_SELL_ROWS + row_begin;
+      unsigned lrow = s * LSB_SELL_ROWS;
+      // prologue: the operands of step 0 -- the plane below, the centre, the plane above
+      col_ops<NF> cur, nxt;
+      sell_d2u cm = *(const sell_d2u *)(x + (gu + C.bc - (long long)P) + 2 * lane);
+      sell_d2u c0 = *(const sell_d2u *)(x + (gu + C.bc) + 2 * lane);
+      sell_d2u cp, cn;
+      col_issue<NF, DOT>(cur, cp, C, x, xdot, gu, lrow, P, xlen, lane, true);
+      // the column's masks (wave-uniform, scalar loads beside the gathers) and side values, once
+      unsigned long long mk[2][2] = {{0ull, 0ull}, {0ull, 0ull}};
+#pragma unroll
+      for (int side = 0; side < 2; side++)
+        if (side_k[side] >= 0 && side_kd[side] == 2) {
+          const unsigned long long *mp = mask + 2 * ((size_t)mb + (unsigned)side_k[side]);
+          mk[side][0] = mp[0], mk[side][1] = mp[1];
+        }
+      double vm0 = T->cst[NF], vm1 = vm0, vp0 = T->cst[NF + 2], vp1 = vp0;
+      if (side_k[0] >= 0 || side_k[1] >= 0)
+        tmpl_side_values(T, NF, 0u, lane, side_k, side_kd, mk, vals, f32, vm0, vm1, vp0, vp1);
+      if (stopped)
+        return;
+      // step 0 (K >= 2: there is a next one), steps 1 .. K-2, step K-1
+      col_issue<NF, DOT>(nxt, cn, C, x, xdot, gu + (long long)P, lrow + P, P, xlen, lane, true);
+      double a0, a1;
+      col_compute<NF, DOT>(cur, cm, c0, cp, C, vm0, vm1, vp0, vp1, lane, a0, a1, dot);
+      cm = c0, c0 = cp, cp = cn, cur = nxt;
+      for (unsigned k = 1; k + 1 < K; k++) {
+        gu += (long long)P, lrow += P;
+        col_issue<NF, DOT>(nxt, cn, C, x, xdot, gu + (long long)P, lrow + P, P, xlen, lane, true);
+        {
+          const sell_d2v o = {a0, a1};
+          *(sell_d2v *)(y + (lrow - P) + 2 * lane) = o;
+        }
+        col_compute<NF, DOT>(cur, cm, c0, cp, C, vm0, vm1, vp0, vp1, lane, a0, a1, dot);
+        cm = c0, c0 = cp, cp = cn, cur = nxt;
+      }
+      gu += (long long)P, lrow += P;
+      {
+        const sell_d2v o = {a0, a1};
+        *(sell_d2v *)(y + (lrow - P) + 2 * lane) = o;
+      }
+      col_compute<NF, DOT>(cur, cm, c0, cp, C, vm0, vm1, vp0, vp1, lane, a0, a1, dot);
+      {
+        const sell_d2v o = {a0, a1};
+        *(sell_d2v *)(y + lrow + 2 * lane) = o;
+      }
+    } else { // one slice, slot by slot off the slot records (k_spmv_tmpl's way for a slice without a template)
+      const unsigned row = s * LSB_SELL_ROWS + 2 * lane;
+      const int grow = (int)(row + row_begin);
+      const unsigned q0 = sptr[s] / LSB_SELL_ROWS, len = (sptr[s + 1] - sptr[s]) / LSB_SELL_ROWS;
+      sell_d2v xd = {0.0, 0.0};
+      if (DOT) {
+        if (row + 1 < n)
+          xd = *(const sell_d2v *)(xdot + row);
+        else if (row < n)
+          xd.x = xdot[row];
+      }
+      if (stopped)
+        return;
+      double a0 = 0.0, a1 = 0.0;
+      for (unsigned j = 0; j < len; j++) {
+        const i4v r = ((const i4v *)sbase)[q0 + j]; // {base, -1 (no codes where templates exist), value slot or -1, 0}
+        if (r.z < 0) {
+          const double k = vconst[q0 + j];
+          const sell_d2u v = *(const sell_d2u *)(x + (grow + r.x));
+          a0 = fma(k, v.x, a0), a1 = fma(k, v.y, a1);
+        } else {
+          double v0, v1;
+          if (f32) {
+            const vt2<float>::type v = *((const vt2<float>::type *)((const float *)vals + (size_t)r.z * LSB_SELL_ROWS) + lane);
+            v0 = (double)v.x, v1 = (double)v.y;
+          } else {
+            const sell_d2v v = *((const sell_d2v *)((const double *)vals + (size_t)r.z * LSB_SELL_ROWS) + lane);
+            v0 = v.x, v1 = v.y;
+          }
+          const bool p0 = v0 != 0.0, p1 = v1 != 0.0; // padding: no gather, an exact 0
+          const double t0 = x[p0 ? grow + r.x : 0], t1 = x[p1 ? grow + 1 + r.x : 0];
+          a0 = fma(v0, p0 ? t0 : 0.0, a0), a1 = fma(v1, p1 ? t1 : 0.0, a1);
+        }
+      }
+      if (row + 1 < n) {
+        const sell_d2v o = {a0, a1};
+        *(sell_d2v *)(y + row) = o;
+        if (DOT)
+          dot = fma(a0, xd.x, dot), dot = fma(a1, xd.y, dot);
+      } else if (row < n) {
+        y[row] = a0;
+        if (DOT)
+          dot = fma(a0, xd.x, dot);
+      }
+    }
+  }
+  if (stopped)
+    return;
+  spmv_publish(partials, dot, sred, tail);
+}
+
 // (Round 4, measured and taken out again: k_spmv_tmpl_deep -- a wave takes 2 or 4 of its turns AT ONCE,
 // all their slice records in one batch of scalar loads, all 10 / 20 gathers, edge elements and mask
 // words in flight together, the stores of the group before behind them; 90 / 136 VGPRs, 5 / 3 waves per
@@ -2119,6 +2332,48 @@ void lsb_k_spmv_tmpl(unsigned flags, unsigned grid_cap, unsigned period, const u
   default: errx(EXIT_FAILURE, "lsb_k_spmv_tmpl: %u far slots per side", nfar);
   }
 #undef LSB_TMPL
+}
+
+/* The template layout walked in z-columns (k_spmv_tmpl_col): plan = xbeg[NXCD + 1], padding to 16
+ * unsigneds, then nitem 16-byte items (lsb_sell_tmpl_columns).  Whole launches only (every slice of
+ * the shard is in exactly one item). */
+void lsb_k_spmv_tmpl_col(unsigned flags, unsigned grid_cap, unsigned period, const unsigned *plan, unsigned nitem,
+                         int centre0, unsigned n, unsigned row_begin, unsigned xlen, const unsigned *sptr,
+                         const unsigned long long *mask, const struct lsb_sell_tmpl *td, unsigned nfar,
+                         const int *sbase, const void *vals, const double *vconst, const double *x, double *y,
+                         const double *xdot, double *partials, unsigned *npartials,
+                         const struct lsb_pcg_state *st, const struct lsb_ar_tail *tail_in, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const lsb_ar_tail tail = tail_for(tail_in, partials);
+  const unsigned g = lsb_k_spmv_grid(LSB_SPMV_SELL, n, nitem, 0, grid_cap ? grid_cap : 1536);
+  if (npartials)
+    *npartials = g;
+  if (period < NXCD || !plan)
+    errx(EXIT_FAILURE, "lsb_k_spmv_tmpl_col: no column plan (period %u)", period);
+  const int f32 = (flags & LSB_SP_F32) != 0;
+  // the centre pair is the dot's operand where the dot is with the gathered vector itself (and the
+  // centre base is 0: true of every operator with a diagonal; the kernel's DOT = 1 relies on it,
+  // the plan builder says so in lsb_tmpl_cols.centre0)
+  const int dot = !partials || !xdot ? 0 : (xdot == x + row_begin && centre0) ? 1 : 2;
+#define LSB_COL(NF, D)                                                                                \
+  k_spmv_tmpl_col<NF, D><<<g, WG, 0, s>>>(plan, period, n, row_begin, xlen, sptr, mask, td, sbase, vals, f32, vconst, x, y, \
+                                          xdot, partials, st, tail)
+#define LSB_COLD(NF)                                                                                  \
+  do {                                                                                                \
+    if (dot == 0)                                                                                     \
+      LSB_COL(NF, 0);                                                                                 \
+    else if (dot == 1)                                                                                \
+      LSB_COL(NF, 1);                                                                                 \
+    else                                                                                              \
+      LSB_COL(NF, 2);                                                                                 \
+  } while (0)
+  switch (nfar) {
+  case 1: LSB_COLD(1); break;
+  case 2: LSB_COLD(2); break;
+  default: errx(EXIT_FAILURE, "lsb_k_spmv_tmpl_col: %u far slots per side", nfar);
+  }
+#undef LSB_COLD
+#undef LSB_COL
 }
 
 void lsb_k_reduce_final(const double *partials, unsigned nparts, unsigned width,

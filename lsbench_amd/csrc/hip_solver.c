@@ -370,6 +370,25 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
             for (unsigned k = 0; k < H->nslice; k++)
               if (TT->tid[k] == 255)
                 s->tmpl_bytes += (unsigned long long)(H->sptr[k + 1] - H->sptr[k]) / LSB_SELL_ROWS * 24 + 8;
+            /* 3-D stencil with planes of whole slices: the z-column plan (k_spmv_tmpl_col) */
+            if (s->sell_period && !getenv("LSBENCH_HIP_NO_COL")) {
+              const char *ek = getenv("LSBENCH_HIP_COL_K");
+              struct lsb_tmpl_cols *CC = lsb_sell_tmpl_columns(TT, s->sell_period, ek ? (unsigned)atoi(ek) : 8u);
+              if (CC) {
+                char why[256];
+                if (lsb_tmpl_cols_check(TT, CC, why, sizeof why))
+                  errx(EXIT_FAILURE, "hip_cdna4: z-column plan breaks a rule its kernel relies on: %s", why);
+                unsigned *plan = lsb_calloc(unsigned, 16 + 4 * ((size_t)CC->nitem + 1));
+                memcpy(plan, CC->xbeg, sizeof CC->xbeg);
+                memcpy(plan + 16, CC->item, 4 * (size_t)CC->nitem * sizeof(unsigned));
+                s->d_colplan = (unsigned *)dev_upload(plan, (16 + 4 * ((size_t)CC->nitem + 1)) * sizeof(unsigned));
+                LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+                free(plan);
+                s->col_items = CC->nitem, s->col_kmax = CC->kmax, s->col_centre0 = CC->centre0;
+                s->col_slices = CC->in_cols;
+                lsb_tmpl_cols_free(CC);
+              }
+            }
             LSB_CHK_HIP(hipStreamSynchronize(g_stream));
             lsb_sell_tmpls_free(TT);
           }
@@ -482,7 +501,7 @@ void shard_free(struct shard *s) {
   lsb_hip_free(s->d_sptr), lsb_hip_free(s->d_scols), lsb_hip_free(s->d_svals);
   lsb_hip_free(s->d_sptr16), lsb_hip_free(s->d_scodes), lsb_hip_free(s->d_sbase);
   lsb_hip_free(s->d_svals16), lsb_hip_free(s->d_svconst);
-  lsb_hip_free(s->d_srec), lsb_hip_free(s->d_tmpl), lsb_hip_free(s->d_tmask);
+  lsb_hip_free(s->d_srec), lsb_hip_free(s->d_tmpl), lsb_hip_free(s->d_tmask), lsb_hip_free(s->d_colplan);
   free(s->h_pblk);
   lsb_hip_free(s->bd_chunk), lsb_hip_free(s->bd_rows), lsb_hip_free(s->bd_cols);
   lsb_hip_free(s->bd_vals);
@@ -747,6 +766,9 @@ int lsb_hip_solver_spmv_variant(const lsb_hip_solver *s) { return s->sh[0].varia
 unsigned lsb_hip_solver_spmv_flags(const lsb_hip_solver *s) { return s->sh[0].sp_flags; }
 unsigned lsb_hip_solver_spmv_grid(const lsb_hip_solver *s) { return s->sh[0].sp_grid; }
 unsigned lsb_hip_solver_spmv_period(const lsb_hip_solver *s) { return s->sh[0].sp_period; }
+unsigned long long lsb_hip_solver_spmv_col_slices(const lsb_hip_solver *s) {
+  return s->sh[0].d_colplan ? s->sh[0].col_slices : 0ull;
+}
 void lsb_hip_solver_sell_value_slots(const lsb_hip_solver *s, unsigned *kept, unsigned *total) {
   const struct shard *h = &s->sh[0];
   const int on = h->variant == LSB_SPMV_SELL && (h->sp_flags & LSB_SP_C16) && h->d_scodes;
@@ -808,7 +830,14 @@ void sell_launch(struct shard *s, unsigned s0, unsigned ns, const double *xfull,
                         const double *xdot, double *partials, unsigned *np,
                         const struct lsb_pcg_state *st) {
   const unsigned f32 = s->mixed ? LSB_SP_F32 : 0u; /* the value arrays hold floats then */
-  if ((s->sp_flags & LSB_SP_C16) && (s->sp_flags & LSB_SP_TMPL) && s->d_srec && s->d_scodes)
+  /* whole launches of a shard with a z-column plan (a Chebyshev epilogue and the split interior /
+   * boundary launches go through k_spmv_tmpl) */
+  if ((s->sp_flags & LSB_SP_C16) && (s->sp_flags & LSB_SP_TMPL) && (s->sp_flags & LSB_SP_COL) && s->d_colplan &&
+      s->d_srec && s->d_scodes && s0 == 0 && ns == s->nslice && !s->epi.zout)
+    lsb_k_spmv_tmpl_col(s->sp_flags | f32, s->sp_grid, s->sell_period, s->d_colplan, s->col_items, s->col_centre0, s->n,
+                        s->row_begin, s->n_glob, s->d_sptr16, s->d_tmask, s->d_tmpl, s->tmpl_nfar, s->d_sbase,
+                        s->d_svals16, s->d_svconst, xfull, y, xdot, partials, np, st, &s->tail, g_stream);
+  else if ((s->sp_flags & LSB_SP_C16) && (s->sp_flags & LSB_SP_TMPL) && s->d_srec && s->d_scodes)
     lsb_k_spmv_tmpl(s->sp_flags | f32, s->sp_grid, s->sp_period, s->d_sptr16, s0, ns, s->n, s->row_begin, s->n_glob,
                     s->d_srec, s->d_tmask, s->d_tmpl, s->tmpl_nfar, s->d_sbase, s->d_svals16, s->d_svconst, xfull, y, xdot, partials, np, st,
                     &s->tail, &s->epi, g_stream);
@@ -900,7 +929,7 @@ void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
   if (getenv("LSBENCH_HIP_FORCE_PERIOD")) /* tests: the plane-periodic dealing on small operators */
     s->sp_period = s->sell_period;
   if (o->spmv_tune >= 0) {
-    s->sp_flags = (unsigned)o->spmv_tune & (31u | LSB_SP_TMPL | LSB_SP_DEFER); /* bit 2: 16-bit codes, where that copy exists;
+    s->sp_flags = (unsigned)o->spmv_tune & (31u | LSB_SP_TMPL | LSB_SP_DEFER | LSB_SP_COL); /* bit 2: 16-bit codes, where that copy exists;
                                                    bits 3, 4: binned form's gather flavour; bit 6: slice
                                                    templates, where the constant-slot layout has them */
     return;
@@ -980,6 +1009,9 @@ void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
           if (periodic)
             CAND(LSB_SPMV_SELL, fd, gd, s->sell_period);
         }
+        /* the z-column walk of a 3-D stencil (k_spmv_tmpl_col): one new plane per step */
+        if (s->d_colplan)
+          CAND(LSB_SPMV_SELL, f | LSB_SP_COL, o->spmv_grid <= 0 ? 1536u : grid0, 0);
       }
     }
 #undef CAND
@@ -1035,6 +1067,10 @@ void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
   if (!(bv == LSB_SPMV_SELL && (bf & LSB_SP_TMPL))) {
     lsb_hip_free(s->d_srec), lsb_hip_free(s->d_tmpl), lsb_hip_free(s->d_tmask);
     s->d_srec = NULL, s->d_tmpl = NULL, s->d_tmask = NULL;
+  }
+  if (!(bv == LSB_SPMV_SELL && (bf & LSB_SP_COL))) {
+    lsb_hip_free(s->d_colplan);
+    s->d_colplan = NULL;
   }
   if (any && !(bv == LSB_SPMV_SELL && !(bf & LSB_SP_C16))) {
     lsb_hip_free(s->d_scols), lsb_hip_free(s->d_svals);

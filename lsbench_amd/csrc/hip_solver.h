@@ -103,6 +103,12 @@ struct shard {
   struct lsb_sell_tmpl *d_tmpl;
   unsigned tmpl_nfar, tmpl_count;
   unsigned long long tmpl_pure, tmpl_shaped, tmpl_bytes;
+  /* z-column plan of the template layout (lsb_sell_tmpl_columns; LSB_SP_COL in sp_flags): xbeg[9],
+   * padding to 16 unsigneds, 16-byte items */
+  unsigned *d_colplan;
+  unsigned col_items, col_kmax;
+  int col_centre0;
+  unsigned long long col_slices; /* slices inside columns */
   unsigned sell_ulen;      /* != 0: every slice of the 16-bit copy has this many slots */
   double *d_parts_pq, *d_parts2;
   double *d_scal; /* [0] p.q   [1] r.z'  [2] r.r   (multi-shard path) */

@@ -122,6 +122,14 @@ void lsb_k_spmv_tmpl(unsigned flags, unsigned grid_cap, unsigned period, const u
                      const double *vconst, const double *x, double *y, const double *xdot,
                      double *partials, unsigned *npartials, const struct lsb_pcg_state *st,
                      const struct lsb_ar_tail *tail, const struct lsb_cheb_epi *epi, void *stream);
+#define LSB_SP_COL 256u /* k_spmv_tmpl_col: the template layout walked in z-columns (whole launches of a
+                           shard that has a column plan; implies LSB_SP_TMPL) */
+void lsb_k_spmv_tmpl_col(unsigned flags, unsigned grid_cap, unsigned period, const unsigned *plan, unsigned nitem,
+                         int centre0, unsigned n, unsigned row_begin, unsigned xlen, const unsigned *sptr,
+                         const unsigned long long *mask, const struct lsb_sell_tmpl *td, unsigned nfar,
+                         const int *sbase, const void *vals, const double *vconst, const double *x, double *y,
+                         const double *xdot, double *partials, unsigned *npartials,
+                         const struct lsb_pcg_state *st, const struct lsb_ar_tail *tail, void *stream);
 void lsb_k_spmv_binned(unsigned flags, unsigned chunk_cap, const unsigned *chunk_begin, unsigned c0,
                        unsigned nchunk, const unsigned *rows, const unsigned *cols, const double *vals,
                        const double *x, double *y, const struct lsb_pcg_state *st, void *stream);

@@ -1429,6 +1429,136 @@ int lsb_tmpl_check(const struct lsb_sell *S, const struct lsb_sell_vc *V, const 
 #undef TC_FAIL
 }
 
+/* ---- z-columns of the template layout (include/lsbench_hip.h: struct lsb_tmpl_cols) ---- */
+#define LSB_COL_XCDS 8 /* = NXCD of the kernels: the items are dealt per XCD */
+
+/* may slice s stand inside a z-column of planes of `period` slices?  A shaped template whose
+ * outermost far slots reach exactly one plane down and up, constant or masked slots only */
+static int col_member(const struct lsb_sell_tmpls *T, unsigned s, unsigned period) {
+  if (T->tid[s] == 255 || T->nfar < 1)
+    return 0;
+  const struct lsb_sell_tmpl *t = &T->t[T->tid[s]];
+  const int c = (int)T->nfar + 1, last = 2 * (int)T->nfar + 2;
+  if (!t->shaped || t->nslots != last + 1)
+    return 0;
+  for (int j = 0; j < t->nslots; j++)
+    if (t->kind[j] == 1)
+      return 0;
+  const long long plane = (long long)LSB_SELL_ROWS * period;
+  return (long long)t->base[0] == (long long)t->base[c] - plane && (long long)t->base[last] == (long long)t->base[c] + plane;
+}
+/* the same template and, bit for bit, the same mask words */
+static int col_same(const struct lsb_sell_tmpls *T, unsigned a, unsigned b) {
+  if (T->tid[a] != T->tid[b])
+    return 0;
+  const struct lsb_sell_tmpl *t = &T->t[T->tid[a]];
+  size_t nmk = 0;
+  for (int j = 0; j < t->nslots; j++)
+    nmk += t->kind[j] == 2;
+  return !nmk || !memcmp(T->mask + 2 * (size_t)T->vbase[2 * (size_t)a + 1], T->mask + 2 * (size_t)T->vbase[2 * (size_t)b + 1],
+                         2 * nmk * sizeof(unsigned long long));
+}
+
+struct lsb_tmpl_cols *lsb_sell_tmpl_columns(const struct lsb_sell_tmpls *T, unsigned period, unsigned kmax) {
+  if (!T || period < LSB_COL_XCDS || T->nslice < 2 * period || T->nfar < 1)
+    return NULL;
+  if (kmax < 2)
+    kmax = 2;
+  if (kmax > LSB_TMPL_COL_MAX)
+    kmax = LSB_TMPL_COL_MAX;
+  const unsigned ns = T->nslice, nplanes = (ns + period - 1) / period;
+  struct lsb_tmpl_cols *C = lsb_calloc(struct lsb_tmpl_cols, 1);
+  C->kmax = kmax, C->period = period, C->centre0 = 1;
+  C->item = lsb_calloc(unsigned, 4 * ((size_t)ns + 1));
+  unsigned ni = 0;
+  for (unsigned k = 0; k < LSB_COL_XCDS; k++) {
+    C->xbeg[k] = ni;
+    const unsigned qlo = (unsigned)((unsigned long long)period * k / LSB_COL_XCDS),
+                   qhi = (unsigned)((unsigned long long)period * (k + 1) / LSB_COL_XCDS);
+    for (unsigned z0 = 0; z0 < nplanes; z0 += kmax) {
+      const unsigned zend = z0 + kmax < nplanes ? z0 + kmax : nplanes;
+      for (unsigned p = qlo; p < qhi; p++)
+        for (unsigned z = z0; z < zend;) {
+          const unsigned long long s = (unsigned long long)z * period + p;
+          if (s >= ns)
+            break;
+          unsigned run = 1;
+          if (col_member(T, (unsigned)s, period))
+            while (z + run < zend && s + (unsigned long long)run * period < ns &&
+                   col_member(T, (unsigned)(s + (unsigned long long)run * period), period) &&
+                   col_same(T, (unsigned)s, (unsigned)(s + (unsigned long long)run * period)))
+              run++;
+          unsigned *it = C->item + 4 * (size_t)ni++;
+          it[0] = (unsigned)s, it[1] = run, it[2] = T->tid[s], it[3] = T->vbase[2 * (size_t)s + 1];
+          if (run >= 2) {
+            C->in_cols += run;
+            C->centre0 &= T->t[T->tid[s]].base[T->nfar + 1] == 0;
+          }
+          z += run;
+        }
+    }
+  }
+  C->xbeg[LSB_COL_XCDS] = C->nitem = ni;
+  if (C->in_cols * 4 < (unsigned long long)ns * 3) {
+    lsb_tmpl_cols_free(C);
+    return NULL;
+  }
+  return C;
+}
+
+int lsb_tmpl_cols_check(const struct lsb_sell_tmpls *T, const struct lsb_tmpl_cols *C, char *why, size_t whylen) {
+#define CC_FAIL(code, ...)                                                                     \
+  do {                                                                                         \
+    if (why && whylen)                                                                         \
+      snprintf(why, whylen, __VA_ARGS__);                                                      \
+    free(seen);                                                                                \
+    return code;                                                                               \
+  } while (0)
+  unsigned char *seen = NULL;
+  if (!T || !C || !C->item)
+    CC_FAIL(1, "no column plan");
+  const unsigned ns = T->nslice, period = C->period;
+  if (period < LSB_COL_XCDS || C->kmax < 2 || C->kmax > LSB_TMPL_COL_MAX || C->xbeg[0] != 0 || C->xbeg[LSB_COL_XCDS] != C->nitem)
+    CC_FAIL(2, "period %u, columns of up to %u slices, items [%u, %u) of %u", period, C->kmax, C->xbeg[0],
+            C->xbeg[LSB_COL_XCDS], C->nitem);
+  for (unsigned k = 0; k < LSB_COL_XCDS; k++)
+    if (C->xbeg[k] > C->xbeg[k + 1])
+      CC_FAIL(3, "item ranges of the XCDs not ascending at %u", k);
+  seen = (unsigned char *)calloc((size_t)ns + 1, 1);
+  if (!seen)
+    CC_FAIL(4, "out of memory");
+  for (unsigned i = 0; i < C->nitem; i++) {
+    const unsigned *it = C->item + 4 * (size_t)i;
+    const unsigned s = it[0], run = it[1];
+    if (run < 1 || run > C->kmax || s >= ns || (unsigned long long)s + (unsigned long long)(run - 1) * period >= ns)
+      CC_FAIL(5, "item %u: %u slices from slice %u, every %u, of %u", i, run, s, period, ns);
+    for (unsigned k = 0; k < run; k++) {
+      const unsigned sk = s + k * period;
+      if (seen[sk]++)
+        CC_FAIL(6, "item %u: slice %u is in two items", i, sk);
+      if (run >= 2 && (!col_member(T, sk, period) || !col_same(T, s, sk)))
+        CC_FAIL(7, "item %u: slice %u does not continue the column of slice %u", i, sk, s);
+    }
+    if (run >= 2 && C->centre0 && T->t[T->tid[s]].base[T->nfar + 1] != 0)
+      CC_FAIL(10, "item %u: centre base %d in a plan that says 0", i, T->t[T->tid[s]].base[T->nfar + 1]);
+    if (run >= 2 && (it[2] != T->tid[s] || it[3] != T->vbase[2 * (size_t)s + 1]))
+      CC_FAIL(8, "item %u: template %u / first mask %u, its first slice has %u / %u", i, it[2], it[3], T->tid[s],
+              T->vbase[2 * (size_t)s + 1]);
+  }
+  for (unsigned s = 0; s < ns; s++)
+    if (!seen[s])
+      CC_FAIL(9, "slice %u is in no item", s);
+  free(seen);
+  return 0;
+#undef CC_FAIL
+}
+
+void lsb_tmpl_cols_free(struct lsb_tmpl_cols *C) {
+  if (!C)
+    return;
+  free(C->item), free(C);
+}
+
 void lsb_sell_tmpls_free(struct lsb_sell_tmpls *T) {
   if (!T)
     return;

@@ -784,6 +784,71 @@ def test_tmpl_check_states_the_template_kernels_bounds():
             lib.lsb_sell_vc_free(V), lib.lsb_sell_free(H)
 
 
+def test_z_column_plan_of_a_3d_stencil():
+    """lsb_sell_tmpl_columns (host side of k_spmv_tmpl_col): on a 3-D stencil whose planes are whole
+    slices every slice lands in exactly one item; interior z-columns become runs of 2..kmax slices
+    one plane apart that share a template (outermost far slots exactly one plane away, constant or
+    masked slots only) and their mask words; the first and last plane -- no neighbour plane on one
+    side -- stay single items; XCD k owns the same eighth of every plane; shards cut inside a plane
+    and ragged z-groups included.  lsb_tmpl_cols_check states the rules and catches a broken one."""
+    import ctypes as C
+    lib = la._lib.load()
+    why = C.create_string_buffer(256)
+    for spec, period in (("lap3d:nx=128,ny=64,nz=21", 64), ("lap3d:nx=256,ny=32,nz=40", 64), ("lap3d:nx=200,ny=64,nz=30", 100)):
+        n = la.lsbench_matrix_synth(spec, 0, 1).n_global
+        for r0, r1 in ((0, n), (0, (n // 2 + 4096 + 640) & ~127), (5 * period * 128, n)):
+            A = la.lsbench_matrix_synth(spec, r0, r1)
+            H = lib.lsb_csr_sellize16(A.ptr, r0)
+            V = lib.lsb_sell16_value_slots(H)
+            T = lib.lsb_sell16_templates(H, V)
+            assert T and T.contents.nfar == 2
+            ns = T.contents.nslice
+            tid = np.ctypeslib.as_array(T.contents.tid, (ns,))
+            for kmax in (2, 5, 8, 16):
+                Cp = lib.lsb_sell_tmpl_columns(T, period, kmax)
+                if kmax == 2 and not Cp:                               # (pairs on a short shard: under 3/4 in columns)
+                    continue
+                assert Cp, (spec, r0, kmax)
+                c = Cp.contents
+                assert lib.lsb_tmpl_cols_check(T, Cp, why, 256) == 0, why.value
+                assert c.kmax == kmax and c.period == period and c.centre0 == 1
+                it = np.ctypeslib.as_array(c.item, (4 * c.nitem,)).reshape(-1, 4).copy()
+                xb = list(c.xbeg)
+                assert xb[0] == 0 and xb[8] == c.nitem and xb == sorted(xb)
+                seen = np.zeros(ns, int)
+                for k in range(8):                                     # XCD k: its eighth of every plane
+                    for s0, run, t, mb in it[xb[k]:xb[k + 1]]:
+                        assert period * k // 8 <= s0 % period < period * (k + 1) // 8
+                        assert 1 <= run <= kmax
+                        sl = s0 + period * np.arange(run)
+                        seen[sl] += 1
+                        if run > 1:
+                            assert np.all(tid[sl] == t) and t != 255
+                            # a column never leaves its z-group of kmax planes
+                            assert (s0 // period) // kmax == (sl[-1] // period) // kmax
+                assert np.all(seen == 1)
+                cols = int(it[it[:, 1] > 1, 1].sum())
+                assert cols == c.in_cols and 4 * cols >= 3 * ns
+                if r0 == 0:                                            # the operator's first plane: single items
+                    assert np.all(it[np.isin(it[:, 0], np.arange(period)), 1] == 1)
+                if kmax == 8:                                          # a broken rule is caught
+                    big = int(np.argmax(it[:, 1]))
+                    keep = int(c.item[4 * big + 1])
+                    c.item[4 * big + 1] = keep + 1 if keep < kmax else keep - 1
+                    assert lib.lsb_tmpl_cols_check(T, Cp, why, 256) in (5, 6, 7, 9)
+                    c.item[4 * big + 1] = keep
+                lib.lsb_tmpl_cols_free(Cp)
+            assert not lib.lsb_sell_tmpl_columns(T, period + 1, 8)                  # not this operator's plane
+            lib.lsb_sell_tmpls_free(T), lib.lsb_sell_vc_free(V), lib.lsb_sell_free(H)
+    # a 2-D operator has no plane-reaching far slots
+    A = la.lsbench_matrix_synth("lap2d:nx=411,ny=203")
+    H = lib.lsb_csr_sellize16(A.ptr, 0)
+    V = lib.lsb_sell16_value_slots(H)
+    T = lib.lsb_sell16_templates(H, V)
+    assert T and not lib.lsb_sell_tmpl_columns(T, 16, 8)
+    lib.lsb_sell_tmpls_free(T), lib.lsb_sell_vc_free(V), lib.lsb_sell_free(H)
+
+
 def test_bench_quotes_pmc_traffic_only_for_what_it_was_measured_on(tmp_path, monkeypatch):
     """bench.py's roofline.traffic comes from profiles/pmc_traffic.json -- a LIST of profiled flavours
     per workload -- and is quoted only where kernel name, hash of the kernel sources, kept / all value

@@ -215,6 +215,53 @@ def test_plane_periodic_dealing_of_a_3d_stencil(hip, nz, nvirt, overlap, comm, m
     assert np.array_equal(d_y0.cpu().numpy(), y)          # a row's sum does not depend on the dealing
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("spec,nvirt,overlap,precision,kmax", [
+    ("lap3d:nx=128,ny=64,nz=21", 1, 0, "FP64", 8), ("lap3d:nx=128,ny=64,nz=21", 1, 0, "FP64", 2),
+    ("lap3d:nx=128,ny=64,nz=21", 1, 0, "FP64", 3), ("lap3d:nx=200,ny=64,nz=30", 1, 0, "FP64", 8),
+    ("lap3d:nx=200,ny=64,nz=30", 1, 0, "FP64", 16), ("lap3d:nx=256,ny=32,nz=40", 1, 0, "MIXED", 5),
+    ("lap3d:nx=200,ny=64,nz=37", 3, 0, "FP64", 8), ("lap3d:nx=128,ny=64,nz=64", 4, 1, "FP64", 8),
+    ("lap3d:nx=128,ny=64,nz=64", 2, 0, "FP64", 16)])
+def test_z_column_walk_changes_no_bit_of_y(hip, monkeypatch, spec, nvirt, overlap, precision, kmax):
+    """k_spmv_tmpl_col (LSB_SP_COL = 256 of the flags): the template layout of a 3-D stencil walked
+    in z-columns -- a wave keeps three centre pairs in registers and gathers one new plane per
+    step, the plane below / above being the centre of the step before / after.  The same operands
+    and products in the same order as k_spmv_tmpl: y bit for bit, for columns of 2..16 slices,
+    grid lines that end inside slices (masked slots), fp32 constants, row-range shards (whole
+    planes or cut inside one; with the split interior / boundary launches the boundary parts go
+    through k_spmv_tmpl).  The fused dot follows the kernel's own fixed dealing: solves repeat bit
+    for bit run to run and agree with the template kernel's to rounding."""
+    import torch
+    monkeypatch.setenv("LSBENCH_HIP_COL_K", str(kmax))
+    A = hip.lsbench_matrix_synth(spec)
+    b = O.rhs(A.nrows)
+    xs = np.sin(np.arange(A.nrows, dtype=np.float64))
+    out = {}
+    for name, tune in (("tmpl", 6 | 64), ("col", 6 | 64 | 256)):
+        s = hip.Solver(A, hip.default_opts(op_mode=hip.OP_RAW, spmv_variant=hip.SPMV_SELL, nvirt=nvirt, overlap=overlap,
+                                           comm=1 if nvirt > 1 else 0, tol=1e-10,
+                                           precision=getattr(hip, "PREC_" + precision), spmv_tune=tune, use_graph=0))
+        assert s.spmv_variant == hip.SPMV_SELL and s.spmv_flags == tune
+        assert s.spmv_col_slices * 4 >= (A.nrows // nvirt // 128) * 3        # the plan exists: most slices in columns
+        d_y = torch.full((A.nrows,), float("nan"), dtype=torch.float64, device="cuda:0")
+        s.spmv_dev(torch.from_numpy(xs).to("cuda:0"), d_y)
+        x, r = s.solve(b)
+        for _ in range(2):                                        # run to run: the same bits
+            d_y2 = torch.empty_like(d_y)
+            s.spmv_dev(torch.from_numpy(xs).to("cuda:0"), d_y2)
+            x2, r2 = s.solve(b)
+            assert torch.equal(d_y, d_y2) and np.array_equal(x, x2) and r2.iters == r.iters
+        s.destroy()
+        assert r.status == hip.STATUS_CONVERGED
+        out[name] = (d_y.cpu().numpy(), x, int(r.iters))
+    assert np.array_equal(out["tmpl"][0], out["col"][0])          # y: bit for bit
+    assert abs(out["tmpl"][2] - out["col"][2]) <= 2
+    assert np.linalg.norm(out["tmpl"][1] - out["col"][1]) <= 1e-8 * np.linalg.norm(out["tmpl"][1])
+    if precision == "FP64":
+        yo = O.spmv(A.offs, A.cols, A.vals, xs)
+        assert np.allclose(out["col"][0], yo, rtol=1e-13, atol=1e-13)
+
+
 def _penta(n):
     """1-D pentadiagonal SPD operator (bases -2 .. 2): a far slot on each side of the (c-1, c, c+1) group."""
     import scipy.sparse as sp
