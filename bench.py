@@ -421,7 +421,7 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
     # (the committed PMC profile is of the fp64 forms: no traffic figure for fp32 values)
     vslots = solver.sell_value_slots
     if solver.spmv_flags & la.SPMV_FLAG_TMPL and kernel == "k_spmv_sell16":
-        kernel = "k_spmv_tmpl"
+        kernel = "k_spmv_tmpl_col" if solver.spmv_flags & la.SPMV_FLAG_COL and solver.spmv_col_slices else "k_spmv_tmpl"
     traffic, traffic_src = pmc_traffic(key if world == 1 and a.precision == "fp64" else None, kernel, vslots,
                                        solver.spmv_flags, solver.spmv_period)
     # Bytes the roofline figure is quoted on.  SURVEY 8(d)'s CSR count is the figure for a

@@ -491,8 +491,11 @@ int lsb_tmpl_check(const struct lsb_sell *S, const struct lsb_sell_vc *V, const 
  * after z-group (kmax planes each), positions ascending -- the order the chip sweeps them in.
  * Lossless: the same operands and products in the same order as k_spmv_tmpl / k_spmv_sell16. */
 #define LSB_TMPL_COL_MAX 16
+#define LSB_TMPL_COL_LOCKSTEP 0x80000000u /* bit 31 of an item's slice count: the four items of a workgroup's
+                                             turn are columns of one length (a barrier per plane keeps them in step) */
 struct lsb_tmpl_cols {
   unsigned nitem, kmax, period;
+  unsigned s_lo, s_hi;          /* the slices the items cover: [s_lo, s_hi) */
   unsigned xbeg[9];
   unsigned *item;               /* 4 * (nitem + 1) */
   unsigned long long in_cols;   /* slices inside columns (the rest are single items) */
@@ -502,9 +505,13 @@ struct lsb_tmpl_cols {
 /* NULL where the layout has no such columns (period < 8, no shaped template with plane-reaching
  * far slots) or fewer than 3/4 of the slices fall inside columns. */
 struct lsb_tmpl_cols *lsb_sell_tmpl_columns(const struct lsb_sell_tmpls *T, unsigned period, unsigned kmax);
+/* the same for the slices [s_lo, s_hi) only (the interior launch of a sharded SpMV that runs while
+ * the halo travels): every slice of the range in exactly one item, none outside it */
+struct lsb_tmpl_cols *lsb_sell_tmpl_columns_range(const struct lsb_sell_tmpls *T, unsigned period, unsigned kmax,
+                                                  unsigned s_lo, unsigned s_hi);
 void lsb_tmpl_cols_free(struct lsb_tmpl_cols *C);
 /* The rules k_spmv_tmpl_col relies on, as host assertions (run at every upload): every slice in
- * exactly one item; a column's slices s + k period exist, share the item's template -- shaped,
+ * [s_lo, s_hi) in exactly one item, none outside; a column's slices s + k period share the item's template -- shaped,
  * constant or masked slots only, outermost far slots one plane away -- and its mask words bit
  * for bit.  0 or a rule number with the rule in `why`. */
 int lsb_tmpl_cols_check(const struct lsb_sell_tmpls *T, const struct lsb_tmpl_cols *C, char *why, size_t whylen);

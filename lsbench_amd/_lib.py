@@ -26,7 +26,7 @@ SPMV_AUTO, SPMV_ADAPTIVE, SPMV_SUBWAVE, SPMV_SCALAR, SPMV_PANEL, SPMV_SELL, SPMV
 SELL_ROWS = 128
 BIN_CHUNK = 2048
 PB_COLS, PB_ROWS = 8192, 2048
-SPMV_FLAG_PREFETCH, SPMV_FLAG_NT, SPMV_FLAG_C16, SPMV_FLAG_TMPL, SPMV_FLAG_DEFER = 1, 2, 4, 64, 128
+SPMV_FLAG_PREFETCH, SPMV_FLAG_NT, SPMV_FLAG_C16, SPMV_FLAG_TMPL, SPMV_FLAG_DEFER, SPMV_FLAG_COL = 1, 2, 4, 64, 128, 256
 STATUS_RUNNING, STATUS_CONVERGED, STATUS_BREAKDOWN, STATUS_MAXIT = 0, 1, 2, 3
 STATUS_COMM = 4
 COMM_AUTO, COMM_RCCL, COMM_P2P = 0, 1, 2
@@ -116,7 +116,8 @@ class SellTmpls(C.Structure):
 
 class TmplCols(C.Structure):
     """struct lsb_tmpl_cols."""
-    _fields_ = [("nitem", C.c_uint), ("kmax", C.c_uint), ("period", C.c_uint), ("xbeg", C.c_uint * 9),
+    _fields_ = [("nitem", C.c_uint), ("kmax", C.c_uint), ("period", C.c_uint), ("s_lo", C.c_uint), ("s_hi", C.c_uint),
+                ("xbeg", C.c_uint * 9),
                 ("item", C.POINTER(C.c_uint)), ("in_cols", C.c_ulonglong), ("centre0", C.c_int)]
 
 
@@ -200,6 +201,7 @@ SIGNATURES = {
     "lsb_tmpl_check": (_i, [C.POINTER(Sell), C.POINTER(SellVc), C.POINTER(SellTmpls), _u, _u, _u, _i,
                             C.c_char_p, C.c_size_t]),
     "lsb_sell_tmpl_columns": (C.POINTER(TmplCols), [C.POINTER(SellTmpls), _u, _u]),
+    "lsb_sell_tmpl_columns_range": (C.POINTER(TmplCols), [C.POINTER(SellTmpls), _u, _u, _u, _u]),
     "lsb_tmpl_cols_free": (None, [C.POINTER(TmplCols)]),
     "lsb_tmpl_cols_check": (_i, [C.POINTER(SellTmpls), C.POINTER(TmplCols), C.c_char_p, C.c_size_t]),
     "lsb_csr_mean_scatter": (_d, [_csrp, _u]),

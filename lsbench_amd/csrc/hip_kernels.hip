@@ -1716,7 +1716,11 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_tmpl_col(
     if (it >= i1)
       continue;
     const u4v rec = items[it];
-    const unsigned s = __builtin_amdgcn_readfirstlane(rec.x), K = __builtin_amdgcn_readfirstlane(rec.y);
+    const unsigned s = __builtin_amdgcn_readfirstlane(rec.x), Kw = __builtin_amdgcn_readfirstlane(rec.y);
+    const unsigned K = Kw & ~LSB_TMPL_COL_LOCKSTEP;
+    // lockstep: the four items of this turn are columns of one length (the host says so in bit 31 of
+    // all four): a barrier per plane keeps the workgroup's requests together
+    const bool lockstep = (Kw & LSB_TMPL_COL_LOCKSTEP) != 0;
     if (K >= 2) {
       const unsigned t = __builtin_amdgcn_readfirstlane(rec.z), mb = __builtin_amdgcn_readfirstlane(rec.w);
       const lsb_sell_tmpl *T = td + t;
@@ -1757,6 +1761,8 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_tmpl_col(
       cm = c0, c0 = cp, cp = cn, cur = nxt;
       for (unsigned k = 1; k + 1 < K; k++) {
         gu += (long long)P, lrow += P;
+        if (lockstep)
+          __builtin_amdgcn_s_barrier();
         col_issue<NF, DOT>(nxt, cn, C, x, xdot, gu + (long long)P, lrow + P, P, xlen, lane, true);
         {
           const sell_d2v o = {a0, a1};

@@ -373,19 +373,56 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
             /* 3-D stencil with planes of whole slices: the z-column plan (k_spmv_tmpl_col) */
             if (s->sell_period && !getenv("LSBENCH_HIP_NO_COL")) {
               const char *ek = getenv("LSBENCH_HIP_COL_K");
-              struct lsb_tmpl_cols *CC = lsb_sell_tmpl_columns(TT, s->sell_period, ek ? (unsigned)atoi(ek) : 8u);
-              if (CC) {
+              /* columns of up to 16 slices: every plane of x is then read 18 / 16 times (64 M-row 7-point
+               * operator: 222 us against 233 us with columns of 8, profiles/r04_col.txt) */
+              const unsigned kmax = ek ? (unsigned)atoi(ek) : 16u;
+              /* [0]: every slice of the shard; [1]: the slices that need no halo, where the shard has
+               * such a range (the interior launch of the split SpMV; the boundary launches go
+               * through k_spmv_tmpl) */
+              for (int w = 0; w < 2; w++) {
+                if (w == 1 && !(s->d_colplan && s->ov_sok && (s->ov_s1 > 0 || s->ov_s2 < TT->nslice)))
+                  break;
+                struct lsb_tmpl_cols *CC = w == 0 ? lsb_sell_tmpl_columns(TT, s->sell_period, kmax)
+                                                  : lsb_sell_tmpl_columns_range(TT, s->sell_period, kmax, s->ov_s1, s->ov_s2);
+                if (!CC)
+                  break;
                 char why[256];
                 if (lsb_tmpl_cols_check(TT, CC, why, sizeof why))
                   errx(EXIT_FAILURE, "hip_cdna4: z-column plan breaks a rule its kernel relies on: %s", why);
                 unsigned *plan = lsb_calloc(unsigned, 16 + 4 * ((size_t)CC->nitem + 1));
                 memcpy(plan, CC->xbeg, sizeof CC->xbeg);
                 memcpy(plan + 16, CC->item, 4 * (size_t)CC->nitem * sizeof(unsigned));
-                s->d_colplan = (unsigned *)dev_upload(plan, (16 + 4 * ((size_t)CC->nitem + 1)) * sizeof(unsigned));
+                if (getenv("LSBENCH_HIP_COL_NOSYNC")) /* experiments: no barrier per plane */
+                  for (unsigned q = 0; q < CC->nitem; q++)
+                    plan[16 + 4 * (size_t)q + 1] &= ~LSB_TMPL_COL_LOCKSTEP;
+                unsigned *d = (unsigned *)dev_upload(plan, (16 + 4 * ((size_t)CC->nitem + 1)) * sizeof(unsigned));
                 LSB_CHK_HIP(hipStreamSynchronize(g_stream));
                 free(plan);
-                s->col_items = CC->nitem, s->col_kmax = CC->kmax, s->col_centre0 = CC->centre0;
-                s->col_slices = CC->in_cols;
+                if (w == 0) {
+                  s->d_colplan = d, s->col_items = CC->nitem, s->col_kmax = CC->kmax, s->col_centre0 = CC->centre0;
+                  s->col_slices = CC->in_cols;
+                  /* what a launch of the z-column walk streams besides x and y: a 16-byte item per
+                   * column or single slice, the templates, a column's masks once, and for the single
+                   * slices their slot records, constants and kept values */
+                  s->col_bytes = 16ull * CC->nitem + (unsigned long long)TT->ntmpl * sizeof(struct lsb_sell_tmpl);
+                  for (unsigned q = 0; q < CC->nitem; q++) {
+                    const unsigned sl = CC->item[4 * (size_t)q], run = CC->item[4 * (size_t)q + 1] & ~LSB_TMPL_COL_LOCKSTEP;
+                    if (run >= 2) {
+                      const struct lsb_sell_tmpl *t = &TT->t[TT->tid[sl]];
+                      for (int j = 0; j < t->nslots; j++)
+                        s->col_bytes += t->kind[j] == 2 ? 16ull : 0ull;
+                    } else {
+                      const unsigned q0 = H->sptr[sl] / LSB_SELL_ROWS, len = (H->sptr[sl + 1] - H->sptr[sl]) / LSB_SELL_ROWS;
+                      s->col_bytes += 24ull * len + 8;
+                      for (unsigned j = 0; j < len; j++)
+                        if (V->slots[4 * ((size_t)q0 + j) + 2] >= 0)
+                          s->col_bytes += LSB_SELL_ROWS * (s->mixed ? 4ull : 8ull);
+                    }
+                  }
+                } else {
+                  s->d_colplan_in = d, s->col_items_in = CC->nitem;
+                  s->col_centre0 &= CC->centre0;
+                }
                 lsb_tmpl_cols_free(CC);
               }
             }
@@ -501,7 +538,7 @@ void shard_free(struct shard *s) {
   lsb_hip_free(s->d_sptr), lsb_hip_free(s->d_scols), lsb_hip_free(s->d_svals);
   lsb_hip_free(s->d_sptr16), lsb_hip_free(s->d_scodes), lsb_hip_free(s->d_sbase);
   lsb_hip_free(s->d_svals16), lsb_hip_free(s->d_svconst);
-  lsb_hip_free(s->d_srec), lsb_hip_free(s->d_tmpl), lsb_hip_free(s->d_tmask), lsb_hip_free(s->d_colplan);
+  lsb_hip_free(s->d_srec), lsb_hip_free(s->d_tmpl), lsb_hip_free(s->d_tmask), lsb_hip_free(s->d_colplan), lsb_hip_free(s->d_colplan_in);
   free(s->h_pblk);
   lsb_hip_free(s->bd_chunk), lsb_hip_free(s->bd_rows), lsb_hip_free(s->bd_cols);
   lsb_hip_free(s->bd_vals);
@@ -810,7 +847,9 @@ unsigned long long lsb_hip_solver_spmv_layout_bytes(const lsb_hip_solver *s) {
   unsigned long long m = 12ull * h->nnz + 4ull * ((unsigned long long)h->n + 1); /* the CSR arrays */
   if (h->variant == LSB_SPMV_SELL)
     m = (h->sp_flags & LSB_SP_C16) && h->d_scodes
-            ? ((h->sp_flags & LSB_SP_TMPL) && h->d_srec ? h->tmpl_bytes : h->sell16_bytes)
+            ? ((h->sp_flags & LSB_SP_TMPL) && h->d_srec
+                   ? ((h->sp_flags & LSB_SP_COL) && h->d_colplan ? h->col_bytes : h->tmpl_bytes)
+                   : h->sell16_bytes)
             : h->sell32_bytes;
   else if (h->variant == LSB_SPMV_TWOPHASE || h->variant == LSB_SPMV_BINNED)
     return 0; /* more than one pass over intermediate data: no single-pass figure */
@@ -832,9 +871,12 @@ void sell_launch(struct shard *s, unsigned s0, unsigned ns, const double *xfull,
   const unsigned f32 = s->mixed ? LSB_SP_F32 : 0u; /* the value arrays hold floats then */
   /* whole launches of a shard with a z-column plan (a Chebyshev epilogue and the split interior /
    * boundary launches go through k_spmv_tmpl) */
-  if ((s->sp_flags & LSB_SP_C16) && (s->sp_flags & LSB_SP_TMPL) && (s->sp_flags & LSB_SP_COL) && s->d_colplan &&
-      s->d_srec && s->d_scodes && s0 == 0 && ns == s->nslice && !s->epi.zout)
-    lsb_k_spmv_tmpl_col(s->sp_flags | f32, s->sp_grid, s->sell_period, s->d_colplan, s->col_items, s->col_centre0, s->n,
+  const int col_all = s->d_colplan && s0 == 0 && ns == s->nslice;
+  const int col_in = s->d_colplan_in && s0 == s->ov_s1 && ns == s->ov_s2 - s->ov_s1;
+  if ((s->sp_flags & LSB_SP_C16) && (s->sp_flags & LSB_SP_TMPL) && (s->sp_flags & LSB_SP_COL) && (col_all || col_in) &&
+      s->d_srec && s->d_scodes && !s->epi.zout)
+    lsb_k_spmv_tmpl_col(s->sp_flags | f32, s->sp_grid, s->sell_period, col_all ? s->d_colplan : s->d_colplan_in,
+                        col_all ? s->col_items : s->col_items_in, s->col_centre0, s->n,
                         s->row_begin, s->n_glob, s->d_sptr16, s->d_tmask, s->d_tmpl, s->tmpl_nfar, s->d_sbase,
                         s->d_svals16, s->d_svconst, xfull, y, xdot, partials, np, st, &s->tail, g_stream);
   else if ((s->sp_flags & LSB_SP_C16) && (s->sp_flags & LSB_SP_TMPL) && s->d_srec && s->d_scodes)
@@ -1010,8 +1052,16 @@ void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
             CAND(LSB_SPMV_SELL, fd, gd, s->sell_period);
         }
         /* the z-column walk of a 3-D stencil (k_spmv_tmpl_col): one new plane per step */
-        if (s->d_colplan)
-          CAND(LSB_SPMV_SELL, f | LSB_SP_COL, o->spmv_grid <= 0 ? 1536u : grid0, 0);
+        /* (fewer resident workgroups than the other flavours: 3-4 per CU measured 232-233 us on the
+         * 64 M-row 7-point operator, 5 / 6 / 8 per CU 246 / 246 / 253, profiles/r04_col.txt) */
+        if (s->d_colplan) {
+          if (o->spmv_grid <= 0) {
+            CAND(LSB_SPMV_SELL, f | LSB_SP_COL, 768, 0);
+            CAND(LSB_SPMV_SELL, f | LSB_SP_COL, 1024, 0);
+            CAND(LSB_SPMV_SELL, f | LSB_SP_COL, 1536, 0);
+          } else
+            CAND(LSB_SPMV_SELL, f | LSB_SP_COL, grid0, 0);
+        }
       }
     }
 #undef CAND
@@ -1069,8 +1119,8 @@ void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
     s->d_srec = NULL, s->d_tmpl = NULL, s->d_tmask = NULL;
   }
   if (!(bv == LSB_SPMV_SELL && (bf & LSB_SP_COL))) {
-    lsb_hip_free(s->d_colplan);
-    s->d_colplan = NULL;
+    lsb_hip_free(s->d_colplan), lsb_hip_free(s->d_colplan_in);
+    s->d_colplan = s->d_colplan_in = NULL;
   }
   if (any && !(bv == LSB_SPMV_SELL && !(bf & LSB_SP_C16))) {
     lsb_hip_free(s->d_scols), lsb_hip_free(s->d_svals);

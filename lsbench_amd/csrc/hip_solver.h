@@ -105,10 +105,11 @@ struct shard {
   unsigned long long tmpl_pure, tmpl_shaped, tmpl_bytes;
   /* z-column plan of the template layout (lsb_sell_tmpl_columns; LSB_SP_COL in sp_flags): xbeg[9],
    * padding to 16 unsigneds, 16-byte items */
-  unsigned *d_colplan;
-  unsigned col_items, col_kmax;
+  unsigned *d_colplan, *d_colplan_in; /* all slices; the interior range [ov_s1, ov_s2) of the split SpMV */
+  unsigned col_items, col_items_in, col_kmax;
   int col_centre0;
   unsigned long long col_slices; /* slices inside columns */
+  unsigned long long col_bytes;  /* matrix-side bytes one launch of the z-column walk streams */
   unsigned sell_ulen;      /* != 0: every slice of the 16-bit copy has this many slots */
   double *d_parts_pq, *d_parts2;
   double *d_scal; /* [0] p.q   [1] r.z'  [2] r.r   (multi-shard path) */

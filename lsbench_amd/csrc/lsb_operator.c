@@ -1460,7 +1460,12 @@ static int col_same(const struct lsb_sell_tmpls *T, unsigned a, unsigned b) {
 }
 
 struct lsb_tmpl_cols *lsb_sell_tmpl_columns(const struct lsb_sell_tmpls *T, unsigned period, unsigned kmax) {
-  if (!T || period < LSB_COL_XCDS || T->nslice < 2 * period || T->nfar < 1)
+  return lsb_sell_tmpl_columns_range(T, period, kmax, 0, T ? T->nslice : 0);
+}
+
+struct lsb_tmpl_cols *lsb_sell_tmpl_columns_range(const struct lsb_sell_tmpls *T, unsigned period, unsigned kmax,
+                                                  unsigned s_lo, unsigned s_hi) {
+  if (!T || period < LSB_COL_XCDS || T->nslice < 2 * period || T->nfar < 1 || s_hi > T->nslice || s_lo >= s_hi)
     return NULL;
   if (kmax < 2)
     kmax = 2;
@@ -1468,23 +1473,30 @@ struct lsb_tmpl_cols *lsb_sell_tmpl_columns(const struct lsb_sell_tmpls *T, unsi
     kmax = LSB_TMPL_COL_MAX;
   const unsigned ns = T->nslice, nplanes = (ns + period - 1) / period;
   struct lsb_tmpl_cols *C = lsb_calloc(struct lsb_tmpl_cols, 1);
-  C->kmax = kmax, C->period = period, C->centre0 = 1;
+  C->kmax = kmax, C->period = period, C->centre0 = 1, C->s_lo = s_lo, C->s_hi = s_hi;
   C->item = lsb_calloc(unsigned, 4 * ((size_t)ns + 1));
   unsigned ni = 0;
   for (unsigned k = 0; k < LSB_COL_XCDS; k++) {
     C->xbeg[k] = ni;
     const unsigned qlo = (unsigned)((unsigned long long)period * k / LSB_COL_XCDS),
                    qhi = (unsigned)((unsigned long long)period * (k + 1) / LSB_COL_XCDS);
-    for (unsigned z0 = 0; z0 < nplanes; z0 += kmax) {
-      const unsigned zend = z0 + kmax < nplanes ? z0 + kmax : nplanes;
+    /* z-groups of at most kmax planes, as equal as they come (50 planes, kmax 16: 13, 13, 12, 12) */
+    const unsigned ngroups = (nplanes + kmax - 1) / kmax;
+    for (unsigned zg = 0; zg < ngroups; zg++) {
+      const unsigned z0 = (unsigned)((unsigned long long)nplanes * zg / ngroups),
+                     zend = (unsigned)((unsigned long long)nplanes * (zg + 1) / ngroups);
       for (unsigned p = qlo; p < qhi; p++)
         for (unsigned z = z0; z < zend;) {
           const unsigned long long s = (unsigned long long)z * period + p;
-          if (s >= ns)
+          if (s >= s_hi)
             break;
+          if (s < s_lo) {
+            z++;
+            continue;
+          }
           unsigned run = 1;
           if (col_member(T, (unsigned)s, period))
-            while (z + run < zend && s + (unsigned long long)run * period < ns &&
+            while (z + run < zend && s + (unsigned long long)run * period < s_hi &&
                    col_member(T, (unsigned)(s + (unsigned long long)run * period), period) &&
                    col_same(T, (unsigned)s, (unsigned)(s + (unsigned long long)run * period)))
               run++;
@@ -1499,7 +1511,18 @@ struct lsb_tmpl_cols *lsb_sell_tmpl_columns(const struct lsb_sell_tmpls *T, unsi
     }
   }
   C->xbeg[LSB_COL_XCDS] = C->nitem = ni;
-  if (C->in_cols * 4 < (unsigned long long)ns * 3) {
+  /* LOCKSTEP groups: the four items a workgroup takes in one turn (items xbeg + 4g .. 4g + 3 of its
+   * XCD) are four neighbouring columns of equal length -- bit 31 of their slice count says so, and
+   * the four waves then keep step through a barrier per plane, so that a workgroup asks for 4 KB of
+   * consecutive addresses at a time */
+  for (unsigned k = 0; k < LSB_COL_XCDS; k++)
+    for (unsigned i = C->xbeg[k]; i + 4 <= C->xbeg[k + 1]; i += 4) {
+      const unsigned *it = C->item + 4 * (size_t)i;
+      if (it[1] >= 2 && it[5] == it[1] && it[9] == it[1] && it[13] == it[1])
+        for (int w = 0; w < 4; w++)
+          C->item[4 * (size_t)(i + w) + 1] |= LSB_TMPL_COL_LOCKSTEP;
+    }
+  if (C->in_cols * 4 < (unsigned long long)(s_hi - s_lo) * 3) {
     lsb_tmpl_cols_free(C);
     return NULL;
   }
@@ -1518,6 +1541,8 @@ int lsb_tmpl_cols_check(const struct lsb_sell_tmpls *T, const struct lsb_tmpl_co
   if (!T || !C || !C->item)
     CC_FAIL(1, "no column plan");
   const unsigned ns = T->nslice, period = C->period;
+  if (C->s_hi > ns || C->s_lo >= C->s_hi)
+    CC_FAIL(11, "slices [%u, %u) of %u", C->s_lo, C->s_hi, ns);
   if (period < LSB_COL_XCDS || C->kmax < 2 || C->kmax > LSB_TMPL_COL_MAX || C->xbeg[0] != 0 || C->xbeg[LSB_COL_XCDS] != C->nitem)
     CC_FAIL(2, "period %u, columns of up to %u slices, items [%u, %u) of %u", period, C->kmax, C->xbeg[0],
             C->xbeg[LSB_COL_XCDS], C->nitem);
@@ -1529,9 +1554,20 @@ int lsb_tmpl_cols_check(const struct lsb_sell_tmpls *T, const struct lsb_tmpl_co
     CC_FAIL(4, "out of memory");
   for (unsigned i = 0; i < C->nitem; i++) {
     const unsigned *it = C->item + 4 * (size_t)i;
-    const unsigned s = it[0], run = it[1];
-    if (run < 1 || run > C->kmax || s >= ns || (unsigned long long)s + (unsigned long long)(run - 1) * period >= ns)
-      CC_FAIL(5, "item %u: %u slices from slice %u, every %u, of %u", i, run, s, period, ns);
+    const unsigned s = it[0], run = it[1] & ~LSB_TMPL_COL_LOCKSTEP;
+    if (it[1] & LSB_TMPL_COL_LOCKSTEP) { /* the whole turn of a workgroup: four columns of one length */
+      unsigned xk = 0; /* the XCD whose range holds item i */
+      while (xk + 1 < LSB_COL_XCDS && C->xbeg[xk + 1] <= i)
+        xk++;
+      const unsigned g0 = C->xbeg[xk] + (i - C->xbeg[xk]) / 4 * 4;
+      if (g0 + 4 > C->xbeg[xk + 1])
+        CC_FAIL(12, "item %u: lockstep in a turn of fewer than four items", i);
+      for (unsigned w = 0; w < 4; w++)
+        if (C->item[4 * (size_t)(g0 + w) + 1] != it[1] || run < 2)
+          CC_FAIL(12, "item %u: lockstep, but item %u of its turn has another length", i, g0 + w);
+    }
+    if (run < 1 || run > C->kmax || s < C->s_lo || (unsigned long long)s + (unsigned long long)(run - 1) * period >= C->s_hi)
+      CC_FAIL(5, "item %u: %u slices from slice %u, every %u, of [%u, %u)", i, run, s, period, C->s_lo, C->s_hi);
     for (unsigned k = 0; k < run; k++) {
       const unsigned sk = s + k * period;
       if (seen[sk]++)
@@ -1545,7 +1581,7 @@ int lsb_tmpl_cols_check(const struct lsb_sell_tmpls *T, const struct lsb_tmpl_co
       CC_FAIL(8, "item %u: template %u / first mask %u, its first slice has %u / %u", i, it[2], it[3], T->tid[s],
               T->vbase[2 * (size_t)s + 1]);
   }
-  for (unsigned s = 0; s < ns; s++)
+  for (unsigned s = C->s_lo; s < C->s_hi; s++)
     if (!seen[s])
       CC_FAIL(9, "slice %u is in no item", s);
   free(seen);

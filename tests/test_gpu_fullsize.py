@@ -158,6 +158,20 @@ def test_lap3d_64m_rows(hip):
     s.destroy()
     del d_b, d_x
     torch.cuda.empty_cache()
+    # the z-column walk (k_spmv_tmpl_col) at full size: planes 1 .. 398 in columns but for the 8 slices of
+    # every plane that hold rows of its first / last grid line, y bit for bit what the template kernel stores
+    d_xr = _dev(x)
+    ys = []
+    for tune in (6 | 64, 6 | 64 | 256):
+        st = hip.Solver(A, hip.default_opts(op_mode=hip.OP_RAW, spmv_variant=hip.SPMV_SELL, spmv_tune=tune, use_graph=0))
+        assert st.spmv_flags == tune and st.spmv_col_slices == 398 * (1250 - 8)
+        d_y = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda:0")
+        st.spmv_dev(d_xr, d_y)
+        ys.append(d_y)
+        st.destroy()
+    assert torch.equal(ys[0], ys[1])
+    del ys, d_xr, d_y
+    torch.cuda.empty_cache()
     # config 4 AS BASELINE.json states it: row-partitioned 8 ways (50 planes of
     # 400 x 400 per shard, one 1.28 MB plane per neighbour and exchange).  Eight
     # row-range shards on the one device run the multi-GPU defaults (single-

@@ -817,25 +817,36 @@ def test_z_column_plan_of_a_3d_stencil():
                 assert xb[0] == 0 and xb[8] == c.nitem and xb == sorted(xb)
                 seen = np.zeros(ns, int)
                 for k in range(8):                                     # XCD k: its eighth of every plane
-                    for s0, run, t, mb in it[xb[k]:xb[k + 1]]:
+                    turn = it[xb[k]:xb[k + 1]]
+                    for g in range(0, len(turn), 4):                   # lockstep: a full turn of equal columns
+                        runs = turn[g:g + 4, 1]
+                        lock = runs >> 31
+                        assert lock.min() == lock.max()
+                        assert bool(lock[0]) == (len(runs) == 4 and len(set(runs.tolist())) == 1 and (runs[0] & 0x7fffffff) >= 2)
+                    for s0, run, t, mb in turn:
+                        run &= 0x7fffffff
                         assert period * k // 8 <= s0 % period < period * (k + 1) // 8
                         assert 1 <= run <= kmax
                         sl = s0 + period * np.arange(run)
                         seen[sl] += 1
                         if run > 1:
                             assert np.all(tid[sl] == t) and t != 255
-                            # a column never leaves its z-group of kmax planes
-                            assert (s0 // period) // kmax == (sl[-1] // period) // kmax
+                            # a column never leaves its z-group (at most kmax planes, as equal as they come)
+                            npl = -(-ns // period)
+                            ng = -(-npl // kmax)
+                            grp = lambda z: next(g for g in range(ng) if npl * g // ng <= z < npl * (g + 1) // ng)
+                            assert grp(s0 // period) == grp(sl[-1] // period)
                 assert np.all(seen == 1)
-                cols = int(it[it[:, 1] > 1, 1].sum())
+                runs_all = it[:, 1] & 0x7fffffff
+                cols = int(runs_all[runs_all > 1].sum())
                 assert cols == c.in_cols and 4 * cols >= 3 * ns
                 if r0 == 0:                                            # the operator's first plane: single items
-                    assert np.all(it[np.isin(it[:, 0], np.arange(period)), 1] == 1)
+                    assert np.all(runs_all[np.isin(it[:, 0], np.arange(period))] == 1)
                 if kmax == 8:                                          # a broken rule is caught
-                    big = int(np.argmax(it[:, 1]))
+                    big = int(np.argmax(runs_all))
                     keep = int(c.item[4 * big + 1])
-                    c.item[4 * big + 1] = keep + 1 if keep < kmax else keep - 1
-                    assert lib.lsb_tmpl_cols_check(T, Cp, why, 256) in (5, 6, 7, 9)
+                    c.item[4 * big + 1] = (keep & 0x7fffffff) + 1 if (keep & 0x7fffffff) < kmax else (keep & 0x7fffffff) - 1
+                    assert lib.lsb_tmpl_cols_check(T, Cp, why, 256) in (5, 6, 7, 9, 12)
                     c.item[4 * big + 1] = keep
                 lib.lsb_tmpl_cols_free(Cp)
             assert not lib.lsb_sell_tmpl_columns(T, period + 1, 8)                  # not this operator's plane

@@ -70,6 +70,7 @@ pmc2() { local tag=$1; shift
   step pmc_write$tag 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write$tag" -- python3 bench.py "$@" --steps 1 --warmup 0 $Q; }
 pmc2 _f70 --fixed-iters 60 --spmv 5 --spmv-tune 70
 pmc2 _f198 --fixed-iters 60 --spmv 5 --spmv-tune 198
+pmc2 _lap3d_f326 --workload lap3d --fixed-iters 40 --spmv 5 --spmv-tune 326
 pmc2 _lap3d_f198 --workload lap3d --fixed-iters 40 --spmv 5 --spmv-tune 198
 pmc2 _lap3d_f70 --workload lap3d --fixed-iters 40 --spmv 5 --spmv-tune 70
 export LSBENCH_HIP_FORCE_PERIOD=1

@@ -41,7 +41,7 @@ def bench_line_of(tag):
 VARIANTS = [("lap2d", "", ""), ("lap2d_coef", "_coef", ""), ("lap3d", "_lap3d", ""), ("powerlaw", "_powerlaw", ""),
             ("lap2d", "_f70", "_f70"), ("lap2d", "_f198", "_f198"), ("lap3d", "_lap3d_f198", "_f198"),
             ("lap3d", "_lap3d_f198p", "_f198p"), ("lap3d", "_lap3d_f70", "_f70"), ("lap3d", "_lap3d_f70p", "_f70p"),
-            ("lap2d_coef", "_coef_f6", "_f6")]
+            ("lap3d", "_lap3d_f326", "_f326"), ("lap2d_coef", "_coef_f6", "_f6")]
 for wl, suffix, vtag in VARIANTS:
     pmc = {}
     for cname, tag in (("FETCH_SIZE", "pmc_fetch" + suffix), ("WRITE_SIZE", "pmc_write" + suffix)):
