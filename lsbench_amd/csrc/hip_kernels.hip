@@ -579,7 +579,8 @@ __global__ __launch_bounds__(WG) void k_pcg_init_state(
     st->pq = 0.0;
     st->iters = 0;
     st->maxit = maxit;
-    st->pad = 0; // "maxit-th update done, status pending" marker of k_cg1_update
+    st->pad = 0; // "maxit-th update done, status pending" marker of k_cg1_update / k_pcg_col_px
+    st->xpend = 0; // k_pcg_col_px: no x update pending
     // b == 0 => x = 0 is the solution; maxit == 0 => nothing to do
     st->status = (v[1] == 0.0) ? LSB_STATUS_CONVERGED
                                : (maxit <= 0 ? LSB_STATUS_MAXIT : LSB_STATUS_RUNNING);
@@ -724,6 +725,9 @@ __global__ __launch_bounds__(WG) void k_pcg_update_p(
   // as in k_pcg_update_xr: one round trip for status, scalars and operands
   const int stopped = st->status;
   const double rz_old = st->rz[parity], thresh2 = st->thresh2;
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    st->xpend = 0; // (two-launch column form: k_pcg_xfix, the launch before this one, has applied it; nobody
+                   // reads the word in this launch)
   d2v rv = {0.0, 0.0}, dv = rv, pv = rv, rw = rv, dw = rv, pw = rv;
   const bool first = V2 && gtid < n2;
   bool second = X2 && V2 && gtid + gsz < n2;
@@ -1694,8 +1698,10 @@ __device__ __forceinline__ void col_compute(const col_ops<NF> &o, const sell_d2u
 }
 
 #define LSB_COL_HEAD 16 // unsigneds in front of the items: xbeg[NXCD + 1]
+// (a loaded dot operand is four more registers per step in flight: five workgroups per CU instead of six
+// rather than spills -- the walk runs best from three or four anyway)
 template <int NF, int DOT>
-__global__ __launch_bounds__(WG, 6) void k_spmv_tmpl_col(
+__global__ __launch_bounds__(WG, DOT == 2 ? 5 : 6) void k_spmv_tmpl_col(
     const unsigned *__restrict__ plan, unsigned period, unsigned n, unsigned row_begin, unsigned xlen,
     const unsigned *__restrict__ sptr, const unsigned long long *__restrict__ mask,
     const lsb_sell_tmpl *__restrict__ td, const int *__restrict__ sbase, const void *__restrict__ vals, int f32,
@@ -1830,6 +1836,390 @@ __global__ __launch_bounds__(WG, 6) void k_spmv_tmpl_col(
   if (stopped)
     return;
   spmv_publish(partials, dot, sred, tail);
+}
+
+// --------------------------------------------------------------------------
+// a2-5 on a z-column plan: the classic PCG iteration in TWO launches and 72 instead of 88 bytes per
+// row (one shard, constant Jacobi diagonal dc).
+//   [k_pcg_col_px]   (r.z, r.r) of the sweep before -> stop test, beta;  alpha = the step of the
+//                    iteration before (st->alpha[0], left there by k_pcg_update_r);  per row
+//                      p' = dc r + beta p        (pnew_of: k_pcg_update_p's expression)
+//                      x += alpha p              (the x half of k_pcg_update_xr, one iteration late:
+//                                                 p is in registers here anyway)
+//                      q  = S p',  partials of p'.q
+//                    -- reads r, p, x and writes p' (the OTHER direction buffer), x, q: 48 B per row
+//   [k_pcg_update_r] alpha = r.z / p'.q;  r -= alpha q;  partials of (r.z', r.r) -- 24 B per row
+// against k_spmv_tmpl_col (16) + k_pcg_update_xr (48) + k_pcg_update_p (24).  What makes the fold pay
+// where k_spmv_tmpl_p's did not (round 3: every gathered operand of every slice formed p' anew, five
+// or seven times per row): a column forms p' ONCE per plane and row and keeps it in registers for the
+// three steps that use it as the plane above, the centre and the plane below; only the +-line
+// operands of a 3-D stencil (NF = 2) are formed a second time, out of r and p lines that sit in L2.
+// Ownership: a column loads, updates and stores x and p' for ITS planes only; the plane below its
+// first and above its last slice belong to other columns -- p' is formed for them, nothing stored.
+// The x update of the LAST iteration of a run has no k_pcg_col_px behind it: st->xpend (set by
+// k_pcg_update_r, cleared here) says so and k_pcg_xfix applies it (hip_pcg.c).  maxit: the launch
+// that counts the maxit-th iteration sets st->pad and does all of its work (x included); the next
+// k_pcg_update_r turns that into the status -- never set and tested in the same launch.
+// Pipeline of a column as in k_spmv_tmpl_col: a step issues the NEXT step's loads, then the stores
+// of the step before (q, x, p'), then waits for its own operands, which are older than both.
+// --------------------------------------------------------------------------
+template <int NF> struct colp_c { // centre-side loads of one step, issued ONE step ahead
+  sell_d2u rn, pn;                // r, p of the plane ahead (it becomes this step's "plane above")
+  sell_d2v xn;                    // x of that plane, where the column owns it
+  double re, pe;                  // r, p of the element in front of / behind the wave's 128 centre operands
+};
+// the +-line operands of a step (3-D stencil), issued TWO steps ahead: the lines a column gathers for plane z are
+// the centre lines of the columns three slices to either side, which fetch them one step before they use them as
+// "the plane ahead".  Asked for at that same time the request meets theirs in L2; asked for a step later (as in
+// k_spmv_tmpl_col, whose steps are a quarter as long) half of them had left it again: 20.98 M fabric read requests
+// per launch on the 64 M-row 7-point operator where 13 M are compulsory (profiles/r04_px.txt)
+template <int NF> struct colp_m {
+  sell_d2u rlo[NF > 1 ? NF - 1 : 1], plo[NF > 1 ? NF - 1 : 1], rhi[NF > 1 ? NF - 1 : 1], phi[NF > 1 ? NF - 1 : 1];
+};
+struct colp_out { // results of a step, stored by the next one
+  sell_d2v q, x, p;
+};
+// gu: global row of lane 0's first row of the step's slice (one shard: = its local row)
+template <int NF, bool WITH_X, int NT>
+__device__ __forceinline__ void colp_issue_c(colp_c<NF> &o, const col_tmpl<NF> &T, const double *__restrict__ r,
+                                             const double *__restrict__ pold, const double *__restrict__ x,
+                                             long long gu, unsigned P, unsigned xlen, unsigned lane) {
+  const long long ga = gu + T.bc + (long long)P; // the plane ahead
+  o.rn = *(const sell_d2u *)(r + ga + 2 * lane);
+  o.pn = *(const sell_d2u *)(pold + ga + 2 * lane);
+  if (WITH_X) { // x is touched once per launch: nontemporal (NT & 1) keeps it out of the way of the r / p lines
+                // the neighbouring columns gather again
+    if (NT & 1)
+      o.xn = __builtin_nontemporal_load((const sell_d2v *)(x + (gu + (long long)P) + 2 * lane));
+    else
+      o.xn = *(const sell_d2v *)(x + (gu + (long long)P) + 2 * lane);
+  }
+  long long el = gu + T.bc - 1, er = gu + T.bc + (long long)LSB_SELL_ROWS; // wave-uniform, clamped (see col_issue)
+  el = el < 0 ? 0 : el, er = er >= (long long)xlen ? (long long)xlen - 1 : er;
+  const long long e = lane < 32u ? el : er;
+  o.re = r[e], o.pe = pold[e];
+}
+template <int NF>
+__device__ __forceinline__ void colp_issue_m(colp_m<NF> &o, const col_tmpl<NF> &T, const double *__restrict__ r,
+                                             const double *__restrict__ pold, long long gu, unsigned lane) {
+#pragma unroll
+  for (int k = 0; k < NF - 1; k++) {
+    o.rlo[k] = *(const sell_d2u *)(r + (gu + T.bl[k]) + 2 * lane);
+    o.plo[k] = *(const sell_d2u *)(pold + (gu + T.bl[k]) + 2 * lane);
+    o.rhi[k] = *(const sell_d2u *)(r + (gu + T.bh[k]) + 2 * lane);
+    o.phi[k] = *(const sell_d2u *)(pold + (gu + T.bh[k]) + 2 * lane);
+  }
+}
+// one step: q of the centre plane from (below, centre, above) = (pm, p0, p' of the plane ahead); OWNED: the
+// plane ahead is the column's own -- its x is updated and it and p' go to `out`
+template <int NF, bool OWNED>
+__device__ __forceinline__ void colp_compute(const colp_c<NF> &o, const colp_m<NF> &m, const sell_d2u &pm,
+                                             const sell_d2u &p0, sell_d2u &pp, const col_tmpl<NF> &T, double vm0,
+                                             double vm1, double vp0, double vp1, double beta, double alpha, double dc,
+                                             unsigned lane, colp_out &out, double &dot) {
+  pp.x = pnew_of(dc, o.rn.x, beta, o.pn.x), pp.y = pnew_of(dc, o.rn.y, beta, o.pn.y);
+  if (OWNED) {
+    out.x.x = o.xn.x + alpha * o.pn.x, out.x.y = o.xn.y + alpha * o.pn.y; // k_pcg_update_xr's x += alpha p
+    out.p.x = pp.x, out.p.y = pp.y;
+  }
+  const double edge = pnew_of(dc, o.re, beta, o.pe);
+  double up = lane_above(p0.y), dn = lane_below(p0.x);
+  if (lane == 0)
+    up = edge;
+  if (lane == 63)
+    dn = edge;
+  double a0 = fma(T.k0, pm.x, 0.0), a1 = fma(T.k0, pm.y, 0.0);
+#pragma unroll
+  for (int k = 0; k < NF - 1; k++) {
+    const double l0 = pnew_of(dc, m.rlo[k].x, beta, m.plo[k].x), l1 = pnew_of(dc, m.rlo[k].y, beta, m.plo[k].y);
+    a0 = fma(T.kl[k], l0, a0), a1 = fma(T.kl[k], l1, a1);
+  }
+  a0 = fma(vm0, vm0 != 0.0 ? up : 0.0, a0), a1 = fma(vm1, vm1 != 0.0 ? p0.x : 0.0, a1);
+  a0 = fma(T.kc, p0.x, a0), a1 = fma(T.kc, p0.y, a1);
+  a0 = fma(vp0, vp0 != 0.0 ? p0.y : 0.0, a0), a1 = fma(vp1, vp1 != 0.0 ? dn : 0.0, a1);
+#pragma unroll
+  for (int k = 0; k < NF - 1; k++) {
+    const double h0 = pnew_of(dc, m.rhi[k].x, beta, m.phi[k].x), h1 = pnew_of(dc, m.rhi[k].y, beta, m.phi[k].y);
+    a0 = fma(T.kh[k], h0, a0), a1 = fma(T.kh[k], h1, a1);
+  }
+  a0 = fma(T.kL, pp.x, a0), a1 = fma(T.kL, pp.y, a1);
+  out.q.x = a0, out.q.y = a1;
+  dot = fma(a0, p0.x, dot), dot = fma(a1, p0.y, dot);
+}
+// one slice, slot by slot off the slot records, every operand's p' formed on the fly (first / last
+// plane, ragged ends, columns of two)
+__device__ __forceinline__ void colp_single(unsigned s, unsigned n, unsigned lane, const unsigned *__restrict__ sptr,
+                                            const int *__restrict__ sbase, const double *__restrict__ vals,
+                                            const double *__restrict__ vconst, const double *__restrict__ r,
+                                            const double *__restrict__ pold, double *__restrict__ pnew,
+                                            double *__restrict__ x, double *__restrict__ q, double beta, double alpha,
+                                            double dc, double &dot) {
+  const unsigned row = s * LSB_SELL_ROWS + 2 * lane;
+  const unsigned q0 = sptr[s] / LSB_SELL_ROWS, len = (sptr[s + 1] - sptr[s]) / LSB_SELL_ROWS;
+  const bool l0 = row < n, l1 = row + 1 < n;
+  const double r0 = l0 ? r[row] : 0.0, r1 = l1 ? r[row + 1] : 0.0;
+  const double o0 = l0 ? pold[row] : 0.0, o1 = l1 ? pold[row + 1] : 0.0;
+  const double x0 = l0 ? x[row] : 0.0, x1 = l1 ? x[row + 1] : 0.0;
+  double a0 = 0.0, a1 = 0.0;
+  for (unsigned j = 0; j < len; j++) {
+    const i4v rec = ((const i4v *)sbase)[q0 + j]; // {base, -1 (no codes where templates exist), value slot or -1, 0}
+    if (rec.z < 0) { // a constant slot holds 128 real entries (lsb_tmpl_check): unguarded pairs
+      const double k = vconst[q0 + j];
+      const sell_d2u rv = *(const sell_d2u *)(r + ((int)row + rec.x)), pv = *(const sell_d2u *)(pold + ((int)row + rec.x));
+      a0 = fma(k, pnew_of(dc, rv.x, beta, pv.x), a0), a1 = fma(k, pnew_of(dc, rv.y, beta, pv.y), a1);
+    } else {
+      const sell_d2v v = *((const sell_d2v *)(vals + (size_t)rec.z * LSB_SELL_ROWS) + lane);
+      const bool p0 = v.x != 0.0, p1 = v.y != 0.0; // padding: no gather, an exact 0
+      const int c0 = p0 ? (int)row + rec.x : 0, c1 = p1 ? (int)row + 1 + rec.x : 0;
+      const double t0 = pnew_of(dc, r[c0], beta, pold[c0]), t1 = pnew_of(dc, r[c1], beta, pold[c1]);
+      a0 = fma(v.x, p0 ? t0 : 0.0, a0), a1 = fma(v.y, p1 ? t1 : 0.0, a1);
+    }
+  }
+  const double n0 = pnew_of(dc, r0, beta, o0), n1 = pnew_of(dc, r1, beta, o1);
+  if (l0) {
+    pnew[row] = n0, x[row] = x0 + alpha * o0, q[row] = a0;
+    dot = fma(a0, n0, dot);
+  }
+  if (l1) {
+    pnew[row + 1] = n1, x[row + 1] = x1 + alpha * o1, q[row + 1] = a1;
+    dot = fma(a1, n1, dot);
+  }
+}
+
+#define COLP_ST(PTR, V, BIT)                                                                   \
+  do {                                                                                         \
+    if (NT & (BIT))                                                                            \
+      __builtin_nontemporal_store((V), (sell_d2v *)(PTR));                                     \
+    else                                                                                       \
+      *(sell_d2v *)(PTR) = (V);                                                                \
+  } while (0)
+#define COLP_STORE(OUT, LROW, WITH_Q, WITH_XP)                                                 \
+  do {                                                                                         \
+    if (WITH_Q)                                                                                \
+      COLP_ST(q + (LROW) + 2 * lane, (OUT).q, 2);                                              \
+    if (WITH_XP) {                                                                             \
+      COLP_ST(x + ((LROW) + P) + 2 * lane, (OUT).x, 1);                                        \
+      COLP_ST(pnew + ((LROW) + P) + 2 * lane, (OUT).p, 2);                                     \
+    }                                                                                          \
+  } while (0)
+
+// NT: bit 0 x loaded and stored nontemporal, bit 1 p' and q stored nontemporal
+template <int NF, int NT>
+__global__ __launch_bounds__(WG, NF == 2 ? 3 : 4) void k_pcg_col_px(
+    const unsigned *__restrict__ plan, unsigned period, unsigned n, const unsigned *__restrict__ sptr,
+    const unsigned long long *__restrict__ mask, const lsb_sell_tmpl *__restrict__ td, const int *__restrict__ sbase,
+    const double *__restrict__ vals, const double *__restrict__ vconst, const double *__restrict__ r,
+    const double *__restrict__ pold, double *__restrict__ pnew, double *__restrict__ x, double *__restrict__ q,
+    double dc, double *__restrict__ partials, lsb_pcg_state *__restrict__ st, int parity,
+    const double *__restrict__ parts2, unsigned nparts2) {
+  static_assert(NF >= 1 && NF <= 2, "one or two far slots per side");
+  __shared__ double sred[8];
+  const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const unsigned gx = gridDim.x / NXCD, xcd = blockIdx.x % NXCD, slot = blockIdx.x / NXCD;
+  // ---- k_pcg_update_p's prologue: the sweep's partial sums -> r.z, r.r, stop test, beta
+  const int stopped = st->status;
+  const double rz_old = st->rz[parity], thresh2 = st->thresh2, alpha = st->alpha[0];
+  const unsigned i0 = plan[xcd], i1 = plan[xcd + 1];
+  double v[2];
+  wg_sum_partials<2>(parts2, nparts2, v, sred);
+  if (stopped)
+    return;
+  const double rz_new = v[0], rr = v[1];
+  const bool conv = rr <= thresh2;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { // only this thread touches these words in this launch
+    const int it = st->iters + 1;
+    st->iters = it;
+    st->rr = rr;
+    st->rz[parity ^ 1] = rz_new;
+    if (conv)
+      st->status = LSB_STATUS_CONVERGED; // (the x update of the last iteration stays pending: k_pcg_xfix)
+    else {
+      st->xpend = 0; // this launch applies it
+      if (it >= st->maxit)
+        st->pad = 1; // the next k_pcg_update_r makes it the status; this launch still does all its work
+    }
+  }
+  if (conv)
+    return;
+  const double beta = rz_new / rz_old;
+  const u4v *__restrict__ items = (const u4v *)(plan + LSB_COL_HEAD);
+  const unsigned P = period * LSB_SELL_ROWS;
+  double dot = 0.0;
+  for (unsigned g = slot; i0 + 4 * g < i1; g += gx) {
+    const unsigned it = __builtin_amdgcn_readfirstlane(i0 + 4 * g + wave);
+    if (it >= i1)
+      continue;
+    const u4v rec = items[it];
+    const unsigned s = __builtin_amdgcn_readfirstlane(rec.x);
+    const unsigned K = __builtin_amdgcn_readfirstlane(rec.y) & ~LSB_TMPL_COL_LOCKSTEP;
+    if (K >= 3) {
+      const unsigned t = __builtin_amdgcn_readfirstlane(rec.z), mb = __builtin_amdgcn_readfirstlane(rec.w);
+      const lsb_sell_tmpl *T = td + t;
+      col_tmpl<NF> C;
+      C.bc = T->base[NF + 1];
+      C.k0 = T->cst[0], C.kc = T->cst[NF + 1], C.kL = T->cst[2 * NF + 2];
+#pragma unroll
+      for (int k = 0; k < NF - 1; k++) {
+        C.bl[k] = T->base[1 + k], C.bh[k] = T->base[NF + 3 + k];
+        C.kl[k] = T->cst[1 + k], C.kh[k] = T->cst[NF + 3 + k];
+      }
+      const int side_k[2] = {T->kidx[NF], T->kidx[NF + 2]}, side_kd[2] = {T->kind[NF], T->kind[NF + 2]};
+      long long gu = (long long)s * LSB_SELL_ROWS;
+      unsigned lrow = s * LSB_SELL_ROWS;
+      // prologue: r, p of the plane below (another column's) and of the first plane with its x; step 0's loads
+      const long long gc = gu + C.bc;
+      const sell_d2u rb = *(const sell_d2u *)(r + (gc - (long long)P) + 2 * lane);
+      const sell_d2u pb = *(const sell_d2u *)(pold + (gc - (long long)P) + 2 * lane);
+      const sell_d2u r0 = *(const sell_d2u *)(r + gc + 2 * lane), o0 = *(const sell_d2u *)(pold + gc + 2 * lane);
+      const sell_d2v x0 = *(const sell_d2v *)(x + lrow + 2 * lane);
+      colp_c<NF> c0, c1;
+      colp_m<NF> m0, m1, m2;
+      colp_issue_c<NF, true, NT>(c0, C, r, pold, x, gu, P, n, lane);
+      colp_issue_m<NF>(m0, C, r, pold, gu, lane);
+      colp_issue_m<NF>(m1, C, r, pold, gu + (long long)P, lane);
+      unsigned long long mk[2][2] = {{0ull, 0ull}, {0ull, 0ull}};
+#pragma unroll
+      for (int side = 0; side < 2; side++)
+        if (side_k[side] >= 0 && side_kd[side] == 2) {
+          const unsigned long long *mp = mask + 2 * ((size_t)mb + (unsigned)side_k[side]);
+          mk[side][0] = mp[0], mk[side][1] = mp[1];
+        }
+      double vm0 = T->cst[NF], vm1 = vm0, vp0 = T->cst[NF + 2], vp1 = vp0;
+      if (side_k[0] >= 0 || side_k[1] >= 0)
+        tmpl_side_values(T, NF, 0u, lane, side_k, side_kd, mk, vals, 0, vm0, vm1, vp0, vp1);
+      sell_d2u pm, p0, pp;
+      pm.x = pnew_of(dc, rb.x, beta, pb.x), pm.y = pnew_of(dc, rb.y, beta, pb.y);
+      p0.x = pnew_of(dc, r0.x, beta, o0.x), p0.y = pnew_of(dc, r0.y, beta, o0.y);
+      colp_out prev, res;
+      prev.x.x = x0.x + alpha * o0.x, prev.x.y = x0.y + alpha * o0.y;
+      prev.p.x = p0.x, prev.p.y = p0.y;
+      prev.q = prev.p; // (not stored)
+      // step 0 (K >= 3: the plane after next is the column's own): next loads, the first plane's x and p', compute
+      colp_issue_c<NF, true, NT>(c1, C, r, pold, x, gu + (long long)P, P, n, lane);
+      colp_issue_m<NF>(m2, C, r, pold, gu + 2 * (long long)P, lane);
+      COLP_STORE(prev, lrow - P, false, true);
+      colp_compute<NF, true>(c0, m0, pm, p0, pp, C, vm0, vm1, vp0, vp1, beta, alpha, dc, lane, res, dot);
+      pm = p0, p0 = pp, c0 = c1, m0 = m1, m1 = m2, prev = res;
+      // steps 1 .. K-3: the plane after next is still the column's own
+      for (unsigned k = 1; k + 2 < K; k++) {
+        gu += (long long)P, lrow += P;
+        colp_issue_c<NF, true, NT>(c1, C, r, pold, x, gu + (long long)P, P, n, lane);
+        colp_issue_m<NF>(m2, C, r, pold, gu + 2 * (long long)P, lane);
+        COLP_STORE(prev, lrow - P, true, true);
+        colp_compute<NF, true>(c0, m0, pm, p0, pp, C, vm0, vm1, vp0, vp1, beta, alpha, dc, lane, res, dot);
+        pm = p0, p0 = pp, c0 = c1, m0 = m1, m1 = m2, prev = res;
+      }
+      // step K-2: the plane after next is the one above the column (no x, no +-line operands to ask for)
+      gu += (long long)P, lrow += P;
+      colp_issue_c<NF, false, NT>(c1, C, r, pold, x, gu + (long long)P, P, n, lane);
+      COLP_STORE(prev, lrow - P, true, true);
+      colp_compute<NF, true>(c0, m0, pm, p0, pp, C, vm0, vm1, vp0, vp1, beta, alpha, dc, lane, res, dot);
+      pm = p0, p0 = pp, c0 = c1, m0 = m1, prev = res;
+      // step K-1: nothing to load; the plane ahead is not the column's
+      gu += (long long)P, lrow += P;
+      COLP_STORE(prev, lrow - P, true, true);
+      colp_compute<NF, false>(c0, m0, pm, p0, pp, C, vm0, vm1, vp0, vp1, beta, alpha, dc, lane, res, dot);
+      COLP_STORE(res, lrow, true, false);
+    } else {
+      for (unsigned k = 0; k < K; k++)
+        colp_single(s + k * period, n, lane, sptr, sbase, vals, vconst, r, pold, pnew, x, q, beta, alpha, dc, dot);
+    }
+  }
+  if (partials) {
+    double d[1] = {dot};
+    wg_sum<1>(d, sred);
+    if (threadIdx.x == 0)
+      partials[blockIdx.x] = d[0];
+  }
+}
+#undef COLP_STORE
+#undef COLP_ST
+
+// alpha = r.z / p.q;  r -= alpha q;  partials (r.dinv.r, r.r) -- k_pcg_update_xr without its x half (which
+// k_pcg_col_px does one iteration later); leaves alpha and "x is one update behind, the direction is in
+// buffer pbuf" in the state
+template <bool V2, bool NTQ, bool NTR>
+__global__ __launch_bounds__(WG) void k_pcg_update_r(
+    unsigned n, const double *__restrict__ q, double dc, double *__restrict__ r, lsb_pcg_state *__restrict__ st,
+    int parity, int pbuf, const double *__restrict__ pq_parts, unsigned npq, double *__restrict__ partials2) {
+  __shared__ double sred[8];
+  const size_t gtid = (size_t)blockIdx.x * WG + threadIdx.x;
+  const size_t gsz = (size_t)gridDim.x * WG;
+  const size_t n2 = n / 2;
+  const d2v *q2 = (const d2v *)q;
+  d2v *r2 = (d2v *)r;
+  const int stopped = st->status, pad = st->pad;
+  const double rz = st->rz[parity];
+  d2v qv = {0.0, 0.0}, rv = qv;
+  const bool first = V2 && gtid < n2;
+  if (first)
+    qv = ld2<NTQ>(q2 + gtid), rv = ld2<NTR>(r2 + gtid);
+  double pqv[1];
+  wg_sum_partials<1>(pq_parts, npq, pqv, sred);
+  if (stopped)
+    return;
+  if (pad) { // the launch before counted the maxit-th iteration (and did its x update): stop here
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+      st->status = LSB_STATUS_MAXIT;
+    return;
+  }
+  const double pq = pqv[0];
+  if (!(pq != 0.0) || !isfinite(pq)) { // same decision in every workgroup
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+      st->status = LSB_STATUS_BREAKDOWN;
+    return;
+  }
+  const double alpha = rz / pq;
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    st->pq = pq, st->alpha[0] = alpha, st->xpend = 1 + pbuf;
+  double acc[2] = {0.0, 0.0};
+  if (V2) {
+    if (first) {
+      size_t i = gtid;
+      for (;;) {
+        rv.x -= alpha * qv.x, rv.y -= alpha * qv.y;
+        r2[i] = rv;
+        acc[0] += rv.x * (dc * rv.x);
+        acc[0] += rv.y * (dc * rv.y);
+        acc[1] += rv.x * rv.x;
+        acc[1] += rv.y * rv.y;
+        i += gsz;
+        if (i >= n2)
+          break;
+        qv = ld2<NTQ>(q2 + i), rv = ld2<NTR>(r2 + i);
+      }
+    }
+    if ((n & 1) && gtid == gsz - 1) {
+      const double rs = r[n - 1] - alpha * q[n - 1];
+      r[n - 1] = rs;
+      acc[0] += rs * (dc * rs), acc[1] += rs * rs;
+    }
+  } else {
+    for (size_t i = gtid; i < n; i += gsz) {
+      const double rs = r[i] - alpha * q[i];
+      r[i] = rs;
+      acc[0] += rs * (dc * rs), acc[1] += rs * rs;
+    }
+  }
+  wg_sum<2>(acc, sred);
+  if (threadIdx.x == 0) {
+    partials2[2 * blockIdx.x + 0] = acc[0];
+    partials2[2 * blockIdx.x + 1] = acc[1];
+  }
+}
+
+// the x update a run's last k_pcg_update_r left pending (no k_pcg_col_px came behind it, or that one
+// found the solve converged): x += alpha p with p in the buffer st->xpend names.  Runs whatever the
+// status; the stand-alone k_pcg_update_p behind it clears st->xpend.
+__global__ __launch_bounds__(WG) void k_pcg_xfix(unsigned n, const double *__restrict__ p0, const double *__restrict__ p1,
+                                                 double *__restrict__ x, const lsb_pcg_state *__restrict__ st) {
+  const int pend = st->xpend;
+  if (!pend)
+    return;
+  const double alpha = st->alpha[0];
+  const double *__restrict__ p = pend == 1 ? p0 : p1;
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n; i += (size_t)gridDim.x * WG)
+    x[i] += alpha * p[i];
 }
 
 // (Round 4, measured and taken out again: k_spmv_tmpl_deep -- a wave takes 2 or 4 of its turns AT ONCE,
@@ -2504,6 +2894,70 @@ void lsb_k_pcg_update_xr(unsigned n, const double *p, const double *q,
     k_pcg_update_xr<false, false, false, false><<<g, WG, 0, (hipStream_t)stream>>>(
         n, p, q, dinv, dc, x, r, st, parity, pq_parts, npq, partials2);
   }
+}
+
+void lsb_k_pcg_col_px(unsigned grid_cap, unsigned period, const unsigned *plan, unsigned nitem, unsigned n,
+                      const unsigned *sptr, const unsigned long long *mask, const struct lsb_sell_tmpl *td,
+                      unsigned nfar, const int *sbase, const double *vals, const double *vconst, const double *r,
+                      const double *pold, double *pnew, double *x, double *q, double dc, double *partials,
+                      unsigned *npartials, struct lsb_pcg_state *st, int parity, const double *parts2,
+                      unsigned nparts2, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  /* every workgroup resident: three per CU with two far slots per side (148 VGPRs), four with one (100) */
+  const unsigned res = nfar == 2 ? 768u : 1024u;
+  const unsigned g = lsb_k_spmv_grid(LSB_SPMV_SELL, n, nitem, 0, grid_cap && grid_cap < res ? grid_cap : res);
+  if (npartials)
+    *npartials = g;
+  if (period < NXCD || !plan || pold == pnew)
+    errx(EXIT_FAILURE, "lsb_k_pcg_col_px: no column plan (period %u) or one direction buffer", period);
+  static int nt = -1; /* (experiments: LSBENCH_HIP_PX_NT = 0 .. 3) */
+  if (nt < 0) {
+    const char *e = getenv("LSBENCH_HIP_PX_NT");
+    nt = e ? atoi(e) & 3 : 3;
+  }
+#define LSB_PX(NF, NTM)                                                                               \
+  k_pcg_col_px<NF, NTM><<<g, WG, 0, s>>>(plan, period, n, sptr, mask, td, sbase, vals, vconst, r, pold, pnew, x, q, dc, \
+                                         partials, st, parity, parts2, nparts2)
+#define LSB_PXN(NF)                                                                                   \
+  do {                                                                                                \
+    switch (nt) {                                                                                     \
+    case 0: LSB_PX(NF, 0); break;                                                                     \
+    case 1: LSB_PX(NF, 1); break;                                                                     \
+    case 2: LSB_PX(NF, 2); break;                                                                     \
+    default: LSB_PX(NF, 3); break;                                                                    \
+    }                                                                                                 \
+  } while (0)
+  switch (nfar) {
+  case 1: LSB_PXN(1); break;
+  case 2: LSB_PXN(2); break;
+  default: errx(EXIT_FAILURE, "lsb_k_pcg_col_px: %u far slots per side", nfar);
+  }
+#undef LSB_PXN
+#undef LSB_PX
+}
+
+void lsb_k_pcg_update_r(unsigned n, const double *q, double dc, double *r, struct lsb_pcg_state *st, int parity,
+                        int pbuf, const double *pq_parts, unsigned npq, double *partials2, unsigned *npartials,
+                        void *stream) {
+  const unsigned g = lsb_k_blas1_grid(n);
+  *npartials = g;
+  hipStream_t hs = (hipStream_t)stream;
+#define LSB_UR(V, A, B) k_pcg_update_r<V, A, B><<<g, WG, 0, hs>>>(n, q, dc, r, st, parity, pbuf, pq_parts, npq, partials2)
+  if (aligned16(q) && aligned16(r)) {
+    switch ((g_blas1_nt >> 1) & 3) { /* the mask's bits of k_pcg_update_xr: 1 p and q, 2 r */
+    case 0: LSB_UR(true, false, false); break;
+    case 1: LSB_UR(true, true, false); break;
+    case 2: LSB_UR(true, false, true); break;
+    default: LSB_UR(true, true, true); break;
+    }
+  } else
+    LSB_UR(false, false, false);
+#undef LSB_UR
+}
+
+void lsb_k_pcg_xfix(unsigned n, const double *p0, const double *p1, double *x, const struct lsb_pcg_state *st,
+                    void *stream) {
+  k_pcg_xfix<<<lsb_k_blas1_grid(n), WG, 0, (hipStream_t)stream>>>(n, p0, p1, x, st);
 }
 
 void lsb_k_cg1_update(unsigned n, double *u, const double *w, const double *dinv, double dc,

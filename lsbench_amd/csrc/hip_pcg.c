@@ -179,7 +179,16 @@ int lsb_fuse_p_kind(const lsb_hip_solver *sv) {
   const struct shard *s = &sv->sh[0];
   /* (not while SpMV launches are being event-timed: the fused launch has no SpMV of its own to
    * bracket, and solve_core reads the sample events) */
-  return s->variant == LSB_SPMV_SUBWAVE && sv->o.sample_spmv <= 0;
+  if (sv->o.sample_spmv > 0)
+    return 0;
+  /* 2 = the z-column form of a 3-D stencil with a constant diagonal: direction update AND the x
+   * half of the first sweep ride in the next SpMV launch (k_pcg_col_px + k_pcg_update_r: 72
+   * instead of 88 bytes per row and iteration) */
+  if (s->variant == LSB_SPMV_SELL && (s->sp_flags & LSB_SP_COL) && (s->sp_flags & LSB_SP_TMPL) && s->d_colplan &&
+      s->d_srec && s->dinv_uniform && s->tmpl_nfar >= 1 && s->tmpl_nfar <= 2 && s->row_begin == 0 &&
+      s->n == s->n_glob && sv->o.precond == LSB_PRECOND_JACOBI && !getenv("LSBENCH_HIP_NO_FUSE_PX"))
+    return 2;
+  return s->variant == LSB_SPMV_SUBWAVE;
 }
 static int fuse_p(const lsb_hip_solver *sv) { return lsb_fuse_p_kind(sv) != 0; }
 
@@ -193,8 +202,12 @@ static int fuse_p(const lsb_hip_solver *sv) { return lsb_fuse_p_kind(sv) != 0; }
 unsigned long long lsb_hip_solver_iteration_bytes(const lsb_hip_solver *sv) {
   const struct shard *s = &sv->sh[0];
   const unsigned long long sp = lsb_hip_solver_spmv_layout_bytes(sv), n8 = 8ull * s->n;
-  if (!sp || sv->o.krylov == LSB_KRYLOV_GMRES || generic_precond(sv) || s->mixed || sv->ps.use || fuse_p(sv))
+  if (!sp || sv->o.krylov == LSB_KRYLOV_GMRES || generic_precond(sv) || s->mixed || sv->ps.use ||
+      lsb_fuse_p_kind(sv) == 1)
     return 0;
+  if (lsb_fuse_p_kind(sv) == 2) /* k_pcg_col_px: r p x in, p x q out (the layout's x-in / y-out are two of
+                                   them); k_pcg_update_r: q r in, r out */
+    return sp - 2 * n8 + 9 * n8;
   const unsigned vec = s->dinv_uniform ? 0u : 1u;
   if (use_cg1(sv))
     return sp + n8 * (sv->cg1_implicit ? 9u : 11u + vec);
@@ -205,6 +218,28 @@ static void fused_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int 
   struct shard *s = &sv->sh[0];
   double *buf[2] = {s->d_pfull, s->d_p1};
   unsigned np2 = s->np2;
+  if (lsb_fuse_p_kind(sv) == 2) {
+    /* z-column form: [S p | p' = dc r + beta p, x += alpha p, S p'] then [r -= alpha q]; the x update of an
+     * iteration rides in the NEXT iteration's first launch, the run's last one is applied by k_pcg_xfix */
+    if (pos & 1) { /* first of the run: the direction is in the gather vector, x is up to date */
+      sv->pcur = 0;
+      spmv_shard(s, buf[0], s->d_q, buf[0], s->d_parts_pq, &s->npq, s->d_st);
+    } else {
+      lsb_k_pcg_col_px(s->sp_grid, s->sell_period, s->d_colplan, s->col_items, s->n, s->d_sptr16, s->d_tmask,
+                       s->d_tmpl, s->tmpl_nfar, s->d_sbase, s->d_svals16, s->d_svconst, s->d_r, buf[sv->pcur],
+                       buf[sv->pcur ^ 1], d_x, s->d_q, s->dinv_const, s->d_parts_pq, &s->npq, s->d_st, parity ^ 1,
+                       s->d_parts2, np2, g_stream);
+      sv->pcur ^= 1;
+    }
+    lsb_k_pcg_update_r(s->n, s->d_q, s->dinv_const, s->d_r, s->d_st, parity, sv->pcur, s->d_parts_pq, s->npq,
+                       s->d_parts2, &s->np2, g_stream);
+    if (pos & 2) { /* last of the run: the pending x update, then the direction back into the gather vector */
+      lsb_k_pcg_xfix(s->n, buf[0], buf[1], d_x, s->d_st, g_stream);
+      lsb_k_pcg_update_p(s->n, s->d_r, DINV(s), buf[sv->pcur], buf[0], s->d_st, parity, s->d_parts2, s->np2,
+                         g_stream);
+    }
+    return;
+  }
   if (pos & 1) { /* first of the run: the direction is in the gather vector */
     sv->pcur = 0;
     spmv_shard(s, buf[0], s->d_q, buf[0], s->d_parts_pq, &s->npq, s->d_st);

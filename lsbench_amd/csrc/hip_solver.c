@@ -375,7 +375,16 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
               const char *ek = getenv("LSBENCH_HIP_COL_K");
               /* columns of up to 16 slices: every plane of x is then read 18 / 16 times (64 M-row 7-point
                * operator: 222 us against 233 us with columns of 8, profiles/r04_col.txt) */
-              const unsigned kmax = ek ? (unsigned)atoi(ek) : 16u;
+              /* ... where that still leaves every wave several columns to walk: with a dozen thousand
+               * waves resident a 10 M-row operator (78 k slices) has 1.2 columns of 16 per wave -- columns of 6 */
+              /* (measured through the two-launch iteration, profiles/r04_px.txt: a 10 M-row 5-point grid of
+               * whole-slice lines 120.9 / 128.3 / 130.0 us per iteration with columns of 4 / 6 / 12 -- one far
+               * slot per side, nothing but streams: the shorter the column the more of them per wave; a
+               * 50-plane slab of the 7-point grid 130.1 / 122.6 / 116.6 us -- two far slots: every plane
+               * re-read costs two vectors and their +-line operands) */
+              unsigned kauto = TT->nfar >= 2 ? TT->nslice / 5120u : TT->nslice / 20480u;
+              kauto = kauto < 4u ? 4u : kauto > 16u ? 16u : kauto;
+              const unsigned kmax = ek ? (unsigned)atoi(ek) : kauto;
               /* [0]: every slice of the shard; [1]: the slices that need no halo, where the shard has
                * such a range (the interior launch of the split SpMV; the boundary launches go
                * through k_spmv_tmpl) */

@@ -29,9 +29,13 @@ struct lsb_pcg_state {
   int iters;       /* completed iterations                                   */
   int status;      /* LSB_STATUS_*; != 0 makes every later kernel a no-op    */
   int maxit;
-  int pad;       /* single-reduction CG: 1 = the maxit-th update has run, the next
-                    launch turns it into the final status (never set and tested
-                    in the same launch)                                      */
+  int pad;       /* single-reduction CG and the column form's two-launch iteration:
+                    1 = the maxit-th update has run, the next launch turns it into
+                    the final status (never set and tested in the same launch) */
+  int xpend;     /* two-launch iteration on a z-column plan (k_pcg_col_px): x is one
+                    update behind -- x += alpha[0] p with p in direction buffer
+                    xpend - 1; 0 = x is up to date                             */
+  int pad2_;
 };
 
 /* ---- the direct-xGMI all-reduce folded into neighbouring launches (hip_ar.h) ---
@@ -122,6 +126,18 @@ void lsb_k_spmv_tmpl(unsigned flags, unsigned grid_cap, unsigned period, const u
                      const double *vconst, const double *x, double *y, const double *xdot,
                      double *partials, unsigned *npartials, const struct lsb_pcg_state *st,
                      const struct lsb_ar_tail *tail, const struct lsb_cheb_epi *epi, void *stream);
+/* the classic PCG iteration in two launches on a z-column plan (hip_kernels.hip: k_pcg_col_px) */
+void lsb_k_pcg_col_px(unsigned grid_cap, unsigned period, const unsigned *plan, unsigned nitem, unsigned n,
+                      const unsigned *sptr, const unsigned long long *mask, const struct lsb_sell_tmpl *td,
+                      unsigned nfar, const int *sbase, const double *vals, const double *vconst, const double *r,
+                      const double *pold, double *pnew, double *x, double *q, double dc, double *partials,
+                      unsigned *npartials, struct lsb_pcg_state *st, int parity, const double *parts2,
+                      unsigned nparts2, void *stream);
+void lsb_k_pcg_update_r(unsigned n, const double *q, double dc, double *r, struct lsb_pcg_state *st, int parity,
+                        int pbuf, const double *pq_parts, unsigned npq, double *partials2, unsigned *npartials,
+                        void *stream);
+void lsb_k_pcg_xfix(unsigned n, const double *p0, const double *p1, double *x, const struct lsb_pcg_state *st,
+                    void *stream);
 #define LSB_SP_COL 256u /* k_spmv_tmpl_col: the template layout walked in z-columns (whole launches of a
                            shard that has a column plan; implies LSB_SP_TMPL) */
 void lsb_k_spmv_tmpl_col(unsigned flags, unsigned grid_cap, unsigned period, const unsigned *plan, unsigned nitem,

@@ -51,7 +51,12 @@ def test_hot_kernels_have_no_spills_and_full_occupancy(tmp_path):
     for k, v in sell.items():                                     # no LDS staging, >= 6 workgroups per CU
         assert v["ScratchSize"] == 0 and v["VGPRs"] <= 80 and v["Occupancy"] >= 6, (k, v)
         assert v["LDS Size"] <= 192, (k, v)     # reductions + the folded all-reduce tail; no staging
-    tm = {k: v for k, v in info.items() if "k_spmv_tmpl" in k}
+    col = {k: v for k, v in info.items() if "k_spmv_tmpl_col" in k}
+    # the z-column walk: 1, 2 far slots per side x {no dot, the centre pair as the dot's operand, a loaded one}
+    assert len(col) == 6
+    for k, v in col.items():                                      # registers only: three planes of centre pairs
+        assert v["ScratchSize"] == 0 and v["VGPRs"] <= 96 and v["Occupancy"] >= 5 and v["LDS Size"] <= 192, (k, v)
+    tm = {k: v for k, v in info.items() if "k_spmv_tmpl" in k and k not in col}
     # 0, 1, 2 far slots per side x {plain, Chebyshev epilogue, plain with the deferred store}
     assert len(tm) == 9
     for k, v in tm.items():                                       # straight-line gathers, >= 6 workgroups per CU

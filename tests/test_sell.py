@@ -262,6 +262,53 @@ def test_z_column_walk_changes_no_bit_of_y(hip, monkeypatch, spec, nvirt, overla
         assert np.allclose(out["col"][0], yo, rtol=1e-13, atol=1e-13)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("spec,kmax", [("lap3d:nx=128,ny=64,nz=21", 8), ("lap3d:nx=200,ny=64,nz=30", 16),
+                                       ("lap3d:nx=128,ny=64,nz=40", 3), ("lap3d:nx=256,ny=32,nz=40", 4),
+                                       ("lap2d:nx=8192,ny=40", 16), ("lap2d:nx=8192,ny=37", 5)])
+def test_two_launch_column_iteration(hip, monkeypatch, spec, kmax):
+    """k_pcg_col_px + k_pcg_update_r (hip_kernels.hip): the classic PCG iteration in two launches on a
+    z-column plan -- the direction update AND the x half of the first sweep ride in the next SpMV
+    launch (72 instead of 88 bytes per row), p' formed once per plane and kept in registers; the
+    run's last x update is applied by k_pcg_xfix.  Against the three-launch form of the same solver
+    (LSBENCH_HIP_NO_FUSE_PX=1): the same iteration counts and status, x to rounding -- converged
+    solves, runs cut by maxit at an even and an odd count (the pending x update, the maxit-th
+    iteration's bookkeeping), launches and hipGraph replay, second solves on the first one's hint
+    -- and every solve bit for bit run to run; converged solves against the oracle's PCG.  7-point
+    grids (two far slots per side: the +-line operands formed a second time) and 5-point grids whose
+    lines are whole slices (one far slot: everything out of registers)."""
+    monkeypatch.setenv("LSBENCH_HIP_COL_K", str(kmax))
+    A = hip.lsbench_matrix_synth(spec)
+    b = O.rhs(A.nrows)
+    xo, ito, relo, sto = O.pcg_jacobi(A.offs, A.cols, A.vals, b, 1e-10)
+    out = {}
+    for fused in (1, 0):
+        if fused:
+            monkeypatch.delenv("LSBENCH_HIP_NO_FUSE_PX", raising=False)
+        else:
+            monkeypatch.setenv("LSBENCH_HIP_NO_FUSE_PX", "1")
+        for graph, maxit in ((0, 20000), (1, 20000), (0, 7), (1, 8), (0, 1), (1, 2)):
+            s = hip.Solver(A, hip.default_opts(op_mode=hip.OP_RAW, spmv_variant=hip.SPMV_SELL, tol=1e-10,
+                                               spmv_tune=6 | 64 | 256, use_graph=graph, maxit=maxit))
+            assert s.spmv_col_slices > 0 and s.fused_p == (2 if fused else 0)
+            x, r = s.solve(b)
+            for _ in range(2):                                    # the second on the first one's hint
+                x2, r2 = s.solve(b)
+                assert np.array_equal(x, x2) and r.iters == r2.iters and r.relres == r2.relres and r.status == r2.status
+            s.destroy()
+            assert r.status == (hip.STATUS_CONVERGED if maxit == 20000 else hip.STATUS_MAXIT)
+            if maxit != 20000:
+                assert r.iters == maxit
+            out[(fused, graph, maxit)] = (x, int(r.iters), r.relres)
+    for (fused, graph, maxit), (x, it, rel) in out.items():
+        ref = out[(0, 0, maxit)] if (0, 0, maxit) in out else out[(0, 1, maxit)]
+        assert abs(it - ref[1]) <= (1 if maxit == 20000 else 0), (fused, graph, maxit)
+        tol = 1e-9 if maxit == 20000 else 1e-12                   # a cut run: the very same iterates
+        assert np.linalg.norm(x - ref[0]) <= tol * np.linalg.norm(ref[0]), (fused, graph, maxit)
+    xc = out[(1, 1, 20000)]
+    assert abs(xc[1] - ito) <= 2 and np.linalg.norm(xc[0] - xo) <= 1e-8 * np.linalg.norm(xo)
+
+
 def _penta(n):
     """1-D pentadiagonal SPD operator (bases -2 .. 2): a far slot on each side of the (c-1, c, c+1) group."""
     import scipy.sparse as sp

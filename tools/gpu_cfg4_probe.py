@@ -20,7 +20,8 @@ if os.environ.get("PROBE_TUNE"):
     kw["spmv_tune"] = int(os.environ["PROBE_TUNE"])
 if os.environ.get("PROBE_GRID"):
     kw["spmv_grid"] = int(os.environ["PROBE_GRID"])
-o = la.default_opts(op_mode=la.OP_RAW, tol=1e-30, maxit=iters, verify=0, sample_spmv=16, **kw)
+o = la.default_opts(op_mode=la.OP_RAW, tol=1e-30, maxit=iters, verify=0,
+                    sample_spmv=0 if os.environ.get("PROBE_NOSAMPLE") else 16, **kw)   # (sampling keeps the three-launch form)
 s = la.Solver(A, o)
 ms = s.time_spmv(10, 100)
 d_b = torch.arange(n, dtype=torch.float64, device="cuda")
@@ -30,7 +31,7 @@ s.spmv_dev(torch.sin(d_b), d_y)
 chk = int(d_y.view(torch.int64).sum())
 s.solve_dev(d_b, d_x)
 r = s.solve_dev(d_b, d_x)
-print(f"{label:28s} flags={s.spmv_flags} grid={s.spmv_grid} period={s.spmv_period} nt={s.blas1_nt}: "
+print(f"{label:28s} flags={s.spmv_flags} grid={s.spmv_grid} period={s.spmv_period} nt={s.blas1_nt} fused_p={s.fused_p}: "
       f"SpMV back to back {ms * 1e3:7.1f} us; iteration {r.seconds / r.iters * 1e6:7.1f} us "
       f"(SpMV in the solve {r.spmv_ms * 1e3:7.1f} us) y checksum {chk & 0xffffffffffff:012x}", flush=True)
 s.destroy()

@@ -12,7 +12,7 @@ for d in sorted(glob.glob(os.path.join(root, "*_[0-9]"))):
             tab[(label, k)][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for (label, k), c in sorted(tab.items()):
     n = max(len(v) for v in c.values())
-    if n < 20 or not ("spmv" in k or "update" in k):
+    if n < 20 or not ("spmv" in k or "update" in k or "k_pcg" in k):
         continue
     m = {name: sum(sorted(v)[len(v) // 4: len(v) - len(v) // 4 or None]) / max(1, len(sorted(v)[len(v) // 4: len(v) - len(v) // 4 or None])) for name, v in c.items()}
     print("%-8s %-46s launches %4d" % (label, k[:46], n))
