@@ -275,6 +275,13 @@ void lsb_csr_block_lanes(const struct csr *A, const unsigned *rowblk,
 /* Reverse Cuthill-McKee ordering of a structurally symmetric CSR:
  * perm[new] = old (cf. the host permutation Q of src/cusparse.c:67-85).
  * Returns 0, or 2 on allocation failure. */
+/* Line padding of a constant-coefficient 2-D grid operator (0-based, sorted rows): grid lines of nx
+ * rows re-numbered to start at multiples of `slice` rows, the gained rows holding the same stencil
+ * among themselves (block-diagonal: real block = S).  map[new row] = row of S, or -1 for a pad
+ * row (malloc'ed; free()).  NULL where S is no such operator (offsets out of {-nx, -1, 0, 1, nx}
+ * with one value each, no +-1 entry across a line end), nx is a multiple of `slice` already, or
+ * the padding would exceed 1/16 of the rows.  See lsb_operator.c. */
+struct csr *lsb_csr_pad_lines(const struct csr *S, unsigned slice, unsigned *nx, unsigned *nxp, int **map);
 int lsb_csr_rcm(const struct csr *S, unsigned *perm);
 /* P S P^T for perm[new] = old, as a new 0-based CSR (src/cusparse.c:87-97). */
 struct csr *lsb_csr_permute_sym(const struct csr *S, const unsigned *perm);
@@ -487,8 +494,9 @@ int lsb_tmpl_check(const struct lsb_sell *S, const struct lsb_sell_vc *V, const 
  * Everything else -- first / last plane, slices that keep values, ragged ends -- is an item of
  * one slice and goes slot by slot off the slot records.
  * item[4i..4i+3] = {first slice, slices (1: a single slice; >= 2: a column), template id, first
- * mask}; the items of XCD k are [xbeg[k], xbeg[k+1]): the same eighth of every plane, z-group
- * after z-group (kmax planes each), positions ascending -- the order the chip sweeps them in.
+ * mask}; the items run z-group after z-group (at most kmax planes each, as equal as they come),
+ * positions ascending, and XCD k takes [xbeg[k], xbeg[k+1]): a contiguous run with an eighth of the
+ * slices -- a band of planes.
  * Lossless: the same operands and products in the same order as k_spmv_tmpl / k_spmv_sell16. */
 #define LSB_TMPL_COL_MAX 16
 #define LSB_TMPL_COL_LOCKSTEP 0x80000000u /* bit 31 of an item's slice count: the four items of a workgroup's
@@ -585,6 +593,10 @@ int lsb_hip_solver_jacobi_sweep_dev(lsb_hip_solver *s, double w,
                                     const double *d_b, double *d_x);
 
 unsigned lsb_hip_solver_nrows_local(const lsb_hip_solver *s);
+/* rows the solver added inside: 0, or the pad rows of a line-padded 2-D grid (lsb_csr_pad_lines;
+ * a constant-coefficient grid of >= 1 M rows whose lines are not whole slices, LSBENCH_HIP_PAD_LINES=0
+ * turns it off).  b and x keep the caller's numbering and length. */
+int lsb_hip_solver_padded(const lsb_hip_solver *s);
 unsigned lsb_hip_solver_nrows_global(const lsb_hip_solver *s);
 unsigned long long lsb_hip_solver_nnz_local(const lsb_hip_solver *s);
 unsigned lsb_hip_solver_nblocks(const lsb_hip_solver *s);

@@ -219,6 +219,8 @@ SIGNATURES = {
     "lsb_hip_solver_time_spmv": (_i, [_vp, _i, _i, C.POINTER(_d)]),
     "lsb_hip_solver_jacobi_sweep_dev": (_i, [_vp, _d, _vp, _vp]),
     "lsb_hip_solver_nrows_local": (_u, [_vp]),
+    "lsb_hip_solver_padded": (_i, [_vp]),
+    "lsb_csr_pad_lines": (_csrp, [_csrp, _u, C.POINTER(_u), C.POINTER(_u), C.POINTER(C.POINTER(C.c_int))]),
     "lsb_hip_solver_nrows_global": (_u, [_vp]),
     "lsb_hip_solver_nnz_local": (C.c_ulonglong, [_vp]),
     "lsb_hip_solver_nblocks": (_u, [_vp]),
@@ -274,6 +276,13 @@ def build(force=False):
     if force:
         subprocess.run(["make", "-s", "-C", _CSRC, "clean"], check=True)
     subprocess.run(["make", "-s", "-C", _CSRC, "all"], check=True)
+
+
+def libc_free(ptr):
+    """free() of a block a library function malloc'ed for the caller (lsb_csr_pad_lines' row map)."""
+    libc = C.CDLL(None)
+    libc.free.argtypes, libc.free.restype = [C.c_void_p], None
+    libc.free(C.cast(ptr, C.c_void_p))
 
 
 def load():

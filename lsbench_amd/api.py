@@ -303,6 +303,11 @@ class Solver:
         return L.load().lsb_hip_solver_spmv_grid(self._h)
 
     @property
+    def padded(self):
+        """Pad rows of a line-padded 2-D grid inside the solver (0: none)."""
+        return int(L.load().lsb_hip_solver_padded(self._h))
+
+    @property
     def spmv_col_slices(self):
         """Slices shard 0's z-column plan walks in columns (k_spmv_tmpl_col); 0 = no plan."""
         return int(L.load().lsb_hip_solver_spmv_col_slices(self._h))

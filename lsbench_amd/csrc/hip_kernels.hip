@@ -493,15 +493,20 @@ __global__ __launch_bounds__(WG) void k_jacobi_sweep(
 __global__ __launch_bounds__(WG) void k_perm_gather(unsigned n, const int *__restrict__ perm,
                                                     const double *__restrict__ src,
                                                     double *__restrict__ dst) {
-  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n; i += (size_t)gridDim.x * WG)
-    dst[i] = src[perm[i]];
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n; i += (size_t)gridDim.x * WG) {
+    const int j = perm[i]; // -1: a pad row of a line-padded grid (lsb_csr_pad_lines)
+    dst[i] = j >= 0 ? src[j] : 0.0;
+  }
 }
 
 __global__ __launch_bounds__(WG) void k_perm_scatter(unsigned n, const int *__restrict__ perm,
                                                      const double *__restrict__ src,
                                                      double *__restrict__ dst) {
-  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n; i += (size_t)gridDim.x * WG)
-    dst[perm[i]] = src[i];
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n; i += (size_t)gridDim.x * WG) {
+    const int j = perm[i];
+    if (j >= 0)
+      dst[j] = src[i];
+  }
 }
 
 __global__ __launch_bounds__(WG) void k_fill_index(unsigned n, unsigned first,

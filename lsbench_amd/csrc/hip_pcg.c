@@ -225,7 +225,7 @@ static void fused_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int 
       sv->pcur = 0;
       spmv_shard(s, buf[0], s->d_q, buf[0], s->d_parts_pq, &s->npq, s->d_st);
     } else {
-      lsb_k_pcg_col_px(s->sp_grid, s->sell_period, s->d_colplan, s->col_items, s->n, s->d_sptr16, s->d_tmask,
+      lsb_k_pcg_col_px(s->sp_grid, s->col_period, s->d_colplan, s->col_items, s->n, s->d_sptr16, s->d_tmask,
                        s->d_tmpl, s->tmpl_nfar, s->d_sbase, s->d_svals16, s->d_svconst, s->d_r, buf[sv->pcur],
                        buf[sv->pcur ^ 1], d_x, s->d_q, s->dinv_const, s->d_parts_pq, &s->npq, s->d_st, parity ^ 1,
                        s->d_parts2, np2, g_stream);
@@ -1026,7 +1026,7 @@ int lsb_hip_solver_solve(lsb_hip_solver *sv, const double *b, double *x,
     return 1;
   if (!sv || !b || !x)
     return 2;
-  const size_t bytes = (size_t)sv->n_here * sizeof(double);
+  const size_t bytes = (size_t)sv->n_user * sizeof(double);
   double *d_b = (double *)lsb_hip_malloc(bytes), *d_x = (double *)lsb_hip_malloc(bytes);
   LSB_CHK_HIP(hipMemcpy(d_b, b, bytes, hipMemcpyHostToDevice));
   int rc = lsb_hip_solver_solve_dev(sv, d_b, d_x, res);

@@ -5,6 +5,7 @@
  */
 #define _GNU_SOURCE
 #include "hip_solver.h"
+#define NXCD_HOST 8u /* = NXCD of the kernels (hip_wg.h) */
 
 unsigned pow2_ceil(unsigned v) {
   unsigned p = 1;
@@ -274,6 +275,10 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
           }
         if (bw >= 64 * LSB_SELL_ROWS && bw % LSB_SELL_ROWS == 0 && E->nslice >= 2 * (bw / LSB_SELL_ROWS))
           s->sell_period = bw / LSB_SELL_ROWS;
+        /* ... and of the z-column walk, which only needs a slice for every XCD in a plane (a line-padded
+         * 2-D grid: its "planes" are grid lines of a few dozen slices) */
+        if (bw >= NXCD_HOST * LSB_SELL_ROWS && bw % LSB_SELL_ROWS == 0 && E->nslice >= 2 * (bw / LSB_SELL_ROWS))
+          s->col_period = bw / LSB_SELL_ROWS;
       }
       s->nslice = E->nslice;
       s->sell32_bytes = (unsigned long long)E->stored * (s->mixed ? 8 : 12) + ((unsigned long long)E->nslice + 1) * 4;
@@ -371,7 +376,7 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
               if (TT->tid[k] == 255)
                 s->tmpl_bytes += (unsigned long long)(H->sptr[k + 1] - H->sptr[k]) / LSB_SELL_ROWS * 24 + 8;
             /* 3-D stencil with planes of whole slices: the z-column plan (k_spmv_tmpl_col) */
-            if (s->sell_period && !getenv("LSBENCH_HIP_NO_COL")) {
+            if (s->col_period && !getenv("LSBENCH_HIP_NO_COL")) {
               const char *ek = getenv("LSBENCH_HIP_COL_K");
               /* columns of up to 16 slices: every plane of x is then read 18 / 16 times (64 M-row 7-point
                * operator: 222 us against 233 us with columns of 8, profiles/r04_col.txt) */
@@ -391,8 +396,8 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
               for (int w = 0; w < 2; w++) {
                 if (w == 1 && !(s->d_colplan && s->ov_sok && (s->ov_s1 > 0 || s->ov_s2 < TT->nslice)))
                   break;
-                struct lsb_tmpl_cols *CC = w == 0 ? lsb_sell_tmpl_columns(TT, s->sell_period, kmax)
-                                                  : lsb_sell_tmpl_columns_range(TT, s->sell_period, kmax, s->ov_s1, s->ov_s2);
+                struct lsb_tmpl_cols *CC = w == 0 ? lsb_sell_tmpl_columns(TT, s->col_period, kmax)
+                                                  : lsb_sell_tmpl_columns_range(TT, s->col_period, kmax, s->ov_s1, s->ov_s2);
                 if (!CC)
                   break;
                 char why[256];
@@ -639,10 +644,40 @@ lsb_hip_solver *lsb_hip_solver_create(const struct csr *A,
   /* the operator, 0-based, both triangles */
   struct csr *S = o.op_mode == LSB_OP_CHOLMOD_UPPER ? lsb_csr_symmetrize_upper(A)
                                                     : lsb_csr_copy_base0(A);
+  const unsigned n_user = S->nrows;
+  /* a constant-coefficient 2-D grid whose lines are not whole slices: pad the lines (lsb_csr_pad_lines) --
+   * the +-nx diagonals become whole-slice offsets and the z-column forms apply along y.  b and x
+   * travel through the same gather / scatter as a re-ordering's; the pad unknowns stay exactly 0.
+   * LSBENCH_HIP_PAD_LINES = 0 never, 1 whatever the size; default: operators of >= 1 M rows. */
+  int *padmap = NULL;
+  {
+    const char *e = getenv("LSBENCH_HIP_PAD_LINES");
+    const int want = e ? atoi(e) : (S->nrows >= 1000000u ? 1 : 0);
+    if (want && !o.reorder) {
+      unsigned nx = 0, nxp = 0;
+      struct csr *Sp = lsb_csr_pad_lines(S, LSB_SELL_ROWS, &nx, &nxp, &padmap);
+      if (Sp) {
+        if (o.verbose)
+          fprintf(stderr, "hip_cdna4: grid lines of %u rows padded to %u (%u -> %u rows)\n", nx, nxp, S->nrows,
+                  Sp->nrows);
+        lsb_csr_free(S);
+        S = Sp;
+      }
+    }
+  }
   int P = o.nvirt > 1 ? o.nvirt : 1;
   if ((unsigned)P > S->nrows / 2)
     P = 1;
   lsb_hip_solver *sv = solver_alloc(P, &o);
+  sv->n_user = n_user;
+  if (padmap) { /* map[internal row] = the caller's row, -1 on pad rows */
+    sv->d_perm = (int *)dev_upload(padmap, (size_t)S->nrows * sizeof(int));
+    LSB_CHK_HIP(hipStreamSynchronize(g_stream));
+    free(padmap);
+    sv->d_bp = (double *)lsb_hip_malloc((size_t)S->nrows * sizeof(double));
+    sv->d_xp = (double *)lsb_hip_malloc((size_t)S->nrows * sizeof(double));
+    sv->padded = 1;
+  }
   if (o.reorder) {
     /* Q = RCM(S); S <- Q S Q^T (src/cusparse.c:67-97) */
     unsigned *perm = (unsigned *)malloc((size_t)S->nrows * sizeof(unsigned));
@@ -697,7 +732,7 @@ lsb_hip_solver *lsb_hip_solver_create_dist(const struct csr *A_rows,
     o.precision = LSB_PREC_FP64; /* as in lsb_hip_solver_create */
   const int P = lsb_hip_comm_size(), me = lsb_hip_comm_rank();
   lsb_hip_solver *sv = solver_alloc(1, &o);
-  sv->n_glob = n_global, sv->n_here = A_rows->nrows, sv->row_first = row_begin;
+  sv->n_glob = n_global, sv->n_here = sv->n_user = A_rows->nrows, sv->row_first = row_begin;
   /* LSBENCH_HIP_DIST_ALONE=1: a communicator of ONE rank still runs the sharded
    * iteration -- exchange, all-reduce, single-reduction CG -- so that one GPU can time
    * what a rank's share costs with the communication launches in place
@@ -799,7 +834,8 @@ void lsb_hip_solver_destroy(lsb_hip_solver *sv) {
   free(sv->sh), free(sv);
 }
 
-unsigned lsb_hip_solver_nrows_local(const lsb_hip_solver *s) { return s->n_here; }
+unsigned lsb_hip_solver_nrows_local(const lsb_hip_solver *s) { return s->n_user; } /* (n_here counts pad rows) */
+int lsb_hip_solver_padded(const lsb_hip_solver *s) { return s->padded ? (int)(s->n_here - s->n_user) : 0; }
 unsigned lsb_hip_solver_nrows_global(const lsb_hip_solver *s) { return s->n_glob; }
 unsigned long long lsb_hip_solver_nnz_local(const lsb_hip_solver *s) {
   unsigned long long z = 0;
@@ -884,7 +920,7 @@ void sell_launch(struct shard *s, unsigned s0, unsigned ns, const double *xfull,
   const int col_in = s->d_colplan_in && s0 == s->ov_s1 && ns == s->ov_s2 - s->ov_s1;
   if ((s->sp_flags & LSB_SP_C16) && (s->sp_flags & LSB_SP_TMPL) && (s->sp_flags & LSB_SP_COL) && (col_all || col_in) &&
       s->d_srec && s->d_scodes && !s->epi.zout)
-    lsb_k_spmv_tmpl_col(s->sp_flags | f32, s->sp_grid, s->sell_period, col_all ? s->d_colplan : s->d_colplan_in,
+    lsb_k_spmv_tmpl_col(s->sp_flags | f32, s->sp_grid, s->col_period, col_all ? s->d_colplan : s->d_colplan_in,
                         col_all ? s->col_items : s->col_items_in, s->col_centre0, s->n,
                         s->row_begin, s->n_glob, s->d_sptr16, s->d_tmask, s->d_tmpl, s->tmpl_nfar, s->d_sbase,
                         s->d_svals16, s->d_svconst, xfull, y, xdot, partials, np, st, &s->tail, g_stream);
@@ -1195,6 +1231,27 @@ int lsb_hip_solver_jacobi_sweep_dev(lsb_hip_solver *sv, double w, const double *
     return 1;
   if (!sv || !d_b || !d_x)
     return 2;
+  if (sv->d_perm) { /* re-ordered / line-padded operator: the sweep in the solver's own numbering */
+    lsb_k_perm_gather(sv->n_here, sv->d_perm, d_x, sv->d_xp, g_stream);
+    lsb_k_perm_gather(sv->n_here, sv->d_perm, d_b, sv->d_bp, g_stream);
+    for (int i = 0; i < sv->nshard; i++) {
+      struct shard *s = &sv->sh[i];
+      LSB_CHK_HIP(hipMemcpyAsync(s->d_pfull + s->row_begin, sv->d_xp + (s->row_begin - sv->row_first),
+                                 (size_t)s->n * sizeof(double), hipMemcpyDeviceToDevice, g_stream));
+    }
+    if (sv->multi)
+      exchange_p(sv, 0);
+    for (int i = 0; i < sv->nshard; i++) {
+      struct shard *s = &sv->sh[i];
+      const size_t o = s->row_begin - sv->row_first;
+      spmv_shard_exact(s, s->d_pfull, sv->d_tmp + o, NULL, NULL, NULL, NULL);
+      lsb_k_jacobi_sweep(s->n, w, s->d_dinv, sv->d_bp + o, sv->d_tmp + o, sv->d_xp + o, g_stream);
+    }
+    lsb_k_perm_scatter(sv->n_here, sv->d_perm, sv->d_xp, d_x, g_stream);
+    drain_stream(sv, "lsb_hip_solver_jacobi_sweep_dev");
+    check_aux_status(sv, "lsb_hip_solver_jacobi_sweep_dev");
+    return 0;
+  }
   int rc = lsb_hip_solver_spmv_dev(sv, d_x, sv->d_tmp);
   if (rc)
     return rc;

@@ -62,6 +62,7 @@ struct shard {
   int *d_offs, *d_cols, *d_rowblk;
   unsigned char *d_blklanes;
   unsigned sp_flags, sp_grid; /* adaptive-SpMV flavour, picked by tune_spmv() */
+  unsigned col_period;             /* slices per plane of the z-column plan (a period of at least 8 slices) */
   unsigned sp_period, sell_period; /* sliced-ELL: slices per plane the XCD dealing follows (0 =
                                       contiguous eighths); candidate found at upload */
   double *d_vals, *d_dinv, *d_r, *d_q, *d_pfull;
@@ -167,6 +168,9 @@ struct shard {
 struct lsb_hip_solver {
   unsigned n_glob;   /* rows of the whole operator                         */
   unsigned n_here;   /* rows held by this process (sum over its shards)     */
+  unsigned n_user;   /* ... as the caller counts them: n_here less the pad rows of a line-padded grid */
+  int padded;        /* the operator was line-padded (lsb_csr_pad_lines): d_perm maps internal rows to the
+                        caller's, -1 on pad rows */
   unsigned row_first; /* first row held by this process                     */
   int nshard;        /* shards in this process (1, or nvirt)                */
   int dist;          /* 1: shards of other processes exist (RCCL)           */

@@ -104,6 +104,99 @@ struct csr *lsb_csr_copy_base0(const struct csr *A) {
   return S;
 }
 
+/* LINE PADDING (include/lsbench_hip.h).  The operator of a 2-D grid with constant coefficients --
+ * every row's entries at offsets out of {-nx, -1, 0, +1, +nx}, one value per offset, no +-1 entry
+ * across the end of a grid line -- re-numbered so that every grid line starts at a multiple of
+ * `slice` rows: row (i, j) -> j nxp + i, nxp = nx rounded up.  The nxp - nx rows a line gains hold
+ * the SAME stencil among themselves (a strip of the grid's height, cut off from the real unknowns by
+ * the missing +-1 entry at the line's end): the padded operator is block-diagonal, real block =
+ * the operator, pad block = a principal submatrix of the same stencil on a larger grid (SPD with
+ * it), and with b = 0, x0 = 0 on the pad rows every Krylov vector stays exactly 0 there.  What it
+ * buys: the +-nx diagonals become whole-slice offsets, every interior slot of the sliced-ELL
+ * copy is constant, and the z-column walk / the two-launch iteration (k_spmv_tmpl_col,
+ * k_pcg_col_px) apply to a 2-D grid along y. */
+struct csr *lsb_csr_pad_lines(const struct csr *S, unsigned slice, unsigned *nx_out, unsigned *nxp_out, int **map_out) {
+  if (!S || S->base != 0 || slice < 2 || S->nrows < 4 * slice)
+    return NULL;
+  const unsigned n = S->nrows;
+  /* the far offset: the first row that reaches forward says nx */
+  unsigned nx = 0;
+  for (unsigned r = 0; r < n && !nx; r++)
+    if (S->offs[r + 1] > S->offs[r] && S->cols[S->offs[r + 1] - 1] > r + 1)
+      nx = S->cols[S->offs[r + 1] - 1] - r;
+  if (nx < 2 * slice || n % nx || n / nx < 3)
+    return NULL;
+  const unsigned ny = n / nx, nxp = (nx + slice - 1) / slice * slice;
+  if (nxp == nx || (unsigned long long)(nxp - nx) * 16 > nx || (unsigned long long)ny * nxp > 0x7fffffffull)
+    return NULL;
+  /* offsets out of {-nx, -1, 0, 1, nx}, one value per offset (bit for bit), no +-1 across a line end, a diagonal
+   * everywhere */
+  double val[5] = {0, 0, 0, 0, 0};
+  int have[5] = {0, 0, 0, 0, 0};
+  for (unsigned r = 0; r < n; r++) {
+    int diag = 0;
+    for (unsigned k = S->offs[r]; k < S->offs[r + 1]; k++) {
+      const long long d = (long long)S->cols[k] - (long long)r;
+      const int w = d == -(long long)nx ? 0 : d == -1 ? 1 : d == 0 ? 2 : d == 1 ? 3 : d == (long long)nx ? 4 : -1;
+      if (w < 0 || (w == 1 && r % nx == 0) || (w == 3 && r % nx == nx - 1))
+        return NULL;
+      if (!have[w])
+        val[w] = S->vals[k], have[w] = 1;
+      else if (memcmp(&val[w], &S->vals[k], sizeof(double)))
+        return NULL;
+      diag |= w == 2;
+    }
+    if (!diag)
+      return NULL;
+  }
+  if (!have[0] || !have[1] || !have[3] || !have[4] || val[2] == 0.0)
+    return NULL;
+  const unsigned np = ny * nxp;
+  /* entries: the operator's + at most five per pad row */
+  const unsigned long long cap = (unsigned long long)S->offs[n] + 5ull * (unsigned long long)ny * (nxp - nx);
+  if (cap > 0xffffffffull)
+    return NULL;
+  struct csr *Pd = csr_alloc(np, (unsigned)cap);
+  int *map = (int *)malloc((size_t)np * sizeof(int));
+  if (!map)
+    errx(EXIT_FAILURE, "lsb_csr_pad_lines: out of memory");
+  unsigned at = 0;
+  for (unsigned j = 0; j < ny; j++)
+    for (unsigned i = 0; i < nxp; i++) {
+      const unsigned row = j * nxp + i;
+      Pd->offs[row] = at;
+      if (i < nx) {
+        const unsigned r = j * nx + i;
+        map[row] = (int)r;
+        for (unsigned k = S->offs[r]; k < S->offs[r + 1]; k++) {
+          const unsigned c = S->cols[k];
+          Pd->cols[at] = c / nx * nxp + c % nx, Pd->vals[at] = S->vals[k], at++;
+        }
+      } else {
+        map[row] = -1;
+        if (j > 0)
+          Pd->cols[at] = row - nxp, Pd->vals[at] = val[0], at++;
+        if (i > nx)
+          Pd->cols[at] = row - 1, Pd->vals[at] = val[1], at++;
+        Pd->cols[at] = row, Pd->vals[at] = val[2], at++;
+        if (i + 1 < nxp)
+          Pd->cols[at] = row + 1, Pd->vals[at] = val[3], at++;
+        if (j + 1 < ny)
+          Pd->cols[at] = row + nxp, Pd->vals[at] = val[4], at++;
+      }
+    }
+  Pd->offs[np] = at;
+  if (nx_out)
+    *nx_out = nx;
+  if (nxp_out)
+    *nxp_out = nxp;
+  if (map_out)
+    *map_out = map;
+  else
+    free(map);
+  return Pd;
+}
+
 struct csr *lsb_csr_row_slice(const struct csr *A, unsigned r0, unsigned r1) {
   if (r1 > A->nrows || r0 > r1)
     return NULL;
@@ -1475,41 +1568,51 @@ struct lsb_tmpl_cols *lsb_sell_tmpl_columns_range(const struct lsb_sell_tmpls *T
   struct lsb_tmpl_cols *C = lsb_calloc(struct lsb_tmpl_cols, 1);
   C->kmax = kmax, C->period = period, C->centre0 = 1, C->s_lo = s_lo, C->s_hi = s_hi;
   C->item = lsb_calloc(unsigned, 4 * ((size_t)ns + 1));
-  unsigned ni = 0;
-  for (unsigned k = 0; k < LSB_COL_XCDS; k++) {
-    C->xbeg[k] = ni;
-    const unsigned qlo = (unsigned)((unsigned long long)period * k / LSB_COL_XCDS),
-                   qhi = (unsigned)((unsigned long long)period * (k + 1) / LSB_COL_XCDS);
-    /* z-groups of at most kmax planes, as equal as they come (50 planes, kmax 16: 13, 13, 12, 12) */
-    const unsigned ngroups = (nplanes + kmax - 1) / kmax;
-    for (unsigned zg = 0; zg < ngroups; zg++) {
-      const unsigned z0 = (unsigned)((unsigned long long)nplanes * zg / ngroups),
-                     zend = (unsigned)((unsigned long long)nplanes * (zg + 1) / ngroups);
-      for (unsigned p = qlo; p < qhi; p++)
-        for (unsigned z = z0; z < zend;) {
-          const unsigned long long s = (unsigned long long)z * period + p;
-          if (s >= s_hi)
-            break;
-          if (s < s_lo) {
-            z++;
-            continue;
-          }
-          unsigned run = 1;
-          if (col_member(T, (unsigned)s, period))
-            while (z + run < zend && s + (unsigned long long)run * period < s_hi &&
-                   col_member(T, (unsigned)(s + (unsigned long long)run * period), period) &&
-                   col_same(T, (unsigned)s, (unsigned)(s + (unsigned long long)run * period)))
-              run++;
-          unsigned *it = C->item + 4 * (size_t)ni++;
-          it[0] = (unsigned)s, it[1] = run, it[2] = T->tid[s], it[3] = T->vbase[2 * (size_t)s + 1];
-          if (run >= 2) {
-            C->in_cols += run;
-            C->centre0 &= T->t[T->tid[s]].base[T->nfar + 1] == 0;
-          }
-          z += run;
-        }
+  /* z-groups of at most kmax planes, as equal as they come (50 planes, kmax 16: 13, 13, 12, 12).  A CELL is one
+   * position of one z-group: its slices become one column, or several items where the run breaks (first / last
+   * plane, a slice that keeps values).  Cells in z-group-major order, positions ascending -- the order the chip
+   * sweeps them in -- and cut into eight runs of (nearly) equal slice counts, one per XCD: a contiguous band
+   * of planes each, whole z-groups but for the two a cut falls into.  (Dealing every XCD the same eighth of
+   * every plane instead leaves one XCD 4 of 25 positions where the others have 3 when a "plane" is a grid
+   * line of 25 slices: the launch ran 28 % longer than on a grid of 64-slice lines, profiles/r04_pad.txt.) */
+  const unsigned ngroups = (nplanes + kmax - 1) / kmax;
+  const unsigned long long ncell = (unsigned long long)ngroups * period, total = s_hi - s_lo;
+  unsigned ni = 0, xk = 0;
+  unsigned long long seen = 0; /* slices of the cells emitted so far */
+  C->xbeg[0] = 0;
+  for (unsigned long long cell = 0; cell < ncell; cell++) {
+    const unsigned zg = (unsigned)(cell / period), p = (unsigned)(cell % period);
+    const unsigned z0 = (unsigned)((unsigned long long)nplanes * zg / ngroups),
+                   zend = (unsigned)((unsigned long long)nplanes * (zg + 1) / ngroups);
+    /* the XCD this cell goes to: by the slices in front of it */
+    while (xk + 1 < LSB_COL_XCDS && seen * LSB_COL_XCDS >= total * (xk + 1))
+      C->xbeg[++xk] = ni;
+    for (unsigned z = z0; z < zend;) {
+      const unsigned long long s = (unsigned long long)z * period + p;
+      if (s >= s_hi)
+        break;
+      if (s < s_lo) {
+        z++;
+        continue;
+      }
+      unsigned run = 1;
+      if (col_member(T, (unsigned)s, period))
+        while (z + run < zend && s + (unsigned long long)run * period < s_hi &&
+               col_member(T, (unsigned)(s + (unsigned long long)run * period), period) &&
+               col_same(T, (unsigned)s, (unsigned)(s + (unsigned long long)run * period)))
+          run++;
+      unsigned *it = C->item + 4 * (size_t)ni++;
+      it[0] = (unsigned)s, it[1] = run, it[2] = T->tid[s], it[3] = T->vbase[2 * (size_t)s + 1];
+      if (run >= 2) {
+        C->in_cols += run;
+        C->centre0 &= T->t[T->tid[s]].base[T->nfar + 1] == 0;
+      }
+      seen += run;
+      z += run;
     }
   }
+  while (xk + 1 < LSB_COL_XCDS)
+    C->xbeg[++xk] = ni;
   C->xbeg[LSB_COL_XCDS] = C->nitem = ni;
   /* LOCKSTEP groups: the four items a workgroup takes in one turn (items xbeg + 4g .. 4g + 3 of its
    * XCD) are four neighbouring columns of equal length -- bit 31 of their slice count says so, and

@@ -789,8 +789,9 @@ def test_z_column_plan_of_a_3d_stencil():
     slices every slice lands in exactly one item; interior z-columns become runs of 2..kmax slices
     one plane apart that share a template (outermost far slots exactly one plane away, constant or
     masked slots only) and their mask words; the first and last plane -- no neighbour plane on one
-    side -- stay single items; XCD k owns the same eighth of every plane; shards cut inside a plane
-    and ragged z-groups included.  lsb_tmpl_cols_check states the rules and catches a broken one."""
+    side -- stay single items; the items run z-group after z-group, positions ascending, and every XCD
+    takes a contiguous run of them with an equal share of the slices; shards cut inside a plane and
+    ragged z-groups included.  lsb_tmpl_cols_check states the rules and catches a broken one."""
     import ctypes as C
     lib = la._lib.load()
     why = C.create_string_buffer(256)
@@ -816,7 +817,14 @@ def test_z_column_plan_of_a_3d_stencil():
                 xb = list(c.xbeg)
                 assert xb[0] == 0 and xb[8] == c.nitem and xb == sorted(xb)
                 seen = np.zeros(ns, int)
-                for k in range(8):                                     # XCD k: its eighth of every plane
+                npl = -(-ns // period)
+                ng = -(-npl // kmax)
+                grp = lambda z: next(g for g in range(ng) if npl * g // ng <= z < npl * (g + 1) // ng)
+                cells = [grp(int(s0) // period) * period + int(s0) % period for s0 in it[:, 0]]
+                assert cells == sorted(cells)                          # z-group-major, positions ascending
+                per_xcd = [int((it[xb[k]:xb[k + 1], 1] & 0x7fffffff).sum()) for k in range(8)]
+                assert sum(per_xcd) == ns and max(per_xcd) - min(per_xcd) <= 2 * kmax   # a contiguous, equal share each
+                for k in range(8):
                     turn = it[xb[k]:xb[k + 1]]
                     for g in range(0, len(turn), 4):                   # lockstep: a full turn of equal columns
                         runs = turn[g:g + 4, 1]
@@ -825,16 +833,12 @@ def test_z_column_plan_of_a_3d_stencil():
                         assert bool(lock[0]) == (len(runs) == 4 and len(set(runs.tolist())) == 1 and (runs[0] & 0x7fffffff) >= 2)
                     for s0, run, t, mb in turn:
                         run &= 0x7fffffff
-                        assert period * k // 8 <= s0 % period < period * (k + 1) // 8
                         assert 1 <= run <= kmax
                         sl = s0 + period * np.arange(run)
                         seen[sl] += 1
                         if run > 1:
                             assert np.all(tid[sl] == t) and t != 255
                             # a column never leaves its z-group (at most kmax planes, as equal as they come)
-                            npl = -(-ns // period)
-                            ng = -(-npl // kmax)
-                            grp = lambda z: next(g for g in range(ng) if npl * g // ng <= z < npl * (g + 1) // ng)
                             assert grp(s0 // period) == grp(sl[-1] // period)
                 assert np.all(seen == 1)
                 runs_all = it[:, 1] & 0x7fffffff
@@ -858,6 +862,55 @@ def test_z_column_plan_of_a_3d_stencil():
     T = lib.lsb_sell16_templates(H, V)
     assert T and not lib.lsb_sell_tmpl_columns(T, 16, 8)
     lib.lsb_sell_tmpls_free(T), lib.lsb_sell_vc_free(V), lib.lsb_sell_free(H)
+
+
+def test_line_padding_of_a_2d_grid():
+    """lsb_csr_pad_lines: a constant-coefficient 2-D grid whose lines are not whole slices, re-numbered so
+    that every line starts at a multiple of 128 rows.  The real block of the padded operator IS the
+    operator (entry for entry under the row map), the pad rows couple only among themselves (the
+    same stencil on a strip: block-diagonal, SPD), so with b = 0 there the solve is the same solve;
+    and the padded copy has what the unpadded one lacks -- +-nx as whole-slice offsets: shaped
+    templates with ONE far slot per side whose planes are grid lines, i.e. a z-column plan along y.
+    Refused: general values, 3-D grids, lines that are whole slices already, padding above 1/16."""
+    import ctypes as C
+    import scipy.sparse as sp
+    lib = la._lib.load()
+    A = la.lsbench_matrix_synth("lap2d:nx=1000,ny=64")
+    nx, nxp = C.c_uint(0), C.c_uint(0)
+    mp = C.POINTER(C.c_int)()
+    P = lib.lsb_csr_pad_lines(A.ptr, 128, C.byref(nx), C.byref(nxp), C.byref(mp))
+    assert P and (nx.value, nxp.value) == (1000, 1024)
+    p = P.contents
+    n, npad = A.nrows, p.nrows
+    assert npad == 64 * 1024
+    offs = np.ctypeslib.as_array(p.offs, (npad + 1,)).copy()
+    cols = np.ctypeslib.as_array(p.cols, (offs[-1],)).copy()
+    vals = np.ctypeslib.as_array(p.vals, (offs[-1],)).copy()
+    m = np.ctypeslib.as_array(mp, (npad,)).copy()
+    M = sp.csr_matrix((vals, cols, offs), shape=(npad, npad))
+    S = sp.csr_matrix((A.vals, A.cols, A.offs), shape=(n, n))
+    real = np.flatnonzero(m >= 0)
+    assert np.array_equal(m[real], np.arange(n))                   # every row once, in order
+    assert (M[real][:, real] != S).nnz == 0                        # the real block is the operator
+    pad = np.flatnonzero(m < 0)
+    assert M[real][:, pad].nnz == 0 and M[pad][:, real].nnz == 0   # block-diagonal
+    Pb = M[pad][:, pad]
+    assert (Pb != Pb.T).nnz == 0 and np.all(Pb.diagonal() == 4.0) and Pb.nnz == 5 * len(pad) - 2 * 24 - 2 * 64
+    assert np.linalg.eigvalsh(Pb.toarray()[:480, :480]).min() > 0
+    H = lib.lsb_csr_sellize16(P, 0)
+    V = lib.lsb_sell16_value_slots(H)
+    T = lib.lsb_sell16_templates(H, V)
+    assert T and T.contents.nfar == 1
+    Cp = lib.lsb_sell_tmpl_columns(T, 8, 4)                        # a line = 8 slices
+    assert Cp and Cp.contents.in_cols * 10 >= T.contents.nslice * 9 and Cp.contents.centre0 == 1
+    why = C.create_string_buffer(256)
+    assert lib.lsb_tmpl_cols_check(T, Cp, why, 256) == 0, why.value
+    lib.lsb_tmpl_cols_free(Cp), lib.lsb_sell_tmpls_free(T), lib.lsb_sell_vc_free(V), lib.lsb_sell_free(H)
+    la._lib.libc_free(mp)
+    lib.lsb_csr_free(P)
+    for spec in ("lap2d:nx=1000,ny=64,coef=1", "lap3d:nx=40,ny=36,nz=30", "lap2d:nx=1024,ny=64", "lap2d:nx=411,ny=203"):
+        B = la.lsbench_matrix_synth(spec)
+        assert not lib.lsb_csr_pad_lines(B.ptr, 128, None, None, None), spec
 
 
 def test_bench_quotes_pmc_traffic_only_for_what_it_was_measured_on(tmp_path, monkeypatch):

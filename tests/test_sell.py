@@ -309,6 +309,50 @@ def test_two_launch_column_iteration(hip, monkeypatch, spec, kmax):
     assert abs(xc[1] - ito) <= 2 and np.linalg.norm(xc[0] - xo) <= 1e-8 * np.linalg.norm(xo)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("spec,nvirt", [("lap2d:nx=1000,ny=300", 1), ("lap2d:nx=1000,ny=300", 3), ("lap2d:nx=2050,ny=61", 1)])
+def test_line_padded_grid_solves_the_same_system(hip, monkeypatch, spec, nvirt):
+    """lsb_csr_pad_lines inside the solver (LSBENCH_HIP_PAD_LINES=1; by default for grids of >= 1 M rows):
+    the lines of a constant-coefficient 2-D grid padded to whole slices, b and x through the gather /
+    scatter of a re-ordering, the pad unknowns exactly 0.  The caller sees the same operator -- SpMV
+    entry for entry to rounding, the same solve (x, iteration count to +-2), the Jacobi sweep -- and
+    the padded copy runs the forms the unpadded one has no plan for: the z-column walk along y and,
+    on one shard, the two-launch iteration (fused_p = 2)."""
+    import torch
+    A = hip.lsbench_matrix_synth(spec)
+    b = O.rhs(A.nrows)
+    xs = np.sin(np.arange(A.nrows, dtype=np.float64))
+    yo = O.spmv(A.offs, A.cols, A.vals, xs)
+    xo, ito, relo, sto = O.pcg_jacobi(A.offs, A.cols, A.vals, b, 1e-10)
+    out = {}
+    for pad in ("0", "1"):
+        monkeypatch.setenv("LSBENCH_HIP_PAD_LINES", pad)
+        s = hip.Solver(A, hip.default_opts(op_mode=hip.OP_RAW, spmv_variant=hip.SPMV_SELL, nvirt=nvirt, tol=1e-10,
+                                           comm=1 if nvirt > 1 else 0, spmv_tune=6 | 64 | 256, use_graph=0))
+        assert bool(s.padded) == (pad == "1") and s.n_local == A.nrows
+        if pad == "1":
+            assert s.spmv_col_slices > 0 and s.fused_p == (2 if nvirt == 1 else 0)
+        else:
+            assert s.spmv_col_slices == 0 and s.fused_p == 0
+        d_y = torch.full((A.nrows,), float("nan"), dtype=torch.float64, device="cuda:0")
+        s.spmv_dev(torch.from_numpy(xs).to("cuda:0"), d_y)
+        x, r = s.solve(b)
+        x2, r2 = s.solve(b)
+        assert np.array_equal(x, x2) and r.iters == r2.iters
+        d_b, d_x = torch.from_numpy(b).to("cuda:0"), torch.from_numpy(xs).to("cuda:0")
+        s.jacobi_sweep_dev(0.7, d_b, d_x)
+        s.destroy()
+        assert r.status == hip.STATUS_CONVERGED
+        out[pad] = (d_y.cpu().numpy(), x, int(r.iters), d_x.cpu().numpy())
+    for pad in ("0", "1"):
+        assert np.allclose(out[pad][0], yo, rtol=1e-13, atol=1e-13)
+        assert abs(out[pad][2] - ito) <= 2 and np.linalg.norm(out[pad][1] - xo) <= 1e-8 * np.linalg.norm(xo)
+    assert np.array_equal(out["0"][0], out["1"][0])               # a row's products in the same order
+    assert np.allclose(out["0"][3], out["1"][3], rtol=1e-13, atol=1e-13)
+    sweep = xs + 0.7 * (b - yo) / 4.0
+    assert np.allclose(out["1"][3], sweep, rtol=1e-12, atol=1e-12)
+
+
 def _penta(n):
     """1-D pentadiagonal SPD operator (bases -2 .. 2): a far slot on each side of the (c-1, c, c+1) group."""
     import scipy.sparse as sp
