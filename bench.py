@@ -431,7 +431,11 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
     layout_bytes = solver.spmv_layout_bytes
     it_bytes = solver.iteration_bytes
     single_red = solver.single_reduction
-    fused_p = False
+    # the two-launch iteration on a z-column plan (k_pcg_col_px): the launch that carries the SpMV also forms
+    # p' = dc r + beta p and applies x += alpha p -- r and x in, p' and x out, 32 B per row on top of the layout's
+    fused_p = solver.fused_p == 2
+    rows_inside = solver.n_local + solver.padded   # (a line-padded grid carries its pad rows through every pass)
+    spmv_kernel = kernel
     # A roofline fraction is quoted on bytes the kernel must MOVE: the layout's arrays as stored +
     # x once + y once (lsb_hip_solver_spmv_layout_bytes).  SURVEY 8(d)'s CSR count (12 B per non-zero
     # + 20 B per row) is what a CSR kernel moves; the sliced-ELL layouts move less (8 B per entry
@@ -506,7 +510,15 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
     if spmv_n:
         spmv_avg_ms = spmv_ms / spmv_n  # sampled inside the timed solves
         how = "hipEvent pairs around %d SpMV launches inside the timed solves" % spmv_n
+        if fused_p:
+            kernel = "k_pcg_col_px"
+            bytes_alg = layout_bytes + 32 * rows_inside
+            traffic, traffic_src = pmc_traffic(key if world == 1 and a.precision == "fp64" else None, kernel, vslots,
+                                               solver.spmv_flags, solver.spmv_period)
+            how = ("hipEvent pairs around %d launches of k_pcg_col_px inside the timed solves (the launch that carries "
+                   "the SpMV: p' = dc r + beta p, x += alpha p, q = S p', p'.q)" % spmv_n)
     else:
+        fused_p = False  # (what is timed below is the plain SpMV launch)
         spmv_avg_ms = solver.time_spmv(20, 200)  # graph replay: events do not fit inside
         how = "hipEvents around 200 back-to-back launches after the timed solves"
     gbps = bytes_alg / spmv_avg_ms / 1e6
@@ -581,7 +593,8 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
                      "bytes_basis": ("layout: what the stored layout must move in one launch -- its index / code / "
                                      "slot / template arrays and the values it keeps (value_slots kept / all: one "
                                      "value per slot whose 128 entries are equal), x once, y once"
-                                     + (", r once and p written once (the direction update rides in this launch)"
+                                     + (", and r, x in / p', x out: the direction update and the x update ride in this "
+                                        "launch (two launches and 72 instead of 88 B per row and iteration)"
                                         if fused_p else "")
                                      + "; SURVEY 8(d)'s CSR count is under csr_count (a CSR kernel's bytes: this "
                                      "layout moves fewer, so that ratio is not a fraction of anything)"
@@ -593,8 +606,9 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
                      "value_slots": dict(zip(("kept", "all"), vslots)),
                      "kernel": kernel + (" (panels)" if solver.spmv_variant == la.SPMV_PANEL else "") + " (fused p.q)",
                      "launch_ms": spmv_avg_ms, "back_to_back_launch_ms": b2b_ms,
-                     "back_to_back_kernel": ("k_spmv_tmpl (y = S x alone, %d B)" % (layout_bytes - 16 * nl))
+                     "back_to_back_kernel": ("%s (y = S x alone, %d B)" % (spmv_kernel, layout_bytes))
                      if fused_p else kernel,
+                     "line_padding_rows": solver.padded,
                      "spmv_flags": solver.spmv_flags, "xcd_period_slices": solver.spmv_period,
                      "kernels_sha16": kernels_sha16(), "measured": how},
     }

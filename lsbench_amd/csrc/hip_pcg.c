@@ -177,18 +177,16 @@ int lsb_fuse_p_kind(const lsb_hip_solver *sv) {
   if (sv->multi || use_cg1(sv) || generic_precond(sv) || sv->sh[0].mixed || getenv("LSBENCH_HIP_NO_FUSE_P"))
     return 0;
   const struct shard *s = &sv->sh[0];
-  /* (not while SpMV launches are being event-timed: the fused launch has no SpMV of its own to
-   * bracket, and solve_core reads the sample events) */
-  if (sv->o.sample_spmv > 0)
-    return 0;
   /* 2 = the z-column form of a 3-D stencil with a constant diagonal: direction update AND the x
    * half of the first sweep ride in the next SpMV launch (k_pcg_col_px + k_pcg_update_r: 72
    * instead of 88 bytes per row and iteration) */
   if (s->variant == LSB_SPMV_SELL && (s->sp_flags & LSB_SP_COL) && (s->sp_flags & LSB_SP_TMPL) && s->d_colplan &&
       s->d_srec && s->dinv_uniform && s->tmpl_nfar >= 1 && s->tmpl_nfar <= 2 && s->row_begin == 0 &&
       s->n == s->n_glob && sv->o.precond == LSB_PRECOND_JACOBI && !getenv("LSBENCH_HIP_NO_FUSE_PX"))
-    return 2;
-  return s->variant == LSB_SPMV_SUBWAVE;
+    return 2; /* (event-timed too: the sample brackets the launch that carries the SpMV) */
+  /* (not while SpMV launches are being event-timed: the fused launch has no SpMV of its own to
+   * bracket, and solve_core reads the sample events) */
+  return s->variant == LSB_SPMV_SUBWAVE && sv->o.sample_spmv <= 0;
 }
 static int fuse_p(const lsb_hip_solver *sv) { return lsb_fuse_p_kind(sv) != 0; }
 
@@ -214,13 +212,21 @@ unsigned long long lsb_hip_solver_iteration_bytes(const lsb_hip_solver *sv) {
   return sp + n8 * (9u + 2u * vec);
 }
 
-static void fused_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int pos) {
+static void fused_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int pos, int sample) {
   struct shard *s = &sv->sh[0];
   double *buf[2] = {s->d_pfull, s->d_p1};
   unsigned np2 = s->np2;
   if (lsb_fuse_p_kind(sv) == 2) {
     /* z-column form: [S p | p' = dc r + beta p, x += alpha p, S p'] then [r -= alpha q]; the x update of an
      * iteration rides in the NEXT iteration's first launch, the run's last one is applied by k_pcg_xfix */
+    /* sampling: the launch that carries the SpMV, bracketed as pcg_enqueue_iter brackets a plain one; a run's
+     * first iteration (a plain SpMV launch) gets an EMPTY bracket, which pcg_run discards -- the figure is
+     * k_pcg_col_px's alone */
+    if (sample >= 0 && (pos & 1))
+      for (int e = 0; e < 4; e++)
+        LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + e], g_stream));
+    if (sample >= 0 && !(pos & 1))
+      LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample], g_stream));
     if (pos & 1) { /* first of the run: the direction is in the gather vector, x is up to date */
       sv->pcur = 0;
       spmv_shard(s, buf[0], s->d_q, buf[0], s->d_parts_pq, &s->npq, s->d_st);
@@ -230,6 +236,11 @@ static void fused_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int 
                        buf[sv->pcur ^ 1], d_x, s->d_q, s->dinv_const, s->d_parts_pq, &s->npq, s->d_st, parity ^ 1,
                        s->d_parts2, np2, g_stream);
       sv->pcur ^= 1;
+    }
+    if (sample >= 0 && !(pos & 1)) {
+      LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 1], g_stream));
+      LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 2], g_stream));
+      LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 3], g_stream));
     }
     lsb_k_pcg_update_r(s->n, s->d_q, s->dinv_const, s->d_r, s->d_st, parity, sv->pcur, s->d_parts_pq, s->npq,
                        s->d_parts2, &s->np2, g_stream);
@@ -273,7 +284,7 @@ static void pcg_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int sa
     return;
   }
   if (fuse_p(sv)) {
-    fused_enqueue_iter(sv, d_x, parity, pos);
+    fused_enqueue_iter(sv, d_x, parity, pos, sample);
     return;
   }
   unsigned npq = 0, np2 = 0;

@@ -68,7 +68,7 @@ for wl, suffix, vtag in VARIANTS:
         wb = d["WRITE_SIZE_KB_median"] * 1024
         lines.append("%s,%d,%.1f,%.0f,%.1f,%.0f,%.0f" % (k, d["launches_FETCH_SIZE"], d["FETCH_SIZE_KB_median"], fb,
                                                          d["WRITE_SIZE_KB_median"], wb, fb + wb))
-        if ("k_spmv_" in k or "k_pb_" in k) and d["launches_FETCH_SIZE"] > 20:
+        if ("k_spmv_" in k or "k_pb_" in k or "k_pcg_col_px" in k) and d["launches_FETCH_SIZE"] > 20:
             name = k.split("<")[0].split()[-1]
             if best is None or d["launches_FETCH_SIZE"] > best[1]:
                 best = (name, d["launches_FETCH_SIZE"], fb + wb)
