@@ -2915,29 +2915,16 @@ void lsb_k_pcg_col_px(unsigned grid_cap, unsigned period, const unsigned *plan, 
     *npartials = g;
   if (period < NXCD || !plan || pold == pnew)
     errx(EXIT_FAILURE, "lsb_k_pcg_col_px: no column plan (period %u) or one direction buffer", period);
-  static int nt = -1; /* (experiments: LSBENCH_HIP_PX_NT = 0 .. 3) */
-  if (nt < 0) {
-    const char *e = getenv("LSBENCH_HIP_PX_NT");
-    nt = e ? atoi(e) & 3 : 3;
-  }
-#define LSB_PX(NF, NTM)                                                                               \
-  k_pcg_col_px<NF, NTM><<<g, WG, 0, s>>>(plan, period, n, sptr, mask, td, sbase, vals, vconst, r, pold, pnew, x, q, dc, \
-                                         partials, st, parity, parts2, nparts2)
-#define LSB_PXN(NF)                                                                                   \
-  do {                                                                                                \
-    switch (nt) {                                                                                     \
-    case 0: LSB_PX(NF, 0); break;                                                                     \
-    case 1: LSB_PX(NF, 1); break;                                                                     \
-    case 2: LSB_PX(NF, 2); break;                                                                     \
-    default: LSB_PX(NF, 3); break;                                                                    \
-    }                                                                                                 \
-  } while (0)
+  /* x, p' and q streamed nontemporally (NT = 3; measured against 0 / 1 / 2 on config 4: 950.5 / 950.3 / 905.7 /
+   * 894.1 us per iteration, profiles/r04_px.txt) */
+#define LSB_PX(NF)                                                                                    \
+  k_pcg_col_px<NF, 3><<<g, WG, 0, s>>>(plan, period, n, sptr, mask, td, sbase, vals, vconst, r, pold, pnew, x, q, dc, \
+                                       partials, st, parity, parts2, nparts2)
   switch (nfar) {
-  case 1: LSB_PXN(1); break;
-  case 2: LSB_PXN(2); break;
+  case 1: LSB_PX(1); break;
+  case 2: LSB_PX(2); break;
   default: errx(EXIT_FAILURE, "lsb_k_pcg_col_px: %u far slots per side", nfar);
   }
-#undef LSB_PXN
 #undef LSB_PX
 }
 

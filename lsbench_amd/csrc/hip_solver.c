@@ -406,9 +406,6 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
                 unsigned *plan = lsb_calloc(unsigned, 16 + 4 * ((size_t)CC->nitem + 1));
                 memcpy(plan, CC->xbeg, sizeof CC->xbeg);
                 memcpy(plan + 16, CC->item, 4 * (size_t)CC->nitem * sizeof(unsigned));
-                if (getenv("LSBENCH_HIP_COL_NOSYNC")) /* experiments: no barrier per plane */
-                  for (unsigned q = 0; q < CC->nitem; q++)
-                    plan[16 + 4 * (size_t)q + 1] &= ~LSB_TMPL_COL_LOCKSTEP;
                 unsigned *d = (unsigned *)dev_upload(plan, (16 + 4 * ((size_t)CC->nitem + 1)) * sizeof(unsigned));
                 LSB_CHK_HIP(hipStreamSynchronize(g_stream));
                 free(plan);
