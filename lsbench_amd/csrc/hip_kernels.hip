@@ -1865,8 +1865,8 @@ __global__ __launch_bounds__(WG, DOT == 2 ? 5 : 6) void k_spmv_tmpl_col(
 // k_pcg_update_r, cleared here) says so and k_pcg_xfix applies it (hip_pcg.c).  maxit: the launch
 // that counts the maxit-th iteration sets st->pad and does all of its work (x included); the next
 // k_pcg_update_r turns that into the status -- never set and tested in the same launch.
-// Pipeline of a column as in k_spmv_tmpl_col: a step issues the NEXT step's loads, then the stores
-// of the step before (q, x, p'), then waits for its own operands, which are older than both.
+// Pipeline of a column: a step issues the NEXT step's loads, waits for its own operands (older) and stores
+// q, x, p' right away -- younger than what the next step waits for.
 // --------------------------------------------------------------------------
 template <int NF> struct colp_c { // centre-side loads of one step, issued ONE step ahead
   sell_d2u rn, pn;                // r, p of the plane ahead (it becomes this step's "plane above")
@@ -1881,7 +1881,7 @@ template <int NF> struct colp_c { // centre-side loads of one step, issued ONE s
 template <int NF> struct colp_m {
   sell_d2u rlo[NF > 1 ? NF - 1 : 1], plo[NF > 1 ? NF - 1 : 1], rhi[NF > 1 ? NF - 1 : 1], phi[NF > 1 ? NF - 1 : 1];
 };
-struct colp_out { // results of a step, stored by the next one
+struct colp_out { // results of a step
   sell_d2v q, x, p;
 };
 // gu: global row of lane 0's first row of the step's slice (one shard: = its local row)
@@ -2095,34 +2095,30 @@ __global__ __launch_bounds__(WG, NF == 2 ? 3 : 4) void k_pcg_col_px(
       sell_d2u pm, p0, pp;
       pm.x = pnew_of(dc, rb.x, beta, pb.x), pm.y = pnew_of(dc, rb.y, beta, pb.y);
       p0.x = pnew_of(dc, r0.x, beta, o0.x), p0.y = pnew_of(dc, r0.y, beta, o0.y);
-      colp_out prev, res;
-      prev.x.x = x0.x + alpha * o0.x, prev.x.y = x0.y + alpha * o0.y;
-      prev.p.x = p0.x, prev.p.y = p0.y;
-      prev.q = prev.p; // (not stored)
-      // step 0 (K >= 3: the plane after next is the column's own): next loads, the first plane's x and p', compute
-      colp_issue_c<NF, true, NT>(c1, C, r, pold, x, gu + (long long)P, P, n, lane);
-      colp_issue_m<NF>(m2, C, r, pold, gu + 2 * (long long)P, lane);
-      COLP_STORE(prev, lrow - P, false, true);
-      colp_compute<NF, true>(c0, m0, pm, p0, pp, C, vm0, vm1, vp0, vp1, beta, alpha, dc, lane, res, dot);
-      pm = p0, p0 = pp, c0 = c1, m0 = m1, m1 = m2, prev = res;
-      // steps 1 .. K-3: the plane after next is still the column's own
-      for (unsigned k = 1; k + 2 < K; k++) {
-        gu += (long long)P, lrow += P;
+      // A step issues the NEXT step's loads, waits for its own (older) and stores its results right away: the stores
+      // are younger than the loads the next step waits for, so they are never waited for either (vmcnt counts
+      // loads and stores in one order) -- no parking of results across a step.
+      colp_out res;
+      res.x.x = x0.x + alpha * o0.x, res.x.y = x0.y + alpha * o0.y;
+      res.p.x = p0.x, res.p.y = p0.y;
+      res.q = res.p; // (not stored)
+      COLP_STORE(res, lrow - P, false, true); // the first plane's x and p'
+      // steps 0 .. K-3 (K >= 3): the plane after next is the column's own
+      for (unsigned k = 0; k + 2 < K; k++) {
         colp_issue_c<NF, true, NT>(c1, C, r, pold, x, gu + (long long)P, P, n, lane);
         colp_issue_m<NF>(m2, C, r, pold, gu + 2 * (long long)P, lane);
-        COLP_STORE(prev, lrow - P, true, true);
         colp_compute<NF, true>(c0, m0, pm, p0, pp, C, vm0, vm1, vp0, vp1, beta, alpha, dc, lane, res, dot);
-        pm = p0, p0 = pp, c0 = c1, m0 = m1, m1 = m2, prev = res;
+        COLP_STORE(res, lrow, true, true);
+        pm = p0, p0 = pp, c0 = c1, m0 = m1, m1 = m2;
+        gu += (long long)P, lrow += P;
       }
       // step K-2: the plane after next is the one above the column (no x, no +-line operands to ask for)
-      gu += (long long)P, lrow += P;
       colp_issue_c<NF, false, NT>(c1, C, r, pold, x, gu + (long long)P, P, n, lane);
-      COLP_STORE(prev, lrow - P, true, true);
       colp_compute<NF, true>(c0, m0, pm, p0, pp, C, vm0, vm1, vp0, vp1, beta, alpha, dc, lane, res, dot);
-      pm = p0, p0 = pp, c0 = c1, m0 = m1, prev = res;
-      // step K-1: nothing to load; the plane ahead is not the column's
+      COLP_STORE(res, lrow, true, true);
+      pm = p0, p0 = pp, c0 = c1, m0 = m1;
       gu += (long long)P, lrow += P;
-      COLP_STORE(prev, lrow - P, true, true);
+      // step K-1: nothing to load; the plane ahead is not the column's
       colp_compute<NF, false>(c0, m0, pm, p0, pp, C, vm0, vm1, vp0, vp1, beta, alpha, dc, lane, res, dot);
       COLP_STORE(res, lrow, true, false);
     } else {
@@ -2908,8 +2904,8 @@ void lsb_k_pcg_col_px(unsigned grid_cap, unsigned period, const unsigned *plan, 
                       unsigned *npartials, struct lsb_pcg_state *st, int parity, const double *parts2,
                       unsigned nparts2, void *stream) {
   hipStream_t s = (hipStream_t)stream;
-  /* every workgroup resident: three per CU with two far slots per side (148 VGPRs), four with one (100) */
-  const unsigned res = nfar == 2 ? 768u : 1024u;
+  /* every workgroup resident: three per CU with two far slots per side (142 VGPRs), five with one (96) */
+  const unsigned res = nfar == 2 ? 768u : 1280u;
   const unsigned g = lsb_k_spmv_grid(LSB_SPMV_SELL, n, nitem, 0, grid_cap && grid_cap < res ? grid_cap : res);
   if (npartials)
     *npartials = g;
