@@ -351,6 +351,20 @@ def test_line_padded_grid_solves_the_same_system(hip, monkeypatch, spec, nvirt):
     assert np.allclose(out["0"][3], out["1"][3], rtol=1e-13, atol=1e-13)
     sweep = xs + 0.7 * (b - yo) / 4.0
     assert np.allclose(out["1"][3], sweep, rtol=1e-12, atol=1e-12)
+    if nvirt == 1:
+        # the other solvers see a padded operator as well: GMRES, fp32 matrix values with fp64 refinement,
+        # Chebyshev and block-Jacobi preconditioning (blocks that straddle real and pad rows: decoupled)
+        monkeypatch.setenv("LSBENCH_HIP_PAD_LINES", "1")
+        for kw in (dict(krylov=hip.KRYLOV_GMRES, restart=30, tol=1e-8), dict(precision=hip.PREC_MIXED),
+                   dict(precond=hip.PRECOND_CHEBYSHEV, cheb_degree=4), dict(precond=hip.PRECOND_BLOCKJACOBI, block_size=8)):
+            opts = dict(op_mode=hip.OP_RAW, tol=1e-10, use_graph=0)
+            opts.update(kw)
+            s = hip.Solver(A, hip.default_opts(**opts))
+            assert s.padded > 0
+            x, r = s.solve(b)
+            s.destroy()
+            assert r.status == hip.STATUS_CONVERGED, kw
+            assert np.linalg.norm(x - xo) <= (1e-5 if "krylov" in kw else 1e-7) * np.linalg.norm(xo), kw
 
 
 def _penta(n):
