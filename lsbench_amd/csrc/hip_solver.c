@@ -922,7 +922,10 @@ void sell_launch(struct shard *s, unsigned s0, unsigned ns, const double *xfull,
                         s->row_begin, s->n_glob, s->d_sptr16, s->d_tmask, s->d_tmpl, s->tmpl_nfar, s->d_sbase,
                         s->d_svals16, s->d_svconst, xfull, y, xdot, partials, np, st, &s->tail, g_stream);
   else if ((s->sp_flags & LSB_SP_C16) && (s->sp_flags & LSB_SP_TMPL) && s->d_srec && s->d_scodes)
-    lsb_k_spmv_tmpl(s->sp_flags | f32, s->sp_grid, s->sp_period, s->d_sptr16, s0, ns, s->n, s->row_begin, s->n_glob,
+    /* (a z-column flavour's grid was timed for the walk -- 3-4 workgroups per CU; the launches that go through
+     * k_spmv_tmpl instead -- Chebyshev epilogue, boundary parts of a split SpMV -- take that kernel's own 6 per CU:
+     * config 3 with Chebyshev(16) 941 -> 811 ms per solve) */
+    lsb_k_spmv_tmpl(s->sp_flags | f32, (s->sp_flags & LSB_SP_COL) ? 1536u : s->sp_grid, s->sp_period, s->d_sptr16, s0, ns, s->n, s->row_begin, s->n_glob,
                     s->d_srec, s->d_tmask, s->d_tmpl, s->tmpl_nfar, s->d_sbase, s->d_svals16, s->d_svconst, xfull, y, xdot, partials, np, st,
                     &s->tail, &s->epi, g_stream);
   else if ((s->sp_flags & LSB_SP_C16) && s->d_scodes)

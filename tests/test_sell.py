@@ -352,19 +352,32 @@ def test_line_padded_grid_solves_the_same_system(hip, monkeypatch, spec, nvirt):
     sweep = xs + 0.7 * (b - yo) / 4.0
     assert np.allclose(out["1"][3], sweep, rtol=1e-12, atol=1e-12)
     if nvirt == 1:
-        # the other solvers see a padded operator as well: GMRES, fp32 matrix values with fp64 refinement,
-        # Chebyshev and block-Jacobi preconditioning (blocks that straddle real and pad rows: decoupled)
-        monkeypatch.setenv("LSBENCH_HIP_PAD_LINES", "1")
-        for kw in (dict(krylov=hip.KRYLOV_GMRES, restart=30, tol=1e-8), dict(precision=hip.PREC_MIXED),
+        # the other solvers see a padded operator as well: GMRES (a fixed number of inner steps: restarted GMRES
+        # crawls on a Laplacian), fp32 matrix values with fp64 refinement, Chebyshev and block-Jacobi
+        # preconditioning (blocks that straddle real and pad rows: decoupled) -- the same outcome as unpadded
+        for kw in (dict(krylov=hip.KRYLOV_GMRES, restart=30, tol=1e-8, maxit=90), dict(precision=hip.PREC_MIXED),
                    dict(precond=hip.PRECOND_CHEBYSHEV, cheb_degree=4), dict(precond=hip.PRECOND_BLOCKJACOBI, block_size=8)):
-            opts = dict(op_mode=hip.OP_RAW, tol=1e-10, use_graph=0)
-            opts.update(kw)
-            s = hip.Solver(A, hip.default_opts(**opts))
-            assert s.padded > 0
-            x, r = s.solve(b)
-            s.destroy()
-            assert r.status == hip.STATUS_CONVERGED, kw
-            assert np.linalg.norm(x - xo) <= (1e-5 if "krylov" in kw else 1e-7) * np.linalg.norm(xo), kw
+            got = {}
+            for pad in ("0", "1"):
+                monkeypatch.setenv("LSBENCH_HIP_PAD_LINES", pad)
+                opts = dict(op_mode=hip.OP_RAW, tol=1e-10, use_graph=0)
+                opts.update(kw)
+                s = hip.Solver(A, hip.default_opts(**opts))
+                assert bool(s.padded) == (pad == "1")
+                got[pad] = s.solve(b)
+                s.destroy()
+            (x0, r0), (x1, r1) = got["0"], got["1"]
+            assert r0.status == r1.status == (hip.STATUS_MAXIT if "krylov" in kw else hip.STATUS_CONVERGED), kw
+            # (Chebyshev's interval comes from a power iteration at set-up whose start vector and length see the
+            # pad rows too: the two preconditioners differ -- 283 against 135 iterations on the thin grid --, the
+            # solutions do not)
+            if "cheb_degree" not in kw:
+                assert abs(int(r0.iters) - int(r1.iters)) <= 2 + int(r0.iters) // 20, kw
+            if "krylov" in kw:
+                assert abs(r0.relres - r1.relres) <= 1e-6 * r0.relres, kw
+            assert np.linalg.norm(x1 - x0) <= 1e-7 * np.linalg.norm(x0), kw
+            if "krylov" not in kw:
+                assert np.linalg.norm(x1 - xo) <= 1e-7 * np.linalg.norm(xo), kw
 
 
 def _penta(n):
