@@ -220,11 +220,10 @@ static void fused_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int 
     /* z-column form: [S p | p' = dc r + beta p, x += alpha p, S p'] then [r -= alpha q]; the x update of an
      * iteration rides in the NEXT iteration's first launch, the run's last one is applied by k_pcg_xfix */
     /* sampling: the launch that carries the SpMV, bracketed as pcg_enqueue_iter brackets a plain one; a run's
-     * first iteration (a plain SpMV launch) gets an EMPTY bracket, which pcg_run discards -- the figure is
+     * first iteration (a plain SpMV launch) is marked in samp_skip and left out by pcg_run -- the figure is
      * k_pcg_col_px's alone */
-    if (sample >= 0 && (pos & 1))
-      for (int e = 0; e < 4; e++)
-        LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + e], g_stream));
+    if (sample >= 0)
+      sv->samp_skip[sample] = (pos & 1) != 0;
     if (sample >= 0 && !(pos & 1))
       LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample], g_stream));
     if (pos & 1) { /* first of the run: the direction is in the gather vector, x is up to date */
@@ -803,6 +802,7 @@ static int pcg_run(lsb_hip_solver *sv, const double *d_b, double *d_x, struct ls
   unsigned *hint = &sv->hint_iters[round < LSB_MAX_CORRECTIONS ? round : LSB_MAX_CORRECTIONS];
   const int chunk = sv->o.check_every > 0 ? (sv->o.check_every + 1) & ~1 : auto_chunk(sv);
   const int sampling = sv->o.sample_spmv > 0;
+  memset(sv->samp_skip, 0, sizeof sv->samp_skip);
   const int use_graph = sv->o.use_graph && !sv->multi && !sampling;
   int nsamp = 0;
   unsigned done_iters = 0;
@@ -919,6 +919,8 @@ static int pcg_run(lsb_hip_solver *sv, const double *d_b, double *d_x, struct ls
       /* samples enqueued after convergence time a no-op launch: skip them */
       if ((unsigned)k * (unsigned)sv->o.sample_spmv >= r.iters)
         break;
+      if (sv->samp_skip[k])
+        continue;
       float pair = 0.f;
       LSB_CHK_HIP(hipEventElapsedTime(&ms, sv->ev[4 * k], sv->ev[4 * k + 1]));
       LSB_CHK_HIP(hipEventElapsedTime(&pair, sv->ev[4 * k + 2], sv->ev[4 * k + 3]));

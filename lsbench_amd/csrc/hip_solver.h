@@ -212,6 +212,8 @@ struct lsb_hip_solver {
   int gm_m;
   hipEvent_t ev_poll[2], ev_vec, ev_halo;
   hipEvent_t ev[4 * MAX_SAMPLES], ev_t0, ev_t1; /* per sample: e0 SpMV e1 e2 e3 */
+  unsigned char samp_skip[MAX_SAMPLES];         /* the sample brackets nothing (a run's first iteration in the
+                                                   two-launch form: a plain SpMV launch, not k_pcg_col_px) */
   int have_events;
   double *d_tmp; /* n_here doubles: scratch for spmv_dev / jacobi sweep */
   /* direct xGMI path (hip_p2p.hip), one context per shard; p2p_on: used for
