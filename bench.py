@@ -512,7 +512,7 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
         how = "hipEvent pairs around %d SpMV launches inside the timed solves" % spmv_n
         if fused_p:
             kernel = "k_pcg_col_px"
-            bytes_alg = layout_bytes + 32 * rows_inside
+            bytes_alg = layout_bytes + 16 * rows_inside   # r p x in, p' x out: 40 B per row where the layout counts 16 (q is not stored)
             traffic, traffic_src = pmc_traffic(key if world == 1 and a.precision == "fp64" else None, kernel, vslots,
                                                solver.spmv_flags, solver.spmv_period)
             how = ("hipEvent pairs around %d launches of k_pcg_col_px inside the timed solves (the launch that carries "
@@ -593,8 +593,9 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
                      "bytes_basis": ("layout: what the stored layout must move in one launch -- its index / code / "
                                      "slot / template arrays and the values it keeps (value_slots kept / all: one "
                                      "value per slot whose 128 entries are equal), x once, y once"
-                                     + (", and r, x in / p', x out: the direction update and the x update ride in this "
-                                        "launch (two launches and 72 instead of 88 B per row and iteration)"
+                                     + (" -- here: r, p, x in and p', x out (q = S p' is not stored: the launch that updates r "
+                                        "forms it again), the direction update and the x update ride in this launch (two "
+                                        "launches and 64 instead of 88 B per row and iteration)"
                                         if fused_p else "")
                                      + "; SURVEY 8(d)'s CSR count is under csr_count (a CSR kernel's bytes: this "
                                      "layout moves fewer, so that ratio is not a fraction of anything)"

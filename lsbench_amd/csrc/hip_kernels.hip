@@ -1844,17 +1844,20 @@ __global__ __launch_bounds__(WG, DOT == 2 ? 5 : 6) void k_spmv_tmpl_col(
 }
 
 // --------------------------------------------------------------------------
-// a2-5 on a z-column plan: the classic PCG iteration in TWO launches and 72 instead of 88 bytes per
+// a2-5 on a z-column plan: the classic PCG iteration in TWO launches and 64 instead of 88 bytes per
 // row (one shard, constant Jacobi diagonal dc).
 //   [k_pcg_col_px]   (r.z, r.r) of the sweep before -> stop test, beta;  alpha = the step of the
-//                    iteration before (st->alpha[0], left there by k_pcg_update_r);  per row
+//                    iteration before (st->alpha[0], left there by k_pcg_col_r);  per row
 //                      p' = dc r + beta p        (pnew_of: k_pcg_update_p's expression)
 //                      x += alpha p              (the x half of k_pcg_update_xr, one iteration late:
 //                                                 p is in registers here anyway)
-//                      q  = S p',  partials of p'.q
-//                    -- reads r, p, x and writes p' (the OTHER direction buffer), x, q: 48 B per row
-//   [k_pcg_update_r] alpha = r.z / p'.q;  r -= alpha q;  partials of (r.z', r.r) -- 24 B per row
-// against k_spmv_tmpl_col (16) + k_pcg_update_xr (48) + k_pcg_update_p (24).  What makes the fold pay
+//                      q  = S p' -- NOT stored: only the partials of p'.q leave the launch
+//                    -- reads r, p, x and writes p' (the OTHER direction buffer), x: 40 B per row
+//   [k_pcg_col_r]    alpha = r.z / p'.q;  r -= alpha (S p') with S p' formed AGAIN by the same walk (the same
+//                    operands and products in the same order: the same bits);  partials of (r.z', r.r)
+//                    -- reads p', r and writes r: 24 B per row
+// against k_spmv_tmpl_col (16) + k_pcg_update_xr (48) + k_pcg_update_p (24): the stencil is applied twice and
+// q = S p never travels.  What makes the fold pay
 // where k_spmv_tmpl_p's did not (round 3: every gathered operand of every slice formed p' anew, five
 // or seven times per row): a column forms p' ONCE per plane and row and keeps it in registers for the
 // three steps that use it as the plane above, the centre and the plane below; only the +-line
@@ -1862,11 +1865,11 @@ __global__ __launch_bounds__(WG, DOT == 2 ? 5 : 6) void k_spmv_tmpl_col(
 // Ownership: a column loads, updates and stores x and p' for ITS planes only; the plane below its
 // first and above its last slice belong to other columns -- p' is formed for them, nothing stored.
 // The x update of the LAST iteration of a run has no k_pcg_col_px behind it: st->xpend (set by
-// k_pcg_update_r, cleared here) says so and k_pcg_xfix applies it (hip_pcg.c).  maxit: the launch
+// k_pcg_col_r, cleared here) says so and k_pcg_xfix applies it (hip_pcg.c).  maxit: the launch
 // that counts the maxit-th iteration sets st->pad and does all of its work (x included); the next
-// k_pcg_update_r turns that into the status -- never set and tested in the same launch.
+// k_pcg_col_r turns that into the status -- never set and tested in the same launch.
 // Pipeline of a column: a step issues the NEXT step's loads, waits for its own operands (older) and stores
-// q, x, p' right away -- younger than what the next step waits for.
+// x, p' right away -- younger than what the next step waits for.
 // --------------------------------------------------------------------------
 template <int NF> struct colp_c { // centre-side loads of one step, issued ONE step ahead
   sell_d2u rn, pn;                // r, p of the plane ahead (it becomes this step's "plane above")
@@ -1982,11 +1985,15 @@ __device__ __forceinline__ void colp_single(unsigned s, unsigned n, unsigned lan
   }
   const double n0 = pnew_of(dc, r0, beta, o0), n1 = pnew_of(dc, r1, beta, o1);
   if (l0) {
-    pnew[row] = n0, x[row] = x0 + alpha * o0, q[row] = a0;
+    pnew[row] = n0, x[row] = x0 + alpha * o0;
+    if (q)
+      q[row] = a0;
     dot = fma(a0, n0, dot);
   }
   if (l1) {
-    pnew[row + 1] = n1, x[row + 1] = x1 + alpha * o1, q[row + 1] = a1;
+    pnew[row + 1] = n1, x[row + 1] = x1 + alpha * o1;
+    if (q)
+      q[row + 1] = a1;
     dot = fma(a1, n1, dot);
   }
 }
@@ -2009,16 +2016,19 @@ __device__ __forceinline__ void colp_single(unsigned s, unsigned n, unsigned lan
   } while (0)
 
 // NT: bit 0 x loaded and stored nontemporal, bit 1 p' and q stored nontemporal
+// q = S p' is NOT stored: only its dot with p' leaves the launch -- k_pcg_col_r forms the same q again out of p' when
+// it updates r, and the vector never travels (8 instead of 9 passes per iteration)
 template <int NF, int NT>
 __global__ __launch_bounds__(WG, NF == 2 ? 3 : 4) void k_pcg_col_px(
     const unsigned *__restrict__ plan, unsigned period, unsigned n, const unsigned *__restrict__ sptr,
     const unsigned long long *__restrict__ mask, const lsb_sell_tmpl *__restrict__ td, const int *__restrict__ sbase,
     const double *__restrict__ vals, const double *__restrict__ vconst, const double *__restrict__ r,
-    const double *__restrict__ pold, double *__restrict__ pnew, double *__restrict__ x, double *__restrict__ q,
-    double dc, double *__restrict__ partials, lsb_pcg_state *__restrict__ st, int parity,
+    const double *__restrict__ pold, double *__restrict__ pnew, double *__restrict__ x, double dc,
+    double *__restrict__ partials, lsb_pcg_state *__restrict__ st, int parity,
     const double *__restrict__ parts2, unsigned nparts2) {
   static_assert(NF >= 1 && NF <= 2, "one or two far slots per side");
   __shared__ double sred[8];
+  double *const q = nullptr; // (COLP_STORE's q leg is compiled out)
   const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const unsigned gx = gridDim.x / NXCD, xcd = blockIdx.x % NXCD, slot = blockIdx.x / NXCD;
   // ---- k_pcg_update_p's prologue: the sweep's partial sums -> r.z, r.r, stop test, beta
@@ -2041,7 +2051,7 @@ __global__ __launch_bounds__(WG, NF == 2 ? 3 : 4) void k_pcg_col_px(
     else {
       st->xpend = 0; // this launch applies it
       if (it >= st->maxit)
-        st->pad = 1; // the next k_pcg_update_r makes it the status; this launch still does all its work
+        st->pad = 1; // the next k_pcg_col_r makes it the status; this launch still does all its work
     }
   }
   if (conv)
@@ -2108,22 +2118,22 @@ __global__ __launch_bounds__(WG, NF == 2 ? 3 : 4) void k_pcg_col_px(
         colp_issue_c<NF, true, NT>(c1, C, r, pold, x, gu + (long long)P, P, n, lane);
         colp_issue_m<NF>(m2, C, r, pold, gu + 2 * (long long)P, lane);
         colp_compute<NF, true>(c0, m0, pm, p0, pp, C, vm0, vm1, vp0, vp1, beta, alpha, dc, lane, res, dot);
-        COLP_STORE(res, lrow, true, true);
+        COLP_STORE(res, lrow, false, true);
         pm = p0, p0 = pp, c0 = c1, m0 = m1, m1 = m2;
         gu += (long long)P, lrow += P;
       }
       // step K-2: the plane after next is the one above the column (no x, no +-line operands to ask for)
       colp_issue_c<NF, false, NT>(c1, C, r, pold, x, gu + (long long)P, P, n, lane);
       colp_compute<NF, true>(c0, m0, pm, p0, pp, C, vm0, vm1, vp0, vp1, beta, alpha, dc, lane, res, dot);
-      COLP_STORE(res, lrow, true, true);
+      COLP_STORE(res, lrow, false, true);
       pm = p0, p0 = pp, c0 = c1, m0 = m1;
       gu += (long long)P, lrow += P;
       // step K-1: nothing to load; the plane ahead is not the column's
       colp_compute<NF, false>(c0, m0, pm, p0, pp, C, vm0, vm1, vp0, vp1, beta, alpha, dc, lane, res, dot);
-      COLP_STORE(res, lrow, true, false);
+      COLP_STORE(res, lrow, false, false);
     } else {
       for (unsigned k = 0; k < K; k++)
-        colp_single(s + k * period, n, lane, sptr, sbase, vals, vconst, r, pold, pnew, x, q, beta, alpha, dc, dot);
+        colp_single(s + k * period, n, lane, sptr, sbase, vals, vconst, r, pold, pnew, x, nullptr, beta, alpha, dc, dot);
     }
   }
   if (partials) {
@@ -2136,25 +2146,26 @@ __global__ __launch_bounds__(WG, NF == 2 ? 3 : 4) void k_pcg_col_px(
 #undef COLP_STORE
 #undef COLP_ST
 
-// alpha = r.z / p.q;  r -= alpha q;  partials (r.dinv.r, r.r) -- k_pcg_update_xr without its x half (which
-// k_pcg_col_px does one iteration later); leaves alpha and "x is one update behind, the direction is in
-// buffer pbuf" in the state
-template <bool V2, bool NTQ, bool NTR>
-__global__ __launch_bounds__(WG) void k_pcg_update_r(
-    unsigned n, const double *__restrict__ q, double dc, double *__restrict__ r, lsb_pcg_state *__restrict__ st,
-    int parity, int pbuf, const double *__restrict__ pq_parts, unsigned npq, double *__restrict__ partials2) {
+// The r half of the first sweep WITHOUT q: alpha = r.z / p.q (p.q from k_pcg_col_px's partials), then per row
+// r -= alpha (S p) with S p formed again by the z-column walk of k_spmv_tmpl_col -- the same operands and products in
+// the same order as in k_pcg_col_px, so the same bits -- and the partials of (r.z', r.r).  Reads p and r, writes r:
+// three passes, as a sweep over a stored q and r would make, but k_pcg_col_px need not write q: 8 passes per
+// iteration instead of 9.  Leaves alpha and "x is one update behind, the direction is in buffer pbuf" (xpend) in
+// the state and promotes a pending maxit (st->pad) to the status.
+template <int NF>
+__global__ __launch_bounds__(WG, 5) void k_pcg_col_r(
+    const unsigned *__restrict__ plan, unsigned period, unsigned n, const unsigned *__restrict__ sptr,
+    const unsigned long long *__restrict__ mask, const lsb_sell_tmpl *__restrict__ td, const int *__restrict__ sbase,
+    const double *__restrict__ vals, const double *__restrict__ vconst, const double *__restrict__ p,
+    double *__restrict__ r, double dc, lsb_pcg_state *__restrict__ st, int parity, int pbuf,
+    const double *__restrict__ pq_parts, unsigned npq, double *__restrict__ partials2) {
+  static_assert(NF >= 1 && NF <= 2, "one or two far slots per side");
   __shared__ double sred[8];
-  const size_t gtid = (size_t)blockIdx.x * WG + threadIdx.x;
-  const size_t gsz = (size_t)gridDim.x * WG;
-  const size_t n2 = n / 2;
-  const d2v *q2 = (const d2v *)q;
-  d2v *r2 = (d2v *)r;
+  const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const unsigned gx = gridDim.x / NXCD, xcd = blockIdx.x % NXCD, slot = blockIdx.x / NXCD;
   const int stopped = st->status, pad = st->pad;
   const double rz = st->rz[parity];
-  d2v qv = {0.0, 0.0}, rv = qv;
-  const bool first = V2 && gtid < n2;
-  if (first)
-    qv = ld2<NTQ>(q2 + gtid), rv = ld2<NTR>(r2 + gtid);
+  const unsigned i0 = plan[xcd], i1 = plan[xcd + 1];
   double pqv[1];
   wg_sum_partials<1>(pq_parts, npq, pqv, sred);
   if (stopped)
@@ -2173,35 +2184,100 @@ __global__ __launch_bounds__(WG) void k_pcg_update_r(
   const double alpha = rz / pq;
   if (blockIdx.x == 0 && threadIdx.x == 0)
     st->pq = pq, st->alpha[0] = alpha, st->xpend = 1 + pbuf;
-  double acc[2] = {0.0, 0.0};
-  if (V2) {
-    if (first) {
-      size_t i = gtid;
-      for (;;) {
-        rv.x -= alpha * qv.x, rv.y -= alpha * qv.y;
-        r2[i] = rv;
-        acc[0] += rv.x * (dc * rv.x);
-        acc[0] += rv.y * (dc * rv.y);
-        acc[1] += rv.x * rv.x;
-        acc[1] += rv.y * rv.y;
-        i += gsz;
-        if (i >= n2)
-          break;
-        qv = ld2<NTQ>(q2 + i), rv = ld2<NTR>(r2 + i);
+  const u4v *__restrict__ items = (const u4v *)(plan + LSB_COL_HEAD);
+  const unsigned P = period * LSB_SELL_ROWS;
+  double acc[2] = {0.0, 0.0}, nodot = 0.0;
+#define COLR_FINISH(A0, A1, RV, LROW)                                                          \
+  do {                                                                                         \
+    sell_d2v rn_;                                                                              \
+    rn_.x = (RV).x - alpha * (A0), rn_.y = (RV).y - alpha * (A1);                              \
+    *(sell_d2v *)(r + (LROW) + 2 * lane) = rn_;                                                \
+    acc[0] += rn_.x * (dc * rn_.x);                                                            \
+    acc[0] += rn_.y * (dc * rn_.y);                                                            \
+    acc[1] += rn_.x * rn_.x;                                                                   \
+    acc[1] += rn_.y * rn_.y;                                                                   \
+  } while (0)
+  for (unsigned g = slot; i0 + 4 * g < i1; g += gx) {
+    const unsigned it = __builtin_amdgcn_readfirstlane(i0 + 4 * g + wave);
+    if (it >= i1)
+      continue;
+    const u4v rec = items[it];
+    const unsigned s = __builtin_amdgcn_readfirstlane(rec.x);
+    const unsigned K = __builtin_amdgcn_readfirstlane(rec.y) & ~LSB_TMPL_COL_LOCKSTEP;
+    if (K >= 3) { // (columns of two go slice by slice, as in k_pcg_col_px: the same sums either way)
+      const unsigned t = __builtin_amdgcn_readfirstlane(rec.z), mb = __builtin_amdgcn_readfirstlane(rec.w);
+      const lsb_sell_tmpl *T = td + t;
+      col_tmpl<NF> C;
+      C.bc = T->base[NF + 1];
+      C.k0 = T->cst[0], C.kc = T->cst[NF + 1], C.kL = T->cst[2 * NF + 2];
+#pragma unroll
+      for (int k = 0; k < NF - 1; k++) {
+        C.bl[k] = T->base[1 + k], C.bh[k] = T->base[NF + 3 + k];
+        C.kl[k] = T->cst[1 + k], C.kh[k] = T->cst[NF + 3 + k];
+      }
+      const int side_k[2] = {T->kidx[NF], T->kidx[NF + 2]}, side_kd[2] = {T->kind[NF], T->kind[NF + 2]};
+      long long gu = (long long)s * LSB_SELL_ROWS;
+      unsigned lrow = s * LSB_SELL_ROWS;
+      col_ops<NF> cur, nxt;
+      sell_d2u cm = *(const sell_d2u *)(p + (gu + C.bc - (long long)P) + 2 * lane);
+      sell_d2u c0 = *(const sell_d2u *)(p + (gu + C.bc) + 2 * lane);
+      sell_d2u cp, cn;
+      col_issue<NF, 2>(cur, cp, C, p, r, gu, lrow, P, n, lane, true); // (the "dot operand" slot carries r's pair)
+      unsigned long long mk[2][2] = {{0ull, 0ull}, {0ull, 0ull}};
+#pragma unroll
+      for (int side = 0; side < 2; side++)
+        if (side_k[side] >= 0 && side_kd[side] == 2) {
+          const unsigned long long *mp = mask + 2 * ((size_t)mb + (unsigned)side_k[side]);
+          mk[side][0] = mp[0], mk[side][1] = mp[1];
+        }
+      double vm0 = T->cst[NF], vm1 = vm0, vp0 = T->cst[NF + 2], vp1 = vp0;
+      if (side_k[0] >= 0 || side_k[1] >= 0)
+        tmpl_side_values(T, NF, 0u, lane, side_k, side_kd, mk, vals, 0, vm0, vm1, vp0, vp1);
+      for (unsigned k = 0; k + 1 < K; k++) {
+        col_issue<NF, 2>(nxt, cn, C, p, r, gu + (long long)P, lrow + P, P, n, lane, true);
+        double a0, a1;
+        col_compute<NF, 0>(cur, cm, c0, cp, C, vm0, vm1, vp0, vp1, lane, a0, a1, nodot);
+        COLR_FINISH(a0, a1, cur.xd, lrow);
+        cm = c0, c0 = cp, cp = cn, cur = nxt;
+        gu += (long long)P, lrow += P;
+      }
+      double a0, a1;
+      col_compute<NF, 0>(cur, cm, c0, cp, C, vm0, vm1, vp0, vp1, lane, a0, a1, nodot);
+      COLR_FINISH(a0, a1, cur.xd, lrow);
+    } else {
+      for (unsigned k = 0; k < K; k++) { // one slice, slot by slot off the slot records
+        const unsigned sl = s + k * period, row = sl * LSB_SELL_ROWS + 2 * lane;
+        const unsigned q0 = sptr[sl] / LSB_SELL_ROWS, len = (sptr[sl + 1] - sptr[sl]) / LSB_SELL_ROWS;
+        const bool l0 = row < n, l1 = row + 1 < n;
+        const double r0 = l0 ? r[row] : 0.0, r1 = l1 ? r[row + 1] : 0.0;
+        double a0 = 0.0, a1 = 0.0;
+        for (unsigned j = 0; j < len; j++) {
+          const i4v rec2 = ((const i4v *)sbase)[q0 + j];
+          if (rec2.z < 0) {
+            const double kk = vconst[q0 + j];
+            const sell_d2u pv = *(const sell_d2u *)(p + ((int)row + rec2.x));
+            a0 = fma(kk, pv.x, a0), a1 = fma(kk, pv.y, a1);
+          } else {
+            const sell_d2v v = *((const sell_d2v *)(vals + (size_t)rec2.z * LSB_SELL_ROWS) + lane);
+            const bool p0 = v.x != 0.0, p1 = v.y != 0.0; // padding: no gather, an exact 0
+            const double t0 = p[p0 ? (int)row + rec2.x : 0], t1 = p[p1 ? (int)row + 1 + rec2.x : 0];
+            a0 = fma(v.x, p0 ? t0 : 0.0, a0), a1 = fma(v.y, p1 ? t1 : 0.0, a1);
+          }
+        }
+        if (l0) {
+          const double rn0 = r0 - alpha * a0;
+          r[row] = rn0;
+          acc[0] += rn0 * (dc * rn0), acc[1] += rn0 * rn0;
+        }
+        if (l1) {
+          const double rn1 = r1 - alpha * a1;
+          r[row + 1] = rn1;
+          acc[0] += rn1 * (dc * rn1), acc[1] += rn1 * rn1;
+        }
       }
     }
-    if ((n & 1) && gtid == gsz - 1) {
-      const double rs = r[n - 1] - alpha * q[n - 1];
-      r[n - 1] = rs;
-      acc[0] += rs * (dc * rs), acc[1] += rs * rs;
-    }
-  } else {
-    for (size_t i = gtid; i < n; i += gsz) {
-      const double rs = r[i] - alpha * q[i];
-      r[i] = rs;
-      acc[0] += rs * (dc * rs), acc[1] += rs * rs;
-    }
   }
+#undef COLR_FINISH
   wg_sum<2>(acc, sred);
   if (threadIdx.x == 0) {
     partials2[2 * blockIdx.x + 0] = acc[0];
@@ -2209,7 +2285,7 @@ __global__ __launch_bounds__(WG) void k_pcg_update_r(
   }
 }
 
-// the x update a run's last k_pcg_update_r left pending (no k_pcg_col_px came behind it, or that one
+// the x update a run's last k_pcg_col_r left pending (no k_pcg_col_px came behind it, or that one
 // found the solve converged): x += alpha p with p in the buffer st->xpend names.  Runs whatever the
 // status; the stand-alone k_pcg_update_p behind it clears st->xpend.
 __global__ __launch_bounds__(WG) void k_pcg_xfix(unsigned n, const double *__restrict__ p0, const double *__restrict__ p1,
@@ -2900,7 +2976,7 @@ void lsb_k_pcg_update_xr(unsigned n, const double *p, const double *q,
 void lsb_k_pcg_col_px(unsigned grid_cap, unsigned period, const unsigned *plan, unsigned nitem, unsigned n,
                       const unsigned *sptr, const unsigned long long *mask, const struct lsb_sell_tmpl *td,
                       unsigned nfar, const int *sbase, const double *vals, const double *vconst, const double *r,
-                      const double *pold, double *pnew, double *x, double *q, double dc, double *partials,
+                      const double *pold, double *pnew, double *x, double dc, double *partials,
                       unsigned *npartials, struct lsb_pcg_state *st, int parity, const double *parts2,
                       unsigned nparts2, void *stream) {
   hipStream_t s = (hipStream_t)stream;
@@ -2914,8 +2990,8 @@ void lsb_k_pcg_col_px(unsigned grid_cap, unsigned period, const unsigned *plan, 
   /* x, p' and q streamed nontemporally (NT = 3; measured against 0 / 1 / 2 on config 4: 950.5 / 950.3 / 905.7 /
    * 894.1 us per iteration, profiles/r04_px.txt) */
 #define LSB_PX(NF)                                                                                    \
-  k_pcg_col_px<NF, 3><<<g, WG, 0, s>>>(plan, period, n, sptr, mask, td, sbase, vals, vconst, r, pold, pnew, x, q, dc, \
-                                       partials, st, parity, parts2, nparts2)
+  k_pcg_col_px<NF, 3><<<g, WG, 0, s>>>(plan, period, n, sptr, mask, td, sbase, vals, vconst, r, pold, pnew, x, dc, partials, \
+                                       st, parity, parts2, nparts2)
   switch (nfar) {
   case 1: LSB_PX(1); break;
   case 2: LSB_PX(2); break;
@@ -2924,23 +3000,27 @@ void lsb_k_pcg_col_px(unsigned grid_cap, unsigned period, const unsigned *plan, 
 #undef LSB_PX
 }
 
-void lsb_k_pcg_update_r(unsigned n, const double *q, double dc, double *r, struct lsb_pcg_state *st, int parity,
-                        int pbuf, const double *pq_parts, unsigned npq, double *partials2, unsigned *npartials,
-                        void *stream) {
-  const unsigned g = lsb_k_blas1_grid(n);
+void lsb_k_pcg_col_r(unsigned grid_cap, unsigned period, const unsigned *plan, unsigned nitem, unsigned n,
+                     const unsigned *sptr, const unsigned long long *mask, const struct lsb_sell_tmpl *td, unsigned nfar,
+                     const int *sbase, const double *vals, const double *vconst, const double *p, double *r, double dc,
+                     struct lsb_pcg_state *st, int parity, int pbuf, const double *pq_parts, unsigned npq,
+                     double *partials2, unsigned *npartials, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned g = lsb_k_spmv_grid(LSB_SPMV_SELL, n, nitem, 0, grid_cap && grid_cap < 1280u ? grid_cap : 1280u);
   *npartials = g;
-  hipStream_t hs = (hipStream_t)stream;
-#define LSB_UR(V, A, B) k_pcg_update_r<V, A, B><<<g, WG, 0, hs>>>(n, q, dc, r, st, parity, pbuf, pq_parts, npq, partials2)
-  if (aligned16(q) && aligned16(r)) {
-    switch ((g_blas1_nt >> 1) & 3) { /* the mask's bits of k_pcg_update_xr: 1 p and q, 2 r */
-    case 0: LSB_UR(true, false, false); break;
-    case 1: LSB_UR(true, true, false); break;
-    case 2: LSB_UR(true, false, true); break;
-    default: LSB_UR(true, true, true); break;
-    }
-  } else
-    LSB_UR(false, false, false);
-#undef LSB_UR
+  if (period < NXCD || !plan)
+    errx(EXIT_FAILURE, "lsb_k_pcg_col_r: no column plan (period %u)", period);
+  switch (nfar) {
+  case 1:
+    k_pcg_col_r<1><<<g, WG, 0, s>>>(plan, period, n, sptr, mask, td, sbase, vals, vconst, p, r, dc, st, parity, pbuf,
+                                    pq_parts, npq, partials2);
+    break;
+  case 2:
+    k_pcg_col_r<2><<<g, WG, 0, s>>>(plan, period, n, sptr, mask, td, sbase, vals, vconst, p, r, dc, st, parity, pbuf,
+                                    pq_parts, npq, partials2);
+    break;
+  default: errx(EXIT_FAILURE, "lsb_k_pcg_col_r: %u far slots per side", nfar);
+  }
 }
 
 void lsb_k_pcg_xfix(unsigned n, const double *p0, const double *p1, double *x, const struct lsb_pcg_state *st,

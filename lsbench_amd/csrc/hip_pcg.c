@@ -178,8 +178,8 @@ int lsb_fuse_p_kind(const lsb_hip_solver *sv) {
     return 0;
   const struct shard *s = &sv->sh[0];
   /* 2 = the z-column form of a 3-D stencil with a constant diagonal: direction update AND the x
-   * half of the first sweep ride in the next SpMV launch (k_pcg_col_px + k_pcg_update_r: 72
-   * instead of 88 bytes per row and iteration) */
+   * half of the first sweep ride in the next SpMV launch, the r half forms S p again instead of reading a
+   * stored q (k_pcg_col_px + k_pcg_col_r: 64 instead of 88 bytes per row and iteration) */
   if (s->variant == LSB_SPMV_SELL && (s->sp_flags & LSB_SP_COL) && (s->sp_flags & LSB_SP_TMPL) && s->d_colplan &&
       s->d_srec && s->dinv_uniform && s->tmpl_nfar >= 1 && s->tmpl_nfar <= 2 && s->row_begin == 0 &&
       s->n == s->n_glob && sv->o.precond == LSB_PRECOND_JACOBI && !getenv("LSBENCH_HIP_NO_FUSE_PX"))
@@ -203,9 +203,9 @@ unsigned long long lsb_hip_solver_iteration_bytes(const lsb_hip_solver *sv) {
   if (!sp || sv->o.krylov == LSB_KRYLOV_GMRES || generic_precond(sv) || s->mixed || sv->ps.use ||
       lsb_fuse_p_kind(sv) == 1)
     return 0;
-  if (lsb_fuse_p_kind(sv) == 2) /* k_pcg_col_px: r p x in, p x q out (the layout's x-in / y-out are two of
-                                   them); k_pcg_update_r: q r in, r out */
-    return sp - 2 * n8 + 9 * n8;
+  if (lsb_fuse_p_kind(sv) == 2) /* k_pcg_col_px: r p x in, p' x out; k_pcg_col_r: p' r in, r out; the layout's
+                                   matrix-side bytes (sp less its x-in / y-out) in both */
+    return 2 * (sp - 2 * n8) + 8 * n8;
   const unsigned vec = s->dinv_uniform ? 0u : 1u;
   if (use_cg1(sv))
     return sp + n8 * (sv->cg1_implicit ? 9u : 11u + vec);
@@ -217,7 +217,7 @@ static void fused_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int 
   double *buf[2] = {s->d_pfull, s->d_p1};
   unsigned np2 = s->np2;
   if (lsb_fuse_p_kind(sv) == 2) {
-    /* z-column form: [S p | p' = dc r + beta p, x += alpha p, S p'] then [r -= alpha q]; the x update of an
+    /* z-column form: [S p | p' = dc r + beta p, x += alpha p, p'.(S p')] then [r -= alpha S p']; the x update of an
      * iteration rides in the NEXT iteration's first launch, the run's last one is applied by k_pcg_xfix */
     /* sampling: the launch that carries the SpMV, bracketed as pcg_enqueue_iter brackets a plain one; a run's
      * first iteration (a plain SpMV launch) is marked in samp_skip and left out by pcg_run -- the figure is
@@ -232,8 +232,8 @@ static void fused_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int 
     } else {
       lsb_k_pcg_col_px(s->sp_grid, s->col_period, s->d_colplan, s->col_items, s->n, s->d_sptr16, s->d_tmask,
                        s->d_tmpl, s->tmpl_nfar, s->d_sbase, s->d_svals16, s->d_svconst, s->d_r, buf[sv->pcur],
-                       buf[sv->pcur ^ 1], d_x, s->d_q, s->dinv_const, s->d_parts_pq, &s->npq, s->d_st, parity ^ 1,
-                       s->d_parts2, np2, g_stream);
+                       buf[sv->pcur ^ 1], d_x, s->dinv_const, s->d_parts_pq,
+                       &s->npq, s->d_st, parity ^ 1, s->d_parts2, np2, g_stream);
       sv->pcur ^= 1;
     }
     if (sample >= 0 && !(pos & 1)) {
@@ -241,8 +241,10 @@ static void fused_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int 
       LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 2], g_stream));
       LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 3], g_stream));
     }
-    lsb_k_pcg_update_r(s->n, s->d_q, s->dinv_const, s->d_r, s->d_st, parity, sv->pcur, s->d_parts_pq, s->npq,
-                       s->d_parts2, &s->np2, g_stream);
+    /* r -= alpha S p with S p formed again out of p (k_pcg_col_r): q never travels -- 8 passes per iteration */
+    lsb_k_pcg_col_r(s->sp_grid, s->col_period, s->d_colplan, s->col_items, s->n, s->d_sptr16, s->d_tmask, s->d_tmpl,
+                    s->tmpl_nfar, s->d_sbase, s->d_svals16, s->d_svconst, buf[sv->pcur], s->d_r, s->dinv_const, s->d_st,
+                    parity, sv->pcur, s->d_parts_pq, s->npq, s->d_parts2, &s->np2, g_stream);
     if (pos & 2) { /* last of the run: the pending x update, then the direction back into the gather vector */
       lsb_k_pcg_xfix(s->n, buf[0], buf[1], d_x, s->d_st, g_stream);
       lsb_k_pcg_update_p(s->n, s->d_r, DINV(s), buf[sv->pcur], buf[0], s->d_st, parity, s->d_parts2, s->np2,

@@ -130,12 +130,15 @@ void lsb_k_spmv_tmpl(unsigned flags, unsigned grid_cap, unsigned period, const u
 void lsb_k_pcg_col_px(unsigned grid_cap, unsigned period, const unsigned *plan, unsigned nitem, unsigned n,
                       const unsigned *sptr, const unsigned long long *mask, const struct lsb_sell_tmpl *td,
                       unsigned nfar, const int *sbase, const double *vals, const double *vconst, const double *r,
-                      const double *pold, double *pnew, double *x, double *q, double dc, double *partials,
+                      const double *pold, double *pnew, double *x, double dc, double *partials,
                       unsigned *npartials, struct lsb_pcg_state *st, int parity, const double *parts2,
                       unsigned nparts2, void *stream);
-void lsb_k_pcg_update_r(unsigned n, const double *q, double dc, double *r, struct lsb_pcg_state *st, int parity,
-                        int pbuf, const double *pq_parts, unsigned npq, double *partials2, unsigned *npartials,
-                        void *stream);
+/* the r half: alpha, r -= alpha S p with S p formed again out of p (q is never stored), partials of (r.z', r.r) */
+void lsb_k_pcg_col_r(unsigned grid_cap, unsigned period, const unsigned *plan, unsigned nitem, unsigned n,
+                     const unsigned *sptr, const unsigned long long *mask, const struct lsb_sell_tmpl *td, unsigned nfar,
+                     const int *sbase, const double *vals, const double *vconst, const double *p, double *r, double dc,
+                     struct lsb_pcg_state *st, int parity, int pbuf, const double *pq_parts, unsigned npq,
+                     double *partials2, unsigned *npartials, void *stream);
 void lsb_k_pcg_xfix(unsigned n, const double *p0, const double *p1, double *x, const struct lsb_pcg_state *st,
                     void *stream);
 #define LSB_SP_COL 256u /* k_spmv_tmpl_col: the template layout walked in z-columns (whole launches of a

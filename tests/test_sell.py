@@ -267,10 +267,10 @@ def test_z_column_walk_changes_no_bit_of_y(hip, monkeypatch, spec, nvirt, overla
                                        ("lap3d:nx=128,ny=64,nz=40", 3), ("lap3d:nx=256,ny=32,nz=40", 4),
                                        ("lap2d:nx=8192,ny=40", 16), ("lap2d:nx=8192,ny=37", 5)])
 def test_two_launch_column_iteration(hip, monkeypatch, spec, kmax):
-    """k_pcg_col_px + k_pcg_update_r (hip_kernels.hip): the classic PCG iteration in two launches on a
+    """k_pcg_col_px + k_pcg_col_r (hip_kernels.hip): the classic PCG iteration in two launches on a
     z-column plan -- the direction update AND the x half of the first sweep ride in the next SpMV
-    launch (72 instead of 88 bytes per row), p' formed once per plane and kept in registers; the
-    run's last x update is applied by k_pcg_xfix.  Against the three-launch form of the same solver
+    launch, p' formed once per plane and kept in registers; the r half forms S p' again instead of
+    reading a stored q (64 instead of 88 bytes per row); the run's last x update is applied by k_pcg_xfix.  Against the three-launch form of the same solver
     (LSBENCH_HIP_NO_FUSE_PX=1): the same iteration counts and status, x to rounding -- converged
     solves, runs cut by maxit at an even and an odd count (the pending x update, the maxit-th
     iteration's bookkeeping), launches and hipGraph replay, second solves on the first one's hint
