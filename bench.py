@@ -512,7 +512,7 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
         how = "hipEvent pairs around %d SpMV launches inside the timed solves" % spmv_n
         if fused_p:
             kernel = "k_pcg_col_px"
-            bytes_alg = layout_bytes + 16 * rows_inside   # r p x in, p' x out: 40 B per row where the layout counts 16 (q is not stored)
+            bytes_alg = layout_bytes + 24 * rows_inside   # r p x in, p' x out: 40 B per row where the layout counts 16 (q is not stored)
             traffic, traffic_src = pmc_traffic(key if world == 1 and a.precision == "fp64" else None, kernel, vslots,
                                                solver.spmv_flags, solver.spmv_period)
             how = ("hipEvent pairs around %d launches of k_pcg_col_px inside the timed solves (the launch that carries "

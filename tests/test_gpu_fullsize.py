@@ -225,12 +225,12 @@ def test_bench_line_contract():
     csr = 12 * 49978572 + 20 * 9998244 + 4
     # the grid's lines (3162 rows) are padded to 25 whole slices inside the solver; the iteration is the
     # two-launch form on the z-column plan along y, and the launch that carries the SpMV (k_pcg_col_px) also
-    # reads r, x and writes p', x instead of q: 16 B per row (pad rows included) on top of the layout's bytes
+    # reads r, x and writes p', x instead of q: 24 B per row (pad rows included) on top of the layout's bytes
     rows_in = 9998244 + rf["line_padding_rows"]
     assert rf["line_padding_rows"] == 3162 * 38 and rf["kernel"].startswith("k_pcg_col_px")
     assert rf["direction_update_in_this_launch"] is True and rf["back_to_back_kernel"].startswith("k_spmv_tmpl_col")
     assert rf["csr_count"]["bytes"] == csr and rf["layout_bytes"] < csr // 3
-    assert rf["algorithmic_bytes"] == rf["layout_bytes"] + 16 * rows_in     # r p x in, p' x out; q is not stored
+    assert rf["algorithmic_bytes"] == rf["layout_bytes"] + 24 * rows_in     # r p x in, p' x out (40 B per row); q is not stored
     assert rf["layout_bytes"] >= 16 * rows_in                 # x once + y once at the very least
     assert rf["back_to_back_launch_ms"] < rf["launch_ms"]     # (the SpMV alone)
     assert rf["traffic"] is None or (0.3 < rf["frac_fabric"] <= 1.0 and rf["traffic"] >= 0.9 * rf["algorithmic_bytes"])

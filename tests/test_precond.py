@@ -310,11 +310,18 @@ def test_chebyshev_epilogue_over_shards(hip, monkeypatch, nvirt, comm):
                                            spmv_variant=hip.SPMV_SELL))
         x, r = s.solve(b)
         x2, r2 = s.solve(b)
+        mode = s.comm[0]
         s.destroy()
         assert r.status == 1 and r2.iters == r.iters and np.array_equal(x, x2)
-        out[fuse] = (x, int(r.iters), r.relres)
-    assert out["0"][1] == out["1"][1] and out["0"][2] == out["1"][2]
-    assert np.array_equal(out["0"][0], out["1"][0])
+        out[fuse] = (x, int(r.iters), r.relres, mode)
+    if out["0"][3] == out["1"][3]:
+        assert out["0"][1] == out["1"][1] and out["0"][2] == out["1"][2]
+        assert np.array_equal(out["0"][0], out["1"][0])
+    else:
+        # COMM_AUTO times both transports at creation and the two solvers took different ones: the all-reduce
+        # adds the shards' sums in another order -- the same solve to rounding, not to the bit
+        assert abs(out["0"][1] - out["1"][1]) <= 1 and abs(out["0"][2] - out["1"][2]) <= 1e-9 * out["0"][2]
+        assert np.linalg.norm(out["0"][0] - out["1"][0]) <= 1e-12 * np.linalg.norm(out["0"][0])
     offs, cols, vals = O.lap3d(40, 36, 30)
     xo, ito, _, sto, _, _ = O.pcg_prec(offs, cols, vals, b, 1e-11, kind="cheb", param=3)
     assert sto == 1 and abs(out["1"][1] - ito) <= max(2, ito // 25)
