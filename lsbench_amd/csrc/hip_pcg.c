@@ -174,7 +174,10 @@ static void pcg_enqueue_init(lsb_hip_solver *sv, const double *d_b, double *d_x)
  * its 7-point instantiation turned out not to be repeatable run to run once the masked slots
  * came in (gpurun_out/r3_mask, tools/gpu_tmpl_diag3.py): DESIGN.md section 4. */
 int lsb_fuse_p_kind(const lsb_hip_solver *sv) {
-  if (sv->multi || use_cg1(sv) || generic_precond(sv) || sv->sh[0].mixed || getenv("LSBENCH_HIP_NO_FUSE_P"))
+  /* (asked for every iteration that is enqueued: the two environment switches were looked at when the solver
+   * was made) */
+  const int no_fuse_p = sv->env_no_fuse_p, no_fuse_px = sv->env_no_fuse_px;
+  if (sv->multi || use_cg1(sv) || generic_precond(sv) || sv->sh[0].mixed || no_fuse_p)
     return 0;
   const struct shard *s = &sv->sh[0];
   /* 2 = the z-column form of a 3-D stencil with a constant diagonal: direction update AND the x
@@ -182,7 +185,7 @@ int lsb_fuse_p_kind(const lsb_hip_solver *sv) {
    * stored q (k_pcg_col_px + k_pcg_col_r: 64 instead of 88 bytes per row and iteration) */
   if (s->variant == LSB_SPMV_SELL && (s->sp_flags & LSB_SP_COL) && (s->sp_flags & LSB_SP_TMPL) && s->d_colplan &&
       s->d_srec && s->dinv_uniform && s->tmpl_nfar >= 1 && s->tmpl_nfar <= 2 && s->row_begin == 0 &&
-      s->n == s->n_glob && sv->o.precond == LSB_PRECOND_JACOBI && !getenv("LSBENCH_HIP_NO_FUSE_PX"))
+      s->n == s->n_glob && sv->o.precond == LSB_PRECOND_JACOBI && !no_fuse_px)
     return 2; /* (event-timed too: the sample brackets the launch that carries the SpMV) */
   /* (not while SpMV launches are being event-timed: the fused launch has no SpMV of its own to
    * bracket, and solve_core reads the sample events) */

@@ -576,6 +576,7 @@ lsb_hip_solver *solver_alloc(int nshard, const struct lsb_hip_opts *o) {
   sv->sh = lsb_calloc(struct shard, nshard);
   sv->o = *o;
   LSB_CHK_HIP(hipHostMalloc((void **)&sv->h_st, 2 * sizeof(struct lsb_pcg_state), 0));
+  sv->env_no_fuse_p = getenv("LSBENCH_HIP_NO_FUSE_P") != NULL, sv->env_no_fuse_px = getenv("LSBENCH_HIP_NO_FUSE_PX") != NULL;
   return sv;
 }
 

@@ -222,6 +222,7 @@ struct lsb_hip_solver {
    * rank has the same constant Jacobi diagonal (k_cg1_update<UI>) */
   int cg1_implicit;
   int pcur, rcur; /* launch-bound fused paths: which direction / residual buffer is current */
+  int env_no_fuse_p, env_no_fuse_px; /* LSBENCH_HIP_NO_FUSE_P / _NO_FUSE_PX at creation (tests compare the forms) */
   int nt_mask;    /* which operands of the BLAS-1 sweeps are loaded nontemporal (tune_blas1_nt) */
 #define LSB_CHEB_MAX 32
   int cheb_m, cheb_fused; /* fused: the steps ride in the SpMV's epilogue (one shard, 16-bit sliced-ELL) */
