@@ -1133,6 +1133,13 @@ void tune_spmv(lsb_hip_solver *sv, struct shard *s) {
      * back) -- a plain flavour has to win by 3 % to be taken */
     if (!(s->sp_flags & LSB_SP_NT))
       ms *= 1.03f;
+    /* the z-column walk is also what the two-launch iteration runs on (k_pcg_col_px + k_pcg_col_r: 8 vector passes
+     * instead of 11): where that form will apply -- one shard, Jacobi with a constant diagonal, classic PCG, fp64 --
+     * a flavour without it has to beat the walk by 15 % as an SpMV to be worth the three launches */
+    if ((s->sp_flags & LSB_SP_COL) && s->d_colplan && sv->nshard == 1 && !sv->dist && !sv->multi && s->dinv_uniform &&
+        !s->mixed && o->precond == LSB_PRECOND_JACOBI && (o->krylov == LSB_KRYLOV_PCG || o->krylov == LSB_KRYLOV_AUTO) &&
+        !sv->env_no_fuse_px)
+      ms *= 0.85f;
     if (ms < best)
       best = ms, bf = s->sp_flags, bv = s->variant, bg = s->sp_grid, bp = s->sp_period;
   }

@@ -122,5 +122,49 @@ int main(void) {
     lsb_csr_free(A);
     printf("ok %s\n", specs[k]);
   }
+  /* line padding of a 2-D grid and the z-column plans of the padded copy and of a 3-D grid (their builders and
+   * checks walk every slice; a broken item must be CAUGHT) */
+  {
+    const char *grids[] = {"lap2d:nx=1000,ny=12", "lap3d:nx=128,ny=16,nz=9"};
+    for (unsigned k = 0; k < 2; k++) {
+      unsigned n;
+      struct csr *A = lsbench_matrix_synth(grids[k], 0, 0, &n);
+      struct csr *S = lsb_csr_copy_base0(A);
+      unsigned nx = 0, nxp = 0;
+      int *map = NULL;
+      struct csr *P = lsb_csr_pad_lines(S, 128, &nx, &nxp, &map);
+      if ((k == 0) != (P != NULL)) { printf("pad_lines: %s\n", grids[k]); return 1; }
+      if (P) {
+        if (nx != 1000 || nxp != 1024 || P->nrows != 12u * 1024u) { printf("pad_lines: %u -> %u, %u rows\n", nx, nxp, P->nrows); return 1; }
+        for (unsigned r = 0; r < P->nrows; r++)
+          if ((map[r] >= 0) != (r % nxp < nx)) { printf("pad_lines: map\n"); return 1; }
+      }
+      struct csr *G = P ? P : S;
+      struct lsb_sell *H = lsb_csr_sellize16(G, 0);
+      struct lsb_sell_vc *V = H ? lsb_sell16_value_slots(H) : NULL;
+      struct lsb_sell_tmpls *T = V ? lsb_sell16_templates(H, V) : NULL;
+      const unsigned period = k == 0 ? 8u : 16u; /* a padded line: 8 slices; a plane of the 3-D grid: 16 */
+      for (unsigned kmax = 2; T && kmax <= 16; kmax += 7) {
+        struct lsb_tmpl_cols *C = lsb_sell_tmpl_columns(T, period, kmax);
+        struct lsb_tmpl_cols *Cr = lsb_sell_tmpl_columns_range(T, period, kmax, T->nslice / 4, T->nslice - 1);
+        char why[256];
+        if (C && lsb_tmpl_cols_check(T, C, why, sizeof why)) { printf("cols_check: %s\n", why); return 1; }
+        if (Cr && lsb_tmpl_cols_check(T, Cr, why, sizeof why)) { printf("cols_check (range): %s\n", why); return 1; }
+        if (C && C->nitem) {
+          const unsigned keep = C->item[0];
+          C->item[0] = T->nslice; /* a first slice past the layout */
+          if (!lsb_tmpl_cols_check(T, C, why, sizeof why)) { printf("cols_check accepted an item past the layout\n"); return 1; }
+          C->item[0] = keep;
+        }
+        lsb_tmpl_cols_free(C), lsb_tmpl_cols_free(Cr);
+      }
+      lsb_sell_tmpls_free(T), lsb_sell_vc_free(V), lsb_sell_free(H);
+      free(map);
+      if (P)
+        lsb_csr_free(P);
+      lsb_csr_free(S), lsb_csr_free(A);
+      printf("ok %s (padding / z-columns)\n", grids[k]);
+    }
+  }
   return 0;
 }

@@ -25,4 +25,5 @@ def test_host_layout_builders_under_asan_ubsan(tmp_path):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", OMP_NUM_THREADS="4")
     r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    assert r.stdout.count("ok ") == 7 and "ERROR" not in r.stderr and "runtime error" not in r.stderr
+    # seven operators + the two grids of the padding / z-column block
+    assert r.stdout.count("ok ") == 9 and "ERROR" not in r.stderr and "runtime error" not in r.stderr
