@@ -382,7 +382,7 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
     if a.fixed_iters > 0:
         tol, maxit = 0.0, a.fixed_iters
     opts = la.default_opts(op_mode=la.OP_RAW, tol=tol, maxit=maxit, spmv_variant=a.spmv,
-                           use_graph=1 if small else 0, sample_spmv=0 if small else 16,
+                           use_graph=1 if small else 0, sample_spmv=0 if small else 15,   # (odd: both kinds of k_pcg_col_px launch get sampled)
                            spmv_tune=a.spmv_tune, overlap=a.overlap,
                            comm={"auto": la.COMM_AUTO, "rccl": la.COMM_RCCL, "p2p": la.COMM_P2P}[a.comm],
                            krylov={"cg": la.KRYLOV_PCG, "cg1": la.KRYLOV_PCG1,
@@ -512,7 +512,9 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
         how = "hipEvent pairs around %d SpMV launches inside the timed solves" % spmv_n
         if fused_p:
             kernel = "k_pcg_col_px"
-            bytes_alg = layout_bytes + 24 * rows_inside   # r p x in, p' x out: 40 B per row where the layout counts 16 (q is not stored)
+            # a run's even iterations: r p x p'' in, p' x out (48 B per row; x is updated every second iteration, with two
+            # directions at once); odd ones: r p in, p' out (24): 36 on average where the layout's count has 16 (q is not stored)
+            bytes_alg = layout_bytes + 20 * rows_inside
             traffic, traffic_src = pmc_traffic(key if world == 1 and a.precision == "fp64" else None, kernel, vslots,
                                                solver.spmv_flags, solver.spmv_period)
             how = ("hipEvent pairs around %d launches of k_pcg_col_px inside the timed solves (the launch that carries "
@@ -593,9 +595,10 @@ def run_workload(a, c, workload, steps, warmup, cpu_leg):
                      "bytes_basis": ("layout: what the stored layout must move in one launch -- its index / code / "
                                      "slot / template arrays and the values it keeps (value_slots kept / all: one "
                                      "value per slot whose 128 entries are equal), x once, y once"
-                                     + (" -- here: r, p, x in and p', x out (q = S p' is not stored: the launch that updates r "
-                                        "forms it again), the direction update and the x update ride in this launch (two "
-                                        "launches and 64 instead of 88 B per row and iteration)"
+                                     + (" -- here, averaged over a run's even and odd iterations: r, p in and p' out, every second "
+                                        "time also x and the direction before in and x out (q = S p' is not stored: the launch "
+                                        "that updates r forms it again); the direction update and the x update ride in this "
+                                        "launch (two launches and 60 instead of 88 B per row and iteration)"
                                         if fused_p else "")
                                      + "; SURVEY 8(d)'s CSR count is under csr_count (a CSR kernel's bytes: this "
                                      "layout moves fewer, so that ratio is not a fraction of anything)"

@@ -1873,7 +1873,8 @@ __global__ __launch_bounds__(WG, DOT == 2 ? 5 : 6) void k_spmv_tmpl_col(
 // --------------------------------------------------------------------------
 template <int NF> struct colp_c { // centre-side loads of one step, issued ONE step ahead
   sell_d2u rn, pn;                // r, p of the plane ahead (it becomes this step's "plane above")
-  sell_d2v xn;                    // x of that plane, where the column owns it
+  sell_d2v xn, sn;                // x of that plane and the direction of TWO iterations ago (what the buffer p' goes to
+                                  // still holds), where the column owns the plane and this launch updates x
   double re, pe;                  // r, p of the element in front of / behind the wave's 128 centre operands
 };
 // the +-line operands of a step (3-D stencil), issued TWO steps ahead: the lines a column gathers for plane z are
@@ -1891,16 +1892,20 @@ struct colp_out { // results of a step
 template <int NF, bool WITH_X, int NT>
 __device__ __forceinline__ void colp_issue_c(colp_c<NF> &o, const col_tmpl<NF> &T, const double *__restrict__ r,
                                              const double *__restrict__ pold, const double *__restrict__ x,
-                                             long long gu, unsigned P, unsigned xlen, unsigned lane) {
+                                             const double *pstale, long long gu, unsigned P, unsigned xlen,
+                                             unsigned lane) {
   const long long ga = gu + T.bc + (long long)P; // the plane ahead
   o.rn = *(const sell_d2u *)(r + ga + 2 * lane);
   o.pn = *(const sell_d2u *)(pold + ga + 2 * lane);
-  if (WITH_X) { // x is touched once per launch: nontemporal (NT & 1) keeps it out of the way of the r / p lines
-                // the neighbouring columns gather again
-    if (NT & 1)
+  if (WITH_X) { // x and the stale direction are touched once per launch: nontemporal (NT & 1) keeps them out of the
+                // way of the r / p lines the neighbouring columns gather again
+    if (NT & 1) {
       o.xn = __builtin_nontemporal_load((const sell_d2v *)(x + (gu + (long long)P) + 2 * lane));
-    else
+      o.sn = __builtin_nontemporal_load((const sell_d2v *)(pstale + (gu + (long long)P) + 2 * lane));
+    } else {
       o.xn = *(const sell_d2v *)(x + (gu + (long long)P) + 2 * lane);
+      o.sn = *(const sell_d2v *)(pstale + (gu + (long long)P) + 2 * lane);
+    }
   }
   long long el = gu + T.bc - 1, er = gu + T.bc + (long long)LSB_SELL_ROWS; // wave-uniform, clamped (see col_issue)
   el = el < 0 ? 0 : el, er = er >= (long long)xlen ? (long long)xlen - 1 : er;
@@ -1920,14 +1925,18 @@ __device__ __forceinline__ void colp_issue_m(colp_m<NF> &o, const col_tmpl<NF> &
 }
 // one step: q of the centre plane from (below, centre, above) = (pm, p0, p' of the plane ahead); OWNED: the
 // plane ahead is the column's own -- its x is updated and it and p' go to `out`
-template <int NF, bool OWNED>
+// XUPD: this launch applies the two pending x updates (alpha of the iteration before with its direction p, alpha2 of
+// the one before that with the stale direction)
+template <int NF, bool OWNED, bool XUPD>
 __device__ __forceinline__ void colp_compute(const colp_c<NF> &o, const colp_m<NF> &m, const sell_d2u &pm,
                                              const sell_d2u &p0, sell_d2u &pp, const col_tmpl<NF> &T, double vm0,
-                                             double vm1, double vp0, double vp1, double beta, double alpha, double dc,
-                                             unsigned lane, colp_out &out, double &dot) {
+                                             double vm1, double vp0, double vp1, double beta, double alpha, double alpha2,
+                                             double dc, unsigned lane, colp_out &out, double &dot) {
   pp.x = pnew_of(dc, o.rn.x, beta, o.pn.x), pp.y = pnew_of(dc, o.rn.y, beta, o.pn.y);
   if (OWNED) {
-    out.x.x = o.xn.x + alpha * o.pn.x, out.x.y = o.xn.y + alpha * o.pn.y; // k_pcg_update_xr's x += alpha p
+    if (XUPD) { // x += alpha2 p'' + alpha p: k_pcg_update_xr's x += alpha p, two iterations' worth in their order
+      out.x.x = (o.xn.x + alpha2 * o.sn.x) + alpha * o.pn.x, out.x.y = (o.xn.y + alpha2 * o.sn.y) + alpha * o.pn.y;
+    }
     out.p.x = pp.x, out.p.y = pp.y;
   }
   const double edge = pnew_of(dc, o.re, beta, o.pe);
@@ -1959,15 +1968,16 @@ __device__ __forceinline__ void colp_compute(const colp_c<NF> &o, const colp_m<N
 __device__ __forceinline__ void colp_single(unsigned s, unsigned n, unsigned lane, const unsigned *__restrict__ sptr,
                                             const int *__restrict__ sbase, const double *__restrict__ vals,
                                             const double *__restrict__ vconst, const double *__restrict__ r,
-                                            const double *__restrict__ pold, double *__restrict__ pnew,
+                                            const double *__restrict__ pold, double *pnew,
                                             double *__restrict__ x, double *__restrict__ q, double beta, double alpha,
-                                            double dc, double &dot) {
+                                            double alpha2, bool xupd, double dc, double &dot) {
   const unsigned row = s * LSB_SELL_ROWS + 2 * lane;
   const unsigned q0 = sptr[s] / LSB_SELL_ROWS, len = (sptr[s + 1] - sptr[s]) / LSB_SELL_ROWS;
   const bool l0 = row < n, l1 = row + 1 < n;
   const double r0 = l0 ? r[row] : 0.0, r1 = l1 ? r[row + 1] : 0.0;
   const double o0 = l0 ? pold[row] : 0.0, o1 = l1 ? pold[row + 1] : 0.0;
-  const double x0 = l0 ? x[row] : 0.0, x1 = l1 ? x[row + 1] : 0.0;
+  const double x0 = xupd && l0 ? x[row] : 0.0, x1 = xupd && l1 ? x[row + 1] : 0.0;
+  const double s0 = xupd && l0 ? pnew[row] : 0.0, s1 = xupd && l1 ? pnew[row + 1] : 0.0; // the direction of two iterations ago
   double a0 = 0.0, a1 = 0.0;
   for (unsigned j = 0; j < len; j++) {
     const i4v rec = ((const i4v *)sbase)[q0 + j]; // {base, -1 (no codes where templates exist), value slot or -1, 0}
@@ -1985,13 +1995,17 @@ __device__ __forceinline__ void colp_single(unsigned s, unsigned n, unsigned lan
   }
   const double n0 = pnew_of(dc, r0, beta, o0), n1 = pnew_of(dc, r1, beta, o1);
   if (l0) {
-    pnew[row] = n0, x[row] = x0 + alpha * o0;
+    pnew[row] = n0;
+    if (xupd)
+      x[row] = (x0 + alpha2 * s0) + alpha * o0;
     if (q)
       q[row] = a0;
     dot = fma(a0, n0, dot);
   }
   if (l1) {
-    pnew[row + 1] = n1, x[row + 1] = x1 + alpha * o1;
+    pnew[row + 1] = n1;
+    if (xupd)
+      x[row + 1] = (x1 + alpha2 * s1) + alpha * o1;
     if (q)
       q[row + 1] = a1;
     dot = fma(a1, n1, dot);
@@ -2010,7 +2024,8 @@ __device__ __forceinline__ void colp_single(unsigned s, unsigned n, unsigned lan
     if (WITH_Q)                                                                                \
       COLP_ST(q + (LROW) + 2 * lane, (OUT).q, 2);                                              \
     if (WITH_XP) {                                                                             \
-      COLP_ST(x + ((LROW) + P) + 2 * lane, (OUT).x, 1);                                        \
+      if (XUPD)                                                                                \
+        COLP_ST(x + ((LROW) + P) + 2 * lane, (OUT).x, 1);                                      \
       COLP_ST(pnew + ((LROW) + P) + 2 * lane, (OUT).p, 2);                                     \
     }                                                                                          \
   } while (0)
@@ -2018,12 +2033,16 @@ __device__ __forceinline__ void colp_single(unsigned s, unsigned n, unsigned lan
 // NT: bit 0 x loaded and stored nontemporal, bit 1 p' and q stored nontemporal
 // q = S p' is NOT stored: only its dot with p' leaves the launch -- k_pcg_col_r forms the same q again out of p' when
 // it updates r, and the vector never travels (8 instead of 9 passes per iteration)
-template <int NF, int NT>
+// XUPD: x is updated every SECOND iteration of a run, with two directions at once -- x += alpha2 p'' + alpha p: p is
+// the direction this launch reads anyway, p'' the one of the iteration before it, which is what the buffer p' goes
+// to still holds (each lane reads its own rows' p'' just before it overwrites them; nobody else reads that
+// buffer in this launch).  Launches of odd run index leave x alone: x is read and written half as often.
+template <int NF, int NT, bool XUPD>
 __global__ __launch_bounds__(WG, NF == 2 ? 3 : 4) void k_pcg_col_px(
     const unsigned *__restrict__ plan, unsigned period, unsigned n, const unsigned *__restrict__ sptr,
     const unsigned long long *__restrict__ mask, const lsb_sell_tmpl *__restrict__ td, const int *__restrict__ sbase,
     const double *__restrict__ vals, const double *__restrict__ vconst, const double *__restrict__ r,
-    const double *__restrict__ pold, double *__restrict__ pnew, double *__restrict__ x, double dc,
+    const double *__restrict__ pold, double *pnew, double *__restrict__ x, double dc,
     double *__restrict__ partials, lsb_pcg_state *__restrict__ st, int parity,
     const double *__restrict__ parts2, unsigned nparts2) {
   static_assert(NF >= 1 && NF <= 2, "one or two far slots per side");
@@ -2033,7 +2052,7 @@ __global__ __launch_bounds__(WG, NF == 2 ? 3 : 4) void k_pcg_col_px(
   const unsigned gx = gridDim.x / NXCD, xcd = blockIdx.x % NXCD, slot = blockIdx.x / NXCD;
   // ---- k_pcg_update_p's prologue: the sweep's partial sums -> r.z, r.r, stop test, beta
   const int stopped = st->status;
-  const double rz_old = st->rz[parity], thresh2 = st->thresh2, alpha = st->alpha[0];
+  const double rz_old = st->rz[parity], thresh2 = st->thresh2, alpha = st->alpha[0], alpha2 = st->alpha[1];
   const unsigned i0 = plan[xcd], i1 = plan[xcd + 1];
   double v[2];
   wg_sum_partials<2>(parts2, nparts2, v, sred);
@@ -2047,9 +2066,10 @@ __global__ __launch_bounds__(WG, NF == 2 ? 3 : 4) void k_pcg_col_px(
     st->rr = rr;
     st->rz[parity ^ 1] = rz_new;
     if (conv)
-      st->status = LSB_STATUS_CONVERGED; // (the x update of the last iteration stays pending: k_pcg_xfix)
+      st->status = LSB_STATUS_CONVERGED; // (the pending x updates stay pending: k_pcg_xfix)
     else {
-      st->xpend = 0; // this launch applies it
+      if (XUPD)
+        st->xpend = 0; // this launch applies them
       if (it >= st->maxit)
         st->pad = 1; // the next k_pcg_col_r makes it the status; this launch still does all its work
     }
@@ -2086,10 +2106,12 @@ __global__ __launch_bounds__(WG, NF == 2 ? 3 : 4) void k_pcg_col_px(
       const sell_d2u rb = *(const sell_d2u *)(r + (gc - (long long)P) + 2 * lane);
       const sell_d2u pb = *(const sell_d2u *)(pold + (gc - (long long)P) + 2 * lane);
       const sell_d2u r0 = *(const sell_d2u *)(r + gc + 2 * lane), o0 = *(const sell_d2u *)(pold + gc + 2 * lane);
-      const sell_d2v x0 = *(const sell_d2v *)(x + lrow + 2 * lane);
+      sell_d2v x0 = {0.0, 0.0}, s0 = {0.0, 0.0};
+      if (XUPD) // (a compile-time branch: no join in front of the loads)
+        x0 = *(const sell_d2v *)(x + lrow + 2 * lane), s0 = *(const sell_d2v *)(pnew + lrow + 2 * lane);
       colp_c<NF> c0, c1;
       colp_m<NF> m0, m1, m2;
-      colp_issue_c<NF, true, NT>(c0, C, r, pold, x, gu, P, n, lane);
+      colp_issue_c<NF, XUPD, NT>(c0, C, r, pold, x, pnew, gu, P, n, lane);
       colp_issue_m<NF>(m0, C, r, pold, gu, lane);
       colp_issue_m<NF>(m1, C, r, pold, gu + (long long)P, lane);
       unsigned long long mk[2][2] = {{0ull, 0ull}, {0ull, 0ull}};
@@ -2109,31 +2131,32 @@ __global__ __launch_bounds__(WG, NF == 2 ? 3 : 4) void k_pcg_col_px(
       // are younger than the loads the next step waits for, so they are never waited for either (vmcnt counts
       // loads and stores in one order) -- no parking of results across a step.
       colp_out res;
-      res.x.x = x0.x + alpha * o0.x, res.x.y = x0.y + alpha * o0.y;
+      res.x.x = (x0.x + alpha2 * s0.x) + alpha * o0.x, res.x.y = (x0.y + alpha2 * s0.y) + alpha * o0.y;
       res.p.x = p0.x, res.p.y = p0.y;
       res.q = res.p; // (not stored)
       COLP_STORE(res, lrow - P, false, true); // the first plane's x and p'
       // steps 0 .. K-3 (K >= 3): the plane after next is the column's own
       for (unsigned k = 0; k + 2 < K; k++) {
-        colp_issue_c<NF, true, NT>(c1, C, r, pold, x, gu + (long long)P, P, n, lane);
+        colp_issue_c<NF, XUPD, NT>(c1, C, r, pold, x, pnew, gu + (long long)P, P, n, lane);
         colp_issue_m<NF>(m2, C, r, pold, gu + 2 * (long long)P, lane);
-        colp_compute<NF, true>(c0, m0, pm, p0, pp, C, vm0, vm1, vp0, vp1, beta, alpha, dc, lane, res, dot);
+        colp_compute<NF, true, XUPD>(c0, m0, pm, p0, pp, C, vm0, vm1, vp0, vp1, beta, alpha, alpha2, dc, lane, res, dot);
         COLP_STORE(res, lrow, false, true);
         pm = p0, p0 = pp, c0 = c1, m0 = m1, m1 = m2;
         gu += (long long)P, lrow += P;
       }
       // step K-2: the plane after next is the one above the column (no x, no +-line operands to ask for)
-      colp_issue_c<NF, false, NT>(c1, C, r, pold, x, gu + (long long)P, P, n, lane);
-      colp_compute<NF, true>(c0, m0, pm, p0, pp, C, vm0, vm1, vp0, vp1, beta, alpha, dc, lane, res, dot);
+      colp_issue_c<NF, false, NT>(c1, C, r, pold, x, pnew, gu + (long long)P, P, n, lane);
+      colp_compute<NF, true, XUPD>(c0, m0, pm, p0, pp, C, vm0, vm1, vp0, vp1, beta, alpha, alpha2, dc, lane, res, dot);
       COLP_STORE(res, lrow, false, true);
       pm = p0, p0 = pp, c0 = c1, m0 = m1;
       gu += (long long)P, lrow += P;
       // step K-1: nothing to load; the plane ahead is not the column's
-      colp_compute<NF, false>(c0, m0, pm, p0, pp, C, vm0, vm1, vp0, vp1, beta, alpha, dc, lane, res, dot);
+      colp_compute<NF, false, XUPD>(c0, m0, pm, p0, pp, C, vm0, vm1, vp0, vp1, beta, alpha, alpha2, dc, lane, res, dot);
       COLP_STORE(res, lrow, false, false);
     } else {
       for (unsigned k = 0; k < K; k++)
-        colp_single(s + k * period, n, lane, sptr, sbase, vals, vconst, r, pold, pnew, x, nullptr, beta, alpha, dc, dot);
+        colp_single(s + k * period, n, lane, sptr, sbase, vals, vconst, r, pold, pnew, x, nullptr, beta, alpha, alpha2,
+                    XUPD, dc, dot);
     }
   }
   if (partials) {
@@ -2157,7 +2180,7 @@ __global__ __launch_bounds__(WG, 5) void k_pcg_col_r(
     const unsigned *__restrict__ plan, unsigned period, unsigned n, const unsigned *__restrict__ sptr,
     const unsigned long long *__restrict__ mask, const lsb_sell_tmpl *__restrict__ td, const int *__restrict__ sbase,
     const double *__restrict__ vals, const double *__restrict__ vconst, const double *__restrict__ p,
-    double *__restrict__ r, double dc, lsb_pcg_state *__restrict__ st, int parity, int pbuf,
+    double *__restrict__ r, double dc, lsb_pcg_state *__restrict__ st, int parity, int pbuf, int xtwo,
     const double *__restrict__ pq_parts, unsigned npq, double *__restrict__ partials2) {
   static_assert(NF >= 1 && NF <= 2, "one or two far slots per side");
   __shared__ double sred[8];
@@ -2182,8 +2205,11 @@ __global__ __launch_bounds__(WG, 5) void k_pcg_col_r(
     return;
   }
   const double alpha = rz / pq;
-  if (blockIdx.x == 0 && threadIdx.x == 0)
-    st->pq = pq, st->alpha[0] = alpha, st->xpend = 1 + pbuf;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // x is now one update behind (the run's even iterations: k_pcg_col_px has just applied the two before) or two
+    // (odd ones: the launch before left x alone): xpend = 1 + pbuf / 3 + pbuf, the steps in alpha[0] and alpha[1]
+    st->pq = pq, st->alpha[1] = st->alpha[0], st->alpha[0] = alpha, st->xpend = (xtwo ? 3 : 1) + pbuf;
+  }
   const u4v *__restrict__ items = (const u4v *)(plan + LSB_COL_HEAD);
   const unsigned P = period * LSB_SELL_ROWS;
   double acc[2] = {0.0, 0.0}, nodot = 0.0;
@@ -2293,10 +2319,16 @@ __global__ __launch_bounds__(WG) void k_pcg_xfix(unsigned n, const double *__res
   const int pend = st->xpend;
   if (!pend)
     return;
-  const double alpha = st->alpha[0];
-  const double *__restrict__ p = pend == 1 ? p0 : p1;
-  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n; i += (size_t)gridDim.x * WG)
-    x[i] += alpha * p[i];
+  const double alpha = st->alpha[0], alpha2 = st->alpha[1];
+  if (pend <= 2) { // one update behind: the direction is in buffer pend - 1
+    const double *__restrict__ p = pend == 1 ? p0 : p1;
+    for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n; i += (size_t)gridDim.x * WG)
+      x[i] += alpha * p[i];
+  } else { // two: the last direction in buffer pend - 3, the one before it in the other
+    const double *__restrict__ p = pend == 3 ? p0 : p1, *__restrict__ pp = pend == 3 ? p1 : p0;
+    for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n; i += (size_t)gridDim.x * WG)
+      x[i] = (x[i] + alpha2 * pp[i]) + alpha * p[i];
+  }
 }
 
 // (Round 4, measured and taken out again: k_spmv_tmpl_deep -- a wave takes 2 or 4 of its turns AT ONCE,
@@ -2976,7 +3008,7 @@ void lsb_k_pcg_update_xr(unsigned n, const double *p, const double *q,
 void lsb_k_pcg_col_px(unsigned grid_cap, unsigned period, const unsigned *plan, unsigned nitem, unsigned n,
                       const unsigned *sptr, const unsigned long long *mask, const struct lsb_sell_tmpl *td,
                       unsigned nfar, const int *sbase, const double *vals, const double *vconst, const double *r,
-                      const double *pold, double *pnew, double *x, double dc, double *partials,
+                      const double *pold, double *pnew, double *x, int xupd, double dc, double *partials,
                       unsigned *npartials, struct lsb_pcg_state *st, int parity, const double *parts2,
                       unsigned nparts2, void *stream) {
   hipStream_t s = (hipStream_t)stream;
@@ -2990,8 +3022,14 @@ void lsb_k_pcg_col_px(unsigned grid_cap, unsigned period, const unsigned *plan, 
   /* x, p' and q streamed nontemporally (NT = 3; measured against 0 / 1 / 2 on config 4: 950.5 / 950.3 / 905.7 /
    * 894.1 us per iteration, profiles/r04_px.txt) */
 #define LSB_PX(NF)                                                                                    \
-  k_pcg_col_px<NF, 3><<<g, WG, 0, s>>>(plan, period, n, sptr, mask, td, sbase, vals, vconst, r, pold, pnew, x, dc, partials, \
-                                       st, parity, parts2, nparts2)
+  do {                                                                                                \
+    if (xupd)                                                                                         \
+      k_pcg_col_px<NF, 3, true><<<g, WG, 0, s>>>(plan, period, n, sptr, mask, td, sbase, vals, vconst, r, pold, pnew, x, dc, \
+                                                 partials, st, parity, parts2, nparts2);              \
+    else                                                                                              \
+      k_pcg_col_px<NF, 3, false><<<g, WG, 0, s>>>(plan, period, n, sptr, mask, td, sbase, vals, vconst, r, pold, pnew, x, \
+                                                  dc, partials, st, parity, parts2, nparts2);         \
+  } while (0)
   switch (nfar) {
   case 1: LSB_PX(1); break;
   case 2: LSB_PX(2); break;
@@ -3003,7 +3041,7 @@ void lsb_k_pcg_col_px(unsigned grid_cap, unsigned period, const unsigned *plan, 
 void lsb_k_pcg_col_r(unsigned grid_cap, unsigned period, const unsigned *plan, unsigned nitem, unsigned n,
                      const unsigned *sptr, const unsigned long long *mask, const struct lsb_sell_tmpl *td, unsigned nfar,
                      const int *sbase, const double *vals, const double *vconst, const double *p, double *r, double dc,
-                     struct lsb_pcg_state *st, int parity, int pbuf, const double *pq_parts, unsigned npq,
+                     struct lsb_pcg_state *st, int parity, int pbuf, int xtwo, const double *pq_parts, unsigned npq,
                      double *partials2, unsigned *npartials, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   const unsigned g = lsb_k_spmv_grid(LSB_SPMV_SELL, n, nitem, 0, grid_cap && grid_cap < 1280u ? grid_cap : 1280u);
@@ -3013,11 +3051,11 @@ void lsb_k_pcg_col_r(unsigned grid_cap, unsigned period, const unsigned *plan, u
   switch (nfar) {
   case 1:
     k_pcg_col_r<1><<<g, WG, 0, s>>>(plan, period, n, sptr, mask, td, sbase, vals, vconst, p, r, dc, st, parity, pbuf,
-                                    pq_parts, npq, partials2);
+                                    xtwo, pq_parts, npq, partials2);
     break;
   case 2:
     k_pcg_col_r<2><<<g, WG, 0, s>>>(plan, period, n, sptr, mask, td, sbase, vals, vconst, p, r, dc, st, parity, pbuf,
-                                    pq_parts, npq, partials2);
+                                    xtwo, pq_parts, npq, partials2);
     break;
   default: errx(EXIT_FAILURE, "lsb_k_pcg_col_r: %u far slots per side", nfar);
   }

@@ -208,7 +208,7 @@ unsigned long long lsb_hip_solver_iteration_bytes(const lsb_hip_solver *sv) {
     return 0;
   if (lsb_fuse_p_kind(sv) == 2) /* k_pcg_col_px: r p x in, p' x out; k_pcg_col_r: p' r in, r out; the layout's
                                    matrix-side bytes (sp less its x-in / y-out) in both */
-    return 2 * (sp - 2 * n8) + 8 * n8;
+    return 2 * (sp - 2 * n8) + 15 * n8 / 2; /* (x and the stale direction only every second iteration: 6 and 3 passes) */
   const unsigned vec = s->dinv_uniform ? 0u : 1u;
   if (use_cg1(sv))
     return sp + n8 * (sv->cg1_implicit ? 9u : 11u + vec);
@@ -235,7 +235,8 @@ static void fused_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int 
     } else {
       lsb_k_pcg_col_px(s->sp_grid, s->col_period, s->d_colplan, s->col_items, s->n, s->d_sptr16, s->d_tmask,
                        s->d_tmpl, s->tmpl_nfar, s->d_sbase, s->d_svals16, s->d_svconst, s->d_r, buf[sv->pcur],
-                       buf[sv->pcur ^ 1], d_x, s->dinv_const, s->d_parts_pq,
+                       buf[sv->pcur ^ 1], d_x, /* x updated by the run's even iterations, two steps at once */ parity == 0,
+                       s->dinv_const, s->d_parts_pq,
                        &s->npq, s->d_st, parity ^ 1, s->d_parts2, np2, g_stream);
       sv->pcur ^= 1;
     }
@@ -247,7 +248,8 @@ static void fused_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int 
     /* r -= alpha S p with S p formed again out of p (k_pcg_col_r): q never travels -- 8 passes per iteration */
     lsb_k_pcg_col_r(s->sp_grid, s->col_period, s->d_colplan, s->col_items, s->n, s->d_sptr16, s->d_tmask, s->d_tmpl,
                     s->tmpl_nfar, s->d_sbase, s->d_svals16, s->d_svconst, buf[sv->pcur], s->d_r, s->dinv_const, s->d_st,
-                    parity, sv->pcur, s->d_parts_pq, s->npq, s->d_parts2, &s->np2, g_stream);
+                    parity, sv->pcur, /* x is two updates behind after an odd iteration */ parity != 0, s->d_parts_pq, s->npq,
+                    s->d_parts2, &s->np2, g_stream);
     if (pos & 2) { /* last of the run: the pending x update, then the direction back into the gather vector */
       lsb_k_pcg_xfix(s->n, buf[0], buf[1], d_x, s->d_st, g_stream);
       lsb_k_pcg_update_p(s->n, s->d_r, DINV(s), buf[sv->pcur], buf[0], s->d_st, parity, s->d_parts2, s->np2,

@@ -32,9 +32,10 @@ struct lsb_pcg_state {
   int pad;       /* single-reduction CG and the column form's two-launch iteration:
                     1 = the maxit-th update has run, the next launch turns it into
                     the final status (never set and tested in the same launch) */
-  int xpend;     /* two-launch iteration on a z-column plan (k_pcg_col_px): x is one
+  int xpend;     /* two-launch iteration on a z-column plan (k_pcg_col_px): 1, 2 = x is one
                     update behind -- x += alpha[0] p with p in direction buffer
-                    xpend - 1; 0 = x is up to date                             */
+                    xpend - 1; 3, 4 = two behind -- x += alpha[1] p'' + alpha[0] p, p in
+                    buffer xpend - 3, p'' in the other; 0 = x is up to date      */
   int pad2_;
 };
 
@@ -130,14 +131,14 @@ void lsb_k_spmv_tmpl(unsigned flags, unsigned grid_cap, unsigned period, const u
 void lsb_k_pcg_col_px(unsigned grid_cap, unsigned period, const unsigned *plan, unsigned nitem, unsigned n,
                       const unsigned *sptr, const unsigned long long *mask, const struct lsb_sell_tmpl *td,
                       unsigned nfar, const int *sbase, const double *vals, const double *vconst, const double *r,
-                      const double *pold, double *pnew, double *x, double dc, double *partials,
+                      const double *pold, double *pnew, double *x, int xupd, double dc, double *partials,
                       unsigned *npartials, struct lsb_pcg_state *st, int parity, const double *parts2,
                       unsigned nparts2, void *stream);
 /* the r half: alpha, r -= alpha S p with S p formed again out of p (q is never stored), partials of (r.z', r.r) */
 void lsb_k_pcg_col_r(unsigned grid_cap, unsigned period, const unsigned *plan, unsigned nitem, unsigned n,
                      const unsigned *sptr, const unsigned long long *mask, const struct lsb_sell_tmpl *td, unsigned nfar,
                      const int *sbase, const double *vals, const double *vconst, const double *p, double *r, double dc,
-                     struct lsb_pcg_state *st, int parity, int pbuf, const double *pq_parts, unsigned npq,
+                     struct lsb_pcg_state *st, int parity, int pbuf, int xtwo, const double *pq_parts, unsigned npq,
                      double *partials2, unsigned *npartials, void *stream);
 void lsb_k_pcg_xfix(unsigned n, const double *p0, const double *p1, double *x, const struct lsb_pcg_state *st,
                     void *stream);

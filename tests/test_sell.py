@@ -270,7 +270,9 @@ def test_two_launch_column_iteration(hip, monkeypatch, spec, kmax):
     """k_pcg_col_px + k_pcg_col_r (hip_kernels.hip): the classic PCG iteration in two launches on a
     z-column plan -- the direction update AND the x half of the first sweep ride in the next SpMV
     launch, p' formed once per plane and kept in registers; the r half forms S p' again instead of
-    reading a stored q (64 instead of 88 bytes per row); the run's last x update is applied by k_pcg_xfix.  Against the three-launch form of the same solver
+    reading a stored q, and x is updated every second iteration with two directions at once -- the one
+    before last out of the buffer p' is about to overwrite (60 instead of 88 bytes per row); what is
+    pending at a run's end, one update or two, is applied by k_pcg_xfix.  Against the three-launch form of the same solver
     (LSBENCH_HIP_NO_FUSE_PX=1): the same iteration counts and status, x to rounding -- converged
     solves, runs cut by maxit at an even and an odd count (the pending x update, the maxit-th
     iteration's bookkeeping), launches and hipGraph replay, second solves on the first one's hint
@@ -287,7 +289,7 @@ def test_two_launch_column_iteration(hip, monkeypatch, spec, kmax):
             monkeypatch.delenv("LSBENCH_HIP_NO_FUSE_PX", raising=False)
         else:
             monkeypatch.setenv("LSBENCH_HIP_NO_FUSE_PX", "1")
-        for graph, maxit in ((0, 20000), (1, 20000), (0, 7), (1, 8), (0, 1), (1, 2)):
+        for graph, maxit in ((0, 20000), (1, 20000), (0, 7), (1, 8), (0, 1), (1, 2), (0, 3), (1, 4), (0, 5), (1, 6)):
             s = hip.Solver(A, hip.default_opts(op_mode=hip.OP_RAW, spmv_variant=hip.SPMV_SELL, tol=1e-10,
                                                spmv_tune=6 | 64 | 256, use_graph=graph, maxit=maxit))
             assert s.spmv_col_slices > 0 and s.fused_p == (2 if fused else 0)
