@@ -1844,15 +1844,16 @@ __global__ __launch_bounds__(WG, DOT == 2 ? 5 : 6) void k_spmv_tmpl_col(
 }
 
 // --------------------------------------------------------------------------
-// a2-5 on a z-column plan: the classic PCG iteration in TWO launches and 64 instead of 88 bytes per
+// a2-5 on a z-column plan: the classic PCG iteration in TWO launches and 60 instead of 88 bytes per
 // row (one shard, constant Jacobi diagonal dc).
-//   [k_pcg_col_px]   (r.z, r.r) of the sweep before -> stop test, beta;  alpha = the step of the
-//                    iteration before (st->alpha[0], left there by k_pcg_col_r);  per row
+//   [k_pcg_col_px]   (r.z, r.r) of the sweep before -> stop test, beta;  alpha, alpha2 = the steps of the two
+//                    iterations before (st->alpha[0], [1], left there by k_pcg_col_r);  per row
 //                      p' = dc r + beta p        (pnew_of: k_pcg_update_p's expression)
-//                      x += alpha p              (the x half of k_pcg_update_xr, one iteration late:
-//                                                 p is in registers here anyway)
 //                      q  = S p' -- NOT stored: only the partials of p'.q leave the launch
-//                    -- reads r, p, x and writes p' (the OTHER direction buffer), x: 40 B per row
+//                      every SECOND iteration of a run (XUPD):  x += alpha2 p'' + alpha p  -- the x half of
+//                        k_pcg_update_xr, two iterations' worth: p is in registers here anyway, and p'', the
+//                        direction before it, is what the buffer p' goes to still holds
+//                    -- reads r, p (+ x, p'') and writes p' (the OTHER direction buffer) (+ x): 24 / 48 B per row
 //   [k_pcg_col_r]    alpha = r.z / p'.q;  r -= alpha (S p') with S p' formed AGAIN by the same walk (the same
 //                    operands and products in the same order: the same bits);  partials of (r.z', r.r)
 //                    -- reads p', r and writes r: 24 B per row
@@ -1864,8 +1865,9 @@ __global__ __launch_bounds__(WG, DOT == 2 ? 5 : 6) void k_spmv_tmpl_col(
 // operands of a 3-D stencil (NF = 2) are formed a second time, out of r and p lines that sit in L2.
 // Ownership: a column loads, updates and stores x and p' for ITS planes only; the plane below its
 // first and above its last slice belong to other columns -- p' is formed for them, nothing stored.
-// The x update of the LAST iteration of a run has no k_pcg_col_px behind it: st->xpend (set by
-// k_pcg_col_r, cleared here) says so and k_pcg_xfix applies it (hip_pcg.c).  maxit: the launch
+// What is pending at the end of a run (one update after an even iteration, two after an odd one) has no
+// k_pcg_col_px behind it: st->xpend (set by k_pcg_col_r, cleared by an updating launch here) says so and k_pcg_xfix
+// applies it (hip_pcg.c).  maxit: the launch
 // that counts the maxit-th iteration sets st->pad and does all of its work (x included); the next
 // k_pcg_col_r turns that into the status -- never set and tested in the same launch.
 // Pipeline of a column: a step issues the NEXT step's loads, waits for its own operands (older) and stores
@@ -2032,7 +2034,7 @@ __device__ __forceinline__ void colp_single(unsigned s, unsigned n, unsigned lan
 
 // NT: bit 0 x loaded and stored nontemporal, bit 1 p' and q stored nontemporal
 // q = S p' is NOT stored: only its dot with p' leaves the launch -- k_pcg_col_r forms the same q again out of p' when
-// it updates r, and the vector never travels (8 instead of 9 passes per iteration)
+// it updates r, and the vector never travels
 // XUPD: x is updated every SECOND iteration of a run, with two directions at once -- x += alpha2 p'' + alpha p: p is
 // the direction this launch reads anyway, p'' the one of the iteration before it, which is what the buffer p' goes
 // to still holds (each lane reads its own rows' p'' just before it overwrites them; nobody else reads that
@@ -2172,8 +2174,7 @@ __global__ __launch_bounds__(WG, NF == 2 ? 3 : 4) void k_pcg_col_px(
 // The r half of the first sweep WITHOUT q: alpha = r.z / p.q (p.q from k_pcg_col_px's partials), then per row
 // r -= alpha (S p) with S p formed again by the z-column walk of k_spmv_tmpl_col -- the same operands and products in
 // the same order as in k_pcg_col_px, so the same bits -- and the partials of (r.z', r.r).  Reads p and r, writes r:
-// three passes, as a sweep over a stored q and r would make, but k_pcg_col_px need not write q: 8 passes per
-// iteration instead of 9.  Leaves alpha and "x is one update behind, the direction is in buffer pbuf" (xpend) in
+// three passes, as a sweep over a stored q and r would make, but k_pcg_col_px need not write q.  Leaves alpha and "x is one update behind, the direction is in buffer pbuf" (xpend) in
 // the state and promotes a pending maxit (st->pad) to the status.
 template <int NF>
 __global__ __launch_bounds__(WG, 5) void k_pcg_col_r(

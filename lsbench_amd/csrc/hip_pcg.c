@@ -182,7 +182,8 @@ int lsb_fuse_p_kind(const lsb_hip_solver *sv) {
   const struct shard *s = &sv->sh[0];
   /* 2 = the z-column form of a 3-D stencil with a constant diagonal: direction update AND the x
    * half of the first sweep ride in the next SpMV launch, the r half forms S p again instead of reading a
-   * stored q (k_pcg_col_px + k_pcg_col_r: 64 instead of 88 bytes per row and iteration) */
+   * stored q, x is updated every second iteration with two directions at once (k_pcg_col_px + k_pcg_col_r: 60
+   * instead of 88 bytes per row and iteration) */
   if (s->variant == LSB_SPMV_SELL && (s->sp_flags & LSB_SP_COL) && (s->sp_flags & LSB_SP_TMPL) && s->d_colplan &&
       s->d_srec && s->dinv_uniform && s->tmpl_nfar >= 1 && s->tmpl_nfar <= 2 && s->row_begin == 0 &&
       s->n == s->n_glob && sv->o.precond == LSB_PRECOND_JACOBI && !no_fuse_px)
@@ -245,7 +246,7 @@ static void fused_enqueue_iter(lsb_hip_solver *sv, double *d_x, int parity, int 
       LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 2], g_stream));
       LSB_CHK_HIP(hipEventRecord(sv->ev[4 * sample + 3], g_stream));
     }
-    /* r -= alpha S p with S p formed again out of p (k_pcg_col_r): q never travels -- 8 passes per iteration */
+    /* r -= alpha S p with S p formed again out of p (k_pcg_col_r): q never travels */
     lsb_k_pcg_col_r(s->sp_grid, s->col_period, s->d_colplan, s->col_items, s->n, s->d_sptr16, s->d_tmask, s->d_tmpl,
                     s->tmpl_nfar, s->d_sbase, s->d_svals16, s->d_svconst, buf[sv->pcur], s->d_r, s->dinv_const, s->d_st,
                     parity, sv->pcur, /* x is two updates behind after an odd iteration */ parity != 0, s->d_parts_pq, s->npq,
