@@ -387,7 +387,9 @@ void shard_upload(struct shard *s, const struct csr *S, unsigned r0,
                * slot per side, nothing but streams: the shorter the column the more of them per wave; a
                * 50-plane slab of the 7-point grid 130.1 / 122.6 / 116.6 us -- two far slots: every plane
                * re-read costs two vectors and their +-line operands) */
-              unsigned kauto = TT->nfar >= 2 ? TT->nslice / 5120u : TT->nslice / 20480u;
+              /* (final form of the iteration, config 3 padded: 111.0 / 110.0 / 108.6 / 115.8 / 116.7 us with columns
+               * of 3 / 4 / 5 / 6 / 8) */
+              unsigned kauto = TT->nfar >= 2 ? TT->nslice / 5120u : TT->nslice / 15000u;
               kauto = kauto < 4u ? 4u : kauto > 16u ? 16u : kauto;
               const unsigned kmax = ek ? (unsigned)atoi(ek) : kauto;
               /* [0]: every slice of the shard; [1]: the slices that need no halo, where the shard has
