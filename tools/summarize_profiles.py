@@ -68,12 +68,15 @@ for wl, suffix, vtag in VARIANTS:
         wb = d["WRITE_SIZE_KB_median"] * 1024
         lines.append("%s,%d,%.1f,%.0f,%.1f,%.0f,%.0f" % (k, d["launches_FETCH_SIZE"], d["FETCH_SIZE_KB_median"], fb,
                                                          d["WRITE_SIZE_KB_median"], wb, fb + wb))
-        if ("k_spmv_" in k or "k_pb_" in k or "k_pcg_col_px" in k) and d["launches_FETCH_SIZE"] > 20:
+        if ("k_spmv_" in k or "k_pb_" in k or "k_pcg_col_px" in k) and d["launches_FETCH_SIZE"] > (10 if "k_pcg_col_px" in k else 20):
             name = k.split("<")[0].split()[-1]
             if best is None or d["launches_FETCH_SIZE"] > best[1]:
                 best = (name, d["launches_FETCH_SIZE"], fb + wb)
-            if name == "k_pcg_col_px":   # the launch that carries the SpMV in the two-launch iteration: an entry of its own
-                also = (name, d["launches_FETCH_SIZE"], fb + wb)
+            if name == "k_pcg_col_px":   # the launch that carries the SpMV in the two-launch iteration: an entry of its own,
+                # the mean over its two instantiations (with / without the x update of every second iteration)
+                n0, b0 = (also[1], also[2]) if also else (0, 0.0)
+                n1 = d["launches_FETCH_SIZE"]
+                also = (name, n0 + n1, (b0 * n0 + (fb + wb) * n1) / (n0 + n1))
     if wl == "powerlaw":
         # one SpMV of the two-phase form = k_pb_products + k_pb_reduce: per-launch means of the two
         # (the FETCH and WRITE passes are separate runs)
